@@ -1,0 +1,528 @@
+"""
+ktf_oracle — CPU restatement (NumPy) of the reference's wav -> x-vector hot path.
+
+TEST INFRASTRUCTURE ONLY. Nothing under `kaldi-tflite_amd/` imports this module; only
+`tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` do, and
+only as the checker / the reported CPU baseline, never as the product path.
+
+What it restates: the arithmetic the reference expresses as TensorFlow 2.8 op graphs
+inside its Keras layers (reference = shahruk10/kaldi-tflite v0.1.0; paths below are
+relative to /root/reference/kaldi_tflite/lib). TensorFlow itself (third-party,
+`tensorflow==2.8.0`, setup.py:49) is not available offline, so each function restates
+the published semantics of the TF ops at the reference's call sites.
+
+Pinning: every function here is checked in tests/test_oracle_golden.py against the
+reference's own Kaldi-generated golden vectors (tests/golden/*.npz, produced by
+tests/golden/make_golden.py) at the reference's own tolerances. Stages with no golden
+(compaction a7, LDA/length-norm a12 and the whole pipeline on the real pretrained
+weights, which are not shipped with the reference) are pinned only through the other
+stages: "parity unpinned" for those, as stated in DESIGN.md.
+
+`dtype` selects the arithmetic: np.float32 mirrors the reference's fp32 graph;
+np.float64 gives a high-precision value that sits between fp32 implementations
+(used as the comparison target for the HIP kernels).
+"""
+
+import numpy as np
+
+__all__ = [
+    "framing", "pad_waveform", "window_function", "windowing", "mel_bank", "filterbank", "dct_matrix", "dct",
+    "lifter_coeffs", "mfcc", "vad", "cmvn", "tdnn", "relu", "batchnorm", "stats_pooling",
+    "xvector_post", "plda", "sequential_forward", "xvector_forward",
+]
+
+
+# --------------------------------------------------------------------------- a1 Framing
+def frame_params(frame_length_ms=25.0, frame_shift_ms=10.0, sample_frequency=16000.0):
+    """layers/dsp/framing.py:92-104 — sizes in samples; half = size // 2."""
+    if frame_length_ms <= 0 or frame_shift_ms <= 0 or sample_frequency <= 0:
+        raise ValueError("frame_length, frame_shift and sample_frequency should be > 0")
+    size = int(sample_frequency * frame_length_ms / 1000.0)
+    shift = int(sample_frequency * frame_shift_ms / 1000.0)
+    if size <= 0 or shift <= 0:
+        raise ValueError("frame_length / frame_shift too small")
+    return size, shift, size // 2
+
+
+def framing(x, frame_length_ms=25.0, frame_shift_ms=10.0, sample_frequency=16000.0):
+    """layers/dsp/framing.py:212-265. x (..., N) -> (..., T, 2*half). No padding:
+    centres = range(half, N-half+1, shift); frame = x[c-half : c+half]."""
+    size, shift, half = frame_params(frame_length_ms, frame_shift_ms, sample_frequency)
+    N = x.shape[-1]
+    if N < size:
+        raise ValueError("input shorter than one frame")
+    centres = np.arange(half, N - half + 1, shift)
+    idx = centres[:, None] + np.arange(-half, half)[None, :]
+    return x[..., idx]
+
+
+def pad_waveform(x, frame_size, frame_shift):
+    """kaldi_numpy/frame_extraction.py:28-89 (MirrorPad + PadWaveform): the caller-side
+    step that turns the layer's snip-edges=true framing into Kaldi's snip-edges=false."""
+    N = x.shape[-1]
+    M = (N + frame_shift // 2) // frame_shift
+    Nv = (M - 1) * frame_shift + frame_size
+    left = (frame_size - frame_shift) // 2
+    right = abs(N - Nv) - left
+    lp = np.flip(x[..., :left], axis=-1)
+    rp = np.flip(x[..., -right:], axis=-1)
+    return np.concatenate([lp, x, rp], axis=-1)
+
+
+# --------------------------------------------------------------------------- a2 Windowing
+def window_function(window_type, M, blackman_coeff=0.42):
+    """layers/dsp/windowing.py:110-156 (float64 NumPy, later cast)."""
+    t = window_type.lower()
+    n = np.arange(0, M)
+    if M == 1:
+        return np.ones(1, float)
+    if t == "hamming":
+        return np.hamming(M)
+    if t == "hanning":
+        return np.hanning(M)
+    if t == "povey":
+        return (0.5 - 0.5 * np.cos(2.0 * np.pi * n / (M - 1))) ** 0.85
+    if t == "rectangular":
+        return np.ones((M,))
+    if t == "sine":
+        return np.sin(np.pi * n / (M - 1))
+    if t == "blackman":
+        w = np.blackman(M)
+        if blackman_coeff != 0.42:
+            w = w - 0.42 + blackman_coeff
+        return w
+    raise ValueError(f"window_type '{window_type}' is not recognized")
+
+
+def _log_energy(x, eps, energy_floor, dtype):
+    """layers/dsp/windowing.py:174-178: clip(log(relu(sum x^2) + eps), floor, max)."""
+    e = np.sum(x * x, axis=-1, keepdims=True, dtype=dtype)
+    e = np.log(np.maximum(e, 0) + dtype(eps))
+    return np.clip(e, dtype(energy_floor), np.finfo(dtype).max).astype(dtype)
+
+
+def windowing(frames, window_type="povey", blackman_coeff=0.42, dither=0.0, remove_dc_offset=True,
+              preemphasis_coefficient=0.97, return_energy=True, raw_energy=True, energy_floor=0.0,
+              epsilon=1e-7, dtype=np.float32, rng=None):
+    """layers/dsp/windowing.py:180-209."""
+    if preemphasis_coefficient < 0 or preemphasis_coefficient > 1.0:
+        raise ValueError("preemphasis_coefficient should be between 0.0 and 1.0")
+    x = np.asarray(frames, dtype=dtype)
+    M = x.shape[-1]
+    w = window_function(window_type, M, blackman_coeff).astype(dtype)
+    if dither != 0.0:
+        rng = rng or np.random.default_rng(0)
+        x = x + rng.standard_normal(x.shape).astype(dtype) * dtype(dither)
+    if remove_dc_offset:
+        x = x - np.mean(x, axis=-1, keepdims=True, dtype=dtype)
+    energy = None
+    if return_energy and raw_energy:
+        energy = _log_energy(x, epsilon, energy_floor, dtype)
+    if preemphasis_coefficient > 0:
+        c = dtype(preemphasis_coefficient)
+        y = np.empty_like(x)
+        y[..., 1:] = x[..., 1:] - c * x[..., :-1]
+        y[..., 0] = x[..., 0] - c * x[..., 0]
+        x = y
+    x = x * w
+    if return_energy:
+        if not raw_energy:
+            energy = _log_energy(x, epsilon, energy_floor, dtype)
+        return x, energy
+    return x
+
+
+# --------------------------------------------------------------------------- a3 FilterBank
+def next_pow2(n):
+    """layers/dsp/filterbank.py:133-136."""
+    if n & (n - 1) == 0 and n != 0:
+        return n
+    return 2 ** (n - 1).bit_length()
+
+
+def mel_scale(f):
+    return 1127.0 * np.log(1.0 + f / 700.0)
+
+
+def mel_bank(window_size, num_bins=23, sample_frequency=16000.0, high_freq_cutoff=0.0, low_freq_cutoff=20.0):
+    """layers/dsp/filterbank.py:141-189 -> (nfft, bank[(nfft/2+1), num_bins] float32).
+    Weights computed in float64, stored float32; bin nfft/2 has no weight; strict
+    left < mel < right."""
+    if num_bins <= 2:
+        raise ValueError("num_bins must be >= 3")
+    if sample_frequency <= 0:
+        raise ValueError("sample_frequency must be > 0")
+    nyq = sample_frequency / 2.0
+    if low_freq_cutoff > nyq or low_freq_cutoff < 0:
+        raise ValueError("low_freq_cutoff out of range")
+    hi = high_freq_cutoff
+    if hi <= 0:
+        hi += nyq
+    if low_freq_cutoff >= hi:
+        raise ValueError("lower_freq_cutoff must be < higher_freq_cutoff")
+    nfft = next_pow2(window_size)
+    bins = nfft // 2
+    bw = sample_frequency / nfft
+    mlo, mhi = mel_scale(low_freq_cutoff), mel_scale(hi)
+    delta = (mhi - mlo) / (num_bins + 1)
+    bank = np.zeros([num_bins, bins + 1], dtype=np.float32)
+    mel = mel_scale(bw * np.arange(bins))
+    for i in range(num_bins):
+        left = mlo + i * delta
+        center = left + delta
+        right = center + delta
+        for j in range(bins):
+            m = mel[j]
+            if left < m < right:
+                if m <= center:
+                    bank[i, j] = (m - left) / (center - left)
+                else:
+                    bank[i, j] = (right - m) / (right - center)
+    return nfft, bank.T.copy()
+
+
+def filterbank(frames, num_bins=23, sample_frequency=16000.0, high_freq_cutoff=0.0, low_freq_cutoff=20.0,
+               use_log_fbank=True, use_power=True, epsilon=1e-7, dtype=np.float32):
+    """layers/dsp/filterbank.py:225-242: pad -> rfft -> abs -> ^2 -> @ mel -> log(relu + eps)."""
+    x = np.asarray(frames, dtype=dtype)
+    M = x.shape[-1]
+    nfft, bank = mel_bank(M, num_bins, sample_frequency, high_freq_cutoff, low_freq_cutoff)
+    spec = np.fft.rfft(x, n=nfft, axis=-1)
+    spec = np.abs(spec).astype(dtype)
+    if use_power:
+        spec = spec * spec
+    feats = spec @ bank.astype(dtype)
+    if use_log_fbank:
+        feats = np.log(np.maximum(feats, 0) + dtype(epsilon))
+    return feats.astype(dtype)
+
+
+# --------------------------------------------------------------------------- a4 DCT
+def dct_matrix(input_length, length):
+    """layers/dsp/dct.py:98-143 -> (input_length, length) float64; column 0 = sqrt(1/N)."""
+    if length <= 0:
+        raise ValueError("DCT length must be > 0")
+    if input_length < length:
+        raise ValueError("input feature length must be >= DCT length")
+    N = float(input_length)
+    n = np.arange(input_length)
+    k = np.arange(length, dtype=np.float64)[:, None]
+    d = np.cos(np.pi / N * (n + 0.5) * k)
+    d[0] *= 1.0 / np.sqrt(2.0)
+    d *= np.sqrt(2.0 / N)
+    d = d.T
+    d[:, 0] = np.sqrt(1.0 / N)
+    return d
+
+
+def dct(x, length, dtype=np.float32):
+    """layers/dsp/dct.py:175-176."""
+    x = np.asarray(x, dtype=dtype)
+    return x @ dct_matrix(x.shape[-1], length).astype(dtype)
+
+
+# --------------------------------------------------------------------------- a5 MFCC
+def lifter_coeffs(num_mfccs, q):
+    """layers/dsp/mfcc.py:146-159."""
+    n = np.arange(0, num_mfccs)
+    return 1 + 0.5 * np.sin(np.pi * n / q) * q
+
+
+def mfcc(frames, num_mfccs=23, num_mels=23, cepstral_lifter=22, use_energy=True, sample_frequency=16000.0,
+         high_freq_cutoff=0.0, low_freq_cutoff=20.0, use_log_fbank=True, use_power=True, window_type="povey",
+         dither=0.0, remove_dc_offset=True, preemphasis_coefficient=0.97, raw_energy=True, energy_floor=0.0,
+         epsilon=1e-7, dtype=np.float32, rng=None):
+    """layers/dsp/mfcc.py:197-244. frames (B,T,M) -> (B,T,num_mfccs)."""
+    if num_mfccs > num_mels:
+        raise ValueError("num_mfccs must be <= num_mels")
+    r = windowing(frames, window_type=window_type, dither=dither, remove_dc_offset=remove_dc_offset,
+                  preemphasis_coefficient=preemphasis_coefficient, raw_energy=raw_energy,
+                  return_energy=use_energy, energy_floor=energy_floor, epsilon=epsilon, dtype=dtype, rng=rng)
+    win, energy = r if use_energy else (r, None)
+    fb = filterbank(win, num_bins=num_mels, sample_frequency=sample_frequency, high_freq_cutoff=high_freq_cutoff,
+                    low_freq_cutoff=low_freq_cutoff, use_log_fbank=use_log_fbank, use_power=use_power,
+                    epsilon=epsilon, dtype=dtype)
+    c = dct(fb, num_mfccs, dtype=dtype)
+    if cepstral_lifter > 1:
+        c = c * lifter_coeffs(num_mfccs, cepstral_lifter).astype(dtype)
+    if use_energy:
+        c = c.copy()
+        c[..., 0] = energy[..., 0]
+    return c.astype(dtype)
+
+
+# --------------------------------------------------------------------------- a6 VAD
+def vad(feats, energy_mean_scale=0.5, energy_threshold=5.0, frames_context=0, proportion_threshold=0.6,
+        return_indexes=True, energy_coeff=0, dtype=np.float32):
+    """layers/dsp/vad.py:156-203. feats (B,T,D). Returns int64 (n,2) [batch, frame] rows if
+    return_indexes else a (B,T,1) mask of `dtype`."""
+    if energy_mean_scale < 0:
+        raise ValueError("`energy_mean_scale` must be >= 0")
+    if frames_context < 0:
+        raise ValueError("`frames_context` must be >= 0")
+    if proportion_threshold <= 0 or proportion_threshold >= 1:
+        raise ValueError("`proportion_threshold` must be between 0 and 1 (exclusive)")
+    x = np.asarray(feats, dtype=dtype)
+    logE = x[..., energy_coeff:energy_coeff + 1]
+    T = logE.shape[-2]
+    thr = dtype(energy_threshold)
+    if energy_mean_scale > 0:
+        thr = thr + dtype(energy_mean_scale) * np.mean(logE, axis=-2, keepdims=True, dtype=dtype)
+    dec = logE > thr
+    W = 2 * frames_context + 1
+    if W > 1:
+        d = dec.astype(dtype)[..., 0]                      # (B,T)
+        pad = np.pad(d, [(0, 0)] * (d.ndim - 1) + [(frames_context, frames_context)])
+        counts = np.zeros_like(d)
+        for k in range(W):
+            counts = counts + pad[..., k:k + T]
+        sizes = np.full((T,), W, dtype=dtype)
+        # vad.py:124-135,187-193: edge window sizes scattered at indexes mod T
+        edge_sizes = list(range(W // 2 + 1, W, 1)) + list(range(W - 1, W // 2, -1))
+        edge_idx = list(range(0, W // 2)) + list(range(-W // 2 + 1, 0))
+        for i, s in zip(edge_idx, edge_sizes):
+            sizes[(i + T) % T] = s
+        prop = counts / sizes
+        dec = (prop >= dtype(proportion_threshold))[..., None]
+    if return_indexes:
+        return np.argwhere(dec[..., 0]).astype(np.int64)
+    return dec.astype(dtype)
+
+
+# --------------------------------------------------------------------------- a8 CMVN
+def cmvn(x, center=True, norm_vars=False, window=600, min_window=100, padding="SAME", dtype=np.float32):
+    """layers/normalization/cmvn.py:146-250. x (B,T,D). Sliding window mean from fp
+    cumulative sums of the zero-prefixed input; whole-utterance stats if T <= window."""
+    if not center:
+        raise NotImplementedError("CMVN with center=False not supported yet")
+    if window <= 0 or min_window <= 0:
+        raise ValueError("`window` and `min_window` must be > 0")
+    padding = padding.upper()
+    if padding not in ("SAME", "VALID"):
+        raise ValueError("bad padding")
+    x = np.asarray(x, dtype=dtype)
+    T = x.shape[-2]
+    N = window
+
+    def wsum(v):
+        cs = np.cumsum(np.concatenate([np.zeros_like(v[..., :1, :]), v], axis=-2), axis=-2, dtype=dtype)
+        s = cs[..., N:, :] - cs[..., :-N, :]
+        if padding == "SAME":
+            s = np.concatenate([np.repeat(s[..., :1, :], N // 2, axis=-2), s,
+                                np.repeat(s[..., -1:, :], (N - 1) // 2, axis=-2)], axis=-2)
+        return s
+
+    if T <= N:
+        mean = np.sum(x, axis=-2, keepdims=True, dtype=dtype) / dtype(T)
+        std = None
+        if norm_vars:
+            std = np.sqrt(np.sum(x * x, axis=-2, keepdims=True, dtype=dtype) / dtype(T) - mean * mean)
+    else:
+        mean = wsum(x) / dtype(N)
+        std = None
+        if norm_vars:
+            std = np.sqrt(wsum(x * x) / dtype(N) - mean * mean)
+    if padding == "VALID":
+        a = N // 2
+        b = T - (N - 1) // 2
+        x = x[..., a:b, :]
+    y = x - mean
+    if norm_vars:
+        y = y / std
+    return y.astype(dtype)
+
+
+# --------------------------------------------------------------------------- a9/a10 TDNN, ReLU, BatchNorm
+def tdnn_eval_indices(T, context, subsampling_factor=1, padding="SAME"):
+    """layers/tdnn/tdnn.py:224-249 -> (T_out, K) int row indexes."""
+    ctx = sorted(context)
+    start, end = 0, T
+    if padding.upper() == "VALID":
+        if ctx[0] < 0:
+            start = -ctx[0]
+        if ctx[-1] > 0:
+            end = T - ctx[-1]
+    idx = np.arange(start, end, subsampling_factor)[:, None] + np.asarray(ctx)[None, :]
+    if padding.upper() == "SAME":
+        idx = np.clip(idx, 0, T - 1)
+    return idx
+
+
+def tdnn(x, W, b=None, context=(0,), subsampling_factor=1, padding="SAME", activation=None, dtype=np.float32):
+    """layers/tdnn/tdnn.py:251-280 with Kaldi-format weights W (units, K*D)
+    (kernel[0,k,d,u] = W[u, k*D + d], layers/tdnn/utils.py:28). x (B,T,D) -> (B,T_out,units)."""
+    x = np.asarray(x, dtype=dtype)
+    B, T, D = x.shape
+    idx = tdnn_eval_indices(T, list(context), subsampling_factor, padding)
+    g = x[:, idx, :].reshape(B, idx.shape[0], -1)          # (B,T_out,K*D) im2col, k-major
+    y = g @ np.asarray(W, dtype=dtype).T
+    if b is not None:
+        y = y + np.asarray(b, dtype=dtype)
+    if activation is not None:
+        a = activation.lower()
+        if a == "relu":
+            y = np.maximum(y, 0)
+        elif a == "sigmoid":
+            y = 1.0 / (1.0 + np.exp(-y))
+        elif a == "tanh":
+            y = np.tanh(y)
+        elif a != "linear":
+            raise ValueError(f"unsupported activation {activation}")
+    return y.astype(dtype)
+
+
+def relu(x):
+    return np.maximum(x, 0)
+
+
+def batchnorm(x, target_rms, mean, var, epsilon=1e-3, dtype=np.float32):
+    """layers/normalization/batchnorm.py:78-88,131-134: gamma*(x-mean)/sqrt(var+eps), gamma=target_rms."""
+    x = np.asarray(x, dtype=dtype)
+    gamma = dtype(target_rms) * np.ones_like(np.asarray(mean, dtype=dtype))
+    return ((x - np.asarray(mean, dtype)) * (gamma / np.sqrt(np.asarray(var, dtype) + dtype(epsilon)))).astype(dtype)
+
+
+# --------------------------------------------------------------------------- a11 StatsPooling
+def stats_pooling(x, left_context=0, right_context=0, input_period=1, output_period=1, include_std=True,
+                  padding="SAME", epsilon=1e-10, reduce_time_axis=False, dtype=np.float32):
+    """layers/stats/stats_pooling.py:161-316."""
+    if left_context > 0 or right_context < 0:
+        raise ValueError("'left_context' must be <= 0 and 'right_context' must be >= 0")
+    if input_period <= 0 or output_period <= 0:
+        raise ValueError("periods must be > 0")
+    if output_period % input_period != 0 and not reduce_time_axis:
+        raise ValueError("'output_period' must be a multiple of 'input_period'")
+    padding = padding.upper()
+    x = np.asarray(x, dtype=dtype)
+    T = x.shape[1]
+    eps = dtype(epsilon)
+
+    def across_all(v):
+        if input_period > 1:
+            v = v[:, ::input_period, :]
+        mean = np.mean(v, axis=1, keepdims=True, dtype=dtype)
+        if not include_std:
+            return mean
+        var = np.mean(v * v, axis=1, keepdims=True, dtype=dtype) - mean * mean
+        return np.concatenate([mean, np.sqrt(np.maximum(var, 0) + eps)], -1).astype(dtype)
+
+    def across_windows(v):
+        start, end = 0, T
+        if padding != "SAME":
+            if left_context < 0:
+                start = -left_context
+            if right_context > 0 and (right_context - left_context + 1) < T:
+                end = T - right_context
+            end = end + 1
+        idx = np.arange(start, end, output_period)
+        rc = min(right_context + 1, T)
+        off = np.arange(left_context, rc, input_period)
+        ind = idx[:, None] + off[None, :]
+        mask = ((ind >= 0) & (ind < T)).astype(dtype)[None, :, :, None]
+        ind = np.clip(ind, 0, T - 1)
+        n = mask.sum(axis=2)
+        g = v[:, ind, :]
+        mean = (g * mask).sum(axis=2, dtype=dtype) / n
+        if not include_std:
+            return mean.astype(dtype)
+        var = ((v * v)[:, ind, :] * mask).sum(axis=2, dtype=dtype) / n - mean * mean
+        return np.concatenate([mean, np.sqrt(np.maximum(var, 0) + eps)], -1).astype(dtype)
+
+    if reduce_time_axis:
+        return across_all(x)
+    if padding == "SAME":
+        s = across_windows(x)
+        return np.repeat(s, output_period, axis=1) if output_period > 1 else s
+    if T > (right_context - left_context + 1):
+        return across_windows(x)
+    return across_all(x)
+
+
+# --------------------------------------------------------------------------- a12 x-vector post-processing
+def xvector_post(x, global_mean, lda_mat, dtype=np.float32):
+    """models/kaldi/xvector_extractor.py:123-134,174-184. x (B,1,512) or (B,512);
+    lda_mat is transform.mat (out, in+1): last column is the offset."""
+    x = np.asarray(x, dtype=dtype).reshape(-1, np.asarray(global_mean).shape[-1])
+    A = np.asarray(lda_mat, dtype=dtype)
+    off = A[:, -1:].T
+    A = A[:, :-1].T
+    y = (x - np.asarray(global_mean, dtype)) @ A + off
+    norm = np.linalg.norm(y, ord=2, axis=-1, keepdims=True)
+    return (y / (norm / np.sqrt(dtype(y.shape[-1])))).astype(dtype)
+
+
+# --------------------------------------------------------------------------- a16 PLDA
+def plda(x, mean, transform, psi, normalize_length=True, simple_length_norm=False, dtype=np.float64):
+    """layers/plda/plda.py:163-263. x (B,dim) or (B,1,dim) -> (scores (B,B), transformed (B,dim,1))."""
+    mean = np.asarray(mean, dtype).reshape(-1, 1)
+    psi = np.asarray(psi, dtype).reshape(-1, 1)
+    A = np.asarray(transform, dtype)
+    dim = dtype(mean.shape[0])
+    x = np.asarray(x, dtype)
+    x = x[..., None] if x.ndim == 2 else np.transpose(x, [0, 2, 1])    # (B,dim,1)
+    y = -(A @ mean) + A @ x
+    if normalize_length:
+        if simple_length_norm:
+            f = np.sqrt(dim) / np.linalg.norm(y, ord=2, axis=1, keepdims=True)
+        else:
+            inv = 1.0 / (psi + 1.0)
+            f = np.sqrt(dim / np.sum(inv * y * y, axis=1, keepdims=True))
+        y = y * f
+    log2pi = dtype(1.8378770664093456)
+
+    def ll(v, m, var):
+        logdet = np.sum(np.log(var))
+        return -0.5 * (logdet + log2pi * dim + np.sum((v - m) ** 2 / var, axis=1))
+
+    m = (psi * y) / (psi + 1.0)
+    m = np.transpose(m, [2, 1, 0])                                   # (1,dim,B)
+    given = ll(y, m, 1.0 + psi / (psi + 1.0))
+    without = ll(y, np.zeros_like(m), 1.0 + psi)
+    return (given - without).astype(dtype), y.astype(dtype)
+
+
+# --------------------------------------------------------------------------- a13/a14 model forward
+def sequential_forward(layers, x, dtype=np.float32, upto=None):
+    """models/kaldi/sequential.py:86-143 forward. `layers` is a list of dicts:
+    {"kind": "tdnn", "W","b","context",...} | {"kind":"relu"} | {"kind":"bn","rms","mean","var"} |
+    {"kind":"stats", **cfg}."""
+    for i, L in enumerate(layers):
+        k = L["kind"]
+        if k == "tdnn":
+            x = tdnn(x, L["W"], L.get("b"), L.get("context", [0]), L.get("subsampling_factor", 1),
+                     L.get("padding", "SAME"), L.get("activation"), dtype=dtype)
+        elif k == "relu":
+            x = relu(x)
+        elif k == "bn":
+            x = batchnorm(x, L["rms"], L["mean"], L["var"], L.get("epsilon", 1e-3), dtype=dtype)
+        elif k == "stats":
+            x = stats_pooling(x, **{a: b for a, b in L.items() if a != "kind"}, dtype=dtype)
+        else:
+            raise ValueError(k)
+        if upto is not None and i == upto:
+            break
+    return x
+
+
+def xvector_forward(wav, cfg, layers, global_mean, lda_mat, dtype=np.float32, return_intermediates=False):
+    """models/kaldi/xvector_extractor.py:136-186, evaluated PER UTTERANCE (the reference
+    concatenates the voiced frames of all batch rows, :164-165, so it is only defined for
+    B=1; a batch here is B independent B=1 calls). wav (B,N) -> (B, lda_dim)."""
+    wav = np.asarray(wav, dtype=dtype)
+    outs, inter = [], []
+    fcfg = {k: v for k, v in cfg["framing"].items() if k != "dynamic_input_shape"}
+    for b in range(wav.shape[0]):
+        fr = framing(wav[b:b + 1], **fcfg)
+        m = mfcc(fr, **cfg["mfcc"], dtype=dtype)
+        vcfg = dict(cfg["vad"])
+        vcfg["return_indexes"] = True
+        idx = vad(m, **vcfg, dtype=dtype)
+        v = m[idx[:, 0], idx[:, 1]][None]
+        c = cmvn(v, **cfg["cmvn"], dtype=dtype)
+        h = sequential_forward(layers, c, dtype=dtype)
+        y = xvector_post(h, global_mean, lda_mat, dtype=dtype)
+        outs.append(y[0])
+        if return_intermediates:
+            inter.append({"mfcc": m[0], "voiced": idx[:, 1], "cmvn": c[0], "tdnn6": h.reshape(-1)})
+    y = np.stack(outs, 0)
+    return (y, inter) if return_intermediates else y

@@ -1,0 +1,204 @@
+"""Pins oracle/ktf_oracle.py to the reference's own Kaldi-generated golden vectors at the
+reference's own tolerances. CPU only."""
+
+import json
+
+import numpy as np
+import pytest
+
+import _golden as G
+from oracle import ktf_oracle as O
+
+
+def _frames(cfg, wav):
+    f = cfg["framing"]
+    if not cfg["snip_edges"]:
+        m = int(f["frame_length_ms"] / 1000.0 * f["sample_frequency"])
+        k = int(f["frame_shift_ms"] / 1000.0 * f["sample_frequency"])
+        wav = O.pad_waveform(wav, m, k)
+    return O.framing(wav, **f)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_mfcc_goldens(dtype):
+    # layers/dsp/mfcc_test.py:32,168-203  RMSE < 2.25e-4 on 54 Kaldi cases
+    worst = 0.0
+    for name in G.mfcc_case_names():
+        cfg, wav, want = G.mfcc_case(name)
+        got = O.mfcc(_frames(cfg, wav), **cfg["mfcc"], dtype=dtype)
+        assert got.shape == want.shape, name
+        e = G.rmse(want, got)
+        worst = max(worst, e)
+        assert e < 2.25e-4, (name, e)
+    print("mfcc worst rmse", worst)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fbank_goldens(dtype):
+    # layers/dsp/filterbank_test.py:32,157-195  RMSE < 2.25e-5 on 48 Kaldi cases
+    names = G.fbank_case_names()
+    assert len(names) >= 48   # the reference tests the first 48; all 54 dirs carry fbank goldens
+    for name in names:
+        cfg, wav, want = G.fbank_case(name)
+        w = O.windowing(_frames(cfg, wav), **cfg["windowing"], dtype=dtype)
+        got = O.filterbank(w, **cfg["fbank"], dtype=dtype)
+        assert got.shape == want.shape, name
+        assert G.rmse(want, got) < 2.25e-5, (name, G.rmse(want, got))
+
+
+def test_vad_goldens():
+    # layers/dsp/vad_test.py:132-152 exact on 46 Kaldi cases
+    for name in G.vad_case_names():
+        cfg, feats, want = G.vad_case(name)
+        got = O.vad(feats, **cfg)
+        assert got.shape == want.shape
+        assert np.array_equal(got, want), name
+        cfg["return_indexes"] = True
+        idx = O.vad(feats, **cfg)
+        assert np.array_equal(idx[:, 1], np.nonzero(want[0, :, 0])[0])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_cmvn_goldens(dtype):
+    # layers/normalization/cmvn_test.py:31,153-195  RMSE < 1e-5, SAME and VALID (= trimmed SAME)
+    for name in G.cmvn_case_names():
+        cfg, feats, want = G.cmvn_case(name)
+        got = O.cmvn(feats, **cfg, padding="SAME", dtype=dtype)
+        assert got.shape == want.shape
+        assert G.rmse(want, got) < 1e-5, name
+        N, T = cfg["window"], want.shape[-2]
+        got = O.cmvn(feats, **cfg, padding="VALID", dtype=dtype)
+        wv = want[..., N // 2: T - (N - 1) // 2, :]
+        if N > T:
+            assert got.size == 0 or wv.size == 0
+        else:
+            assert got.shape == wv.shape and G.rmse(wv, got) < 1e-5, name
+
+
+def test_windowing_vs_reference_numpy():
+    # layers/dsp/windowing_test.py:32,85-120 (vs the reference's ProcessFrames)  RMSE < 2e-7
+    z = G.load("kaldi_numpy.npz")
+    frames = z["frames"]
+    for i, o in enumerate(json.loads(str(z["configs_json"]))):
+        cfg = {"window_type": "povey", "blackman_coeff": 0.42, "dither": 0.0, "remove_dc_offset": True,
+               "preemphasis_coefficient": 0.97, "raw_energy": True, "return_energy": True, "energy_floor": 0.0,
+               "epsilon": float(np.finfo(np.float32).eps)}
+        cfg.update(o)
+        w, e = O.windowing(frames, **cfg, dtype=np.float32)
+        assert G.rmse(z[f"windows_{i}"], w) < 2e-7, o
+        assert G.rmse(z[f"energy_{i}"], e) < 2e-7, o
+
+
+def test_framing_analytic():
+    # layers/dsp/framing_test.py:42-73 exact vs ExtractFrames on arange, snip-edges true and false
+    z = G.load("kaldi_numpy.npz")
+    for i, (fl, fs, sf) in enumerate(z["framing_configs"]):
+        N = int(10 * sf)
+        m, k = int(sf * fl / 1000.0), int(sf * fs / 1000.0)
+        x = np.arange(0, N)
+        fr = O.framing(x, fl, fs, sf)
+        assert tuple(z[f"framing_{i}_snip_shape"]) == fr.shape
+        assert np.array_equal(fr[:, 0], z[f"framing_{i}_snip_first_col"])
+        assert np.array_equal(fr, fr[:, :1] + np.arange(m)[None, :])
+        xp = O.pad_waveform(x, m, k)
+        assert xp.shape[-1] == int(z[f"framing_{i}_pad_len"])
+        assert np.array_equal(xp[: 2 * m], z[f"framing_{i}_pad_head"])
+        assert np.array_equal(xp[-2 * m:], z[f"framing_{i}_pad_tail"])
+        frp = O.framing(xp, fl, fs, sf)
+        assert tuple(z[f"framing_{i}_nosnip_shape"]) == frp.shape
+        assert np.array_equal(frp[:, 0], z[f"framing_{i}_nosnip_first_col"])
+        assert np.array_equal(frp[-1], z[f"framing_{i}_nosnip_last_row"])
+
+
+def test_cmvn_vs_reference_numpy():
+    z = G.load("kaldi_numpy.npz")
+    x = z["cmvn_np_in"]
+    for j, (w, nv, pad) in enumerate([(300, False, "SAME"), (300, True, "SAME"), (201, False, "VALID"), (900, True, "SAME")]):
+        got = O.cmvn(x, window=w, norm_vars=nv, padding=pad, dtype=np.float32)
+        want = z[f"cmvn_np_out_{j}"]
+        assert got.shape == want.shape
+        assert G.rmse(want, got) < 2e-6
+
+
+def test_tdnn_single_layer():
+    # layers/tdnn/tdnn_test.py:31,45-57  RMSE <= 1e-6
+    z = G.load("tdnn.npz")
+    cfg = json.loads(str(z["single_cfg_json"]))
+    got = O.tdnn(z["single_inputs"], z["single_W"], z["single_b"], cfg["context"], cfg["subsampling_factor"],
+                 cfg["padding"], cfg["activation"])
+    assert got.shape == z["single_outputs"].shape
+    assert G.rmse(z["single_outputs"], got) <= 1e-6
+
+
+def test_tdnn_narrow():
+    # layers/tdnn/tdnn_test.py:105-119  RMSE <= 5e-4
+    layers, _, x, want = G.narrow_layers()
+    got = O.sequential_forward(layers, x)
+    assert got.shape == want.shape
+    assert G.rmse(want, got) <= 5e-4
+
+
+def test_stats_pooling_goldens():
+    # layers/stats/stats_pooling_test.py:26,48-88  RMSE <= 4e-6
+    for name in G.STATS_CONFIGS:
+        cfg, x, want = G.stats_case(name)
+        got = O.stats_pooling(x, **cfg)
+        assert got.shape == want.shape, name
+        assert G.rmse(want, got) <= 4e-6, name
+    cfg, x, want = G.stats_case("stats_mean_std")
+    cfg["reduce_time_axis"] = True
+    got = O.stats_pooling(x, **cfg)
+    assert G.rmse(want[:, 0:1, :], got) <= 4e-6
+
+
+def _plda_model():
+    import struct
+    raw = open(G.GOLDEN + "/plda.bin", "rb").read()
+    # minimal independent parse of <Plda> mean(DV/FV) transform(DM/FM) psi(DV/FV) for the oracle test
+    pos = raw.index(b"<Plda>") + 7
+
+    def vec(pos):
+        t = raw[pos:pos + 3]
+        ds, dt = (8, np.float64) if t == b"DV " else (4, np.float32)
+        n = struct.unpack("<i", raw[pos + 4:pos + 8])[0]
+        return np.frombuffer(raw[pos + 8:pos + 8 + n * ds], dt), pos + 8 + n * ds
+
+    def mat(pos):
+        t = raw[pos:pos + 3]
+        ds, dt = (8, np.float64) if t == b"DM " else (4, np.float32)
+        r = struct.unpack("<i", raw[pos + 4:pos + 8])[0]
+        c = struct.unpack("<i", raw[pos + 9:pos + 13])[0]
+        return np.frombuffer(raw[pos + 13:pos + 13 + r * c * ds], dt).reshape(r, c), pos + 13 + r * c * ds
+
+    mean, pos = vec(pos)
+    A, pos = mat(pos)
+    psi, pos = vec(pos)
+    return mean, A, psi
+
+
+@pytest.mark.parametrize("dtype,tol", [(np.float32, 2e-4), (np.float64, 2e-5)])
+def test_plda_goldens(dtype, tol):
+    # layers/plda/plda_test.py:30,45-62  RMSE <= 2e-4 (fp32 layer)
+    z = G.load("plda.npz")
+    mean, A, psi = _plda_model()
+    assert np.allclose(mean, z["plda_model_mean"], atol=1e-9) and np.allclose(psi, z["plda_model_psi"], atol=1e-9)
+    scores, tr = O.plda(z["plda_input"], mean, A, psi, dtype=dtype)
+    assert tr.shape == z["plda_transformed"].shape and scores.shape == z["plda_scores"].shape
+    assert G.rmse(z["plda_transformed"], tr) <= tol
+    assert G.rmse(z["plda_scores"], scores) <= tol
+
+
+def test_xvector_post_consistency():
+    # a12 has no stand-alone golden; check the algebra on the reference's own 512-d Kaldi x-vectors with the
+    # real mean.vec / transform.mat: output has norm sqrt(128) and equals a direct fp64 evaluation.
+    z = G.load("plda.npz")
+    from kaldi_tflite_amd.io import ReadKaldiArray
+    mean = ReadKaldiArray(G.GOLDEN + "/xvectors_train_combined_200k.mean.vec.txt", binary=False)
+    lda = ReadKaldiArray(G.GOLDEN + "/xvectors_train_combined_200k.transform.mat", binary=True)
+    assert mean.shape == (512,) and lda.shape == (128, 513)
+    y = O.xvector_post(z["xvectors"], mean, lda)
+    assert y.shape == (29, 128)
+    assert np.allclose(np.linalg.norm(y, axis=-1), np.sqrt(128.0), rtol=1e-5)
+    ref = (z["xvectors"].astype(np.float64) - mean) @ lda[:, :-1].T.astype(np.float64) + lda[:, -1]
+    ref = ref * np.sqrt(128.0) / np.linalg.norm(ref, axis=-1, keepdims=True)
+    assert np.abs(ref - y).max() < 1e-5
