@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""
+bench.py — x-vectors/sec of the wav -> x-vector hot path on MI355X (BASELINE.json metric).
+
+One step = one pass of the whole hot path (fused MFCC -> VAD/compaction/CMVN -> 5 TDNN GEMMs -> stats pooling ->
+tdnn6 -> LDA/length-norm) over one batch of synthetic 10 s / 16 kHz utterances that is already resident in HBM.
+Workload (config.workload): the BASELINE "8 192 utterances over 8 GPUs" configuration = 1 024 utterances per GPU
+(weak scaling: per-GPU batch fixed), 0008_sitw_v2_1a topology with seeded random weights, dither 0.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line. `roofline` is for the dominant kernel (the TDNN MFMA GEMM launches, timed live with HIP
+events on the launch stream); `cpu_baseline` times the NumPy oracle (a port of the reference's TF-CPU op graph) on a
+bounded sample of the same workload on this box's host cores.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FLOP_PER_FRAME_TDNN = 2 * 2_679_808          # 5 frame-level layers
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU per step")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--gemm", default="bf16", choices=["bf16", "bf16x3", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-utts", type=int, default=200)
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the fp32 / parity side measurements")
+    args = ap.parse_args()
+
+    import kaldi_tflite_amd as ktf
+    from kaldi_tflite_amd import ops, parallel
+    import synth
+
+    rank, local_rank, world = parallel.init_from_env()
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = synth.extractor_cfg(dither=0.0)
+    w = synth.make_weights(seed=4321, narrow=False)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm=args.gemm)
+
+    B, N = args.batch, int(args.seconds * 16000)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    wav = torch.clamp(torch.round(1000.0 * torch.randn((B, N), generator=g, device=dev)), -32767, 32767)
+    T = mdl.framing.numFrames(N)
+
+    def step():
+        y = mdl(wav)
+        if world > 1 and not args.no_gather:
+            y = parallel.gather_embeddings(y, world)
+        return y
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps between barrier + synchronize
+    ops_prof = _GemmProfiler(ops)
+    parallel.barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    parallel.barrier(world)
+    torch.cuda.synchronize()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, world, dev)
+    gemm_stats = ops_prof.finish()
+
+    lens = mdl._ws[next(iter(mdl._ws))]["lens"].cpu().numpy()
+    assert int(lens.min()) == T and int(lens.max()) == T, "synthetic stationary noise must keep every frame voiced"
+    assert bool(torch.isfinite(y).all())
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    value = world * B * args.steps / dt
+    out = {
+        "metric": "x-vectors/sec (10 s @16 kHz)", "value": value, "unit": "x-vectors/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "bf16x3": "bf16x3", "f32": "f32"}[args.gemm],
+        "data": "synthetic",
+        "config": {"workload": "0008_sitw_v2_1a wav->x-vector, 10 s @16 kHz utterances, 1024 per GPU "
+                               "(BASELINE config: 8192 utterances batch-sharded over 8 GPUs), dither 0, all 998 frames voiced",
+                   "utterances_per_gpu": B, "samples_per_utterance": N, "frames_per_utterance": T,
+                   "tdnn_gemm": args.gemm, "weights": "synthetic seed 4321 (pretrained final.raw not shipped)",
+                   "gather": bool(world > 1 and not args.no_gather)},
+    }
+    # ---- roofline of the dominant kernel: TDNN GEMM launches (5 per step), algorithmic FLOPs / measured duration
+    flops_per_step = B * T * FLOP_PER_FRAME_TDNN
+    gemm_ms_per_step = gemm_stats["total_ms"] / args.steps
+    achieved = flops_per_step / (gemm_ms_per_step * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[args.gemm]
+    out["roofline"] = {
+        "bound": "mfma", "kernel": "tdnn_bf16_kernel" if args.gemm != "f32" else "tdnn_f32_kernel",
+        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+        "launches_per_step": gemm_stats["launches"] // args.steps, "avg_launch_ms": gemm_stats["total_ms"] / max(gemm_stats["launches"], 1),
+        "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],
+        "algorithmic_flop_per_step": flops_per_step,
+        "note": "bf16x3 issues 3 MFMA passes per algorithmic FLOP" if args.gemm == "bf16x3" else "",
+    }
+    out["mfcc"] = _bench_mfcc(mdl, wav, ops)
+    if not args.no_extra:
+        out["parity"] = _parity_sample(ktf, synth, cfg, w, args.gemm, dev)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = _cpu_baseline(synth, cfg, w, args.cpu_utts, N)
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+class _GemmProfiler:
+    """Brackets every ktf_tdnn launch of the frame-level layers with HIP events on the launch stream."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.orig = ops.tdnn
+        self.events = []
+        prof = self
+
+        def wrapped(x, lens, desc, *a, **k):
+            if x.shape[0] * x.shape[1] < 4096:          # tdnn6 (one row per utterance) is not the dominant kernel
+                return prof.orig(x, lens, desc, *a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = prof.orig(x, lens, desc, *a, **k)
+            e.record()
+            prof.events.append(((int(desc.units), int(desc.nctx), int(desc.din)), s, e))
+            return r
+
+        ops.tdnn = wrapped
+
+    def finish(self):
+        self.ops.tdnn = self.orig
+        total, per = 0.0, {}
+        for key, s, e in self.events:
+            ms = s.elapsed_time(e)
+            total += ms
+            name = f"{key[1]}x{key[2]}->{key[0]}"
+            per[name] = per.get(name, 0.0) + ms
+        n = max(len(self.events), 1)
+        steps = max(len(self.events) // 5, 1)
+        return {"total_ms": total, "launches": len(self.events), "per_layer_ms": {k: v / steps for k, v in per.items()}, "n": n}
+
+
+def _bench_mfcc(mdl, wav, ops, iters=5):
+    """Secondary BASELINE metric: MFCC frames/s per GPU (fused Framing+MFCC kernel alone), HBM roofline fraction."""
+    from kaldi_tflite_amd import _lib as L
+    B, N = wav.shape
+    fr, mf = mdl.framing, mdl.mfcc
+    T = fr.numFrames(N)
+    cfg = L.FrontendCfg.from_buffer_copy(mf._cfg)
+    cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift
+    out = torch.empty((B, T, mf.numMfccs), dtype=torch.float32, device=wav.device)
+    tabs = mf.tables(wav.device)
+    ops.frontend(wav, L.IN_WAV, cfg, tabs, L.OUT_MFCC, N, B, T, out=out)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        ops.frontend(wav, L.IN_WAV, cfg, tabs, L.OUT_MFCC, N, B, T, out=out)
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / iters
+    frames = B * T
+    gbs = frames * (fr.frameShift * 4 + mf.numMfccs * 4) / (ms * 1e-3) / 1e9
+    return {"frames_per_s": frames / (ms * 1e-3), "ms": ms, "algorithmic_bytes_per_frame": fr.frameShift * 4 + mf.numMfccs * 4,
+            "achieved_GBps": gbs, "hbm_peak_GBps": 8000.0, "frac_of_hbm_peak": gbs / 8000.0}
+
+
+def _parity_sample(ktf, synth, cfg, w, gemm, dev):
+    """max-abs deviation of the benchmarked configuration against the fp64 CPU oracle on 2 shorter utterances."""
+    from oracle import ktf_oracle as O
+    wav = synth.make_wav(2, 16000 * 3, seed=4242, ragged=True)
+    want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+    res = {}
+    for g in sorted({gemm, "f32"}):
+        got = synth.build_extractor(ktf, cfg, w, gemm=g)(torch.as_tensor(wav, device=dev)).cpu().numpy()
+        res[f"max_abs_dev_{g}"] = float(np.abs(got - want).max())
+    return res
+
+
+def _cpu_baseline(synth, cfg, w, n_utts, N):
+    """The NumPy oracle (a port of the reference's TF-CPU op graph: materialised frames, rfft, dense mel matmul,
+    materialised im2col + GEMM) on `n_utts` utterances of the same workload, fp32, all host cores via BLAS threads."""
+    from oracle import ktf_oracle as O
+    layers = synth.oracle_layers(w)
+    wav = synth.make_wav(1, N, seed=1)
+    O.xvector_forward(wav, cfg, layers, w["mean"], w["lda"], dtype=np.float32)     # warm-up
+    wav = synth.make_wav(n_utts, N, seed=2)
+    t0 = time.perf_counter()
+    O.xvector_forward(wav, cfg, layers, w["mean"], w["lda"], dtype=np.float32)
+    dt = time.perf_counter() - t0
+    return {"value": n_utts / dt, "unit": "x-vectors/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_utts} utterances of the same 10 s workload, one at a time (the reference is batch-1 only), "
+                      f"NumPy fp32 oracle, {dt:.1f} s of CPU work"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,231 @@
+/*
+ * ktf_hip.h — C-ABI of libktf_hip.so: the MI355X (gfx950) kernels behind the
+ * wav -> x-vector hot path of shahruk10/kaldi-tflite.
+ *
+ * The reference has no FFI of its own: its operator API is the Keras layer protocol
+ * and every layer's `call` is a chain of TensorFlow ops. Each entry point below
+ * replaces the TF op chain of one (or a fused run of) reference layer call(s); the
+ * reference location it replaces is cited per function (paths relative to
+ * kaldi_tflite/lib/ in the reference tree). The Python host side
+ * (kaldi-tflite_amd/kaldi_tflite_amd) mirrors the reference's ktf.layers / ktf.models
+ * surface and binds these symbols with ctypes; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain C symbols, plain pointers and sizes, no C++/torch types;
+ *  - every pointer is a DEVICE pointer unless stated; the caller owns every buffer
+ *    (including workspaces); the library allocates nothing and keeps no state except a
+ *    thread-local error string;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *    default stream) and is safe to capture into a hipGraph;
+ *  - return value: 0 = KTF_OK, negative = error (ktf_last_error() has the text);
+ *  - fp32 tensors are row-major; "ld*" arguments are row strides in ELEMENTS;
+ *  - ragged batches: activations are kept utterance-strided (B, T_max, D) with a device
+ *    int32 `lens[B]` giving the number of valid rows of each utterance (NULL = all T).
+ */
+#ifndef KTF_HIP_H_
+#define KTF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KTF_OK 0
+#define KTF_EINVAL (-1)     /* bad argument */
+#define KTF_ELAUNCH (-2)    /* HIP launch/runtime error */
+#define KTF_EUNSUPPORTED (-3)
+
+/* element types of activation / weight buffers */
+#define KTF_F32 0
+#define KTF_BF16 1
+
+/* GEMM arithmetic of ktf_tdnn */
+#define KTF_GEMM_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity path) */
+#define KTF_GEMM_BF16 1     /* v_mfma_f32_*_bf16: bf16 operands, fp32 accumulate */
+#define KTF_GEMM_BF16X3 2   /* split-bf16: x=hi+lo, w=hi+lo, 3 bf16 MFMA passes, fp32 accumulate */
+
+/* activations fused into the ktf_tdnn epilogue */
+#define KTF_ACT_NONE 0
+#define KTF_ACT_RELU 1
+#define KTF_ACT_SIGMOID 2
+#define KTF_ACT_TANH 3
+
+int32_t ktf_version(void);
+/* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
+size_t ktf_last_error(char* buf, size_t cap);
+
+/* ------------------------------------------------------------------ front-end (a1-a5)
+ * Framing   layers/dsp/framing.py:243-265       (tf.gather of frame indexes)
+ * Windowing layers/dsp/windowing.py:180-209     (dither, DC removal, log-energy, pre-emphasis, window)
+ * FilterBank layers/dsp/filterbank.py:225-242   (pad, tf.signal.rfft, abs, pow, matmul mel, log)
+ * DCT       layers/dsp/dct.py:175-176           (matmul)
+ * MFCC      layers/dsp/mfcc.py:197-244          (the three above + lifter + C0 <- energy)
+ */
+typedef struct KtfFrontendCfg {
+    int32_t frame_size;    /* samples per frame (= 2*(size//2), framing.py:104-106)            */
+    int32_t frame_shift;   /* samples between frame starts                                      */
+    int32_t nfft;          /* power of two >= frame_size, 64..2048 (filterbank.py:156-157)       */
+    int32_t num_mels;      /* mel bins  (<= 128)                                                 */
+    int32_t num_ceps;      /* cepstra kept (<= num_mels)                                         */
+    int32_t remove_dc;     /* windowing.py:186-189                                               */
+    int32_t raw_energy;    /* energy before (1) or after (0) pre-emphasis+window                 */
+    int32_t use_energy;    /* compute log-energy (Windowing.return_energy / MFCC.use_energy)     */
+    int32_t use_power;     /* |X|^2 (1) or |X| (0)                                               */
+    int32_t use_log;       /* log(max(.,0)+eps) after the mel bank                               */
+    int32_t use_lifter;    /* multiply cepstra by `lifter` (mfcc.py:211-212)                     */
+    float preemph;         /* 0 disables                                                         */
+    float dither;          /* 0 disables; else x += N(0,1)*dither (counter-based RNG, `seed`)    */
+    float energy_floor;    /* clip of the LOG energy from below (windowing.py:177)               */
+    float eps;             /* epsilon inside both logs                                           */
+} KtfFrontendCfg;
+
+typedef struct KtfFrontendTables {   /* all DEVICE pointers, built once by the host */
+    const float* window;       /* [frame_size]                                             */
+    const float* twiddle;      /* [nfft]   : (cos,-sin)(2*pi*k/(nfft/2)), k < nfft/2        */
+    const float* rtwiddle;     /* [nfft]   : (cos,-sin)(2*pi*k/nfft),     k < nfft/2        */
+    const int32_t* mel_start;  /* [num_mels] first FFT bin of each filter                  */
+    const int32_t* mel_len;    /* [num_mels] number of bins of each filter                 */
+    const float* mel_w;        /* [num_mels][mel_stride] weights from mel_start            */
+    const float* dct;          /* [num_mels][num_ceps] (filterbank.py melBank / dct.py dct) */
+    const float* lifter;       /* [num_ceps] or NULL                                       */
+    int32_t mel_stride;
+    int32_t reserved;
+} KtfFrontendTables;
+
+/* input kinds / output stages of ktf_frontend_f32 */
+#define KTF_IN_WAV 0         /* in = (B, N) samples; frames are gathered on the fly (Framing fused)   */
+#define KTF_IN_FRAMES 1      /* in = (B, T, frame_size) frames                                        */
+#define KTF_IN_WINDOWED 2    /* in = (B, T, frame_size) already-windowed frames (FilterBank alone)     */
+#define KTF_OUT_FRAMES 0     /* out (B,T,frame_size): Framing.call                                    */
+#define KTF_OUT_WINDOWED 1   /* out (B,T,frame_size) [+ energy (B,T)]: Windowing.call                 */
+#define KTF_OUT_FBANK 2      /* out (B,T,num_mels): FilterBank.call                                    */
+#define KTF_OUT_MFCC 3       /* out (B,T,num_ceps): MFCC.call                                          */
+
+/* Number of frames Framing produces from n samples: 1 + (n - frame_size) / frame_shift (0 if n < size). */
+int64_t ktf_num_frames(int64_t n_samples, int32_t frame_size, int32_t frame_shift);
+
+/* One launch for any prefix/suffix of Framing -> Windowing -> FilterBank -> DCT/lifter/C0.
+ * `n` is the number of samples per row for KTF_IN_WAV, else the number of frames T.
+ * `energy` (B,T) may be NULL unless out_stage == KTF_OUT_WINDOWED and cfg->use_energy. */
+int ktf_frontend_f32(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
+                     const KtfFrontendTables* tab, int32_t out_stage, float* out, float* energy,
+                     uint64_t seed, void* stream);
+
+/* DCT.call (layers/dsp/dct.py:175-176) on its own: out[r, c] = sum_m x[r, m] * dct[m, c] (* lifter[c]). */
+int ktf_dct_f32(const float* x, int64_t rows, int32_t in_dim, int32_t out_dim, const float* dct,
+                const float* lifter, float* out, void* stream);
+
+/* ------------------------------------------------------------------ VAD / compaction / CMVN (a6-a8)
+ * VAD.call            layers/dsp/vad.py:156-203
+ * gather_nd+expand    models/kaldi/xvector_extractor.py:163-165 (per utterance; see DESIGN.md on batch>1)
+ * CMVN.call           layers/normalization/cmvn.py:186-250
+ */
+typedef struct KtfVadCfg {
+    float energy_threshold;
+    float energy_mean_scale;    /* 0 disables the mean term */
+    float proportion_threshold;
+    int32_t frames_context;
+    int32_t energy_coeff;       /* column of the log-energy */
+} KtfVadCfg;
+
+typedef struct KtfCmvnCfg {
+    int32_t window;      /* N */
+    int32_t norm_vars;   /* divide by the windowed std (no epsilon, as the reference) */
+    int32_t valid;       /* padding == "VALID": keep frames [N/2, T-(N-1)/2) when T > N */
+    int32_t reserved;
+} KtfCmvnCfg;
+
+/* mask (B,T) fp32 of kept frames (VAD.call with return_indexes=False). */
+int ktf_vad_mask_f32(const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* cfg, float* mask,
+                     void* stream);
+/* per-utterance compaction: idx (B,T) int32 = kept frame numbers in order, lens[B] = their count
+ * (VAD.call with return_indexes=True gives the same rows as [b, idx[b, j]], j < lens[b]). */
+int ktf_vad_index(const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* cfg, int32_t* idx,
+                  int32_t* lens, void* stream);
+/* CMVN of each utterance's first lens[b] rows (lens NULL = T rows). x (B,T,D) rows of stride ldx;
+ * out rows of stride ldo >= D, columns D..ldo-1 are written as zeros. `work` = B*T*2*D floats.
+ * With cfg->valid the output row j holds input frame j + N/2 and out_lens[b] (may be NULL) gets the count. */
+int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int64_t ldx, const int32_t* lens,
+                 const KtfCmvnCfg* cfg, float* out, int64_t ldo, int32_t* out_lens, float* work, void* stream);
+/* Fused hot path: VAD -> per-utterance compaction -> CMVN (xvector_extractor.py:162-166).
+ * out_dtype KTF_F32 or KTF_BF16. idx_work = B*T int32, work = B*T*2*D floats. */
+int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* vad, const KtfCmvnCfg* cmvn,
+                 void* out, int32_t out_dtype, int64_t ldo, int32_t* lens, int32_t* idx_work, float* work,
+                 void* stream);
+
+/* ------------------------------------------------------------------ TDNN stack (a9, a10)
+ * TDNN.call   layers/tdnn/tdnn.py:251-280 (gather im2col + conv2d 1xK + bias + activation)
+ * ReLU / BatchNorm (inference affine)  models/kaldi/sequential.py:72-74, layers/normalization/batchnorm.py:78-88
+ *
+ * y[b, t, u] = post( act( bias[u] + sum_k sum_d x[b, row(t,k), d] * W[u, k*Din_pad + d] ) )
+ *   row(t,k)  = clip(start + t*subsampling + ctx[k], 0, len_b-1)  ("SAME": replicate edges; "VALID": no clip needed)
+ *   post(v)   = v * scale[u] + shift[u]   when scale != NULL (BatchNorm folded to an affine)
+ * x: (B, T, ldx) of x_dtype; W: (units_pad, nctx*Din_pad) row-major of w_dtype, zero padded, where Din_pad is
+ * Din rounded up to a multiple of 32 (must be <= ldx; pad columns of x must be finite) and units_pad is units rounded
+ * up to 128. For KTF_GEMM_BF16X3 `w` holds the hi part and `w_lo` the lo part (both bf16); x is fp32.
+ * y: (B, T_out_max, ldy) of y_dtype; out_lens[b] (may be NULL) receives the valid output rows of utterance b.
+ */
+typedef struct KtfTdnnDesc {
+    int32_t units;
+    int32_t din;            /* logical input feature dim */
+    int32_t din_pad;        /* multiple of 32, <= ldx     */
+    int32_t nctx;           /* <= 16 */
+    int32_t ctx[16];        /* sorted ascending */
+    int32_t subsampling;
+    int32_t valid;          /* padding == "VALID" */
+    int32_t act;            /* KTF_ACT_* */
+    int32_t gemm;           /* KTF_GEMM_* */
+    int32_t x_dtype, w_dtype, y_dtype;
+    int32_t reserved;
+} KtfTdnnDesc;
+
+/* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
+int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);
+
+int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
+             const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
+             void* y, int64_t ldy, int32_t* out_lens, void* stream);
+
+/* elementwise y = act(x) * scale + shift per column (stand-alone ReLU / BatchNorm layers); scale/shift may be NULL */
+int ktf_affine_act_f32(const float* x, int64_t rows, int32_t D, int32_t act, const float* scale, const float* shift,
+                       float* y, void* stream);
+/* dtype conversion / column padding: dst (rows, ld_dst) <- src (rows, D) with zero fill of the pad columns */
+int ktf_convert_pad(const void* src, int32_t src_dtype, int64_t rows, int32_t D, int64_t ld_src, void* dst,
+                    int32_t dst_dtype, int64_t ld_dst, void* stream);
+
+/* ------------------------------------------------------------------ statistics pooling (a11)
+ * StatsPooling.computeStatsAcrossAll  layers/stats/stats_pooling.py:211-240
+ * out (B, ld_out) fp32, columns [0,D) = mean_t and [D,2D) = sqrt(max(E[x^2]-mean^2,0)+eps) over rows
+ * 0, input_period, ... < lens[b]; columns beyond are left untouched. */
+int ktf_stats_pool(const void* x, int32_t x_dtype, int64_t B, int64_t T, int32_t D, int64_t ldx,
+                   const int32_t* lens, int32_t input_period, int32_t include_std, float eps, float* out,
+                   int64_t ld_out, void* stream);
+/* StatsPooling.computeStatsAcrossWindows  layers/stats/stats_pooling.py:179-209,242-295 (fp32).
+ * Output row j covers input rows start + j*output_period + {left..min(right, T-1) step input_period} inside [0,T). */
+int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T, int32_t D, int32_t left, int32_t right,
+                                int32_t input_period, int32_t output_period, int32_t start, int64_t T_out,
+                                int32_t include_std, float eps, float* out, void* stream);
+
+/* ------------------------------------------------------------------ x-vector post-processing (a12)
+ * models/kaldi/xvector_extractor.py:174-184: y = (x - mean) @ A + off ; y *= sqrt(out)/||y||_2
+ * x (B, in) fp32, A (in, out) row-major, off (out). */
+int ktf_xvec_post_f32(const float* x, int64_t B, int32_t in_dim, int32_t out_dim, const float* mean, const float* A,
+                      const float* off, float* y, void* stream);
+
+/* ------------------------------------------------------------------ PLDA (a16)
+ * PLDA.call  layers/plda/plda.py:247-263. fp64 (reference default) and fp32 variants.
+ * x (B, dim); A (dim, dim) row-major; offset = -A*mean (dim); psi (dim).
+ * transformed (B, dim); scores (B, B) with scores[i, j] = LLR(x_i | class of x_j). */
+int ktf_plda_f64(const double* x, int64_t B, int32_t dim, const double* A, const double* offset, const double* psi,
+                 int32_t normalize_length, int32_t simple_length_norm, double* transformed, double* scores,
+                 void* stream);
+int ktf_plda_f32(const float* x, int64_t B, int32_t dim, const float* A, const float* offset, const float* psi,
+                 int32_t normalize_length, int32_t simple_length_norm, float* transformed, float* scores,
+                 void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KTF_HIP_H_ */

@@ -1,0 +1,305 @@
+// Statistics pooling, x-vector post-processing (mean-sub + LDA + length-norm) and PLDA scoring.
+//
+// Replaces: layers/stats/stats_pooling.py:179-295, models/kaldi/xvector_extractor.py:174-184,
+//           layers/plda/plda.py:163-263 of the reference.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------ stats pooling (reduce)
+// One workgroup = one utterance x 128 columns; 4 row-groups (waves) stride the time axis, each lane owns
+// two adjacent columns (8-byte fp32 / 4-byte bf16 loads, 512/256 B per wave-instruction).
+template <typename T>
+__device__ __forceinline__ float2 load2(const T* p);
+template <>
+__device__ __forceinline__ float2 load2<float>(const float* p) { return *reinterpret_cast<const float2*>(p); }
+template <>
+__device__ __forceinline__ float2 load2<unsigned short>(const unsigned short* p) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(p);
+    return make_float2(__uint_as_float(v << 16), __uint_as_float(v & 0xffff0000u));
+}
+template <typename T>
+__device__ __forceinline__ float load1(const T* p);
+template <>
+__device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float load1<unsigned short>(const unsigned short* p) { return bf2f(*p); }
+
+template <typename T, bool VEC2>
+__global__ __launch_bounds__(256) void stats_pool_kernel(const T* __restrict__ x, int64_t Tmax, int D, int64_t ldx,
+                                                         const int32_t* __restrict__ lens, int period, int include_std,
+                                                         float eps, float* __restrict__ out, int64_t ldo) {
+    __shared__ float red[4][2][128];
+    const int b = blockIdx.y;
+    const int len = lens ? lens[b] : (int)Tmax;
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 128 + lane * 2;
+    const T* xb = x + (int64_t)b * Tmax * ldx;
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    const int nrows = len <= 0 ? 0 : (len + period - 1) / period;
+    if (c0 < D) {
+        const bool two = (c0 + 1 < D);
+        for (int j = rg; j < nrows; j += 4) {
+            const T* p = xb + (int64_t)j * period * ldx + c0;
+            float2 v;
+            if (VEC2 && two) v = load2<T>(p);
+            else { v.x = load1<T>(p); v.y = two ? load1<T>(p + 1) : 0.f; }
+            s0 += v.x; s1 += v.y;
+            q0 += v.x * v.x; q1 += v.y * v.y;
+        }
+    }
+    red[rg][0][lane * 2] = s0; red[rg][0][lane * 2 + 1] = s1;
+    red[rg][1][lane * 2] = q0; red[rg][1][lane * 2 + 1] = q1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int c = blockIdx.x * 128 + threadIdx.x;
+        if (c < D) {
+            const float s = red[0][0][threadIdx.x] + red[1][0][threadIdx.x] + red[2][0][threadIdx.x] + red[3][0][threadIdx.x];
+            const float q = red[0][1][threadIdx.x] + red[1][1][threadIdx.x] + red[2][1][threadIdx.x] + red[3][1][threadIdx.x];
+            const float n = (float)nrows;
+            const float mean = s / n;
+            out[(int64_t)b * ldo + c] = mean;
+            if (include_std) {
+                const float var = q / n - mean * mean;
+                out[(int64_t)b * ldo + D + c] = sqrtf(fmaxf(var, 0.0f) + eps);
+            }
+        }
+    }
+}
+
+// windowed statistics (fp32): one thread per (b, output row j, column c)
+__global__ void stats_pool_windowed_kernel(const float* __restrict__ x, int64_t B, int64_t T, int D, int left, int right,
+                                           int in_period, int out_period, int start, int64_t Tout, int include_std,
+                                           float eps, float* __restrict__ out) {
+    const int od = include_std ? 2 * D : D;
+    const int64_t total = B * Tout * D;
+    const int rc = (right + 1 > T) ? (int)T : right + 1;  // stats_pooling.py:186-191
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % D);
+        const int64_t bj = e / D;
+        const int64_t j = bj % Tout, b = bj / Tout;
+        const int64_t centre = start + j * out_period;
+        float s = 0.f, q = 0.f, n = 0.f;
+        for (int o = left; o < rc; o += in_period) {
+            const int64_t t = centre + o;
+            if (t >= 0 && t < T) {
+                const float v = x[(b * T + t) * D + c];
+                s += v; q += v * v; n += 1.f;
+            }
+        }
+        const float mean = s / n;
+        out[(b * Tout + j) * od + c] = mean;
+        if (include_std) out[(b * Tout + j) * od + D + c] = sqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+    }
+}
+
+// ------------------------------------------------------------------------------------ x-vector post-processing
+// one workgroup per embedding: LDS holds (x - mean); thread j owns output column j.
+__global__ __launch_bounds__(256) void xvec_post_kernel(const float* __restrict__ x, int in_dim, int out_dim,
+                                                        const float* __restrict__ mean, const float* __restrict__ A,
+                                                        const float* __restrict__ off, float* __restrict__ y) {
+    extern __shared__ float sm[];  // in_dim + out_dim + 4
+    float* xc = sm;
+    float* yo = sm + in_dim;
+    float* red = yo + out_dim;
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < in_dim; i += 256) xc[i] = x[(int64_t)b * in_dim + i] - (mean ? mean[i] : 0.f);
+    __syncthreads();
+    float ss = 0.f;
+    for (int j = threadIdx.x; j < out_dim; j += 256) {
+        float acc = 0.f;
+        for (int i = 0; i < in_dim; ++i) acc += xc[i] * A[(int64_t)i * out_dim + j];
+        acc += off ? off[j] : 0.f;
+        yo[j] = acc;
+        ss += acc * acc;
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    const float ratio = norm / sqrtf((float)out_dim);   // xvector_extractor.py:178-181
+    for (int j = threadIdx.x; j < out_dim; j += 256) y[(int64_t)b * out_dim + j] = yo[j] / ratio;
+}
+
+// ------------------------------------------------------------------------------------ PLDA
+template <typename R>
+__device__ __forceinline__ R wsum(R v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <typename R>
+__device__ __forceinline__ R rsqrt_(R v);
+template <> __device__ __forceinline__ float rsqrt_<float>(float v) { return sqrtf(v); }
+template <> __device__ __forceinline__ double rsqrt_<double>(double v) { return sqrt(v); }
+template <typename R>
+__device__ __forceinline__ R rlog_(R v);
+template <> __device__ __forceinline__ float rlog_<float>(float v) { return logf(v); }
+template <> __device__ __forceinline__ double rlog_<double>(double v) { return log(v); }
+
+// transformVector (plda.py:163-196): one workgroup per input vector; one wave per output row (strided).
+template <typename R>
+__global__ __launch_bounds__(256) void plda_transform_kernel(const R* __restrict__ x, int dim, const R* __restrict__ A,
+                                                             const R* __restrict__ offset, const R* __restrict__ psi,
+                                                             int normalize, int simple, R* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    R* xs = reinterpret_cast<R*>(smraw);
+    R* ys = xs + dim;
+    R* red = ys + dim;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < dim; i += 256) xs[i] = x[(int64_t)b * dim + i];
+    __syncthreads();
+    for (int r = wave; r < dim; r += 4) {
+        R acc = 0;
+        for (int c = lane; c < dim; c += 64) acc += A[(int64_t)r * dim + c] * xs[c];
+        acc = wsum<R>(acc);
+        if (lane == 0) ys[r] = acc + offset[r];
+    }
+    __syncthreads();
+    R f = 1;
+    if (normalize) {
+        R part = 0;
+        for (int r = threadIdx.x; r < dim; r += 256) {
+            const R v = ys[r];
+            part += simple ? v * v : v * v / (psi[r] + (R)1);
+        }
+        part = wsum<R>(part);
+        if (lane == 0) red[wave] = part;
+        __syncthreads();
+        const R tot = red[0] + red[1] + red[2] + red[3];
+        f = simple ? rsqrt_<R>((R)dim) / rsqrt_<R>(tot) : rsqrt_<R>((R)dim / tot);
+    }
+    for (int r = threadIdx.x; r < dim; r += 256) out[(int64_t)b * dim + r] = ys[r] * f;
+}
+
+// logLikelihoodRatio (plda.py:198-245): 16x16 (i, j) tile per workgroup, d-loop over LDS-staged rows.
+template <typename R>
+__global__ __launch_bounds__(256) void plda_score_kernel(const R* __restrict__ y, int64_t B, int dim,
+                                                         const R* __restrict__ psi, R* __restrict__ scores) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    R* yi = reinterpret_cast<R*>(smraw);       // 16 x dim
+    R* yj = yi + 16 * dim;                     // 16 x dim
+    R* ps = yj + 16 * dim;                     // dim
+    R* red = ps + dim;                         // 8
+    const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+    const int64_t i0 = (int64_t)blockIdx.y * 16, j0 = (int64_t)blockIdx.x * 16;
+    for (int e = threadIdx.x; e < 16 * dim; e += 256) {
+        const int r = e / dim, d = e - r * dim;
+        yi[e] = (i0 + r < B) ? y[(i0 + r) * dim + d] : (R)0;
+        yj[e] = (j0 + r < B) ? y[(j0 + r) * dim + d] : (R)0;
+    }
+    for (int d = threadIdx.x; d < dim; d += 256) ps[d] = psi[d];
+    __syncthreads();
+    // constant terms: sum log(var1) and sum log(var2)
+    R l1 = 0, l2 = 0;
+    for (int d = threadIdx.x; d < dim; d += 256) {
+        const R p = ps[d];
+        l1 += rlog_<R>((R)1 + p / (p + (R)1));
+        l2 += rlog_<R>((R)1 + p);
+    }
+    l1 = wsum<R>(l1); l2 = wsum<R>(l2);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = l1; red[4 + (threadIdx.x >> 6)] = l2; }
+    __syncthreads();
+    const R logdet1 = red[0] + red[1] + red[2] + red[3];
+    const R logdet2 = red[4] + red[5] + red[6] + red[7];
+    R a = 0, c = 0;
+    for (int d = 0; d < dim; ++d) {
+        const R p = ps[d];
+        const R v = yi[ti * dim + d];
+        const R m = p * yj[tj * dim + d] / (p + (R)1);
+        const R diff = v - m;
+        a += diff * diff / ((R)1 + p / (p + (R)1));
+        c += v * v / ((R)1 + p);
+    }
+    if (i0 + ti < B && j0 + tj < B)
+        scores[(i0 + ti) * B + (j0 + tj)] = (R)(-0.5) * (logdet1 + a) - (R)(-0.5) * (logdet2 + c);
+}
+
+template <typename R>
+static int plda_launch(const char* who, const R* x, int64_t B, int32_t dim, const R* A, const R* offset, const R* psi,
+                       int32_t normalize_length, int32_t simple_length_norm, R* transformed, R* scores, void* stream) {
+    KTF_REQUIRE(x && A && offset && psi && transformed, "%s: null argument", who);
+    KTF_REQUIRE(B >= 0 && dim > 0, "%s: bad sizes", who);
+    if (B == 0) return KTF_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds1 = sizeof(R) * (2 * (size_t)dim + 8);
+    KTF_REQUIRE(lds1 <= 64 * 1024, "%s: dim %d too large", who, dim);
+    hipLaunchKernelGGL(plda_transform_kernel<R>, dim3((unsigned)B), dim3(256), lds1, st, x, dim, A, offset, psi,
+                       normalize_length, simple_length_norm, transformed);
+    KTF_CHECK_LAUNCH(who);
+    if (scores) {
+        const size_t lds2 = sizeof(R) * (33 * (size_t)dim + 8);
+        KTF_REQUIRE(lds2 <= 160 * 1024, "%s: dim %d too large for the score tile", who, dim);
+        if (lds2 > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)plda_score_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+        dim3 grid((unsigned)ktf_cdiv(B, 16), (unsigned)ktf_cdiv(B, 16));
+        hipLaunchKernelGGL(plda_score_kernel<R>, grid, dim3(256), lds2, st, transformed, B, dim, psi, scores);
+        KTF_CHECK_LAUNCH(who);
+    }
+    return KTF_OK;
+}
+
+extern "C" int ktf_plda_f64(const double* x, int64_t B, int32_t dim, const double* A, const double* offset,
+                            const double* psi, int32_t normalize_length, int32_t simple_length_norm,
+                            double* transformed, double* scores, void* stream) {
+    return plda_launch<double>("ktf_plda_f64", x, B, dim, A, offset, psi, normalize_length, simple_length_norm,
+                               transformed, scores, stream);
+}
+extern "C" int ktf_plda_f32(const float* x, int64_t B, int32_t dim, const float* A, const float* offset,
+                            const float* psi, int32_t normalize_length, int32_t simple_length_norm, float* transformed,
+                            float* scores, void* stream) {
+    return plda_launch<float>("ktf_plda_f32", x, B, dim, A, offset, psi, normalize_length, simple_length_norm,
+                              transformed, scores, stream);
+}
+
+extern "C" int ktf_stats_pool(const void* x, int32_t x_dtype, int64_t B, int64_t T, int32_t D, int64_t ldx,
+                              const int32_t* lens, int32_t input_period, int32_t include_std, float eps, float* out,
+                              int64_t ld_out, void* stream) {
+    KTF_REQUIRE(x && out, "ktf_stats_pool: null argument");
+    KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ldx >= D, "ktf_stats_pool: bad sizes");
+    KTF_REQUIRE(input_period > 0, "ktf_stats_pool: input_period must be > 0");
+    KTF_REQUIRE(B < 65536, "ktf_stats_pool: B too large");
+    KTF_REQUIRE(ld_out >= (include_std ? 2 : 1) * (int64_t)D, "ktf_stats_pool: ld_out too small");
+    if (B == 0) return KTF_OK;
+    dim3 grid((unsigned)ktf_cdiv(D, 128), (unsigned)B);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
+    if (x_dtype == KTF_F32) {
+        if (vec) hipLaunchKernelGGL((stats_pool_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+        else hipLaunchKernelGGL((stats_pool_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+    } else if (x_dtype == KTF_BF16) {
+        if (vec) hipLaunchKernelGGL((stats_pool_kernel<unsigned short, true>), grid, dim3(256), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+        else hipLaunchKernelGGL((stats_pool_kernel<unsigned short, false>), grid, dim3(256), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+    } else {
+        KTF_REQUIRE(false, "ktf_stats_pool: bad dtype");
+    }
+    KTF_CHECK_LAUNCH("ktf_stats_pool");
+    return KTF_OK;
+}
+
+extern "C" int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T, int32_t D, int32_t left, int32_t right,
+                                           int32_t input_period, int32_t output_period, int32_t start, int64_t T_out,
+                                           int32_t include_std, float eps, float* out, void* stream) {
+    KTF_REQUIRE(x && out, "ktf_stats_pool_windowed_f32: null argument");
+    KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && T_out >= 0, "ktf_stats_pool_windowed_f32: bad sizes");
+    KTF_REQUIRE(left <= 0 && right >= 0, "ktf_stats_pool_windowed_f32: 'left_context' must be <= 0 and 'right_context' must be >= 0");
+    KTF_REQUIRE(input_period > 0 && output_period > 0, "ktf_stats_pool_windowed_f32: periods must be > 0");
+    const int64_t total = B * T_out * D;
+    if (total == 0) return KTF_OK;
+    int blocks = ktf_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(stats_pool_windowed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, T, D, left, right,
+                       input_period, output_period, start, T_out, include_std, eps, out);
+    KTF_CHECK_LAUNCH("ktf_stats_pool_windowed_f32");
+    return KTF_OK;
+}
+
+extern "C" int ktf_xvec_post_f32(const float* x, int64_t B, int32_t in_dim, int32_t out_dim, const float* mean,
+                                 const float* A, const float* off, float* y, void* stream) {
+    KTF_REQUIRE(x && A && y, "ktf_xvec_post_f32: null argument");
+    KTF_REQUIRE(B >= 0 && in_dim > 0 && out_dim > 0, "ktf_xvec_post_f32: bad sizes");
+    if (B == 0) return KTF_OK;
+    const size_t lds = sizeof(float) * ((size_t)in_dim + out_dim + 4);
+    KTF_REQUIRE(lds <= 64 * 1024, "ktf_xvec_post_f32: dims too large");
+    hipLaunchKernelGGL(xvec_post_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, x, in_dim, out_dim, mean, A, off, y);
+    KTF_CHECK_LAUNCH("ktf_xvec_post_f32");
+    return KTF_OK;
+}

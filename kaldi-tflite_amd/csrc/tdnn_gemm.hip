@@ -1,0 +1,479 @@
+// TDNN layer = implicit-im2col GEMM on the gfx950 matrix cores, with the layer's bias,
+// activation and the following BatchNorm (as a per-unit affine) fused into the epilogue.
+//
+//   y[b,t,u] = post(act(bias[u] + sum_k sum_d x[b, row(t,k), d] * W[u, k*Dp + d]))
+//   row(t,k) = clip(start + t*sub + ctx[k], 0, len_b - 1)
+//
+// The (T, K*D) im2col matrix of the reference (tf.gather, tdnn.py:258) is never built: the
+// A-tile rows of one K-step all come from ONE context offset (Dp is a multiple of the K-step),
+// so staging a tile is a row gather of contiguous 64/128-byte pieces straight from the
+// activation matrix, clamped per utterance. M-tiles never straddle utterances (activations
+// are utterance-strided), so edge replication needs no row->utterance map.
+//
+// Three arithmetic modes (KtfTdnnDesc.gemm):
+//   F32    v_mfma_f32_32x32x2_f32  — exact fp32 products / fp32 accumulate (bit-identical to an
+//          fmaf chain); the parity path.
+//   BF16   v_mfma_f32_32x32x16_bf16 — bf16 operands, fp32 accumulate; the throughput path.
+//   BF16X3 x = hi+lo, w = hi+lo (bf16 pairs), acc += hi*hi + lo*hi + hi*lo — ~16 mantissa bits
+//          at 3 MFMA passes.
+//
+// Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88) of the reference.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) float fv4;
+
+struct TdnnParams {
+    const void* x;
+    const int32_t* lens;
+    const void* w;
+    const void* w_lo;
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    void* y;
+    int32_t* out_lens;
+    int64_t T, ldx, ldy, Tout;
+    int32_t units, din_pad, nctx, sub, valid, act, y_dtype, ktot;
+    int32_t ctx[16];
+};
+
+__device__ __forceinline__ int tdnn_out_len(int len, const TdnnParams& p, int& start) {
+    start = 0;
+    int end = len;
+    if (p.valid) {
+        if (p.ctx[0] < 0) start = -p.ctx[0];
+        if (p.ctx[p.nctx - 1] > 0) end = len - p.ctx[p.nctx - 1];
+    }
+    const int n = end - start;
+    return n <= 0 ? 0 : (n + p.sub - 1) / p.sub;
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == KTF_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == KTF_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+    if (act == KTF_ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// Epilogue for the 32x32 accumulator layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+__device__ __forceinline__ void store_tile32(const f32x16& acc, const TdnnParams& p, int64_t out_row0, int rows_valid,
+                                             int m_base, int n_base, int lane) {
+    const int n = n_base + (lane & 31);
+    if (n >= p.units) return;
+    const float bias = p.bias ? p.bias[n] : 0.0f;
+    const float sc = p.scale ? p.scale[n] : 1.0f;
+    const float sh = p.shift ? p.shift[n] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m_base + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < rows_valid) {
+            float v = apply_act(acc[r] + bias, p.act);
+            if (p.scale) v = v * sc + sh;
+            const int64_t off = (out_row0 + m) * p.ldy + n;
+            if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off] = v;
+            else reinterpret_cast<unsigned short*>(p.y)[off] = f2bf(v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ F32
+// 128x128 block tile, K-step 16, 4 waves as 2x2, each wave a 64x64 sub-tile = 2x2 MFMA 32x32 tiles.
+#define F32_BM 128
+#define F32_BN 128
+#define F32_BK 16
+#define F32_PITCH (F32_BK + 1)
+
+__global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
+    __shared__ float As[2][F32_BM * F32_PITCH];
+    __shared__ float Bs[2][F32_BN * F32_PITCH];
+    const int b = blockIdx.z;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = blockIdx.y * F32_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = blockIdx.x * F32_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const float* xb = reinterpret_cast<const float*>(p.x) + (int64_t)b * p.T * p.ldx;
+    const float* wb = reinterpret_cast<const float*>(p.w);
+
+    // staging map: thread loads 2 float4 of A and 2 of B per K-step
+    const int ld_row = tid >> 2;          // 0..63 (+64)
+    const int ld_col = (tid & 3) * 4;     // 0,4,8,12
+    int a_t[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_t[i] = start + (t0 + ld_row + 64 * i) * p.sub;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / F32_BK;
+    const int steps_per_ctx = p.din_pad / F32_BK;
+    float4 ra[2], rb[2];
+
+    auto load_global = [&](int ks) {
+        const int c = ks / steps_per_ctx;
+        const int d0 = (ks - c * steps_per_ctx) * F32_BK;
+        const int off = p.ctx[c];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int r = a_t[i] + off;
+            r = r < 0 ? 0 : (r > len - 1 ? len - 1 : r);
+            ra[i] = *reinterpret_cast<const float4*>(xb + (int64_t)r * p.ldx + d0 + ld_col);
+            rb[i] = *reinterpret_cast<const float4*>(wb + (int64_t)(n0 + ld_row + 64 * i) * p.ktot + ks * F32_BK + ld_col);
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* a = &As[buf][(ld_row + 64 * i) * F32_PITCH + ld_col];
+            a[0] = ra[i].x; a[1] = ra[i].y; a[2] = ra[i].z; a[3] = ra[i].w;
+            float* bb = &Bs[buf][(ld_row + 64 * i) * F32_PITCH + ld_col];
+            bb[0] = rb[i].x; bb[1] = rb[i].y; bb[2] = rb[i].z; bb[3] = rb[i].w;
+        }
+    };
+
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < nk) load_global(ks + 1);
+        const float* a_base = &As[buf][(wm * 64 + (lane & 31)) * F32_PITCH + (lane >> 5)];
+        const float* b_base = &Bs[buf][(wn * 64 + (lane & 31)) * F32_PITCH + (lane >> 5)];
+#pragma unroll
+        for (int kk = 0; kk < F32_BK; kk += 2) {
+            const float a0 = a_base[kk], a1 = a_base[32 * F32_PITCH + kk];
+            const float b0 = b_base[kk], b1 = b_base[32 * F32_PITCH + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (ks + 1 < nk) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile32(acc[i][j], p, out_row0, rows_valid, wm * 64 + i * 32, n0 + wn * 64 + j * 32, lane);
+}
+
+// ------------------------------------------------------------------------------------ BF16 / BF16X3
+// 128x128 block tile, K-step BK (bf16), 4 waves as 2x2, each wave 64x64 = 2x2 tiles of 32x32x16 MFMA.
+// LDS rows are padded by 16 B so that the 16-lane groups of ds_read_b128 hit 16 distinct 16-B slots.
+#define BF_BM 128
+#define BF_BN 128
+
+template <int BK>
+struct BfCfg {
+    static constexpr int PITCH = BK + 8;                    // bf16 elements per LDS row
+    static constexpr int CHUNKS = BK / 8;                   // 16-B chunks per row
+    static constexpr int PER_THREAD = (128 * CHUNKS) / 256; // chunks each thread stages per operand
+};
+
+__device__ __forceinline__ u32x4 pack_bf16x8(const fv4& lo, const fv4& hi) {
+    u32x4 r;
+    r.x = (unsigned)f2bf(lo.x) | ((unsigned)f2bf(lo.y) << 16);
+    r.y = (unsigned)f2bf(lo.z) | ((unsigned)f2bf(lo.w) << 16);
+    r.z = (unsigned)f2bf(hi.x) | ((unsigned)f2bf(hi.y) << 16);
+    r.w = (unsigned)f2bf(hi.z) | ((unsigned)f2bf(hi.w) << 16);
+    return r;
+}
+__device__ __forceinline__ fv4 bf_residual(const fv4& v, unsigned p01, unsigned p23) {
+    fv4 r;
+    r.x = v.x - bf2f((unsigned short)(p01 & 0xffff)); r.y = v.y - bf2f((unsigned short)(p01 >> 16));
+    r.z = v.z - bf2f((unsigned short)(p23 & 0xffff)); r.w = v.w - bf2f((unsigned short)(p23 >> 16));
+    return r;
+}
+
+// XF32: activations are fp32 in memory (converted while staging); X3: split-bf16 3-pass mode (needs XF32).
+template <int BK, bool XF32, bool X3>
+__global__ __launch_bounds__(256) void tdnn_bf16_kernel(TdnnParams p) {
+    using C = BfCfg<BK>;
+    constexpr int NBUF_A = X3 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem[];
+    // layout: [stage 2][A hi (,A lo)][B hi (,B lo)] each 128 x PITCH
+    constexpr int TILE = 128 * C::PITCH;
+    constexpr int STAGE = TILE * 2 * NBUF_A;
+
+    const int b = blockIdx.z;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = blockIdx.y * BF_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = blockIdx.x * BF_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int64_t xbase = (int64_t)b * p.T * p.ldx;
+    const unsigned short* wb = reinterpret_cast<const unsigned short*>(p.w);
+    const unsigned short* wlo = reinterpret_cast<const unsigned short*>(p.w_lo);
+
+    int ld_row[C::PER_THREAD], ld_chunk[C::PER_THREAD], a_t[C::PER_THREAD];
+#pragma unroll
+    for (int i = 0; i < C::PER_THREAD; ++i) {
+        const int id = tid + 256 * i;
+        ld_row[i] = id / C::CHUNKS;
+        ld_chunk[i] = id % C::CHUNKS;
+        a_t[i] = start + (t0 + ld_row[i]) * p.sub;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / BK;
+    const int steps_per_ctx = p.din_pad / BK;
+    u32x4 ra[C::PER_THREAD], ralo[C::PER_THREAD], rb[C::PER_THREAD], rblo[C::PER_THREAD];
+
+#define BF_LOAD_GLOBAL(KS)                                                                                        \
+    {                                                                                                             \
+        const int ks_ = (KS);                                                                                     \
+        const int c_ = ks_ / steps_per_ctx;                                                                       \
+        const int d0_ = (ks_ - c_ * steps_per_ctx) * BK;                                                          \
+        const int off_ = p.ctx[c_];                                                                               \
+        _Pragma("unroll") for (int i = 0; i < C::PER_THREAD; ++i) {                                               \
+            int r = a_t[i] + off_;                                                                                \
+            r = r < 0 ? 0 : (r > len - 1 ? len - 1 : r);                                                          \
+            const int64_t e = xbase + (int64_t)r * p.ldx + d0_ + ld_chunk[i] * 8;                                 \
+            if (XF32) {                                                                                           \
+                const fv4* src = reinterpret_cast<const fv4*>(reinterpret_cast<const float*>(p.x) + e);           \
+                const fv4 v0 = src[0], v1 = src[1];                                                               \
+                ra[i] = pack_bf16x8(v0, v1);                                                                      \
+                if (X3) ralo[i] = pack_bf16x8(bf_residual(v0, ra[i].x, ra[i].y), bf_residual(v1, ra[i].z, ra[i].w)); \
+            } else {                                                                                              \
+                ra[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(p.x) + e);        \
+            }                                                                                                     \
+            const int64_t we = (int64_t)(n0 + ld_row[i]) * p.ktot + (int64_t)ks_ * BK + ld_chunk[i] * 8;          \
+            rb[i] = *reinterpret_cast<const u32x4*>(wb + we);                                                     \
+            if (X3) rblo[i] = *reinterpret_cast<const u32x4*>(wlo + we);                                          \
+        }                                                                                                         \
+    }
+#define BF_STORE_LDS(STG)                                                                      \
+    {                                                                                          \
+        unsigned short* base = smem + (STG) * STAGE;                                           \
+        _Pragma("unroll") for (int i = 0; i < C::PER_THREAD; ++i) {                            \
+            const int o = ld_row[i] * C::PITCH + ld_chunk[i] * 8;                              \
+            *reinterpret_cast<u32x4*>(base + o) = ra[i];                                       \
+            if (X3) *reinterpret_cast<u32x4*>(base + TILE + o) = ralo[i];                      \
+            *reinterpret_cast<u32x4*>(base + NBUF_A * TILE + o) = rb[i];                       \
+            if (X3) *reinterpret_cast<u32x4*>(base + NBUF_A * TILE + TILE + o) = rblo[i];      \
+        }                                                                                      \
+    }
+
+    BF_LOAD_GLOBAL(0);
+    BF_STORE_LDS(0);
+    __syncthreads();
+    // fragment base offsets: lane (r = lane&31, h = lane>>5) reads row r, k = 16*kstep + 8*h .. +7
+    const int a_off = (wm * 64 + (lane & 31)) * C::PITCH + (lane >> 5) * 8;
+    const int b_off = (wn * 64 + (lane & 31)) * C::PITCH + (lane >> 5) * 8;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int stage = ks & 1;
+        if (ks + 1 < nk) BF_LOAD_GLOBAL(ks + 1);
+        const unsigned short* sa = smem + stage * STAGE;
+        const unsigned short* sb = sa + NBUF_A * TILE;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            bfrag8 a[2], bq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const bfrag8*>(sa + a_off + i * 32 * C::PITCH + kk);
+                bq[i] = *reinterpret_cast<const bfrag8*>(sb + b_off + i * 32 * C::PITCH + kk);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+            if (X3) {
+                bfrag8 al[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    al[i] = *reinterpret_cast<const bfrag8*>(sa + TILE + a_off + i * 32 * C::PITCH + kk);
+                    bl[i] = *reinterpret_cast<const bfrag8*>(sb + TILE + b_off + i * 32 * C::PITCH + kk);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bq[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+        if (ks + 1 < nk) BF_STORE_LDS(stage ^ 1);
+        __syncthreads();
+    }
+
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            store_tile32(acc[i][j], p, out_row0, rows_valid, wm * 64 + i * 32, n0 + wn * 64 + j * 32, lane);
+}
+
+// ------------------------------------------------------------------------------------ elementwise helpers
+__global__ void affine_act_kernel(const float* __restrict__ x, int64_t total, int D, int act,
+                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                  float* __restrict__ y) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int d = (int)(e % D);
+        float v = apply_act(x[e], act);
+        if (scale) v *= scale[d];
+        if (shift) v += shift[d];
+        y[e] = v;
+    }
+}
+
+template <typename S, typename Dd>
+__global__ void convert_pad_kernel(const S* __restrict__ src, int64_t rows, int D, int64_t lds_, Dd* __restrict__ dst,
+                                   int64_t ldd) {
+    const int64_t total = rows * ldd;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / ldd;
+        const int d = (int)(e - r * ldd);
+        float v = 0.0f;
+        if (d < D) {
+            if constexpr (sizeof(S) == 4) v = (float)src[r * lds_ + d];
+            else v = bf2f((unsigned short)src[r * lds_ + d]);
+        }
+        if constexpr (sizeof(Dd) == 4) dst[e] = v;
+        else dst[e] = f2bf(v);
+    }
+}
+
+extern "C" int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d) {
+    if (!d || d->nctx <= 0 || d->subsampling <= 0) return -1;
+    int64_t start = 0, end = len;
+    if (d->valid) {
+        if (d->ctx[0] < 0) start = -d->ctx[0];
+        if (d->ctx[d->nctx - 1] > 0) end = len - d->ctx[d->nctx - 1];
+    }
+    const int64_t n = end - start;
+    return n <= 0 ? 0 : (n + d->subsampling - 1) / d->subsampling;
+}
+
+extern "C" int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
+                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
+                        void* y, int64_t ldy, int32_t* out_lens, void* stream) {
+    KTF_REQUIRE(x && d && w && y, "ktf_tdnn: null argument");
+    KTF_REQUIRE(B >= 0 && T >= 0, "ktf_tdnn: negative size");
+    KTF_REQUIRE(d->units > 0 && d->din > 0, "ktf_tdnn: units/din must be > 0");
+    KTF_REQUIRE(d->nctx >= 1 && d->nctx <= 16, "ktf_tdnn: nctx %d outside [1,16]", d->nctx);
+    for (int i = 1; i < d->nctx; ++i) KTF_REQUIRE(d->ctx[i] > d->ctx[i - 1], "ktf_tdnn: context must be strictly ascending");
+    KTF_REQUIRE(d->subsampling > 0, "ktf_tdnn: subsampling_factor should be > 0");
+    KTF_REQUIRE(d->din_pad >= d->din && d->din_pad % 32 == 0 && d->din_pad <= ldx, "ktf_tdnn: din_pad %d must be a multiple of 32 with din <= din_pad <= ldx", d->din_pad);
+    KTF_REQUIRE(ldx % 8 == 0, "ktf_tdnn: ldx must be a multiple of 8");
+    KTF_REQUIRE(ldy >= d->units, "ktf_tdnn: ldy < units");
+    KTF_REQUIRE(d->act >= KTF_ACT_NONE && d->act <= KTF_ACT_TANH, "ktf_tdnn: bad activation %d", d->act);
+    KTF_REQUIRE(d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16, "ktf_tdnn: bad y_dtype");
+    KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_tdnn: scale and shift go together");
+    KTF_REQUIRE(T < (1ll << 30) && B < 65536, "ktf_tdnn: T or B too large");
+    const int64_t Tout = ktf_tdnn_out_len(T, d);
+    if (B == 0 || T == 0) return KTF_OK;
+    if (Tout == 0) {
+        if (out_lens) (void)hipMemsetAsync(out_lens, 0, sizeof(int32_t) * B, (hipStream_t)stream);
+        return KTF_OK;
+    }
+    TdnnParams p;
+    memset(&p, 0, sizeof(p));
+    p.x = x; p.lens = lens; p.w = w; p.w_lo = w_lo; p.bias = bias; p.scale = scale; p.shift = shift; p.y = y;
+    p.out_lens = out_lens; p.T = T; p.ldx = ldx; p.ldy = ldy; p.Tout = Tout;
+    p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
+    p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
+    for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned ntiles = (unsigned)ktf_cdiv(d->units, 128);
+    if (d->gemm == KTF_GEMM_F32) {
+        KTF_REQUIRE(d->x_dtype == KTF_F32 && d->w_dtype == KTF_F32, "ktf_tdnn: F32 gemm needs fp32 x and w");
+        dim3 grid(ntiles, (unsigned)ktf_cdiv(Tout, F32_BM), (unsigned)B);
+        hipLaunchKernelGGL(tdnn_f32_kernel, grid, dim3(256), 0, st, p);
+    } else if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3) {
+        KTF_REQUIRE(d->w_dtype == KTF_BF16, "ktf_tdnn: bf16 gemm needs bf16 weights");
+        const bool x3 = d->gemm == KTF_GEMM_BF16X3;
+        if (x3) KTF_REQUIRE(d->x_dtype == KTF_F32 && w_lo, "ktf_tdnn: BF16X3 needs fp32 activations and w_lo");
+        dim3 grid(ntiles, (unsigned)ktf_cdiv(Tout, BF_BM), (unsigned)B);
+        // K-step: 64 when the per-context width allows it, else 32
+        const bool k64 = (d->din_pad % 64) == 0;
+#define BF_LAUNCH(BK, XF, X3)                                                                               \
+    do {                                                                                                    \
+        const size_t lds = (size_t)2 * 128 * BfCfg<BK>::PITCH * 2 * (X3 ? 2 : 1) * sizeof(unsigned short);  \
+        if (lds > 64 * 1024)                                                                                \
+            (void)hipFuncSetAttribute((const void*)tdnn_bf16_kernel<BK, XF, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((tdnn_bf16_kernel<BK, XF, X3>), grid, dim3(256), lds, st, p);                     \
+    } while (0)
+        if (x3) {
+            if (k64) BF_LAUNCH(64, true, true); else BF_LAUNCH(32, true, true);
+        } else if (d->x_dtype == KTF_F32) {
+            if (k64) BF_LAUNCH(64, true, false); else BF_LAUNCH(32, true, false);
+        } else {
+            KTF_REQUIRE(d->x_dtype == KTF_BF16, "ktf_tdnn: bad x_dtype");
+            if (k64) BF_LAUNCH(64, false, false); else BF_LAUNCH(32, false, false);
+        }
+#undef BF_LAUNCH
+    } else {
+        KTF_REQUIRE(false, "ktf_tdnn: unknown gemm mode %d", d->gemm);
+    }
+    KTF_CHECK_LAUNCH("ktf_tdnn");
+    return KTF_OK;
+}
+
+extern "C" int ktf_affine_act_f32(const float* x, int64_t rows, int32_t D, int32_t act, const float* scale,
+                                  const float* shift, float* y, void* stream) {
+    KTF_REQUIRE(x && y, "ktf_affine_act_f32: null argument");
+    KTF_REQUIRE(rows >= 0 && D > 0, "ktf_affine_act_f32: bad sizes");
+    KTF_REQUIRE(act >= KTF_ACT_NONE && act <= KTF_ACT_TANH, "ktf_affine_act_f32: bad activation");
+    const int64_t total = rows * D;
+    if (total == 0) return KTF_OK;
+    int blocks = ktf_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(affine_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, total, D, act, scale, shift, y);
+    KTF_CHECK_LAUNCH("ktf_affine_act_f32");
+    return KTF_OK;
+}
+
+extern "C" int ktf_convert_pad(const void* src, int32_t src_dtype, int64_t rows, int32_t D, int64_t ld_src, void* dst,
+                               int32_t dst_dtype, int64_t ld_dst, void* stream) {
+    KTF_REQUIRE(src && dst, "ktf_convert_pad: null argument");
+    KTF_REQUIRE(rows >= 0 && D > 0 && ld_src >= D && ld_dst >= D, "ktf_convert_pad: bad sizes");
+    const int64_t total = rows * ld_dst;
+    if (total == 0) return KTF_OK;
+    int blocks = ktf_cdiv(total, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (src_dtype == KTF_F32 && dst_dtype == KTF_F32)
+        hipLaunchKernelGGL((convert_pad_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, rows, D, ld_src, (float*)dst, ld_dst);
+    else if (src_dtype == KTF_F32 && dst_dtype == KTF_BF16)
+        hipLaunchKernelGGL((convert_pad_kernel<float, unsigned short>), dim3(blocks), dim3(256), 0, st, (const float*)src, rows, D, ld_src, (unsigned short*)dst, ld_dst);
+    else if (src_dtype == KTF_BF16 && dst_dtype == KTF_F32)
+        hipLaunchKernelGGL((convert_pad_kernel<unsigned short, float>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)src, rows, D, ld_src, (float*)dst, ld_dst);
+    else if (src_dtype == KTF_BF16 && dst_dtype == KTF_BF16)
+        hipLaunchKernelGGL((convert_pad_kernel<unsigned short, unsigned short>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)src, rows, D, ld_src, (unsigned short*)dst, ld_dst);
+    else
+        KTF_REQUIRE(false, "ktf_convert_pad: bad dtype");
+    KTF_CHECK_LAUNCH("ktf_convert_pad");
+    return KTF_OK;
+}

@@ -1,0 +1,140 @@
+"""
+ctypes binding of libktf_hip.so (the C-ABI declared in include/ktf_hip.h).
+
+This is the only place the Python host side touches native code. There is NO CPU
+fallback: if the shared library is missing or no MI355X is visible, every compute
+entry point raises (`KtfBackendError`) instead of silently computing elsewhere.
+"""
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libktf_hip.so")
+
+KTF_F32, KTF_BF16 = 0, 1
+GEMM_F32, GEMM_BF16, GEMM_BF16X3 = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+IN_WAV, IN_FRAMES, IN_WINDOWED = 0, 1, 2
+OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
+
+
+class KtfBackendError(RuntimeError):
+    pass
+
+
+class FrontendCfg(C.Structure):
+    _fields_ = [
+        ("frame_size", C.c_int32), ("frame_shift", C.c_int32), ("nfft", C.c_int32), ("num_mels", C.c_int32),
+        ("num_ceps", C.c_int32), ("remove_dc", C.c_int32), ("raw_energy", C.c_int32), ("use_energy", C.c_int32),
+        ("use_power", C.c_int32), ("use_log", C.c_int32), ("use_lifter", C.c_int32), ("preemph", C.c_float),
+        ("dither", C.c_float), ("energy_floor", C.c_float), ("eps", C.c_float),
+    ]
+
+
+class FrontendTables(C.Structure):
+    _fields_ = [
+        ("window", C.c_void_p), ("twiddle", C.c_void_p), ("rtwiddle", C.c_void_p), ("mel_start", C.c_void_p),
+        ("mel_len", C.c_void_p), ("mel_w", C.c_void_p), ("dct", C.c_void_p), ("lifter", C.c_void_p),
+        ("mel_stride", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class VadCfg(C.Structure):
+    _fields_ = [("energy_threshold", C.c_float), ("energy_mean_scale", C.c_float), ("proportion_threshold", C.c_float),
+                ("frames_context", C.c_int32), ("energy_coeff", C.c_int32)]
+
+
+class CmvnCfg(C.Structure):
+    _fields_ = [("window", C.c_int32), ("norm_vars", C.c_int32), ("valid", C.c_int32), ("reserved", C.c_int32)]
+
+
+class TdnnDesc(C.Structure):
+    _fields_ = [("units", C.c_int32), ("din", C.c_int32), ("din_pad", C.c_int32), ("nctx", C.c_int32),
+                ("ctx", C.c_int32 * 16), ("subsampling", C.c_int32), ("valid", C.c_int32), ("act", C.c_int32),
+                ("gemm", C.c_int32), ("x_dtype", C.c_int32), ("w_dtype", C.c_int32), ("y_dtype", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+_P = C.c_void_p
+_i64, _i32, _f32, _u64 = C.c_int64, C.c_int32, C.c_float, C.c_uint64
+
+# name -> (restype, argtypes); mirrors include/ktf_hip.h one to one
+PROTOTYPES = {
+    "ktf_version": (_i32, []),
+    "ktf_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "ktf_num_frames": (_i64, [_i64, _i32, _i32]),
+    "ktf_frontend_f32": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(FrontendCfg), C.POINTER(FrontendTables), _i32, _P, _P, _u64, _P]),
+    "ktf_dct_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P]),
+    "ktf_vad_mask_f32": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(VadCfg), _P, _P]),
+    "ktf_vad_index": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(VadCfg), _P, _P, _P]),
+    "ktf_cmvn_f32": (C.c_int, [_P, _i64, _i64, _i32, _i64, _P, C.POINTER(CmvnCfg), _P, _i64, _P, _P, _P]),
+    "ktf_vad_cmvn": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(VadCfg), C.POINTER(CmvnCfg), _P, _i32, _i64, _P, _P, _P, _P]),
+    "ktf_tdnn_out_len": (_i64, [_i64, C.POINTER(TdnnDesc)]),
+    "ktf_tdnn": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
+    "ktf_affine_act_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P]),
+    "ktf_convert_pad": (C.c_int, [_P, _i32, _i64, _i32, _i64, _P, _i32, _i64, _P]),
+    "ktf_stats_pool": (C.c_int, [_P, _i32, _i64, _i64, _i32, _i64, _P, _i32, _i32, _f32, _P, _i64, _P]),
+    "ktf_stats_pool_windowed_f32": (C.c_int, [_P, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _f32, _P, _P]),
+    "ktf_xvec_post_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P, _P]),
+    "ktf_plda_f64": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
+    "ktf_plda_f32": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen libktf_hip.so and bind every symbol of the header. Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise KtfBackendError(
+            f"{LIB_PATH} not found: build it with `make -C kaldi-tflite_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    lib = load()
+    buf = C.create_string_buffer(512)
+    lib.ktf_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(rc, what):
+    """Map the C return code to the reference's exception convention (ValueError for bad arguments)."""
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc == -1:
+        raise ValueError(msg or what)
+    if rc == -3:
+        raise NotImplementedError(msg or what)
+    raise KtfBackendError(f"{what}: rc={rc}: {msg}")
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise KtfBackendError("no MI355X / ROCm device visible: kaldi_tflite_amd computes only on the GPU (no CPU fallback)")
+    load()
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)."""
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())

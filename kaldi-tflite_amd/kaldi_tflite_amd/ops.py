@@ -1,0 +1,310 @@
+"""
+Thin torch-tensor wrappers over the C-ABI (one function per entry point of include/ktf_hip.h)
+plus the host-side constant tables the kernels consume (window, FFT twiddles, sparse mel bank,
+DCT matrix, lifter), computed once in float64 exactly as the reference's layer `build()`
+methods do and uploaded as fp32.
+
+PyTorch is used for device memory and streams only; all arithmetic on activations happens in
+the HIP kernels.
+"""
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _dev(device=None):
+    L.require_gpu()
+    return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+
+
+def to_device_f32(x, device=None):
+    """numpy / tensor -> contiguous fp32 tensor on the GPU."""
+    dev = _dev(device)
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(np.asarray(x, dtype=np.float32)), device=dev)
+
+
+def round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------- host-side tables
+def window_function(window_type, M, blackman_coeff=0.42):
+    """layers/dsp/windowing.py:110-156 of the reference (float64)."""
+    t = window_type.lower()
+    n = np.arange(0, M)
+    if M == 1:
+        return np.ones(1, float)
+    if t == "hamming":
+        return np.hamming(M)
+    if t == "hanning":
+        return np.hanning(M)
+    if t == "povey":
+        return (0.5 - 0.5 * np.cos(2.0 * np.pi * n / (M - 1))) ** 0.85
+    if t == "rectangular":
+        return np.ones((M,))
+    if t == "sine":
+        return np.sin(np.pi * n / (M - 1))
+    if t == "blackman":
+        w = np.blackman(M)
+        if blackman_coeff != 0.42:
+            w = w - 0.42 + blackman_coeff
+        return w
+    raise ValueError(f"window_type '{window_type}' is not recognized")
+
+
+def next_power_of_2(n):
+    if n & (n - 1) == 0 and n != 0:
+        return n
+    return 2 ** (n - 1).bit_length()
+
+
+def mel_bank_dense(window_size, num_bins, sample_freq, lower, upper):
+    """layers/dsp/filterbank.py:141-189: dense (nfft/2+1, num_bins) fp32 bank (weights in fp64, strict
+    left < mel < right, no weight on the Nyquist bin)."""
+    nfft = next_power_of_2(window_size)
+    bins = nfft // 2
+    bw = sample_freq / nfft
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)  # noqa: E731
+    mlo, mhi = mel(lower), mel(upper)
+    delta = (mhi - mlo) / (num_bins + 1)
+    bank = np.zeros([num_bins, bins + 1], dtype=np.float32)
+    m = mel(bw * np.arange(bins))
+    for i in range(num_bins):
+        left = mlo + i * delta
+        center = left + delta
+        right = center + delta
+        inside = (m > left) & (m < right)
+        up = (m - left) / (center - left)
+        down = (right - m) / (right - center)
+        bank[i, :bins] = np.where(inside, np.where(m <= center, up, down), 0.0)
+    return nfft, bank.T.copy()
+
+
+def dct_matrix(input_length, length):
+    """layers/dsp/dct.py:98-143 (float64, (input_length, length); column 0 overwritten with sqrt(1/N))."""
+    N = float(input_length)
+    n = np.arange(input_length)
+    k = np.arange(length, dtype=np.float64)[:, None]
+    d = np.cos(np.pi / N * (n + 0.5) * k)
+    d[0] *= 1.0 / np.sqrt(2.0)
+    d *= np.sqrt(2.0 / N)
+    d = d.T
+    d[:, 0] = np.sqrt(1.0 / N)
+    return d
+
+
+def lifter_coeffs(num_mfccs, q):
+    n = np.arange(0, num_mfccs)
+    return 1 + 0.5 * np.sin(np.pi * n / q) * q
+
+
+class FrontendTables:
+    """Device copies of every constant ktf_frontend_f32 needs, for one (frame_size, mel, dct) configuration."""
+
+    def __init__(self, frame_size, window=None, mel_bank=None, dct=None, lifter=None, device=None):
+        dev = _dev(device)
+        self.frame_size = int(frame_size)
+        self.nfft = next_power_of_2(self.frame_size)
+        n2 = self.nfft // 2
+        k = np.arange(n2)
+        tw = np.stack([np.cos(2 * np.pi * k / n2), -np.sin(2 * np.pi * k / n2)], -1)
+        rtw = np.stack([np.cos(2 * np.pi * k / self.nfft), -np.sin(2 * np.pi * k / self.nfft)], -1)
+        f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.float32), device=dev)  # noqa: E731
+        i32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32), device=dev)  # noqa: E731
+        self.window = f32(window) if window is not None else None
+        self.twiddle = f32(tw.reshape(-1))
+        self.rtwiddle = f32(rtw.reshape(-1))
+        self.mel_start = self.mel_len = self.mel_w = None
+        self.mel_stride = 0
+        self.num_mels = 0
+        if mel_bank is not None:
+            bank = np.asarray(mel_bank, dtype=np.float32)          # (nfft/2+1, num_mels)
+            assert bank.shape[0] == n2 + 1
+            self.num_mels = bank.shape[1]
+            starts, lens = [], []
+            for f in range(self.num_mels):
+                nz = np.nonzero(bank[:n2, f])[0]
+                if nz.size == 0:
+                    starts.append(0)
+                    lens.append(0)
+                else:
+                    starts.append(int(nz[0]))
+                    lens.append(int(nz[-1] - nz[0] + 1))
+            self.mel_stride = max(1, max(lens))
+            w = np.zeros((self.num_mels, self.mel_stride), np.float32)
+            for f in range(self.num_mels):
+                w[f, :lens[f]] = bank[starts[f]:starts[f] + lens[f], f]
+            self.mel_start, self.mel_len, self.mel_w = i32(starts), i32(lens), f32(w)
+        self.dct = f32(dct) if dct is not None else None
+        self.lifter = f32(lifter) if lifter is not None else None
+        self.struct = L.FrontendTables(
+            window=L.ptr(self.window), twiddle=L.ptr(self.twiddle), rtwiddle=L.ptr(self.rtwiddle),
+            mel_start=L.ptr(self.mel_start), mel_len=L.ptr(self.mel_len), mel_w=L.ptr(self.mel_w),
+            dct=L.ptr(self.dct), lifter=L.ptr(self.lifter), mel_stride=self.mel_stride, reserved=0)
+
+
+# ----------------------------------------------------------------------------- entry-point wrappers
+def num_frames(n_samples, frame_size, frame_shift):
+    return int(L.load().ktf_num_frames(int(n_samples), int(frame_size), int(frame_shift)))
+
+
+def frontend(x, in_kind, cfg, tables, out_stage, n, B, T, seed=0, want_energy=False, out=None):
+    """x: fp32 device tensor. Returns out (B,T,last) [, energy (B,T)]."""
+    lib = L.load()
+    last = {L.OUT_FRAMES: cfg.frame_size, L.OUT_WINDOWED: cfg.frame_size, L.OUT_FBANK: cfg.num_mels,
+            L.OUT_MFCC: cfg.num_ceps}[out_stage]
+    if out is None:
+        out = torch.empty((B, T, last), dtype=torch.float32, device=x.device)
+    energy = torch.empty((B, T), dtype=torch.float32, device=x.device) if want_energy else None
+    with torch.cuda.device(x.device):
+        rc = lib.ktf_frontend_f32(L.ptr(x), B, n, in_kind, C.byref(cfg), C.byref(tables.struct), out_stage, L.ptr(out),
+                                  L.ptr(energy), C.c_uint64(seed & (2**64 - 1)), L.stream_ptr())
+    L.check(rc, "ktf_frontend_f32")
+    return (out, energy) if want_energy else out
+
+
+def dct(x2d, dct_t, lifter_t, out_dim):
+    lib = L.load()
+    rows, in_dim = x2d.shape
+    out = torch.empty((rows, out_dim), dtype=torch.float32, device=x2d.device)
+    with torch.cuda.device(x2d.device):
+        rc = lib.ktf_dct_f32(L.ptr(x2d), rows, in_dim, out_dim, L.ptr(dct_t), L.ptr(lifter_t), L.ptr(out), L.stream_ptr())
+    L.check(rc, "ktf_dct_f32")
+    return out
+
+
+def vad_mask(feats, cfg):
+    lib = L.load()
+    B, T, D = feats.shape
+    mask = torch.empty((B, T), dtype=torch.float32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        rc = lib.ktf_vad_mask_f32(L.ptr(feats), B, T, D, C.byref(cfg), L.ptr(mask), L.stream_ptr())
+    L.check(rc, "ktf_vad_mask_f32")
+    return mask
+
+
+def vad_index(feats, cfg):
+    lib = L.load()
+    B, T, D = feats.shape
+    idx = torch.empty((B, T), dtype=torch.int32, device=feats.device)
+    lens = torch.empty((B,), dtype=torch.int32, device=feats.device)
+    with torch.cuda.device(feats.device):
+        rc = lib.ktf_vad_index(L.ptr(feats), B, T, D, C.byref(cfg), L.ptr(idx), L.ptr(lens), L.stream_ptr())
+    L.check(rc, "ktf_vad_index")
+    return idx, lens
+
+
+def cmvn(x, cfg, lens=None, ldo=None, want_lens=False):
+    lib = L.load()
+    B, T, D = x.shape
+    ldo = D if ldo is None else ldo
+    out = torch.empty((B, T, ldo), dtype=torch.float32, device=x.device)
+    work = torch.empty((B * T * 2 * D + 2 * D,), dtype=torch.float32, device=x.device)
+    out_lens = torch.empty((B,), dtype=torch.int32, device=x.device) if want_lens else None
+    with torch.cuda.device(x.device):
+        rc = lib.ktf_cmvn_f32(L.ptr(x), B, T, D, x.stride(1), L.ptr(lens), C.byref(cfg), L.ptr(out), ldo, L.ptr(out_lens),
+                              L.ptr(work), L.stream_ptr())
+    L.check(rc, "ktf_cmvn_f32")
+    return (out, out_lens) if want_lens else out
+
+
+def vad_cmvn(feats, vad_cfg, cmvn_cfg, out, lens, idx_work, work):
+    lib = L.load()
+    B, T, D = feats.shape
+    dt = L.KTF_BF16 if out.dtype == torch.bfloat16 else L.KTF_F32
+    with torch.cuda.device(feats.device):
+        rc = lib.ktf_vad_cmvn(L.ptr(feats), B, T, D, C.byref(vad_cfg), C.byref(cmvn_cfg), L.ptr(out), dt, out.stride(1),
+                              L.ptr(lens), L.ptr(idx_work), L.ptr(work), L.stream_ptr())
+    L.check(rc, "ktf_vad_cmvn")
+
+
+def tdnn_out_len(T, desc):
+    return int(L.load().ktf_tdnn_out_len(int(T), C.byref(desc)))
+
+
+def tdnn(x, lens, desc, w, w_lo, bias, scale, shift, y, out_lens=None):
+    """x (B,T,ldx) fp32/bf16, y (B,Tout,ldy) preallocated."""
+    lib = L.load()
+    B, T = x.shape[0], x.shape[1]
+    with torch.cuda.device(x.device):
+        rc = lib.ktf_tdnn(L.ptr(x), B, T, x.stride(1), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo), L.ptr(bias),
+                          L.ptr(scale), L.ptr(shift), L.ptr(y), y.stride(1), L.ptr(out_lens), L.stream_ptr())
+    L.check(rc, "ktf_tdnn")
+    return y
+
+
+def affine_act(x, act, scale=None, shift=None):
+    lib = L.load()
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        rc = lib.ktf_affine_act_f32(L.ptr(x), rows, D, act, L.ptr(scale), L.ptr(shift), L.ptr(y), L.stream_ptr())
+    L.check(rc, "ktf_affine_act_f32")
+    return y
+
+
+def convert_pad(src, D, dst):
+    """src (..., ld_src) / dst (..., ld_dst) 2-D-viewable row-major tensors; copies D columns, zero-fills the pad."""
+    lib = L.load()
+    rows = src.numel() // src.shape[-1]
+    sd = L.KTF_BF16 if src.dtype == torch.bfloat16 else L.KTF_F32
+    dd = L.KTF_BF16 if dst.dtype == torch.bfloat16 else L.KTF_F32
+    with torch.cuda.device(src.device):
+        rc = lib.ktf_convert_pad(L.ptr(src), sd, rows, D, src.shape[-1], L.ptr(dst), dd, dst.shape[-1], L.stream_ptr())
+    L.check(rc, "ktf_convert_pad")
+    return dst
+
+
+def stats_pool(x, D, lens, input_period, include_std, eps, out):
+    """x (B,T,ldx) fp32/bf16; out (B, ld_out) fp32 preallocated."""
+    lib = L.load()
+    B, T = x.shape[0], x.shape[1]
+    dt = L.KTF_BF16 if x.dtype == torch.bfloat16 else L.KTF_F32
+    with torch.cuda.device(x.device):
+        rc = lib.ktf_stats_pool(L.ptr(x), dt, B, T, D, x.stride(1), L.ptr(lens), input_period, int(include_std), eps,
+                                L.ptr(out), out.stride(0), L.stream_ptr())
+    L.check(rc, "ktf_stats_pool")
+    return out
+
+
+def stats_pool_windowed(x, left, right, input_period, output_period, start, T_out, include_std, eps):
+    lib = L.load()
+    B, T, D = x.shape
+    out = torch.empty((B, T_out, 2 * D if include_std else D), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ktf_stats_pool_windowed_f32(L.ptr(x), B, T, D, left, right, input_period, output_period, start, T_out,
+                                             int(include_std), eps, L.ptr(out), L.stream_ptr())
+    L.check(rc, "ktf_stats_pool_windowed_f32")
+    return out
+
+
+def xvec_post(x, mean, A, off, out=None):
+    lib = L.load()
+    B, in_dim = x.shape
+    out_dim = A.shape[1]
+    if out is None:
+        out = torch.empty((B, out_dim), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.ktf_xvec_post_f32(L.ptr(x), B, in_dim, out_dim, L.ptr(mean), L.ptr(A), L.ptr(off), L.ptr(out), L.stream_ptr())
+    L.check(rc, "ktf_xvec_post_f32")
+    return out
+
+
+def plda(x, A, offset, psi, normalize_length, simple_length_norm, want_scores=True):
+    lib = L.load()
+    B, dim = x.shape
+    tr = torch.empty_like(x)
+    scores = torch.empty((B, B), dtype=x.dtype, device=x.device) if want_scores else None
+    fn = lib.ktf_plda_f64 if x.dtype == torch.float64 else lib.ktf_plda_f32
+    with torch.cuda.device(x.device):
+        rc = fn(L.ptr(x), B, dim, L.ptr(A), L.ptr(offset), L.ptr(psi), int(normalize_length), int(simple_length_norm),
+                L.ptr(tr), L.ptr(scores), L.stream_ptr())
+    L.check(rc, "ktf_plda")
+    return scores, tr

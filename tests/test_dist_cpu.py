@@ -1,0 +1,78 @@
+"""world_size-2 gloo test (CPU) of the N>1 host path used by bench.py: env init, contiguous utterance shards,
+embedding gather (equal and ragged shards), max-over-ranks timing. The per-utterance 'extractor' here is a CPU stand-in
+(a fixed random projection) because there is no GPU on this box; the collective plumbing is what is under test."""
+
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "kaldi-tflite_amd"))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _fake_extract(x):
+    g = torch.Generator().manual_seed(0)
+    P = torch.randn(x.shape[1], 8, generator=g)
+    return x @ P
+
+
+def _worker(rank, world, port, total, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from kaldi_tflite_amd import parallel as P
+    r, lr, w = P.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(1234)
+    full = torch.randn(total, 16, generator=g)
+    lo, hi = P.shard_range(total, rank, world)
+    local = _fake_extract(full[lo:hi])
+    P.barrier(world)
+    if total % world == 0:
+        allv = P.gather_embeddings(local, world)
+    else:
+        allv = P.gather_ragged_embeddings(local, world)
+    t = P.max_over_ranks(1.0 + rank, world, torch.device("cpu"))
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), allv.numpy())
+    assert t == float(world)
+    torch.distributed.destroy_process_group()
+
+
+def _run(total, tmp_path):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    g = torch.Generator().manual_seed(1234)
+    want = _fake_extract(torch.randn(total, 16, generator=g)).numpy()
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"r{r}.npy"))
+        assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_two_rank_equal_shards(tmp_path):
+    _run(8, tmp_path)
+
+
+def test_two_rank_ragged_shards(tmp_path):
+    _run(7, tmp_path)
+
+
+def test_shard_range_partitions():
+    from kaldi_tflite_amd.parallel import shard_range
+    for total in [0, 1, 7, 8, 8192, 8191]:
+        for world in [1, 2, 3, 8]:
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1

@@ -1,0 +1,402 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X). Every test drives the HIP kernels through the C-ABI via the
+ktf.layers / ktf.models surface and compares with (a) the reference's Kaldi-generated goldens at the reference's own
+tolerances and (b) the CPU oracle (oracle/ktf_oracle.py, fp64) on seeded synthetic inputs.
+Tolerances: integer/index work exact; fp32 stages at the reference's RMSE bounds; whole pipeline max-abs <= 1e-4
+(north_star) on the fp32-MFMA path."""
+
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import _golden as G
+import synth
+import kaldi_tflite_amd as ktf
+from oracle import ktf_oracle as O
+
+pytestmark = pytest.mark.gpu
+Ls = ktf.layers
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda").to(dtype)
+
+
+def host(t):
+    return t.detach().to(torch.float64 if t.dtype == torch.float64 else torch.float32).cpu().numpy()
+
+
+def _pad(cfg, wav):
+    f = cfg["framing"]
+    if not cfg["snip_edges"]:
+        m = int(f["frame_length_ms"] / 1000.0 * f["sample_frequency"])
+        k = int(f["frame_shift_ms"] / 1000.0 * f["sample_frequency"])
+        wav = ktf.kaldi_numpy.PadWaveform(wav, m, k)
+    return wav
+
+
+# ----------------------------------------------------------------------------- a1 Framing (exact)
+def test_framing_exact():
+    z = G.load("kaldi_numpy.npz")
+    for fl, fs, sf in z["framing_configs"]:
+        N = int(10 * sf)
+        m, k = int(sf * fl / 1000.0), int(sf * fs / 1000.0)
+        x = np.arange(0, N)
+        got = host(Ls.Framing(fl, fs, sf)(x))
+        assert np.array_equal(got, ktf.kaldi_numpy.ExtractFrames(x, fl, fs, sf, True))
+        xp = ktf.kaldi_numpy.PadWaveform(x, m, k)
+        got = host(Ls.Framing(fl, fs, sf)(xp))
+        assert np.array_equal(got, ktf.kaldi_numpy.ExtractFrames(xp, fl, fs, sf, False))
+    fr = Ls.Framing(25, 10, 16000, dynamic_input_shape=True)
+    assert tuple(fr(np.zeros((3, 16000), np.float32)).shape) == (3, 98, 400)
+    assert tuple(fr(np.zeros((3, 32000), np.float32)).shape) == (3, 198, 400)
+    with pytest.raises(ValueError):
+        fr(np.zeros((1, 399), np.float32))
+
+
+# ----------------------------------------------------------------------------- a2 Windowing
+def test_windowing_vs_process_frames():
+    z = G.load("kaldi_numpy.npz")
+    frames = z["frames"]
+    for i, o in enumerate(json.loads(str(z["configs_json"]))):
+        cfg = {"window_type": "povey", "blackman_coeff": 0.42, "dither": 0.0, "remove_dc_offset": True,
+               "preemphasis_coefficient": 0.97, "raw_energy": True, "return_energy": True, "energy_floor": 0.0,
+               "epsilon": float(np.finfo(np.float32).eps)}
+        cfg.update(o)
+        w, e = Ls.Windowing(**cfg)(frames)
+        assert tuple(w.shape) == frames.shape and tuple(e.shape) == (1, frames.shape[1], 1)
+        assert G.rmse(z[f"windows_{i}"], host(w)) < 2e-7, o
+        assert G.rmse(z[f"energy_{i}"], host(e)) < 2e-7, o
+        cfg["return_energy"] = False
+        w2 = Ls.Windowing(**cfg)(frames)
+        assert isinstance(w2, torch.Tensor) and torch.equal(w2, w)
+
+
+def test_windowing_dither_statistics():
+    # windowing_test.py:119: with dither the comparison tolerance is 2*dither; also check the noise is N(0, d^2)
+    frames = np.zeros((1, 512, 256), np.float32)
+    cfg = dict(window_type="rectangular", dither=1.0, remove_dc_offset=False, preemphasis_coefficient=0.0, return_energy=False)
+    a = host(Ls.Windowing(**cfg)(frames)).reshape(-1)
+    assert abs(a.mean()) < 0.02 and abs(a.std() - 1.0) < 0.02
+    assert abs(np.mean(a ** 3)) < 0.05 and abs(np.mean(a ** 4) - 3.0) < 0.15
+    lay = Ls.Windowing(**cfg)
+    b, c = host(lay(frames)), host(lay(frames))
+    assert not np.array_equal(b, c)         # fresh noise on every call
+
+
+# ----------------------------------------------------------------------------- a3-a5 FilterBank / MFCC vs Kaldi goldens
+def test_fbank_goldens():
+    for name in G.fbank_case_names():
+        cfg, wav, want = G.fbank_case(name)
+        x = Ls.Framing(**cfg["framing"])(_pad(cfg, wav))
+        x = Ls.Windowing(**cfg["windowing"])(x)
+        got = host(Ls.FilterBank(**cfg["fbank"])(x))
+        assert got.shape == want.shape, name
+        assert G.rmse(want, got) < 2.25e-5, (name, G.rmse(want, got))
+
+
+def test_mfcc_goldens():
+    worst = 0.0
+    for name in G.mfcc_case_names():
+        cfg, wav, want = G.mfcc_case(name)
+        x = Ls.Framing(**cfg["framing"])(_pad(cfg, wav))
+        got = host(Ls.MFCC(**cfg["mfcc"])(x))
+        assert got.shape == want.shape, name
+        e = G.rmse(want, got)
+        worst = max(worst, e)
+        assert e < 2.25e-4, (name, e)
+    print("mfcc worst rmse vs Kaldi", worst)
+
+
+def test_dct_layer_and_unfused_chain_equal_fused():
+    cfg, wav, want = G.mfcc_case("16000_013")
+    frames = Ls.Framing(**cfg["framing"])(_pad(cfg, wav))
+    m = cfg["mfcc"]
+    fused = host(Ls.MFCC(**m)(frames))
+    w, e = Ls.Windowing(window_type=m["window_type"], dither=0.0, remove_dc_offset=m["remove_dc_offset"],
+                        preemphasis_coefficient=m["preemphasis_coefficient"], raw_energy=m["raw_energy"],
+                        return_energy=True, energy_floor=m["energy_floor"], epsilon=m["epsilon"])(frames)
+    fb = Ls.FilterBank(num_bins=m["num_mels"], sample_frequency=m["sample_frequency"], high_freq_cutoff=m["high_freq_cutoff"],
+                       low_freq_cutoff=m["low_freq_cutoff"], epsilon=m["epsilon"])(w)
+    c = host(Ls.DCT(m["num_mfccs"])(fb)) * O.lifter_coeffs(m["num_mfccs"], m["cepstral_lifter"]).astype(np.float32)
+    c[..., 0] = host(e)[..., 0]
+    assert np.abs(c - fused).max() < 2e-5
+    ref = O.dct(host(fb), m["num_mfccs"], dtype=np.float64)
+    assert np.abs(host(Ls.DCT(m["num_mfccs"])(fb)) - ref).max() < 2e-5
+
+
+# ----------------------------------------------------------------------------- a6 VAD (exact)
+def test_vad_goldens_exact():
+    for name in G.vad_case_names():
+        cfg, feats, want = G.vad_case(name)
+        got = host(Ls.VAD(**cfg)(feats))
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        cfg["return_indexes"] = True
+        idx = Ls.VAD(**cfg)(feats)
+        assert idx.dtype == torch.int64 and idx.shape[1] == 2
+        assert np.array_equal(idx.cpu().numpy(), O.vad(feats, **cfg)), name
+
+
+def test_vad_batch_indexes():
+    rng = np.random.default_rng(3)
+    feats = rng.standard_normal((5, 237, 30)).astype(np.float32) * 4 + 8
+    cfg = dict(energy_mean_scale=0.5, energy_threshold=5.5, frames_context=2, proportion_threshold=0.12, return_indexes=True)
+    got = Ls.VAD(**cfg)(feats).cpu().numpy()
+    assert np.array_equal(got, O.vad(feats, **cfg))
+
+
+# ----------------------------------------------------------------------------- a8 CMVN
+def test_cmvn_goldens():
+    for name in G.cmvn_case_names():
+        cfg, feats, want = G.cmvn_case(name)
+        got = host(Ls.CMVN(**cfg, padding="SAME")(feats))
+        assert got.shape == want.shape and G.rmse(want, got) < 1e-5, (name, G.rmse(want, got))
+        N, T = cfg["window"], want.shape[-2]
+        got = host(Ls.CMVN(**cfg, padding="VALID")(feats))
+        wv = want[..., N // 2: T - (N - 1) // 2, :]
+        if N > T:
+            continue
+        assert got.shape == wv.shape and G.rmse(wv, got) < 1e-5, name
+
+
+def test_cmvn_vs_oracle_batched():
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((4, 700, 30)) * 5 + 3).astype(np.float32)
+    for w, nv, pad in [(300, False, "SAME"), (300, True, "SAME"), (201, False, "VALID"), (900, True, "SAME"), (700, False, "SAME")]:
+        got = host(Ls.CMVN(window=w, norm_vars=nv, padding=pad)(x))
+        want = O.cmvn(x, window=w, norm_vars=nv, padding=pad, dtype=np.float64)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 2e-5, (w, nv, pad, np.abs(got - want).max())
+
+
+# ----------------------------------------------------------------------------- a9/a10 TDNN
+def _single_layer(gemm="f32"):
+    z = G.load("tdnn.npz")
+    cfg = json.loads(str(z["single_cfg_json"]))
+    t = Ls.TDNN.from_config(dict(cfg, gemm=gemm))
+    t.build(z["single_inputs"].shape)
+    t.set_weights([z["single_W"], z["single_b"]])
+    return t, z
+
+
+def test_tdnn_single_layer_golden():
+    t, z = _single_layer()
+    got = host(t(z["single_inputs"]))
+    assert got.shape == z["single_outputs"].shape
+    assert G.rmse(z["single_outputs"], got) <= 1e-6          # tdnn_test.py:31
+
+
+def test_tdnn_narrow_golden_fused_and_layerwise():
+    layers, by, x, want = G.narrow_layers()
+    spec = [("tdnn1", 5, [-2, -1, 0, 1, 2], True), ("tdnn2", 8, [-2, 0, 2], True), ("tdnn3", 8, [-3, 0, 3], True),
+            ("tdnn4", 8, [0], True), ("tdnn5", 8, [0], True), ("output", 1, [0], False)]
+    built = []
+    for name, dim, ctx, act in spec:
+        built.append(Ls.TDNN(dim, context=ctx, name=f"{name}.affine"))
+        if act:
+            built += [Ls.ReLU(name=f"{name}.relu"), Ls.BatchNorm(name=f"{name}.batchnorm")]
+    mdl = ktf.models.Sequential([ktf.models.Input(shape=(None, 3))] + built)
+    for l in mdl.layers:
+        c = by.get(l.name)
+        if c is None or "relu" in l.name:
+            continue
+        if "affine" in l.name:
+            l.set_weights([c["params"], c["bias"]])
+        else:
+            l.set_weights([c["target-rms"], c["stats-mean"], c["stats-var"]])
+    got = host(mdl(x, training=False))
+    assert got.shape == want.shape and G.rmse(want, got) <= 5e-4      # tdnn_test.py:117
+    y = dev(x)
+    for l in mdl.layers:
+        y = l(y)
+    assert np.abs(host(y) - got).max() < 1e-5
+    assert np.abs(got - O.sequential_forward(layers, x, dtype=np.float64)).max() < 1e-5
+
+
+@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2)])
+def test_tdnn_options_vs_oracle(gemm, tol):
+    rng = np.random.default_rng(11)
+    for (B, T, D, U, ctx, sub, pad, act) in [
+        (3, 150, 30, 64, [-2, -1, 0, 1, 2], 1, "SAME", None),
+        (2, 333, 64, 200, [-3, 0, 3], 1, "SAME", "relu"),
+        (2, 140, 96, 130, [-2, 0, 2], 1, "VALID", "tanh"),
+        (1, 131, 40, 33, [-1, 0, 2], 3, "SAME", "sigmoid"),
+        (2, 77, 32, 16, [-4, 1], 2, "VALID", None),
+        (5, 1, 128, 48, [0], 1, "SAME", None),
+        (1, 300, 512, 128, [0], 1, "SAME", "relu"),
+    ]:
+        x = rng.standard_normal((B, T, D)).astype(np.float32)
+        W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+        b = rng.standard_normal(U).astype(np.float32)
+        t = Ls.TDNN(U, context=list(ctx), subsampling_factor=sub, padding=pad, activation=act, gemm=gemm)
+        t.build(x.shape)
+        t.set_weights([W, b])
+        got = host(t(x))
+        want = O.tdnn(x, W, b, ctx, sub, pad, act, dtype=np.float64)
+        assert got.shape == want.shape, (got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err < tol, (gemm, B, T, D, U, ctx, sub, pad, act, err)
+
+
+def test_tdnn_gemm_is_linear_at_full_size():
+    # size-independent property at the BASELINE shape (998 frames x 1536 -> 512): f(a*x1 + x2) - f(0) is linear
+    rng = np.random.default_rng(17)
+    B, T, D, U = 2, 998, 512, 512
+    t = Ls.TDNN(U, context=[-2, 0, 2])
+    t.build((B, T, D))
+    x1 = dev(rng.standard_normal((B, T, D)).astype(np.float32))
+    x2 = dev(rng.standard_normal((B, T, D)).astype(np.float32))
+    f0 = t(torch.zeros_like(x1))
+    lhs = t(2.0 * x1 + x2) - f0
+    rhs = 2.0 * (t(x1) - f0) + (t(x2) - f0)
+    assert (lhs - rhs).abs().max().item() < 5e-4
+    # time-shift equivariance away from the clamped edges
+    y = t(x1)
+    ys = t(torch.roll(x1, 5, dims=1))
+    assert (ys[:, 10:-10] - torch.roll(y, 5, dims=1)[:, 10:-10]).abs().max().item() == 0.0
+
+
+# ----------------------------------------------------------------------------- a11 StatsPooling
+def test_stats_pooling_goldens():
+    for name in G.STATS_CONFIGS:
+        cfg, x, want = G.stats_case(name)
+        got = host(Ls.StatsPooling(**cfg, name="stats")(x))
+        assert got.shape == want.shape, (name, got.shape, want.shape)
+        assert G.rmse(want, got) <= 4e-6, name                   # stats_pooling_test.py:26
+    cfg, x, want = G.stats_case("stats_mean_std")
+    cfg["reduce_time_axis"] = True
+    got = host(Ls.StatsPooling(**cfg)(x))
+    assert got.shape == (1, 1, 6) and G.rmse(want[:, 0:1, :], got) <= 4e-6
+
+
+def test_stats_pooling_valid_and_large():
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((3, 61, 10)).astype(np.float32)
+    for kw in [dict(left_context=-4, right_context=4, padding="VALID"), dict(left_context=-3, right_context=6, padding="VALID", input_period=3, output_period=3),
+               dict(left_context=0, right_context=100, padding="VALID")]:
+        got = host(Ls.StatsPooling(**kw)(x))
+        want = O.stats_pooling(x, **kw, dtype=np.float64)
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-5, kw
+    x = (rng.standard_normal((4, 998, 1500)) + 0.5).astype(np.float32)
+    got = host(Ls.StatsPooling(0, 10000, reduce_time_axis=True)(x))
+    want = O.stats_pooling(x, 0, 10000, reduce_time_axis=True, dtype=np.float64)
+    assert got.shape == (4, 1, 3000) and np.abs(got - want).max() < 2e-5
+    xb = dev(x).to(torch.bfloat16)
+    gotb = host(Ls.StatsPooling(0, 10000, reduce_time_axis=True)(xb))
+    wantb = O.stats_pooling(host(xb), 0, 10000, reduce_time_axis=True, dtype=np.float64)
+    assert np.abs(gotb - wantb).max() < 2e-5
+
+
+# ----------------------------------------------------------------------------- a16 PLDA
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.float64, 2e-5)])
+def test_plda_goldens(dtype, tol):
+    z = G.load("plda.npz")
+    p = ktf.io.KaldiPldaReader(G.GOLDEN + "/plda.bin", True)
+    layer = Ls.PLDA(512, p.mean, p.transformMat, p.psi, return_transformed=True, normalize_length=True,
+                    simple_length_norm=False, dtype=dtype)
+    scores, tr = layer(z["plda_input"])
+    assert tuple(tr.shape) == z["plda_transformed"].shape and tuple(scores.shape) == z["plda_scores"].shape
+    assert G.rmse(z["plda_transformed"], host(tr)) <= tol       # plda_test.py:30
+    assert G.rmse(z["plda_scores"], host(scores)) <= tol
+    s64, t64 = O.plda(z["plda_input"], p.mean, p.transformMat, p.psi, dtype=np.float64)
+    lim = 1e-9 if dtype == torch.float64 else 2e-3
+    assert np.abs(host(scores) - s64).max() < lim * max(1.0, np.abs(s64).max())
+    only = Ls.PLDA(512, p.mean, p.transformMat, p.psi, return_transformed=False, dtype=dtype)(z["plda_input"])
+    assert torch.equal(only, scores)
+    simple = Ls.PLDA(512, p.mean, p.transformMat, p.psi, simple_length_norm=True, dtype=dtype)(z["plda_input"][:, 0, :])
+    ssim, _ = O.plda(z["plda_input"], p.mean, p.transformMat, p.psi, simple_length_norm=True, dtype=np.float64)
+    assert np.abs(host(simple[0]) - ssim).max() < (1e-8 if dtype == torch.float64 else 5e-2)
+
+
+def test_plda_1024_trial_matrix_properties():
+    # BASELINE config 5 shape: 1024 x 1024 trials, dim 128, synthetic model; checked against the fp64 oracle on a
+    # subset and through the symmetry of the score matrix (scores[i,j] == scores[j,i] for this model family)
+    rng = np.random.default_rng(31)
+    dim, B = 128, 1024
+    A = (rng.standard_normal((dim, dim)) / np.sqrt(dim) + np.eye(dim)).astype(np.float64)
+    mean = rng.standard_normal(dim) * 0.1
+    psi = np.sort(rng.uniform(0.05, 30.0, dim))[::-1].copy()
+    x = rng.standard_normal((B, dim))
+    scores, tr = Ls.PLDA(dim, mean, A, psi)(x)
+    s = host(scores)
+    assert s.shape == (B, B) and np.abs(s - s.T).max() < 1e-8
+    want, _ = O.plda(x[:48], mean, A, psi, dtype=np.float64)
+    assert np.abs(s[:48, :48] - want).max() < 1e-8
+
+
+# ----------------------------------------------------------------------------- whole pipeline
+def _extract_oracle(wav, cfg, w):
+    return O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64, return_intermediates=True)
+
+
+@pytest.mark.parametrize("narrow", [True, False])
+def test_extractor_f32_vs_oracle(narrow):
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=narrow)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="f32")
+    wav = synth.make_wav(3, 16000 * 4 + 123, seed=1234, ragged=True)
+    want, inter = _extract_oracle(wav, cfg, w)
+    mfcc, feats, lens = mdl.features(dev(wav))
+    lens_h = lens.cpu().numpy()
+    for b in range(wav.shape[0]):
+        assert np.abs(host(mfcc[b]) - inter[b]["mfcc"]).max() < 2e-3      # log-domain features of sigma=1000 noise
+        assert lens_h[b] == len(inter[b]["voiced"]) and 0 < lens_h[b] <= mfcc.shape[1]
+        assert np.abs(host(feats[b, : lens_h[b]]) - inter[b]["cmvn"]).max() < 2e-3
+    assert (lens_h < mfcc.shape[1]).any()           # the ragged input really exercises compaction
+    got = host(mdl(dev(wav)))
+    assert got.shape == want.shape == (3, 128)
+    err = np.abs(got - want).max()
+    print(f"extractor f32 narrow={narrow}: max-abs dev vs fp64 oracle {err:.3e}")
+    assert err <= 1e-4, err                                               # north_star bound
+    assert np.allclose(np.linalg.norm(got, axis=-1), np.sqrt(128.0), rtol=1e-5)
+    # batch semantics: a batch equals independent batch-1 calls (the reference is only defined for B=1)
+    for b in range(wav.shape[0]):
+        one = mdl(dev(wav[b:b + 1]))
+        assert tuple(one.shape) == (128,)
+        assert np.array_equal(host(one), got[b])
+
+
+@pytest.mark.parametrize("gemm,tol", [("bf16x3", 1e-4), ("bf16", 5e-2)])
+def test_extractor_reduced_precision_modes(gemm, tol):
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=False)
+    wav = synth.make_wav(2, 16000 * 3, seed=99, ragged=True)
+    want, _ = _extract_oracle(wav, cfg, w)
+    got = host(synth.build_extractor(ktf, cfg, w, gemm=gemm)(dev(wav)))
+    err = np.abs(got - want).max()
+    print(f"extractor {gemm}: max-abs dev vs fp64 oracle {err:.3e}")
+    assert err <= tol, (gemm, err)
+
+
+def test_extractor_edge_cases():
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=1, narrow=True)
+    mdl = synth.build_extractor(ktf, cfg, w)
+    # utterance shorter than the CMVN window (global-mean branch, cmvn.py:214-222) and exactly one frame more
+    for n in [400 + 160 * 120, 400 + 160 * 300, 400 + 160 * 301]:
+        wav = synth.make_wav(2, n, seed=n)
+        want, _ = _extract_oracle(wav, cfg, w)
+        got = host(mdl(dev(wav)))
+        assert np.abs(got - want).max() <= 1e-4, n
+    with pytest.raises(ValueError):
+        mdl(dev(np.zeros((1, 399), np.float32)))
+    # permutation equivariance over the batch at the full 10 s size
+    wav = synth.make_wav(4, 160000, seed=7, ragged=True)
+    a = host(mdl(dev(wav)))
+    b = host(mdl(dev(wav[::-1].copy())))
+    assert np.array_equal(a, b[::-1])
+
+
+def test_sequential_from_config_dense_input_equals_oracle():
+    w = synth.make_weights(seed=5, narrow=True)
+    mdl = synth.build_sequential(ktf, w)
+    x = np.random.default_rng(2).standard_normal((3, 150, 30)).astype(np.float32)
+    got = host(mdl(x))
+    want = O.sequential_forward(synth.oracle_layers(w), x, dtype=np.float64)
+    assert got.shape == want.shape == (3, 1, 512)
+    assert np.abs(got - want).max() < 1e-4
+    y = dev(x)
+    for l in mdl.layers:
+        y = l(y)
+    assert np.abs(host(y) - want).max() < 1e-4

@@ -1,0 +1,357 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol the header declares, argument validation
+works without a GPU, and the host-side logic (Kaldi readers, kaldi_numpy helpers, config builders, weight import,
+layer constructors) behaves like the reference. No kernel is launched here."""
+
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import yaml
+
+import _golden as G
+import synth
+import kaldi_tflite_amd as ktf
+from kaldi_tflite_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- C-ABI
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ktf_hip.h")).read()
+    declared = set(re.findall(r"\b(ktf_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(L.PROTOTYPES), declared ^ set(L.PROTOTYPES)
+    lib = L.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ktf_version() == 100
+
+
+def test_abi_argument_validation_without_gpu():
+    lib = L.load()
+    cfg = L.FrontendCfg(frame_size=400, frame_shift=160, nfft=500, num_mels=30, num_ceps=30)
+    tab = L.FrontendTables()
+    rc = lib.ktf_frontend_f32(None, 1, 16000, 0, C.byref(cfg), C.byref(tab), 3, None, None, 0, None)
+    assert rc == -1 and "null" in L.last_error()
+    buf = (C.c_float * 4)()
+    rc = lib.ktf_frontend_f32(buf, 1, 16000, 0, C.byref(cfg), C.byref(tab), 3, buf, None, 0, None)
+    assert rc == -1 and "power of two" in L.last_error()
+    with pytest.raises(ValueError):
+        L.check(rc, "x")
+    d = L.TdnnDesc(units=8, din=3, din_pad=32, nctx=2, subsampling=1)
+    d.ctx[0], d.ctx[1] = 1, -1
+    rc = lib.ktf_tdnn(buf, 1, 8, 32, None, C.byref(d), buf, None, None, None, None, buf, 8, None, None)
+    assert rc == -1 and "ascending" in L.last_error()
+    v = L.VadCfg(energy_threshold=5, energy_mean_scale=0.5, proportion_threshold=0.6, frames_context=2, energy_coeff=40)
+    assert lib.ktf_vad_mask_f32(buf, 1, 10, 30, C.byref(v), buf, None) == -1
+
+
+def test_host_side_size_helpers():
+    lib = L.load()
+    assert lib.ktf_num_frames(160000, 400, 160) == 998          # 10 s @ 16 kHz (Framing does not pad)
+    assert lib.ktf_num_frames(48000, 400, 160) == 298
+    assert lib.ktf_num_frames(399, 400, 160) == 0
+    d = L.TdnnDesc(units=8, din=3, din_pad=32, nctx=3, subsampling=1, valid=1)
+    d.ctx[0], d.ctx[1], d.ctx[2] = -2, 0, 2
+    assert lib.ktf_tdnn_out_len(10, C.byref(d)) == 6
+    d.valid = 0
+    d.subsampling = 3
+    assert lib.ktf_tdnn_out_len(10, C.byref(d)) == 4
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(ktf.KtfBackendError):
+        ktf.layers.Framing()(np.arange(16000, dtype=np.float32))
+
+
+# ----------------------------------------------------------------------------- readers (io/kaldi/*_test.py of the reference)
+def test_nnet3_reader_matches_reference_parse():
+    z = G.load("nnet3_narrow_parsed.npz")
+    r = ktf.io.KaldiNnet3Reader(os.path.join(G.GOLDEN, "tdnn_narrow.final.raw"), True)
+    assert r.config == json.loads(str(z["config_json"]))
+    assert [[c["name"], c["type"]] for c in r.components] == json.loads(str(z["names_json"]))
+    n = 0
+    for c in r.components:
+        for k, v in c.items():
+            key = f"{c['name']}|{k}"
+            if key in z.files:
+                assert np.array_equal(np.asarray(v), z[key]), key
+                n += 1
+    assert n >= 30
+    w = r.getWeights("tdnn1.affine")
+    assert len(w) == 2 and w[0].shape == (5, 15) and w[1].shape == (5,)
+    bn = r.getWeights("tdnn1.batchnorm")
+    assert len(bn) == 3 and np.ndim(bn[0]) == 0
+    with pytest.raises(KeyError):
+        r.getWeights("nonexistent")
+    # same values as the python-literal copy the reference keeps (nnet3_reader_test.py)
+    _, by, _, _ = G.narrow_layers()
+    assert np.abs(w[0] - by["tdnn1.affine"]["params"]).max() <= 1e-7
+
+
+def test_nnet3_reader_single_layer_file():
+    r = ktf.io.KaldiNnet3Reader(os.path.join(G.GOLDEN, "tdnn_single_layer.final.raw"), True)
+    z = G.load("tdnn.npz")
+    assert np.array_equal(r.components[0]["params"], z["single_W"])
+    assert np.array_equal(r.components[0]["bias"], z["single_b"])
+
+
+def test_text_mode_object_reader_not_supported():
+    with pytest.raises(NotImplementedError):
+        ktf.io.KaldiObjReader(os.path.join(G.GOLDEN, "xvectors_train_combined_200k.mean.vec.txt"), False)
+
+
+def test_plda_reader():
+    z = G.load("plda_parsed_head.npz")
+    p = ktf.io.KaldiPldaReader(os.path.join(G.GOLDEN, "plda.bin"), True)
+    assert tuple(z["transform_shape"]) == p.transformMat.shape == (512, 512)
+    assert np.array_equal(p.mean, z["mean"]) and np.array_equal(p.psi, z["psi"])
+    assert np.array_equal(p.transformMat[0], z["transform_row0"])
+    lit = G.load("plda.npz")
+    assert np.abs(p.mean - lit["plda_model_mean"]).max() <= 1e-9        # plda_reader_test.py tolerance
+    assert np.abs(np.diag(p.transformMat) - lit["plda_model_transform_diag"]).max() <= 1e-9
+
+
+def test_read_kaldi_array_binary_and_text(tmp_path):
+    vb = ktf.io.ReadKaldiArray(os.path.join(G.GOLDEN, "xvectors_train_combined_200k.mean.vec"), binary=True)
+    vt = ktf.io.ReadKaldiArray(os.path.join(G.GOLDEN, "xvectors_train_combined_200k.mean.vec.txt"), binary=False)
+    assert vb.shape == vt.shape == (512,)
+    assert G.rmse(vb, vt) <= 5e-8                                        # array_reader_test.py tolerance
+    mb = ktf.io.ReadKaldiArray(os.path.join(G.GOLDEN, "xvectors_train_combined_200k.transform.mat"), binary=True)
+    assert mb.shape == (128, 513)
+    head = ktf.io.ReadKaldiArray(os.path.join(G.GOLDEN, "xvectors_train_combined_200k.transform.mat.head4.txt"), binary=False)
+    flat = head.reshape(-1) if head.ndim == 2 else np.concatenate([np.asarray(r) for r in head])
+    assert G.rmse(flat, mb.reshape(-1)[: flat.size]) <= 5e-7
+    # round trip through our own writers (matrix with several rows, text)
+    m = np.arange(12, dtype=np.float32).reshape(3, 4)
+    p = tmp_path / "m.txt"
+    p.write_text(" [\n  0 1 2 3\n  4 5 6 7\n  8 9 10 11 ]\n")
+    assert np.array_equal(ktf.io.ReadKaldiArray(str(p), binary=False), m)
+    synth.write_bin_mat(str(tmp_path / "m.bin"), m)
+    assert np.array_equal(ktf.io.ReadKaldiArray(str(tmp_path / "m.bin"), binary=True), m)
+    (tmp_path / "bad.bin").write_bytes(b"\0BXX 1234")
+    with pytest.raises(ValueError):
+        ktf.io.ReadKaldiArray(str(tmp_path / "bad.bin"), binary=True)
+    (tmp_path / "open.txt").write_text(" [\n 1 2 3\n")
+    with pytest.raises(ValueError):
+        ktf.io.ReadKaldiArray(str(tmp_path / "open.txt"), binary=False)
+
+
+# ----------------------------------------------------------------------------- kaldi_numpy
+def test_kaldi_numpy_matches_reference_outputs():
+    z = G.load("kaldi_numpy.npz")
+    frames = z["frames"]
+    for i, o in enumerate(json.loads(str(z["configs_json"]))):
+        kw = dict(dither=0.0, remove_dc_offset=True, preemphasis_coefficient=0.97, window_type="povey", raw_energy=True)
+        kw.update(o)
+        w, e = ktf.kaldi_numpy.ProcessFrames(frames, **kw)
+        assert np.allclose(w, z[f"windows_{i}"], rtol=0, atol=1e-12)
+        assert np.allclose(e, z[f"energy_{i}"], rtol=0, atol=1e-12)
+    for i, (fl, fs, sf) in enumerate(z["framing_configs"]):
+        N = int(10 * sf)
+        m, k = int(sf * fl / 1000.0), int(sf * fs / 1000.0)
+        x = np.arange(0, N)
+        fr = ktf.kaldi_numpy.ExtractFrames(x, fl, fs, sf, True)
+        assert fr.shape == tuple(z[f"framing_{i}_snip_shape"]) and np.array_equal(fr[:, 0], z[f"framing_{i}_snip_first_col"])
+        xp = ktf.kaldi_numpy.PadWaveform(x, m, k)
+        assert xp.shape[-1] == int(z[f"framing_{i}_pad_len"])
+        assert np.array_equal(xp[: 2 * m], z[f"framing_{i}_pad_head"]) and np.array_equal(xp[-2 * m:], z[f"framing_{i}_pad_tail"])
+        frp = ktf.kaldi_numpy.ExtractFrames(xp, fl, fs, sf, False)
+        assert frp.shape == tuple(z[f"framing_{i}_nosnip_shape"]) and np.array_equal(frp[-1], z[f"framing_{i}_nosnip_last_row"])
+    x = z["cmvn_np_in"]
+    for j, (w, nv, pad) in enumerate([(300, False, "SAME"), (300, True, "SAME"), (201, False, "VALID"), (900, True, "SAME")]):
+        got = ktf.kaldi_numpy.ApplyCMVN(x, center=True, norm_vars=nv, window=w, padding=pad)
+        assert np.allclose(got, z[f"cmvn_np_out_{j}"], rtol=0, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        ktf.kaldi_numpy.ApplyCMVN(x)
+
+
+# ----------------------------------------------------------------------------- layer constructors / config errors
+def test_layer_constructor_errors_match_reference():
+    Ls = ktf.layers
+    for kw in [{"frame_length_ms": 0}, {"frame_shift_ms": -1}, {"sample_frequency": 0}, {"frame_length_ms": 0.01}]:
+        with pytest.raises(ValueError):
+            Ls.Framing(**kw)
+    with pytest.raises(ValueError):
+        Ls.Framing().build((None, None))
+    with pytest.raises(ValueError):
+        Ls.Framing().build((1, 100))
+    with pytest.raises(ValueError):
+        Ls.Windowing(preemphasis_coefficient=1.5)
+    with pytest.raises(ValueError):
+        Ls.Windowing(window_type="kaiser")
+    for kw in [{"num_bins": 2}, {"sample_frequency": 0}, {"low_freq_cutoff": 9000}, {"low_freq_cutoff": 500, "high_freq_cutoff": 400}]:
+        with pytest.raises(ValueError):
+            Ls.FilterBank(**kw)
+    with pytest.raises(NotImplementedError):
+        Ls.DCT(10, dct_type=3)
+    with pytest.raises(NotImplementedError):
+        Ls.DCT(10, norm="none")
+    with pytest.raises(ValueError):
+        Ls.DCT(0)
+    with pytest.raises(ValueError):
+        Ls.DCT(40).build((1, 10, 30))
+    with pytest.raises(ValueError):
+        Ls.MFCC(num_mfccs=31, num_mels=30)
+    for kw in [{"energy_mean_scale": -1}, {"frames_context": -1}, {"proportion_threshold": 0}, {"proportion_threshold": 1}]:
+        with pytest.raises(ValueError):
+            Ls.VAD(**kw)
+    with pytest.raises(NotImplementedError):
+        Ls.CMVN(center=False)
+    with pytest.raises(ValueError):
+        Ls.CMVN(window=0)
+    with pytest.raises(ValueError):
+        Ls.CMVN(padding="causal")
+    with pytest.raises(ValueError):
+        Ls.TDNN(8, subsampling_factor=0)
+    with pytest.raises(ValueError):
+        Ls.TDNN(8, padding="causal")
+    with pytest.raises(ValueError):
+        Ls.TDNN(8, context="x")
+    for kw in [{"left_context": 1, "right_context": 0}, {"left_context": 0, "right_context": -1},
+               {"left_context": 0, "right_context": 1, "input_period": 0},
+               {"left_context": 0, "right_context": 1, "input_period": 2, "output_period": 3}]:
+        with pytest.raises(ValueError):
+            Ls.StatsPooling(**kw)
+    with pytest.raises(AssertionError):
+        Ls.PLDA(4, np.zeros(3), np.eye(4), np.ones(4))
+    with pytest.raises(AssertionError):
+        Ls.PLDA(4, np.zeros(4), np.zeros((4, 3)), np.ones(4))
+
+
+def test_layer_shapes_configs_and_weights():
+    Ls = ktf.layers
+    f = Ls.Framing(25.0, 10.0, 16000.0)
+    assert (f.frameSize, f.frameShift, f.numFrames(160000)) == (400, 160, 998)
+    assert f.compute_output_shape([1, 48000]) == [1, 298, 400]
+    assert f.get_config()["frame_length"] == 25.0
+    t = Ls.TDNN(32, context=[1, -3, 0, -1], activation="relu", name="t")
+    assert t.context == [-3, -1, 0, 1] and t.kernelWidth == 4
+    t2 = Ls.TDNN.from_config({"units": 32, "context": [-3, -1, 0, 1], "subsampling_factor": 1, "padding": "SAME",
+                              "activation": "relu", "use_bias": True})          # tdnn_test.py:40
+    z = G.load("tdnn.npz")
+    t2.build((1, 8, 30))
+    t2.set_weights([z["single_W"], z["single_b"]])
+    assert t2.kernel.shape == (1, 4, 30, 32)
+    assert np.array_equal(t2.kaldi_matrix(), z["single_W"])
+    assert np.array_equal(t2.kernel, Ls.reshapeKaldiTdnnWeights(z["single_W"], 32, 4))
+    assert t2.kernel[0, 2, 7, 5] == z["single_W"][5, 2 * 30 + 7]
+    with pytest.raises(ValueError):
+        t2.set_weights([z["single_W"]])
+    with pytest.raises(ValueError):
+        t2.set_weights([z["single_W"], z["single_b"]], fmt="onnx")
+    t2.set_weights(t2.get_weights(), fmt="tensorflow")
+    assert t2.compute_output_shape((1, 8, 30)) == (1, 8, 32)
+    tv = Ls.TDNN(4, context=[-2, 0, 2], padding="VALID", subsampling_factor=2)
+    assert tv.compute_output_shape((1, 11, 3)) == (1, 4, 4)
+    bn = Ls.BatchNorm(name="bn")
+    bn.set_weights([np.float32(2.0), np.array([1.0, 2.0], np.float32), np.array([4.0, 9.0], np.float32)])
+    g, m, v = bn.get_weights()
+    assert np.array_equal(g, [2.0, 2.0])
+    s, h = bn.affine()
+    assert np.allclose(s, 2.0 / np.sqrt(np.array([4.0, 9.0]) + 1e-3)) and np.allclose(h, -m * s)
+    with pytest.raises(ValueError):
+        bn.set_weights([1.0, m])
+    c = Ls.CMVN(window=300, padding="VALID")
+    assert c.compute_output_shape([1, 998, 30]) == [1, 998 - 299, 30]
+    sp = Ls.StatsPooling(0, 10000, reduce_time_axis=True)
+    assert sp.compute_output_shape((2, 998, 1500)) == (2, 1, 3000)
+    spv = Ls.StatsPooling(-4, 4, padding="VALID")
+    assert spv.compute_output_shape((1, 16, 3)) == (1, 9, 6)
+    m = Ls.MFCC(num_mfccs=30, num_mels=30)
+    m.build((1, 998, 400))
+    assert m._cfg.nfft == 512 and m.filterbank.melBank.shape == (257, 30) and m.dct.dct.shape == (30, 30)
+    assert np.all(m.filterbank.melBank[256] == 0)
+
+
+def test_mel_dct_tables_equal_oracle():
+    from oracle import ktf_oracle as O
+    from kaldi_tflite_amd import ops
+    for nb, hi in [(23, -400.0), (30, 7600.0), (40, 0.0)]:
+        hi_abs = hi if hi > 0 else hi + 8000.0
+        nfft, bank = ops.mel_bank_dense(400, nb, 16000.0, 20.0, hi_abs)
+        nfft2, bank2 = O.mel_bank(400, nb, 16000.0, hi, 20.0)
+        assert nfft == nfft2 == 512 and np.array_equal(bank, bank2)
+    assert np.array_equal(ops.dct_matrix(30, 30), O.dct_matrix(30, 30))
+    assert np.array_equal(ops.lifter_coeffs(30, 22), O.lifter_coeffs(30, 22))
+    for w in ["povey", "hamming", "hanning", "rectangular", "sine", "blackman"]:
+        assert np.array_equal(ops.window_function(w, 400), O.window_function(w, 400))
+
+
+# ----------------------------------------------------------------------------- builders (sequential_test.py / xvector_extractor.py)
+def test_sequential_from_config_errors():
+    S = ktf.models.SequentialFromConfig
+    with pytest.raises(ValueError):
+        S({"layers": []})
+    with pytest.raises(ValueError):
+        S({"layers": [{"name": "tdnn1", "type": "affine", "cfg": {"units": 4}}]})
+    with pytest.raises(ValueError):
+        S({"layers": [{"name": "input", "type": "input", "shape": [None, None, 3]}, {"name": "x", "type": "conv9"}]})
+    with pytest.raises(KeyError):
+        S({"layers": [{"name": "input", "type": "input", "shape": [None, None, 3]}, {"name": "x"}]})
+
+
+def test_sequential_from_config_with_nnet3_file(tmp_path):
+    w = synth.make_weights(seed=7, narrow=True)
+    path = str(tmp_path / "final.raw")
+    synth.write_nnet3(path, w)
+    r = ktf.io.KaldiNnet3Reader(path, True)
+    assert len(r.components) == 18 and r.components[-1]["name"] == "tdnn6.affine"
+    mdl = ktf.models.SequentialFromConfig(synth.model_config(narrow=True), path, "cmvn2xvec")
+    names = [l.name for l in mdl.layers]
+    assert names[:3] == ["tdnn1.affine", "tdnn1.relu", "tdnn1.batchnorm"] and names[-2:] == ["stats", "tdnn6.affine"]
+    assert len(names) == 17
+    for name in ["tdnn1", "tdnn3", "tdnn5"]:
+        W, b = w[f"{name}.affine"]
+        l = mdl.get_layer(f"{name}.affine")
+        assert np.array_equal(l.kaldi_matrix(), W) and np.array_equal(l.bias, b)
+        rms, mean, var = w[f"{name}.batchnorm"]
+        bn = mdl.get_layer(f"{name}.batchnorm")
+        assert np.array_equal(bn.moving_mean, mean) and np.array_equal(bn.moving_variance, var) and np.all(bn.gamma == rms)
+    assert np.array_equal(mdl.get_layer("tdnn6.affine").kaldi_matrix(), w["tdnn6.affine"][0])
+    plan = mdl._plan()
+    assert [s[0] for s in plan] == ["tdnn"] * 5 + ["stats", "tdnn"] and all(s[2] and s[3] is not None for s in plan[:5])
+
+
+def test_xvector_extractor_from_config_builds(tmp_path):
+    w = synth.make_weights(seed=9, narrow=True)
+    mdir = tmp_path / "0008_sitw_v2_1a" / "exp" / "xvector_nnet_1a"
+    (mdir / "xvectors_train_combined_200k").mkdir(parents=True)
+    synth.write_nnet3(str(mdir / "final.raw"), w)
+    synth.write_text_vec(str(mdir / "xvectors_train_combined_200k" / "mean.vec"), w["mean"])
+    synth.write_bin_mat(str(mdir / "xvectors_train_combined_200k" / "transform.mat"), w["lda"])
+    kcfg = {"name": "0008_sitw_v2_1a", "sample_rate": 16000,
+            "download": {"link": "https://kaldi-asr.org/models/8/0008_sitw_v2_1a.tar.gz", "hash": "0" * 64},
+            "model_config": synth.model_config(narrow=True)}
+    (tmp_path / "kaldi.yml").write_text(yaml.safe_dump(kcfg))
+    ecfg = synth.extractor_cfg()
+    ecfg["xvec"] = {"model_config_path": str(tmp_path / "kaldi.yml"), "model_path": str(mdir / "final.raw"),
+                    "global_mean_path": str(mdir / "xvectors_train_combined_200k" / "mean.vec"),
+                    "lda_matrix_path": str(mdir / "xvectors_train_combined_200k" / "transform.mat")}
+    (tmp_path / "extractor.yml").write_text(yaml.safe_dump({"name": "0008_sitw_v2_1a", "extractor": ecfg}))
+    mdl = ktf.models.XvectorExtractorFromConfig(str(tmp_path / "extractor.yml"))
+    assert mdl.ldaMat.shape == (512, 128) and mdl.ldaOffset.shape == (1, 128) and mdl.xvecGlobalMean.shape == (512,)
+    assert np.array_equal(mdl.ldaMat, w["lda"][:, :-1].T) and np.allclose(mdl.xvecGlobalMean, w["mean"])
+    assert np.array_equal(mdl.xvec.get_layer("tdnn2.affine").kaldi_matrix(), w["tdnn2.affine"][0])
+    assert (mdl.framing.frameSize, mdl.mfcc.numMfccs, mdl.vad.framesContext, mdl.cmvn.N) == (400, 30, 2, 300)
+    os.remove(str(mdir / "final.raw"))
+    with pytest.raises(FileNotFoundError):
+        ktf.models.XvectorExtractorFromConfig(str(tmp_path / "extractor.yml"))
+
+
+def test_reference_yaml_topology_is_parseable():
+    # the two nnet3 topologies the reference ships (0008 16 kHz/30-dim, 0006 8 kHz/23-dim/128-out), restated as dicts
+    for feat, out in [(30, 512), (23, 128)]:
+        cfg = synth.model_config()
+        cfg["layers"][0]["shape"] = [None, None, feat]
+        cfg["layers"][-1]["cfg"]["units"] = out
+        mdl = ktf.models.SequentialFromConfig(cfg, None, "cmvn2xvec")
+        assert mdl.get_layer("tdnn1.affine").kernel.shape == (1, 5, feat, 512)
+        assert mdl.get_layer("tdnn6.affine").kernel.shape == (1, 1, 3000, out)
