@@ -186,10 +186,10 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
                 }
             }
             if (cfg.remove_dc) {
-                float s = 0.0f;
+                double s = 0.0;   // fp64 accumulation: one rounding for the mean
 #pragma unroll
-                for (int j = 0; j < NV; ++j) s += v[j];
-                const float mean = wave_sum(s) / (float)M;
+                for (int j = 0; j < NV; ++j) s += (double)v[j];
+                const float mean = (float)(wave_sum_d(s) / (double)M);
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const int i = lane + KTF_WAVE * j;
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
                 }
             }
             if (cfg.use_energy && cfg.raw_energy) {
-                float s = 0.0f;
+                double s = 0.0;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) s += v[j] * v[j];
-                const float e = logf(fmaxf(wave_sum(s), 0.0f) + cfg.eps);
+                for (int j = 0; j < NV; ++j) s += (double)v[j] * (double)v[j];
+                const float e = (float)log(fmax(wave_sum_d(s), 0.0) + (double)cfg.eps);
                 logE = fmaxf(e, cfg.energy_floor);
             }
             if (cfg.preemph > 0.0f) {
@@ -224,10 +224,10 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
                 v[j] = (i < M) ? v[j] * lds[L.window + i] : 0.0f;
             }
             if (cfg.use_energy && !cfg.raw_energy) {
-                float s = 0.0f;
+                double s = 0.0;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) s += v[j] * v[j];
-                const float e = logf(fmaxf(wave_sum(s), 0.0f) + cfg.eps);
+                for (int j = 0; j < NV; ++j) s += (double)v[j] * (double)v[j];
+                const float e = (float)log(fmax(wave_sum_d(s), 0.0) + (double)cfg.eps);
                 logE = fmaxf(e, cfg.energy_floor);
             }
         }

@@ -27,13 +27,13 @@ template <typename T, bool VEC2>
 __global__ __launch_bounds__(256) void stats_pool_kernel(const T* __restrict__ x, int64_t Tmax, int D, int64_t ldx,
                                                          const int32_t* __restrict__ lens, int period, int include_std,
                                                          float eps, float* __restrict__ out, int64_t ldo) {
-    __shared__ float red[4][2][128];
+    __shared__ double red[4][2][128];   // fp64 sums: E[x^2]-mean^2 of a (near-)constant channel must not cancel to noise
     const int b = blockIdx.y;
     const int len = lens ? lens[b] : (int)Tmax;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c0 = blockIdx.x * 128 + lane * 2;
     const T* xb = x + (int64_t)b * Tmax * ldx;
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    double s0 = 0., s1 = 0., q0 = 0., q1 = 0.;
     const int nrows = len <= 0 ? 0 : (len + period - 1) / period;
     if (c0 < D) {
         const bool two = (c0 + 1 < D);
@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const T* __restrict__ x
             float2 v;
             if (VEC2 && two) v = load2<T>(p);
             else { v.x = load1<T>(p); v.y = two ? load1<T>(p + 1) : 0.f; }
-            s0 += v.x; s1 += v.y;
-            q0 += v.x * v.x; q1 += v.y * v.y;
+            s0 += (double)v.x; s1 += (double)v.y;
+            q0 += (double)v.x * (double)v.x; q1 += (double)v.y * (double)v.y;
         }
     }
     red[rg][0][lane * 2] = s0; red[rg][0][lane * 2 + 1] = s1;
@@ -52,14 +52,14 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const T* __restrict__ x
     if (threadIdx.x < 128) {
         const int c = blockIdx.x * 128 + threadIdx.x;
         if (c < D) {
-            const float s = red[0][0][threadIdx.x] + red[1][0][threadIdx.x] + red[2][0][threadIdx.x] + red[3][0][threadIdx.x];
-            const float q = red[0][1][threadIdx.x] + red[1][1][threadIdx.x] + red[2][1][threadIdx.x] + red[3][1][threadIdx.x];
-            const float n = (float)nrows;
-            const float mean = s / n;
-            out[(int64_t)b * ldo + c] = mean;
+            const double s = red[0][0][threadIdx.x] + red[1][0][threadIdx.x] + red[2][0][threadIdx.x] + red[3][0][threadIdx.x];
+            const double q = red[0][1][threadIdx.x] + red[1][1][threadIdx.x] + red[2][1][threadIdx.x] + red[3][1][threadIdx.x];
+            const double n = (double)nrows;
+            const double mean = s / n;
+            out[(int64_t)b * ldo + c] = (float)mean;
             if (include_std) {
-                const float var = q / n - mean * mean;
-                out[(int64_t)b * ldo + D + c] = sqrtf(fmaxf(var, 0.0f) + eps);
+                const double var = q / n - mean * mean;
+                out[(int64_t)b * ldo + D + c] = (float)sqrt(fmax(var, 0.0) + (double)eps);
             }
         }
     }
@@ -77,17 +77,17 @@ __global__ void stats_pool_windowed_kernel(const float* __restrict__ x, int64_t 
         const int64_t bj = e / D;
         const int64_t j = bj % Tout, b = bj / Tout;
         const int64_t centre = start + j * out_period;
-        float s = 0.f, q = 0.f, n = 0.f;
+        double s = 0., q = 0., n = 0.;
         for (int o = left; o < rc; o += in_period) {
             const int64_t t = centre + o;
             if (t >= 0 && t < T) {
                 const float v = x[(b * T + t) * D + c];
-                s += v; q += v * v; n += 1.f;
+                s += (double)v; q += (double)v * (double)v; n += 1.;
             }
         }
-        const float mean = s / n;
-        out[(b * Tout + j) * od + c] = mean;
-        if (include_std) out[(b * Tout + j) * od + D + c] = sqrtf(fmaxf(q / n - mean * mean, 0.f) + eps);
+        const double mean = s / n;
+        out[(b * Tout + j) * od + c] = (float)mean;
+        if (include_std) out[(b * Tout + j) * od + D + c] = (float)sqrt(fmax(q / n - mean * mean, 0.0) + (double)eps);
     }
 }
 

@@ -123,7 +123,7 @@ def test_dct_layer_and_unfused_chain_equal_fused():
     c[..., 0] = host(e)[..., 0]
     assert np.abs(c - fused).max() < 2e-5
     ref = O.dct(host(fb), m["num_mfccs"], dtype=np.float64)
-    assert np.abs(host(Ls.DCT(m["num_mfccs"])(fb)) - ref).max() < 2e-5
+    assert np.abs(host(Ls.DCT(m["num_mfccs"])(fb)) - ref).max() < 5e-5     # 30-term fp32 dot products of |x| ~ 20
 
 
 # ----------------------------------------------------------------------------- a6 VAD (exact)
