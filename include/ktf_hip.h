@@ -164,7 +164,7 @@ int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D, const KtfV
  *   post(v)   = v * scale[u] + shift[u]   when scale != NULL (BatchNorm folded to an affine)
  * x: (B, T, ldx) of x_dtype; W: (units_pad, nctx*Din_pad) row-major of w_dtype, zero padded, where Din_pad is
  * Din rounded up to a multiple of 32 (must be <= ldx; pad columns of x must be finite) and units_pad is units rounded
- * up to 128. For KTF_GEMM_BF16X3 `w` holds the hi part and `w_lo` the lo part (both bf16); x is fp32.
+ * up to 256 (the widest N-tile of the kernels). For KTF_GEMM_BF16X3 `w` holds the hi part and `w_lo` the lo part (both bf16); x is fp32.
  * y: (B, T_out_max, ldy) of y_dtype; out_lens[b] (may be NULL) receives the valid output rows of utterance b.
  */
 typedef struct KtfTdnnDesc {

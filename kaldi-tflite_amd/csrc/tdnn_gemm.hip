@@ -335,6 +335,354 @@ __global__ __launch_bounds__(256) void tdnn_bf16_kernel(TdnnParams p) {
             store_tile32(acc[i][j], p, out_row0, rows_valid, wm * 64 + i * 32, n0 + wn * 64 + j * 32, lane);
 }
 
+// ------------------------------------------------------------------------------------ BF16, direct-to-LDS staging
+// The throughput kernel for bf16 activations: 128x128 tile, K-step 64, both operands staged with
+// global_load_lds_dwordx4 (no VGPR round trip, no ds_write). The LDS image is lane-linear ([row][64] bf16, 128-B rows),
+// so bank conflicts of the ds_read_b128 fragment reads are removed by permuting the 16-B chunks of each row on the
+// SOURCE address (chunk' = chunk ^ ((row>>1)&7)) and applying the same involution on the read address.
+// 1-D grid, XCD-aware: block id -> (xcd = id % 8, slot = id / 8); an XCD walks its own M-tiles and runs all N-tiles of
+// one M-tile back to back, so the gathered activation rows are fetched into that XCD's L2 once.
+// The epilogue stages the fp32 accumulators through LDS and writes whole 256-B row segments.
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef __attribute__((address_space(1))) const void glb_ptr_t;
+
+#define G_BM 128
+#define G_BN 128
+#define G_BK 64
+#define G_TILE_BYTES (128 * G_BK * 2)          // one operand tile: 16 KiB
+#define G_STAGE_BYTES (2 * G_TILE_BYTES)       // A + B
+#define G_EPI_PITCH 132                         // floats per staged output row
+#define G_LDS_BYTES (128 * G_EPI_PITCH * 4)    // 67,584 B >= 2 stages (65,536 B)
+
+__global__ __launch_bounds__(256) void tdnn_bf16g_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = (slot / ntiles) * 8 + xcd;     // global M-tile index
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * G_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = nt * G_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)b * p.T * p.ldx;
+    const unsigned short* wb = reinterpret_cast<const unsigned short*>(p.w);
+
+    // staging map: chunk q = i*256 + tid -> row q/8, LDS position q%8, global chunk (q%8) ^ ((row>>1)&7)
+    int a_t[4];
+    int src_chunk[4];
+    const unsigned short* wrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q >> 3;
+        src_chunk[i] = ((q & 7) ^ ((row >> 1) & 7)) * 8;
+        a_t[i] = start + (t0 + row) * p.sub;
+        wrow[i] = wb + (int64_t)(n0 + row) * p.ktot + src_chunk[i];
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / G_BK;
+    const int steps_per_ctx = p.din_pad / G_BK;
+
+#define G_STAGE(STG, KS)                                                                                              \
+    {                                                                                                                 \
+        const int ks_ = (KS);                                                                                         \
+        const int c_ = ks_ / steps_per_ctx;                                                                           \
+        const int d0_ = (ks_ - c_ * steps_per_ctx) * G_BK;                                                            \
+        const int off_ = p.ctx[c_];                                                                                   \
+        unsigned char* sa_ = gsm + (STG) * G_STAGE_BYTES + wave * 1024;                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                               \
+            int r = a_t[i] + off_;                                                                                    \
+            r = r < 0 ? 0 : (r > len - 1 ? len - 1 : r);                                                              \
+            const unsigned short* ga = xb + (int64_t)r * p.ldx + d0_ + src_chunk[i];                                  \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)ga, (lds_ptr_t*)(sa_ + i * 4096), 16, 0, 0);                  \
+            const unsigned short* gb = wrow[i] + (int64_t)ks_ * G_BK;                                                 \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)gb, (lds_ptr_t*)(sa_ + G_TILE_BYTES + i * 4096), 16, 0, 0);  \
+        }                                                                                                             \
+    }
+
+    G_STAGE(0, 0);
+    __syncthreads();
+    // fragment addressing: lane (r = lane&31, h = lane>>5) reads row R, k = kk + 8h .. +7  ->  chunk (kk/8 + h) ^ ((R>>1)&7)
+    const int rsw = ((lane & 31) >> 1) & 7;
+    const int a_row_off = (wm * 64 + (lane & 31)) * 128;   // bytes
+    const int b_row_off = (wn * 64 + (lane & 31)) * 128;
+    const int hsel = lane >> 5;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int stage = ks & 1;
+        if (ks + 1 < nk) G_STAGE(stage ^ 1, ks + 1);
+        const unsigned char* sa = gsm + stage * G_STAGE_BYTES;
+        const unsigned char* sb = sa + G_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < G_BK / 16; ++kk) {
+            const int coff = (((kk * 2 + hsel) ^ rsw) << 4);
+            bfrag8 a[2], bq[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                a[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 32 * 128 + coff);
+                bq[i] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + i * 32 * 128 + coff);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef G_STAGE
+
+    // ---- epilogue: bias / activation / BN affine on the accumulators, stage fp32 tile in LDS, coalesced row stores
+    float* et = reinterpret_cast<float*>(gsm);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int nl = wn * 64 + j * 32 + (lane & 31);
+        const int n = n0 + nl;
+        const bool nv = n < p.units;
+        const float bias = (nv && p.bias) ? p.bias[n] : 0.0f;
+        const float sc = (nv && p.scale) ? p.scale[n] : 1.0f;
+        const float sh = (nv && p.shift) ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = apply_act(acc[i][j][r] + bias, p.act);
+                if (p.scale) v = v * sc + sh;
+                et[m * G_EPI_PITCH + nl] = v;
+            }
+        }
+    }
+    __syncthreads();
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+    const int cl = (tid & 15) * 4;                 // 4 columns at cl and 4 at 64 + cl
+#pragma unroll
+    for (int pass = 0; pass < 8; ++pass) {
+        const int m = pass * 16 + (tid >> 4);
+        if (m >= rows_valid) continue;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int nl = half * 64 + cl;
+            const int n = n0 + nl;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(et + m * G_EPI_PITCH + nl);
+            const int64_t off = (out_row0 + m) * p.ldy + n;
+            if (n + 4 <= p.units) {
+                if (p.y_dtype == KTF_F32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + off) = v;
+                } else {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                    pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < p.units) {
+                        if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off + e] = v[e];
+                        else reinterpret_cast<unsigned short*>(p.y)[off + e] = f2bf(v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ BF16, 256x256 tile, 4-deep LDS ring
+// The large-layer throughput kernel. One workgroup = 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA 32x32 tiles) owns a
+// 256 x 256 output tile: 32 B of staged operand per MFMA-cycle-pair instead of 64 (the 128x128 kernel is L2->LDS bound).
+// Operands are staged with global_load_lds_dwordx4 into a ring of four 32 KiB stages (K-step 32: 64-B rows, chunk
+// permutation chunk ^ ((row>>2)&3) on the source, same involution on the read). Loads run THREE K-steps ahead and stay
+// in flight across the single raw s_barrier per K-step: the wait before the barrier is a counted s_waitcnt vmcnt(8|4|0)
+// (4 DMA instructions per thread per stage), never a drain.
+#define R_BM 256
+#define R_BN 256
+#define R_BK 32
+#define R_NSTAGE 4
+#define R_TILE_BYTES (256 * R_BK * 2)           // 16 KiB per operand
+#define R_STAGE_BYTES (2 * R_TILE_BYTES)        // 32 KiB
+#define R_EPI_PITCH 260
+#define R_LDS_BYTES (R_NSTAGE * R_STAGE_BYTES)  // 131,072 B (epilogue staging needs 64*260*4 = 66,560 B)
+
+template <int ACT>
+__global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = (slot / ntiles) * 8 + xcd;
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * R_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = nt * R_BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)b * p.T * p.ldx;
+    const unsigned short* wb = reinterpret_cast<const unsigned short*>(p.w);
+
+    // staging map: chunk q = i*512 + tid -> row q/4, LDS position q%4, global chunk (q%4) ^ ((row>>2)&3)
+    int a_t[2], src_chunk[2];
+    const unsigned short* wrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q >> 2;
+        src_chunk[i] = ((q & 3) ^ ((row >> 2) & 3)) * 8;
+        a_t[i] = start + (t0 + row) * p.sub;
+        wrow[i] = wb + (int64_t)(n0 + row) * p.ktot + src_chunk[i];
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / R_BK;
+    const int steps_per_ctx = p.din_pad / R_BK;
+
+#define R_STAGE(KS)                                                                                                   \
+    {                                                                                                                 \
+        const int ks_ = (KS);                                                                                         \
+        const int c_ = ks_ / steps_per_ctx;                                                                           \
+        const int d0_ = (ks_ - c_ * steps_per_ctx) * R_BK;                                                            \
+        const int off_ = p.ctx[c_];                                                                                   \
+        unsigned char* sa_ = rsm + (ks_ & (R_NSTAGE - 1)) * R_STAGE_BYTES + wave * 1024;                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
+            int r = a_t[i] + off_;                                                                                    \
+            r = r < 0 ? 0 : (r > len - 1 ? len - 1 : r);                                                              \
+            const unsigned short* ga = xb + (int64_t)r * p.ldx + d0_ + src_chunk[i];                                  \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)ga, (lds_ptr_t*)(sa_ + i * 8192), 16, 0, 0);                  \
+            const unsigned short* gb = wrow[i] + (int64_t)ks_ * R_BK;                                                 \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)gb, (lds_ptr_t*)(sa_ + R_TILE_BYTES + i * 8192), 16, 0, 0);  \
+        }                                                                                                             \
+    }
+
+    // prologue: three stages in flight
+    R_STAGE(0);
+    if (nk > 1) R_STAGE(1);
+    if (nk > 2) R_STAGE(2);
+
+    const int rsw = ((lane & 31) >> 2) & 3;
+    const int a_row_off = (wm * 128 + (lane & 31)) * 64;   // bytes (64-B rows)
+    const int b_row_off = (wn * 64 + (lane & 31)) * 64;
+    const int hsel = lane >> 5;
+    for (int ks = 0; ks < nk; ++ks) {
+        // stage ks must have landed: everything issued after it may stay in flight (4 DMA instructions per stage)
+        const int ahead = nk - 1 - ks;
+        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // every wave has finished reading stage ks-1 (it is past the barrier): refill that buffer with stage ks+3
+        if (ks + 3 < nk) R_STAGE(ks + 3);
+        const unsigned char* sa = rsm + (ks & (R_NSTAGE - 1)) * R_STAGE_BYTES;
+        const unsigned char* sb = sa + R_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < R_BK / 16; ++kk) {
+            const int coff = (((kk * 2 + hsel) ^ rsw) << 4);
+            bfrag8 a[4], bq[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 32 * 64 + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bq[j] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + j * 32 * 64 + coff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef R_STAGE
+    __syncthreads();   // all fragment reads done before the LDS is reused by the epilogue
+
+    // ---- epilogue: four passes of 64 staged rows (wave (wm, wn) contributes its 32 x 64 block of pass i)
+    float* et = reinterpret_cast<float*>(rsm);
+    float bias[2], sc[2], sh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        const bool nv = n < p.units;
+        bias[j] = (nv && p.bias) ? p.bias[n] : 0.0f;
+        sc[j] = (nv && p.scale) ? p.scale[n] : 1.0f;
+        sh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
+    }
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+    const int nl = lane * 4;                      // this lane's 4 columns of the 256-wide staged row
+    const int n = n0 + nl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r] + bias[j];
+                if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                v = v * sc[j] + sh[j];
+                et[srow * R_EPI_PITCH + col] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {
+            const int srow = sp * 8 + wave;          // one staged row per wave: 256 contiguous columns
+            const int m = (srow >> 5) * 128 + i * 32 + (srow & 31);
+            if (m < rows_valid) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + nl);
+                const int64_t off = (out_row0 + m) * p.ldy + n;
+                if (n + 4 <= p.units) {
+                    if (p.y_dtype == KTF_F32) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + off) = v;
+                    } else {
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.units) {
+                            if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off + e] = v[e];
+                            else reinterpret_cast<unsigned short*>(p.y)[off + e] = f2bf(v[e]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------ elementwise helpers
 __global__ void affine_act_kernel(const float* __restrict__ x, int64_t total, int D, int act,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
@@ -431,7 +779,30 @@ extern "C" int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const 
             if (k64) BF_LAUNCH(64, true, false); else BF_LAUNCH(32, true, false);
         } else {
             KTF_REQUIRE(d->x_dtype == KTF_BF16, "ktf_tdnn: bad x_dtype");
-            if (k64) BF_LAUNCH(64, false, false); else BF_LAUNCH(32, false, false);
+            if (d->units > 128 && ldy % 4 == 0) {
+                // W must be padded to a multiple of 256 rows for this kernel (documented in ktf_hip.h)
+                const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
+                const int64_t gtiles = B * (int64_t)mtiles;
+                const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
+                KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
+#define R_LAUNCH(A)                                                                                                    \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
+        hipLaunchKernelGGL(tdnn_bf16r_kernel<A>, dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles); \
+    } while (0)
+                if (d->act == KTF_ACT_NONE) R_LAUNCH(KTF_ACT_NONE);
+                else if (d->act == KTF_ACT_RELU) R_LAUNCH(KTF_ACT_RELU);
+                else if (d->act == KTF_ACT_SIGMOID) R_LAUNCH(KTF_ACT_SIGMOID);
+                else R_LAUNCH(KTF_ACT_TANH);
+#undef R_LAUNCH
+            } else if (k64 && ldy % 4 == 0) {
+                const int mtiles = ktf_cdiv(Tout, G_BM), ntiles_g = ktf_cdiv(d->units, G_BN);
+                const int64_t gtiles = B * (int64_t)mtiles;
+                const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_g;
+                KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
+                (void)hipFuncSetAttribute((const void*)tdnn_bf16g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+                hipLaunchKernelGGL(tdnn_bf16g_kernel, dim3((unsigned)nblocks), dim3(256), G_LDS_BYTES, st, p, mtiles, ntiles_g, (int)gtiles);
+            } else if (k64) BF_LAUNCH(64, false, false); else BF_LAUNCH(32, false, false);
         }
 #undef BF_LAUNCH
     } else {

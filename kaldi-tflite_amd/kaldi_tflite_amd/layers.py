@@ -706,7 +706,7 @@ class TDNN(Layer):
         if key in self._dev:
             return self._dev[key]
         K, D = self.kernelWidth, self.inputDim
-        Dp, Up = ops.round_up(D, 32), ops.round_up(self.units, 128)
+        Dp, Up = ops.round_up(D, 32), ops.round_up(self.units, 256)
         W = np.zeros((Up, K, Dp), np.float32)
         W[: self.units, :, :D] = np.transpose(self.kernel[0], (2, 0, 1))     # [u, k, d]
         W = torch.as_tensor(W.reshape(Up, K * Dp), device=device)
