@@ -149,15 +149,27 @@ class _GemmProfiler:
             prof.events.append(((int(desc.units), int(desc.nctx), int(desc.din)), s, e))
             return r
 
+        self.orig_stats = ops.tdnn_stats
+
+        def wrapped_stats(x, lens, desc, *a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = prof.orig_stats(x, lens, desc, *a, **k)
+            e.record()
+            prof.events.append(((int(desc.units), int(desc.nctx), int(desc.din), "+stats"), s, e))
+            return r
+
         ops.tdnn = wrapped
+        ops.tdnn_stats = wrapped_stats
 
     def finish(self):
         self.ops.tdnn = self.orig
+        self.ops.tdnn_stats = self.orig_stats
         total, per = 0.0, {}
         for key, s, e in self.events:
             ms = s.elapsed_time(e)
             total += ms
-            name = f"{key[1]}x{key[2]}->{key[0]}"
+            name = f"{key[1]}x{key[2]}->{key[0]}" + (key[3] if len(key) > 3 else "")
             per[name] = per.get(name, 0.0) + ms
         n = max(len(self.events), 1)
         steps = max(len(self.events) // 5, 1)

@@ -13,6 +13,14 @@
 
 #define FE_WAVES 4
 #define FE_THREADS (FE_WAVES * KTF_WAVE)
+// Each wave works on wave-private LDS buffers: the LDS executes one wave's DS instructions in issue order, so a
+// compiler-level ordering point is all a write -> cross-lane read hand-off inside ONE wave needs (no s_barrier).
+#define WAVE_SYNC()                           \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_wave_barrier();      \
+        asm volatile("" ::: "memory");        \
+    } while (0)
 
 struct FeLds {  // offsets (in floats) into the dynamic LDS block
     int window, tw, rtw, dct, lifter, mel_start, mel_len, mel_w, per_wave, wave_stride, total;
@@ -247,14 +255,14 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
         // ---- FilterBank.call: zero-padded real FFT of size NF via a complex FFT of size N2
 #pragma unroll
         for (int j = 0; j < NV; ++j) bufA[lane + KTF_WAVE * j] = v[j];
-        __syncthreads();
+        WAVE_SYNC();
         float2* src = reinterpret_cast<float2*>(bufA);
         float2* dst = reinterpret_cast<float2*>(bufB);
         {
             int nn = N2, ls = 0;
             while (nn > 1) {
                 fft_stage<N2>(src, dst, W, nn, ls, lane);
-                __syncthreads();
+                WAVE_SYNC();
                 if ((nn & 3) == 0) { nn >>= 2; ls += 2; } else { nn >>= 1; ls += 1; }
                 float2* t = src; src = dst; dst = t;
             }
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
             const float mag = sqrtf(xr * xr + xi * xi);
             P[k] = cfg.use_power ? mag * mag : mag;
         }
-        __syncthreads();
+        WAVE_SYNC();
         float* feat = reinterpret_cast<float*>(src);  // FFT output no longer needed
         for (int f = lane; f < nm; f += KTF_WAVE) {
             const int s0 = mel_start[f], len = mel_len[f];
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
                 feat[f] = acc;
             }
         }
-        __syncthreads();
+        WAVE_SYNC();
         if (out_stage == KTF_OUT_FBANK) continue;
 
         // ---- DCT.call + lifter + C0 <- log-energy (mfcc.py:205-228)
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
             if (c == 0 && cfg.use_energy) acc = logE;
             if (valid) out[row * (int64_t)nc + c] = acc;
         }
-        __syncthreads();  // feat/P are rewritten by the next frame
+        WAVE_SYNC();  // feat/P are rewritten by the next frame
     }
 }
 

@@ -18,6 +18,8 @@
 //          at 3 MFMA passes.
 //
 // Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88) of the reference.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
@@ -520,8 +522,11 @@ __global__ __launch_bounds__(256) void tdnn_bf16g_kernel(TdnnParams p, int mtile
 #define R_EPI_PITCH 260
 #define R_LDS_BYTES (R_NSTAGE * R_STAGE_BYTES)  // 131,072 B (epilogue staging needs 64*260*4 = 66,560 B)
 
-template <int ACT>
-__global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles) {
+// STATS: instead of storing y, the epilogue adds every column's sum and sum of squares over the tile's valid rows (fp64)
+// into stats[b][0|1][unit] — statistics pooling fused into the producing GEMM, the (B,T,units) activation never exists.
+template <int ACT, bool STATS, int DBG = 0>
+__global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
+                                                         double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
@@ -536,22 +541,27 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
     const int t0 = mt * R_BM;
     if (t0 >= out_len || len <= 0) return;
     const int n0 = nt * R_BN;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: LDS-DMA bases stay in SGPRs
     const int wm = wave >> 2, wn = wave & 3;
 
-    const unsigned short* xb = reinterpret_cast<const unsigned short*>(p.x) + (int64_t)b * p.T * p.ldx;
-    const unsigned short* wb = reinterpret_cast<const unsigned short*>(p.w);
+    // Uniform 64-bit bases + per-lane 32-bit byte offsets: every DMA address is base(SGPR) + offset(VGPR), so the K-loop
+    // carries no 64-bit vector arithmetic (an utterance's activations and a layer's weights are both < 4 GiB).
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;
+    const char* wb = reinterpret_cast<const char*>(p.w);
+    const unsigned ldxb = (unsigned)p.ldx * 2u;
 
     // staging map: chunk q = i*512 + tid -> row q/4, LDS position q%4, global chunk (q%4) ^ ((row>>2)&3)
-    int a_t[2], src_chunk[2];
-    const unsigned short* wrow[2];
+    int a_t[2];
+    unsigned a_cb[2], w_ob[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int q = i * 512 + tid;
         const int row = q >> 2;
-        src_chunk[i] = ((q & 3) ^ ((row >> 2) & 3)) * 8;
+        const unsigned chunk = (unsigned)(((q & 3) ^ ((row >> 2) & 3)) * 16);   // bytes
+        a_cb[i] = chunk;
         a_t[i] = start + (t0 + row) * p.sub;
-        wrow[i] = wb + (int64_t)(n0 + row) * p.ktot + src_chunk[i];
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + chunk;
     }
 
     f32x16 acc[4][2];
@@ -563,61 +573,121 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = p.ktot / R_BK;
-    const int steps_per_ctx = p.din_pad / R_BK;
+    const int lenm1 = len - 1;
 
-#define R_STAGE(KS)                                                                                                   \
-    {                                                                                                                 \
-        const int ks_ = (KS);                                                                                         \
-        const int c_ = ks_ / steps_per_ctx;                                                                           \
-        const int d0_ = (ks_ - c_ * steps_per_ctx) * R_BK;                                                            \
-        const int off_ = p.ctx[c_];                                                                                   \
-        unsigned char* sa_ = rsm + (ks_ & (R_NSTAGE - 1)) * R_STAGE_BYTES + wave * 1024;                              \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                               \
-            int r = a_t[i] + off_;                                                                                    \
-            r = r < 0 ? 0 : (r > len - 1 ? len - 1 : r);                                                              \
-            const unsigned short* ga = xb + (int64_t)r * p.ldx + d0_ + src_chunk[i];                                  \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)ga, (lds_ptr_t*)(sa_ + i * 8192), 16, 0, 0);                  \
-            const unsigned short* gb = wrow[i] + (int64_t)ks_ * R_BK;                                                 \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)gb, (lds_ptr_t*)(sa_ + R_TILE_BYTES + i * 8192), 16, 0, 0);  \
-        }                                                                                                             \
+    // iterator over the stage being issued: K-step index, context offset of its rows, byte offset inside the context
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 2;
+#define R_DMA_A(i)                                                                                                     \
+    {                                                                                                                  \
+        int r_ = a_t[i] + is_off;                                                                                      \
+        r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
+        const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                          \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_),                                                       \
+            (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + wave * 1024 + (i) * 8192), 16, 0, 0);        \
+    }
+#define R_DMA_B(i)                                                                                                     \
+    {                                                                                                                  \
+        const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                                 \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_),                                                       \
+            (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + R_TILE_BYTES + wave * 1024 + (i) * 8192),    \
+            16, 0, 0);                                                                                                 \
+    }
+#define R_ADVANCE()                                                                                                    \
+    {                                                                                                                  \
+        ++is_ks;                                                                                                       \
+        is_db += R_BK * 2;                                                                                             \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
     }
 
     // prologue: three stages in flight
-    R_STAGE(0);
-    if (nk > 1) R_STAGE(1);
-    if (nk > 2) R_STAGE(2);
+    for (int s_ = 0; s_ < 3 && s_ < nk; ++s_) {
+        R_DMA_A(0) R_DMA_B(0) R_DMA_A(1) R_DMA_B(1)
+        R_ADVANCE()
+    }
 
     const int rsw = ((lane & 31) >> 2) & 3;
     const int a_row_off = (wm * 128 + (lane & 31)) * 64;   // bytes (64-B rows)
     const int b_row_off = (wn * 64 + (lane & 31)) * 64;
     const int hsel = lane >> 5;
+    const int coff0 = ((hsel ^ rsw) << 4), coff1 = (((2 + hsel) ^ rsw) << 4);
+    // Software pipeline: the barrier of K-step ks certifies stages ks AND ks+1 (one stage = 4 DMA instructions per thread
+    // stays in flight), so the first-half fragments of stage ks+1 are read during the MFMAs of stage ks and the matrix
+    // pipe restarts right after the next barrier instead of waiting for an LDS read burst of all 8 lock-stepped waves.
+    bfrag8 a0[4], b0[2];     // fragments of (current stage, k-half 0)
     for (int ks = 0; ks < nk; ++ks) {
-        // stage ks must have landed: everything issued after it may stay in flight (4 DMA instructions per stage)
-        const int ahead = nk - 1 - ks;
-        if (ahead >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if (DBG < 3) __builtin_amdgcn_s_barrier();      // DBG 3,4: no barrier (timing only)
         asm volatile("" ::: "memory");
-        // every wave has finished reading stage ks-1 (it is past the barrier): refill that buffer with stage ks+3
-        if (ks + 3 < nk) R_STAGE(ks + 3);
+        // every wave is past the barrier, i.e. has finished reading stage ks-1: that buffer is refilled with stage ks+3
+        // (the iterator's stage); its four DMA instructions are spread between the MFMA groups
+        const bool refill = (DBG == 0 || DBG == 2) && is_ks < nk;   // DBG 1,3,4: timing-only builds without the steady-state DMA
         const unsigned char* sa = rsm + (ks & (R_NSTAGE - 1)) * R_STAGE_BYTES;
         const unsigned char* sb = sa + R_TILE_BYTES;
+        if (ks == 0) {
 #pragma unroll
-        for (int kk = 0; kk < R_BK / 16; ++kk) {
-            const int coff = (((kk * 2 + hsel) ^ rsw) << 4);
-            bfrag8 a[4], bq[2];
+            for (int i = 0; i < 4; ++i) a0[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 32 * 64 + coff0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 32 * 64 + coff);
+            for (int j = 0; j < 2; ++j) b0[j] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + j * 32 * 64 + coff0);
+        }
+        bfrag8 a1[4], b1[2];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bq[j] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + j * 32 * 64 + coff);
+        for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = half * 2; i < half * 2 + 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+                    if (DBG != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" :: "v"(a0[i]), "v"(b0[j]));
+            __builtin_amdgcn_sched_barrier(0);   // keep the MFMA group ahead of the LDS reads / DMA that follow it
+            if (half == 0 && (DBG != 4 || ks == 0)) {
+                // second-half fragments of this stage: issued behind the first MFMA group so their latency is covered
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 32 * 64 + coff1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b1[j] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + j * 32 * 64 + coff1);
+            }
+            if (refill) {
+                if (half == 0) R_DMA_A(0) else R_DMA_B(0)
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i = half * 2; i < half * 2 + 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    if (DBG != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" :: "v"(a1[i]), "v"(b1[j]));
+            __builtin_amdgcn_sched_barrier(0);
+            if (half == 0 && ks + 1 < nk && DBG != 4) {
+                // pre-read the first-half fragments of stage ks+1 (landed and visible since this K-step's barrier); all
+                // MFMAs that consume the old a0/b0 have been issued
+                const unsigned char* san = rsm + ((ks + 1) & (R_NSTAGE - 1)) * R_STAGE_BYTES;
+                const unsigned char* sbn = san + R_TILE_BYTES;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a0[i] = *reinterpret_cast<const bfrag8*>(san + a_row_off + i * 32 * 64 + coff0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b0[j] = *reinterpret_cast<const bfrag8*>(sbn + b_row_off + j * 32 * 64 + coff0);
+            }
+            if (refill) {
+                if (half == 0) R_DMA_A(1) else R_DMA_B(1)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (is_ks < nk) R_ADVANCE()
     }
+#undef R_DMA_A
+#undef R_DMA_B
+#undef R_ADVANCE
+#define R_STAGE
 #undef R_STAGE
     __syncthreads();   // all fragment reads done before the LDS is reused by the epilogue
 
@@ -633,6 +703,36 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
         sh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
     }
     const int rows_valid = out_len - t0;
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] + bias[j];
+                    if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                    else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                    v = v * sc[j] + sh[j];
+                    if (m < rows_valid) {
+                        s += (double)v;
+                        q += (double)v * (double)v;
+                    }
+                }
+            }
+            s += __shfl_xor(s, 32, 64);      // the two half-waves hold the same column
+            q += __shfl_xor(q, 32, 64);
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (lane < 32 && n < p.units) {
+                double* dst = stats + ((int64_t)b * 2) * p.units + n;
+                atomicAdd(dst, s);
+                atomicAdd(dst + p.units, q);
+            }
+        }
+        return;
+    }
     const int64_t out_row0 = (int64_t)b * p.Tout + t0;
     const int nl = lane * 4;                      // this lane's 4 columns of the 256-wide staged row
     const int n = n0 + nl;
@@ -724,10 +824,15 @@ extern "C" int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d) {
     return n <= 0 ? 0 : (n + d->subsampling - 1) / d->subsampling;
 }
 
-extern "C" int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
-                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
-                        void* y, int64_t ldy, int32_t* out_lens, void* stream) {
-    KTF_REQUIRE(x && d && w && y, "ktf_tdnn: null argument");
+static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
+                       const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
+                       void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream) {
+    KTF_REQUIRE(x && d && w && (y || stats_sums), "ktf_tdnn: null argument");
+    if (stats_sums) {
+        KTF_REQUIRE(d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16 && d->units > 128 && !d->valid && d->subsampling == 1,
+                    "ktf_tdnn_stats: needs the bf16 256x256 kernel (bf16 activations, units > 128, SAME padding, no subsampling)");
+        ldy = (d->units + 3) / 4 * 4;
+    }
     KTF_REQUIRE(B >= 0 && T >= 0, "ktf_tdnn: negative size");
     KTF_REQUIRE(d->units > 0 && d->din > 0, "ktf_tdnn: units/din must be > 0");
     KTF_REQUIRE(d->nctx >= 1 && d->nctx <= 16, "ktf_tdnn: nctx %d outside [1,16]", d->nctx);
@@ -787,9 +892,29 @@ extern "C" int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const 
                 KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
 #define R_LAUNCH(A)                                                                                                    \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
-        hipLaunchKernelGGL(tdnn_bf16r_kernel<A>, dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles); \
+        if (stats_sums) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_bf16r_kernel<A, true>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        } else {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_bf16r_kernel<A, false>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr); \
+        }                                                                                                              \
     } while (0)
+                static const int dbg = getenv("KTF_GEMM_DBG") ? atoi(getenv("KTF_GEMM_DBG")) : 0;   // timing experiments only
+                if (dbg && d->act == KTF_ACT_RELU && !stats_sums) {
+#define R_DBG(N)                                                                                                      \
+    else if (dbg == N) {                                                                                              \
+        (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<KTF_ACT_RELU, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
+        hipLaunchKernelGGL((tdnn_bf16r_kernel<KTF_ACT_RELU, false, N>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr); \
+    }
+                    if (false) {}
+                    R_DBG(1) R_DBG(3) R_DBG(4)
+#undef R_DBG
+                    else {
+                        (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<KTF_ACT_RELU, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
+                        hipLaunchKernelGGL((tdnn_bf16r_kernel<KTF_ACT_RELU, false, 2>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr);
+                    }
+                } else
                 if (d->act == KTF_ACT_NONE) R_LAUNCH(KTF_ACT_NONE);
                 else if (d->act == KTF_ACT_RELU) R_LAUNCH(KTF_ACT_RELU);
                 else if (d->act == KTF_ACT_SIGMOID) R_LAUNCH(KTF_ACT_SIGMOID);
@@ -809,6 +934,49 @@ extern "C" int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const 
         KTF_REQUIRE(false, "ktf_tdnn: unknown gemm mode %d", d->gemm);
     }
     KTF_CHECK_LAUNCH("ktf_tdnn");
+    return KTF_OK;
+}
+
+extern "C" int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
+                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
+                        void* y, int64_t ldy, int32_t* out_lens, void* stream) {
+    KTF_REQUIRE(y, "ktf_tdnn: null output");
+    return tdnn_launch(x, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, y, ldy, out_lens, nullptr, stream);
+}
+
+extern "C" int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
+                              const void* w, const float* bias, const float* scale, const float* shift, double* sums,
+                              void* stream) {
+    KTF_REQUIRE(sums, "ktf_tdnn_stats: null sums");
+    return tdnn_launch(x, B, T, ldx, lens, d, w, nullptr, bias, scale, shift, nullptr, 0, nullptr, sums, stream);
+}
+
+// mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)
+__global__ void stats_finalize_kernel(const double* __restrict__ sums, const int32_t* __restrict__ lens, int64_t T,
+                                      int64_t B, int D, int include_std, float eps, float* __restrict__ out, int64_t ldo) {
+    const int64_t total = B * D;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = e / D;
+        const int c = (int)(e - b * D);
+        const double n = (double)(lens ? lens[b] : (int)T);
+        const double mean = sums[(b * 2) * D + c] / n;
+        out[b * ldo + c] = (float)mean;
+        if (include_std) {
+            const double var = sums[(b * 2 + 1) * D + c] / n - mean * mean;
+            out[b * ldo + D + c] = (float)sqrt(fmax(var, 0.0) + (double)eps);
+        }
+    }
+}
+
+extern "C" int ktf_stats_finalize(const double* sums, const int32_t* lens, int64_t T, int64_t B, int32_t D,
+                                  int32_t include_std, float eps, float* out, int64_t ld_out, void* stream) {
+    KTF_REQUIRE(sums && out, "ktf_stats_finalize: null argument");
+    KTF_REQUIRE(B >= 0 && D > 0 && ld_out >= (include_std ? 2 : 1) * (int64_t)D, "ktf_stats_finalize: bad sizes");
+    if (B == 0) return KTF_OK;
+    int blocks = ktf_cdiv(B * D, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, lens, T, B, D, include_std, eps, out, ld_out);
+    KTF_CHECK_LAUNCH("ktf_stats_finalize");
     return KTF_OK;
 }
 

@@ -369,6 +369,27 @@ def test_extractor_reduced_precision_modes(gemm, tol):
     assert err <= tol, (gemm, err)
 
 
+def test_fused_stats_pooling_matches_unfused():
+    # bf16 mode pools tdnn5's output inside the GEMM epilogue (ktf_tdnn_stats); it must agree with the separate
+    # TDNN -> StatsPooling kernels up to the bf16 rounding of the (otherwise materialised) activations
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=False)
+    wav = synth.make_wav(3, 16000 * 3 + 77, seed=5, ragged=True)
+    want, _ = _extract_oracle(wav, cfg, w)
+    fused = synth.build_extractor(ktf, cfg, w, gemm="bf16")
+    plain = synth.build_extractor(ktf, cfg, w, gemm="bf16")
+    plain.xvec.fuse_stats = False
+    a, b = host(fused(dev(wav))), host(plain(dev(wav)))
+    assert np.abs(a - want).max() < 5e-2 and np.abs(b - want).max() < 5e-2
+    assert np.abs(a - b).max() < 5e-3, np.abs(a - b).max()
+    # the pooled statistics themselves, against the fp64 oracle of the same bf16 network input
+    _, feats, lens = fused.features(dev(wav))
+    h_f = host(fused.xvec.run_ragged(feats, lens))
+    h_p = host(plain.xvec.run_ragged(feats, lens))
+    assert h_f.shape == h_p.shape == (3, 1, 512)
+    assert np.abs(h_f - h_p).max() < 2e-2 * max(1.0, np.abs(h_p).max())
+
+
 def test_extractor_edge_cases():
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=1, narrow=True)
