@@ -90,6 +90,12 @@ typedef struct KtfFrontendTables {   /* all DEVICE pointers, built once by the h
     const float* mel_w;        /* [num_mels][mel_stride] weights from mel_start            */
     const float* dct;          /* [num_mels][num_ceps] (filterbank.py melBank / dct.py dct) */
     const float* lifter;       /* [num_ceps] or NULL                                       */
+    /* optional tables of the register-resident nfft = 512 fast path (all three NULL = generic kernel); `reserved` = bins per mel work item */
+    const float* fast_tw;      /* [64][18] per-lane FFT twiddles: (re,im) of W256^(n0 r), W64^(n1 r), W16^(n2 r), r=1..3,
+                                  n0 = (l>>1)+32(l&1), n1 = (l>>1)&15, n2 = (l>>1)&3                                   */
+    const int32_t* fast_mel_meta; /* [64][4] per-lane mel work item: first bin, bins (<=16), filter (-1 = idle),
+                                     flags (1: lane+1 same filter, 2: lane+2 same filter, 4: first lane of the filter) */
+    const float* fast_mel_w;   /* [64][16] weights of the work item                                                  */
     int32_t mel_stride;
     int32_t reserved;
 } KtfFrontendTables;

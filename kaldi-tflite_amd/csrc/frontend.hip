@@ -334,6 +334,10 @@ __global__ void rowmat_kernel(const float* __restrict__ x, int64_t rows, int in_
     }
 }
 
+int ktf_frontend512_launch(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
+                           const KtfFrontendTables* tab, int32_t out_stage, float* out, uint64_t seed, int64_t T,
+                           hipStream_t st);   // frontend512.hip
+
 extern "C" int64_t ktf_num_frames(int64_t n_samples, int32_t frame_size, int32_t frame_shift) {
     if (frame_size <= 0 || frame_shift <= 0 || n_samples < frame_size) return 0;
     return 1 + (n_samples - frame_size) / frame_shift;
@@ -378,6 +382,9 @@ extern "C" int ktf_frontend_f32(const float* in, int64_t B, int64_t n, int32_t i
     if (in_kind == KTF_IN_WAV) KTF_REQUIRE(B == 0 || n >= cfg->frame_size, "ktf_frontend_f32: input of %lld samples is shorter than a frame (%d)", (long long)n, cfg->frame_size);
     const int64_t rows = B * T;
     if (rows == 0) return KTF_OK;
+    if (cfg->nfft == 512 && out_stage >= KTF_OUT_FBANK && tab->fast_tw && tab->fast_mel_meta && tab->fast_mel_w &&
+        cfg->num_mels <= 32 && (out_stage == KTF_OUT_FBANK || cfg->num_ceps <= 64))
+        return ktf_frontend512_launch(in, B, n, in_kind, cfg, tab, out_stage, out, seed, T, (hipStream_t)stream);
     FeLds L = fe_layout(*cfg, *tab, out_stage);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);
     KTF_REQUIRE(lds_bytes <= 160 * 1024, "ktf_frontend_f32: configuration needs %zu B of LDS (> 160 KiB)", lds_bytes);

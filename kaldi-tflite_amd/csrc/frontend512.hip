@@ -1,0 +1,354 @@
+// Register-resident fast path of the fused front-end for nfft = 512 (the 25 ms / 16 kHz configuration of every golden
+// and of the 0008_sitw_v2_1a model). Same arithmetic as frontend.hip, restructured so that one frame costs a fraction
+// of the vector instructions and no LDS traffic for the FFT:
+//   * the 512-point real FFT is a 256-point complex radix-4 FFT held ENTIRELY in registers (4 complex values per lane);
+//     the three inter-stage data movements are 4x4 register/lane transposes done with cross-lane VALU moves
+//     (v_permlane32_swap / v_permlane16_swap for lane bits 5 and 4, DPP row_ror:8 / row_shl|shr:4 with bank masks for
+//     bits 3 and 2, DPP quad_perm for bits 1 and 0) — no LDS, no address arithmetic; twiddles are per-lane constants;
+//   * one LDS round trip puts the spectrum in natural order for the real-FFT split (X[k], X[256-k]);
+//   * the sparse mel bank is spread over all 64 lanes as (filter, <=16-bin slice) work items with the weights in
+//     registers and a 2-step segmented reduction; the DCT column of each lane lives in registers.
+// Used by ktf_frontend_f32 when the caller provides the KtfFrontendTables.fast_* tables; any other configuration runs
+// the generic kernel of frontend.hip.
+#include "common.h"
+
+#define F5_WAVES 4
+#define F5_THREADS (F5_WAVES * KTF_WAVE)
+#define F5_MAXW 16          // bins per mel work item (upper bound; the table says how many are used)
+#define F5_MAXMEL 32        // DCT rows kept in registers
+
+// ---- cross-lane primitives (all VALU: no LDS pipe)
+#define DPP_QUAD_XOR1 0xB1      // quad_perm:[1,0,3,2]
+#define DPP_QUAD_XOR2 0x4E      // quad_perm:[2,3,0,1]
+#define DPP_ROW_SHL4 0x104
+#define DPP_ROW_SHR4 0x114
+#define DPP_ROW_ROR4 0x124
+#define DPP_ROW_ROR8 0x128
+#define DPP_WAVE_SHR1 0x138
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// lanes selected by BANK_MASK (banks = groups of 4 lanes inside each row of 16) take `src` moved by CTRL, the rest keep `old`
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_merge(float old, float src) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, BANK_MASK, false));
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    v += dpp_mov<DPP_QUAD_XOR2>(v);
+    v += dpp_mov<DPP_ROW_ROR4>(v);
+    v += dpp_mov<DPP_ROW_ROR8>(v);           // every lane: sum of its row of 16
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// radix-4 DIF butterfly with W4 = -i:  y_r = sum_k z_k (-i)^{kr}
+__device__ __forceinline__ void bfly4(float2 (&z)[4]) {
+    const float2 apc = cadd(z[0], z[2]), amc = csub(z[0], z[2]), bpd = cadd(z[1], z[3]);
+    const float2 jbmd = make_float2(-(z[1].y - z[3].y), z[1].x - z[3].x);   // i*(b-d)
+    z[0] = cadd(apc, bpd);
+    z[1] = csub(amc, jbmd);
+    z[2] = csub(apc, bpd);
+    z[3] = cadd(amc, jbmd);
+}
+
+// One step of a 4x4 register/lane transpose: lanes whose bit BIT is 0 hand register `b` to their partner (lane ^ 2^BIT)
+// and receive the partner's register `a` into `b`; lanes whose bit is 1 hand `a` and receive into `a`.
+template <int BIT>
+__device__ __forceinline__ void swap_step(float& a, float& b, int lane) {
+    if constexpr (BIT == 5) {
+        // v_permlane32_swap: lanes 32-63 of the first operand <-> lanes 0-31 of the second
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]);
+        b = __uint_as_float(r[1]);
+    } else if constexpr (BIT == 4) {
+        // v_permlane16_swap: odd rows (of 16 lanes) of the first operand <-> even rows of the second
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        a = __uint_as_float(r[0]);
+        b = __uint_as_float(r[1]);
+    } else if constexpr (BIT == 3) {
+        const float na = dpp_merge<DPP_ROW_ROR8, 0xC>(a, b);     // lanes 8-15 of a row: a <- partner's b
+        const float nb = dpp_merge<DPP_ROW_ROR8, 0x3>(b, a);     // lanes 0-7:           b <- partner's a
+        a = na; b = nb;
+    } else if constexpr (BIT == 2) {
+        const float na = dpp_merge<DPP_ROW_SHR4, 0xA>(a, b);     // lanes 4-7,12-15: a <- b of lane-4
+        const float nb = dpp_merge<DPP_ROW_SHL4, 0x5>(b, a);     // lanes 0-3,8-11:  b <- a of lane+4
+        a = na; b = nb;
+    } else {
+        const bool hi = (lane >> BIT) & 1;
+        const float s = hi ? a : b;
+        const float g = (BIT == 0) ? dpp_mov<DPP_QUAD_XOR1>(s) : dpp_mov<DPP_QUAD_XOR2>(s);
+        if (hi) a = g; else b = g;
+    }
+}
+
+// 4x4 transpose between the 4 registers of a lane and the 4 lanes that differ only in lane bits (BH, BL):
+// afterwards the lane at group position p = 2*bit(BH) + bit(BL) holds in register q what position q held in register p.
+template <int BH, int BL>
+__device__ __forceinline__ void transpose4(float2 (&r)[4], int lane) {
+    swap_step<BH>(r[0].x, r[2].x, lane); swap_step<BH>(r[0].y, r[2].y, lane);
+    swap_step<BH>(r[1].x, r[3].x, lane); swap_step<BH>(r[1].y, r[3].y, lane);
+    swap_step<BL>(r[0].x, r[1].x, lane); swap_step<BL>(r[0].y, r[1].y, lane);
+    swap_step<BL>(r[2].x, r[3].x, lane); swap_step<BL>(r[2].y, r[3].y, lane);
+}
+
+// Philox-based N(0,1) identical to frontend.hip (dither)
+__device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t i) {
+    uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32), c2 = i, c3 = 0x9E3779B9u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll 1
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+}
+
+#define F5_WAVE_SYNC()                           \
+    do {                                         \
+        asm volatile("" ::: "memory");           \
+        __builtin_amdgcn_wave_barrier();         \
+        asm volatile("" ::: "memory");           \
+    } while (0)
+
+template <bool DITHER>
+__global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const float* __restrict__ in, int64_t B, int64_t n,
+                                                                 int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
+                                                                 int out_stage, float* __restrict__ out,
+                                                                 uint64_t seed, int64_t T) {
+    constexpr int NF = 512, N2 = 256, NV = 8;
+    extern __shared__ __attribute__((aligned(16))) float lds5[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = cfg.frame_size;
+    const int nm = cfg.num_mels, nc = cfg.num_ceps;
+    const int maxw = tab.reserved;          // bins per mel work item actually used (<= F5_MAXW)
+
+    // LDS: window[512] | per wave: Z[256] float2, P[256] float, feat[64] float
+    float* win = lds5;
+    float* wbase = lds5 + NF + wave * (2 * N2 + N2 + 64);
+    float2* Zb = reinterpret_cast<float2*>(wbase);
+    float* Pb = wbase + 2 * N2;
+    float* feat = Pb + N2;
+    if (in_kind != KTF_IN_WINDOWED)
+        for (int i = tid; i < NF; i += F5_THREADS) win[i] = (i < M) ? tab.window[i] : 0.0f;
+    if (lane < 64) feat[lane] = 0.0f;
+
+    // ---- per-lane constants (registers for the whole kernel)
+    float2 tw1[3], tw2[3], tw3[3], rw[4];
+    {
+        const float* t = tab.fast_tw + lane * 18;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            tw1[r] = make_float2(t[2 * r], t[2 * r + 1]);
+            tw2[r] = make_float2(t[6 + 2 * r], t[6 + 2 * r + 1]);
+            tw3[r] = make_float2(t[12 + 2 * r], t[12 + 2 * r + 1]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane + 64 * j;
+            rw[j] = make_float2(tab.rtwiddle[2 * k], tab.rtwiddle[2 * k + 1]);
+        }
+    }
+    const int mel_start = tab.fast_mel_meta[lane * 4 + 0];
+    const int mel_filter = tab.fast_mel_meta[lane * 4 + 2];
+    const int mel_flags = tab.fast_mel_meta[lane * 4 + 3];      // bit0: lane+1 same filter, bit1: lane+2 same, bit2: first
+    float melw[F5_MAXW];                                        // zero beyond the item's length
+#pragma unroll
+    for (int j = 0; j < F5_MAXW; ++j) melw[j] = tab.fast_mel_w[lane * F5_MAXW + j];
+    float dctc[F5_MAXMEL];
+    float lift = 1.0f;
+    if (out_stage == KTF_OUT_MFCC) {
+#pragma unroll
+        for (int m = 0; m < F5_MAXMEL; ++m) dctc[m] = (m < nm && lane < nc) ? tab.dct[m * nc + lane] : 0.0f;
+        if (cfg.use_lifter && tab.lifter && lane < nc) lift = tab.lifter[lane];
+    }
+    // output index of this lane's FFT results: X[mo + 64*r4]
+    const int mo = (2 * (lane & 1) + ((lane >> 5) & 1)) + 4 * ((lane >> 3) & 3) + 16 * ((lane >> 1) & 3);
+    const bool even = (lane & 1) == 0;
+    const float invM = 1.0f / (float)M;
+    __syncthreads();
+
+    const int64_t rows = B * T;
+    const int64_t row_step = (int64_t)gridDim.x * F5_WAVES;
+    for (int64_t row0 = (int64_t)blockIdx.x * F5_WAVES; row0 < rows; row0 += row_step) {
+        const int64_t row = row0 + wave;
+        const bool valid = row < rows;   // wave-uniform
+        float v[NV];
+        float logE = 0.0f;
+        if (valid) {
+            const float* src;
+            if (in_kind == KTF_IN_WAV) {
+                const int64_t b = row / T, t = row - b * T;
+                src = in + b * n + t * (int64_t)cfg.frame_shift;
+            } else {
+                src = in + row * (int64_t)M;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + KTF_WAVE * j;
+                v[j] = (i < M) ? src[i] : 0.0f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = 0.0f;
+        }
+
+        // ---- Windowing.call (windowing.py:180-209)
+        if (in_kind != KTF_IN_WINDOWED) {
+            if (DITHER) {
+#pragma unroll 1
+                for (int j = 0; j < NV; ++j) {
+                    const int i = lane + KTF_WAVE * j;
+                    if (i < M) v[j] += gauss_noise5(seed, (uint64_t)row, (uint32_t)i) * cfg.dither;
+                }
+            }
+            if (cfg.remove_dc) {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) s += v[j];
+                const float mean = wave_sum_f(s) * invM;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = lane + KTF_WAVE * j;
+                    if (i < M) v[j] -= mean;
+                }
+            }
+            if (cfg.use_energy && cfg.raw_energy) {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) s = fmaf(v[j], v[j], s);
+                const float e = logf(fmaxf(wave_sum_f(s), 0.0f) + cfg.eps);
+                logE = fmaxf(e, cfg.energy_floor);
+            }
+            if (cfg.preemph > 0.0f) {
+                float y[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const float up = dpp_mov<DPP_WAVE_SHR1>(v[j]);                 // lane l gets lane l-1 (lane 0: 0)
+                    const float wrap = (j > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j > 0 ? j - 1 : 0]), 63))
+                                               : v[0];      // lane 0: sample i-1 lives in lane 63 of the previous register
+                    const float prev = (lane == 0) ? wrap : up;
+                    y[j] = v[j] - cfg.preemph * prev;
+                }
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[j] = y[j];
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] *= win[lane + KTF_WAVE * j];       // window is zero beyond M
+            if (cfg.use_energy && !cfg.raw_energy) {
+                float s = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) s = fmaf(v[j], v[j], s);
+                const float e = logf(fmaxf(wave_sum_f(s), 0.0f) + cfg.eps);
+                logE = fmaxf(e, cfg.energy_floor);
+            }
+        }
+
+        // ---- 256-point complex FFT of z[n] = x[2n] + i x[2n+1], in registers.
+        // lane l holds samples l + 64 j; after one lane^1 exchange it holds z[n0 + 64 k], n0 = (l>>1) + 32 (l&1)
+        float2 z[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float s = even ? v[2 * k + 1] : v[2 * k];          // what the partner needs from this lane
+            const float g = dpp_mov<DPP_QUAD_XOR1>(s);
+            z[k] = even ? make_float2(v[2 * k], g) : make_float2(g, v[2 * k + 1]);
+        }
+        bfly4(z);                                   // over k (stride 64)
+#pragma unroll
+        for (int r = 1; r < 4; ++r) z[r] = cmulf(z[r], tw1[r - 1]);
+        transpose4<0, 5>(z, lane);                  // group = lanes differing in bits {0, 5}  (n0 = n1 + 16 k2)
+        bfly4(z);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) z[r] = cmulf(z[r], tw2[r - 1]);
+        transpose4<4, 3>(z, lane);                  // n1 = n2 + 4 k3
+        bfly4(z);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) z[r] = cmulf(z[r], tw3[r - 1]);
+        transpose4<2, 1>(z, lane);                  // n2 = k4
+        bfly4(z);
+        // natural order through LDS (wave-private): Z[mo + 64 r4]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Zb[mo + 64 * r] = z[r];
+        F5_WAVE_SYNC();
+        // ---- split the packed spectrum, |X[k]|(^2)  (filterbank.py:232-235; bin 256 carries no mel weight)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = lane + 64 * j;
+            const float2 zk = Zb[k], zm = Zb[(N2 - k) & (N2 - 1)];
+            const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
+            const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
+            const float xr = er + rw[j].x * orr - rw[j].y * oi;
+            const float xi = ei + rw[j].x * oi + rw[j].y * orr;
+            const float mag = sqrtf(xr * xr + xi * xi);
+            Pb[k] = cfg.use_power ? mag * mag : mag;
+        }
+        F5_WAVE_SYNC();
+        // ---- sparse mel bank: this lane's slice of one filter (weights are zero beyond the slice; the reads stay inside
+        //      the wave's own P/feat area), then a segmented reduction over <= 4 adjacent lanes
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < F5_MAXW; ++j)
+            if (j < maxw) acc = fmaf(Pb[mel_start + j], melw[j], acc);
+        {
+            const float t1 = __shfl_down(acc, 1, 64);
+            if (mel_flags & 1) acc += t1;
+            const float t2 = __shfl_down(acc, 2, 64);
+            if (mel_flags & 2) acc += t2;
+        }
+        if (cfg.use_log) acc = logf(fmaxf(acc, 0.0f) + cfg.eps);
+        if (mel_flags & 4) {
+            if (out_stage == KTF_OUT_FBANK) {
+                if (valid) out[row * (int64_t)nm + mel_filter] = acc;
+            } else {
+                feat[mel_filter] = acc;
+            }
+        }
+        if (out_stage == KTF_OUT_FBANK) continue;
+        F5_WAVE_SYNC();
+        // ---- DCT (this lane's column, coefficients in registers; log-mel vector broadcast from LDS) + lifter + C0
+        float c = 0.0f;
+#pragma unroll
+        for (int m4 = 0; m4 < F5_MAXMEL / 4; ++m4) {
+            const f32x4 f = *reinterpret_cast<const f32x4*>(feat + 4 * m4);   // rows >= num_mels are zero
+            c = fmaf(f.x, dctc[4 * m4 + 0], c);
+            c = fmaf(f.y, dctc[4 * m4 + 1], c);
+            c = fmaf(f.z, dctc[4 * m4 + 2], c);
+            c = fmaf(f.w, dctc[4 * m4 + 3], c);
+        }
+        c *= lift;
+        if (lane == 0 && cfg.use_energy) c = logE;
+        if (valid && lane < nc) out[row * (int64_t)nc + lane] = c;
+        F5_WAVE_SYNC();
+    }
+}
+
+// launcher used by ktf_frontend_f32 (frontend.hip) when the fast tables are present and the configuration qualifies
+int ktf_frontend512_launch(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
+                           const KtfFrontendTables* tab, int32_t out_stage, float* out, uint64_t seed, int64_t T,
+                           hipStream_t st) {
+    const int64_t rows = B * T;
+    int blocks = ktf_cdiv(rows, F5_WAVES);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const size_t lds = sizeof(float) * (512 + F5_WAVES * (512 + 256 + 64));
+    if (cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED)
+        hipLaunchKernelGGL(frontend512_kernel<true>, dim3(blocks), dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
+                           out_stage, out, seed, T);
+    else
+        hipLaunchKernelGGL(frontend512_kernel<false>, dim3(blocks), dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
+                           out_stage, out, seed, T);
+    KTF_CHECK_LAUNCH("ktf_frontend_f32(fast512)");
+    return KTF_OK;
+}

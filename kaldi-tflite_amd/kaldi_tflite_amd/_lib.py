@@ -36,6 +36,7 @@ class FrontendTables(C.Structure):
     _fields_ = [
         ("window", C.c_void_p), ("twiddle", C.c_void_p), ("rtwiddle", C.c_void_p), ("mel_start", C.c_void_p),
         ("mel_len", C.c_void_p), ("mel_w", C.c_void_p), ("dct", C.c_void_p), ("lifter", C.c_void_p),
+        ("fast_tw", C.c_void_p), ("fast_mel_meta", C.c_void_p), ("fast_mel_w", C.c_void_p),
         ("mel_stride", C.c_int32), ("reserved", C.c_int32),
     ]
 

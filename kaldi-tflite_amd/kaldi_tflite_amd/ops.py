@@ -104,6 +104,61 @@ def lifter_coeffs(num_mfccs, q):
     return 1 + 0.5 * np.sin(np.pi * n / q) * q
 
 
+def fast512_tables(starts, lens, w, maxw=16):
+    """Per-lane constants of frontend512.hip: FFT twiddles of the lane-level radix-4 schedule and the split of the
+    sparse mel bank into <= 64 (filter, <= maxw-bin slice) work items with <= 4 adjacent lanes per filter."""
+    lane = np.arange(64)
+    n0 = (lane >> 1) + 32 * (lane & 1)
+    n1 = (lane >> 1) & 15
+    n2 = (lane >> 1) & 3
+    tw = np.zeros((64, 18), np.float64)
+    for r in (1, 2, 3):
+        for base, nn, N in ((0, n0, 256), (6, n1, 64), (12, n2, 16)):
+            ang = -2.0 * np.pi * nn * r / N
+            tw[:, base + 2 * (r - 1)] = np.cos(ang)
+            tw[:, base + 2 * (r - 1) + 1] = np.sin(ang)
+    def split(width):
+        its = []                                # (filter, start, len)
+        for f, (s0, ln) in enumerate(zip(starts, lens)):
+            if ln == 0:
+                its.append((f, s0, 0))
+                continue
+            parts = -(-ln // width)
+            if parts > 4:
+                return None
+            step = -(-ln // parts)
+            for p in range(parts):
+                a = p * step
+                b = min(ln, a + step)
+                its.append((f, s0 + a, b - a))
+        return its if len(its) <= 64 else None
+
+    items, used = None, None
+    for width in range(8, maxw + 1):            # smallest slice width that fits 64 lanes with <= 4 lanes per filter
+        items = split(width)
+        if items is not None:
+            used = max(ln for _, _, ln in items)
+            break
+    if items is None:
+        return None
+    meta = np.zeros((64, 4), np.int32)
+    meta[:, 2] = -1
+    mw = np.zeros((64, maxw), np.float32)
+    for i, (f, s0, ln) in enumerate(items):
+        meta[i, 0], meta[i, 1], meta[i, 2] = s0, ln, f
+        mw[i, :ln] = w[f, s0 - starts[f]: s0 - starts[f] + ln]
+    for i, (f, _, _) in enumerate(items):
+        fl = 0
+        if i + 1 < len(items) and items[i + 1][0] == f:
+            fl |= 1
+        if i + 2 < len(items) and items[i + 2][0] == f:
+            fl |= 2
+        if i == 0 or items[i - 1][0] != f:
+            fl |= 4
+        meta[i, 3] = fl
+    return tw, meta, mw, max(int(used), 1)
+
+
 class FrontendTables:
     """Device copies of every constant ktf_frontend_f32 needs, for one (frame_size, mel, dct) configuration."""
 
@@ -143,10 +198,20 @@ class FrontendTables:
             self.mel_start, self.mel_len, self.mel_w = i32(starts), i32(lens), f32(w)
         self.dct = f32(dct) if dct is not None else None
         self.lifter = f32(lifter) if lifter is not None else None
+        # tables of the register-resident nfft = 512 fast path (frontend512.hip)
+        self.fast_tw = self.fast_mel_meta = self.fast_mel_w = None
+        fast_maxw = 0
+        if self.nfft == 512 and mel_bank is not None and self.num_mels <= 32:
+            fast = fast512_tables(starts, lens, w)
+            if fast is not None:
+                self.fast_tw, self.fast_mel_meta, self.fast_mel_w = f32(fast[0]), i32(fast[1]), f32(fast[2])
+                fast_maxw = fast[3]
         self.struct = L.FrontendTables(
             window=L.ptr(self.window), twiddle=L.ptr(self.twiddle), rtwiddle=L.ptr(self.rtwiddle),
             mel_start=L.ptr(self.mel_start), mel_len=L.ptr(self.mel_len), mel_w=L.ptr(self.mel_w),
-            dct=L.ptr(self.dct), lifter=L.ptr(self.lifter), mel_stride=self.mel_stride, reserved=0)
+            dct=L.ptr(self.dct), lifter=L.ptr(self.lifter), fast_tw=L.ptr(self.fast_tw),
+            fast_mel_meta=L.ptr(self.fast_mel_meta), fast_mel_w=L.ptr(self.fast_mel_w), mel_stride=self.mel_stride,
+            reserved=fast_maxw)
 
 
 # ----------------------------------------------------------------------------- entry-point wrappers
