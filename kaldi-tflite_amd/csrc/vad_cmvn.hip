@@ -13,7 +13,9 @@
 //           layers/normalization/cmvn.py:186-250 of the reference.
 #include "common.h"
 
-#define VC_THREADS 256
+#define VC_THREADS 1024
+#define VC_RG (VC_THREADS / 32)      // row groups of the (row group, 32 columns) thread map
+#define VC_GM (2 * VC_RG * 32)        // floats of LDS scratch in front of the staging area
 #define VC_WAVES (VC_THREADS / KTF_WAVE)
 #define CMVN_CHUNK 32
 
@@ -58,9 +60,10 @@ __device__ __forceinline__ float vad_threshold(const float* __restrict__ f, int6
     return thr;
 }
 
-// Compacts kept frame numbers of one utterance into idx[0..count); returns count (block-uniform).
+// Compacts kept frame numbers of one utterance into idx[0..count) (if idx != NULL) and/or records each frame's position
+// in the compacted sequence in pos[t] (-1 = dropped; if pos != NULL); returns count (block-uniform).
 __device__ int vad_compact(const float* __restrict__ f, int64_t T, int D, const KtfVadCfg& c, float thr,
-                           int32_t* __restrict__ idx, int* scan /* VC_WAVES+1 ints in LDS */) {
+                           int32_t* __restrict__ idx, int* __restrict__ pos, int* scan /* VC_WAVES+1 ints in LDS */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0;
     for (int64_t t0 = 0; t0 < T; t0 += VC_THREADS) {
@@ -78,7 +81,8 @@ __device__ int vad_compact(const float* __restrict__ f, int64_t T, int D, const 
             if (w < wave) woff += cw;
             tot += cw;
         }
-        if (keep) idx[base + woff + before] = (int32_t)t;
+        if (keep && idx) idx[base + woff + before] = (int32_t)t;
+        if (pos && t < T) pos[t] = keep ? base + woff + before : -1;
         base += tot;
     }
     return base;
@@ -92,91 +96,118 @@ template <>
 __device__ __forceinline__ void store_out<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
 
 // CMVN of one utterance: rows r < len, row r read at x[(idx ? idx[r] : r) * ldx + d].
-// work: 2 * max(len - N + 1, 1) * D floats (window sums, and sums of squares when norm_vars).
+// The (compacted) rows are first staged contiguously into `xs` (len*D floats: LDS when the utterance fits, else the
+// caller's global workspace), which removes the idx indirection and the global-memory latency from the sliding loops.
+// Then every (chunk of CMVN_CHUNK window starts, column) item computes its first window sum directly, slides it, and
+// writes the normalised frames itself — no window-sum array, no second pass. Pad columns [D, ldo) are written as zeros.
+// gm: VC_GM floats of LDS scratch for the whole-utterance branch.
 template <typename OutT>
-__device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ idx, int len, int D,
-                           const KtfCmvnCfg& c, OutT* __restrict__ out, int64_t ldo, float* __restrict__ work,
-                           float* red, int* out_len) {
+__device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* __restrict__ pos, int Tsrc, int len, int D,
+                           const KtfCmvnCfg& c, OutT* __restrict__ out, int64_t ldo, float* __restrict__ xs, float* gm,
+                           int* out_len) {
     const int N = c.window;
     const int tid = threadIdx.x;
     const int ldo_i = (int)ldo;
-    if (len <= N) {
-        // cmvn.py:214-222: statistics over all frames
-        for (int d0 = 0; d0 < D; d0 += 1) {
-            float s = 0.0f, s2 = 0.0f;
-            for (int r = tid; r < len; r += VC_THREADS) {
-                const float v = x[(int64_t)(idx ? idx[r] : r) * ldx + d0];
-                s += v;
-                s2 += v * v;
-            }
-            const float sum = block_sum(s, red);
-            const float sum2 = c.norm_vars ? block_sum(s2, red) : 0.0f;
-            if (tid == 0) {
-                work[d0] = sum / (float)len;
-                work[D + d0] = c.norm_vars ? sqrtf(sum2 / (float)len - (sum / (float)len) * (sum / (float)len)) : 1.0f;
-            }
+    // staging walks the SOURCE rows (coalesced, no dependent loads): row t goes to compacted row pos[t] (or t itself)
+    {
+        const int rs = tid >> 5, dl = tid & 31;
+        for (int d0 = 0; d0 < D; d0 += 32) {
+            const int d = d0 + dl;
+            if (d < D)
+                for (int t = rs; t < Tsrc; t += VC_RG) {
+                    const int pr = pos ? pos[t] : (t < len ? t : -1);
+                    if (pr >= 0) xs[pr * D + d] = x[(int64_t)t * ldx + d];
+                }
         }
-        __syncthreads();
-        for (int e = tid; e < len * ldo_i; e += VC_THREADS) {
-            const int r = e / ldo_i, d = e - r * ldo_i;
-            float v = 0.0f;
-            if (d < D) {
-                v = x[(int64_t)(idx ? idx[r] : r) * ldx + d] - work[d];
-                if (c.norm_vars) v = v / work[D + d];
+    }
+    __syncthreads();
+    if (len <= N) {
+        // cmvn.py:214-222: statistics over all frames. VC_RG row groups x 32 columns per pass.
+        const int rg = tid >> 5, dl = tid & 31;
+        for (int d0 = 0; d0 < ldo_i; d0 += 32) {
+            const int d = d0 + dl;
+            float s = 0.0f, s2 = 0.0f;
+            if (d < D)
+                for (int r = rg; r < len; r += VC_RG) {
+                    const float v = xs[r * D + d];
+                    s += v;
+                    s2 += v * v;
+                }
+            gm[rg * 32 + dl] = s;
+            gm[VC_RG * 32 + rg * 32 + dl] = s2;
+            __syncthreads();
+            float mean = 0.0f, sd = 1.0f;
+            {
+                float ts = 0.0f, ts2 = 0.0f;
+#pragma unroll
+                for (int g = 0; g < VC_RG; ++g) {
+                    ts += gm[g * 32 + dl];
+                    ts2 += gm[VC_RG * 32 + g * 32 + dl];
+                }
+                mean = ts / (float)len;
+                if (c.norm_vars) sd = sqrtf(ts2 / (float)len - mean * mean);
             }
-            store_out<OutT>(out + (int64_t)r * ldo + d, v);
+            for (int r = rg; r < len; r += VC_RG) {
+                if (d < ldo_i) {
+                    float v = 0.0f;
+                    if (d < D) {
+                        v = xs[r * D + d] - mean;
+                        if (c.norm_vars) v = v / sd;
+                    }
+                    store_out<OutT>(out + (int64_t)r * ldo + d, v);
+                }
+            }
+            __syncthreads();
         }
         if (out_len && tid == 0) *out_len = len;
         return;
     }
-    // window sums for every start s in [0, len-N]
+    // cmvn.py:172-182: frame t uses the window starting at clamp(t - N/2, 0, len - N); VALID keeps [N/2, len-(N-1)/2)
     const int nstart = len - N + 1;
     const int nchunk = (nstart + CMVN_CHUNK - 1) / CMVN_CHUNK;
-    float* S = work;
-    float* S2 = work + (int64_t)nstart * D;
-    for (int item = tid; item < nchunk * D; item += VC_THREADS) {
-        const int ch = item / D, d = item - ch * D;
+    const int half = N / 2;
+    const float fN = (float)N;
+    for (int item = tid; item < nchunk * ldo_i; item += VC_THREADS) {
+        const int ch = item / ldo_i, d = item - ch * ldo_i;
         const int s0 = ch * CMVN_CHUNK;
         const int s1 = min(s0 + CMVN_CHUNK, nstart);
+        const bool real = d < D;
         float a = 0.0f, a2 = 0.0f;
-        for (int i = 0; i < N; ++i) {
-            const float v = x[(int64_t)(idx ? idx[s0 + i] : s0 + i) * ldx + d];
-            a += v;
-            a2 += v * v;
-        }
-        S[(int64_t)s0 * D + d] = a;
-        if (c.norm_vars) S2[(int64_t)s0 * D + d] = a2;
-        for (int s = s0 + 1; s < s1; ++s) {
-            const float vn = x[(int64_t)(idx ? idx[s + N - 1] : s + N - 1) * ldx + d];
-            const float vo = x[(int64_t)(idx ? idx[s - 1] : s - 1) * ldx + d];
-            a += vn - vo;
-            a2 += vn * vn - vo * vo;
-            S[(int64_t)s * D + d] = a;
-            if (c.norm_vars) S2[(int64_t)s * D + d] = a2;
-        }
-    }
-    __syncthreads();
-    // cmvn.py:172-182: frame t uses the window starting at clamp(t - N/2, 0, len - N); VALID keeps [N/2, len-(N-1)/2)
-    const int a = c.valid ? N / 2 : 0;
-    const int b = c.valid ? len - (N - 1) / 2 : len;
-    const int nout = b - a;
-    for (int e = tid; e < nout * ldo_i; e += VC_THREADS) {
-        const int j = e / ldo_i, d = e - j * ldo_i;
-        const int t = a + j;
-        float v = 0.0f;
-        if (d < D) {
-            int s = t - N / 2;
-            s = s < 0 ? 0 : (s > len - N ? len - N : s);
-            const float mean = S[(int64_t)s * D + d] / (float)N;
-            v = x[(int64_t)(idx ? idx[t] : t) * ldx + d] - mean;
-            if (c.norm_vars) {
-                const float std = sqrtf(S2[(int64_t)s * D + d] / (float)N - mean * mean);
-                v = v / std;
+        if (real) {
+            const float* p = xs + s0 * D + d;
+#pragma unroll 4
+            for (int i = 0; i < N; ++i) {
+                const float v = p[i * D];
+                a += v;
+                a2 += v * v;
             }
         }
-        store_out<OutT>(out + (int64_t)j * ldo + d, v);
+        for (int s = s0; s < s1; ++s) {
+            if (s > s0 && real) {
+                const float vn = xs[(s + N - 1) * D + d], vo = xs[(s - 1) * D + d];
+                a += vn - vo;
+                a2 += vn * vn - vo * vo;
+            }
+            const float mean = a / fN;
+            const float sd = (real && c.norm_vars) ? sqrtf(a2 / fN - mean * mean) : 1.0f;
+            // frames served by this window start
+            int t_lo = s + half, t_hi = s + half;
+            if (!c.valid) {
+                if (s == 0) t_lo = 0;
+                if (s == nstart - 1) t_hi = len - 1;
+            }
+            for (int t = t_lo; t <= t_hi; ++t) {
+                float v = 0.0f;
+                if (real) {
+                    v = xs[t * D + d] - mean;
+                    if (c.norm_vars) v = v / sd;
+                }
+                const int j = c.valid ? t - half : t;
+                store_out<OutT>(out + (int64_t)j * ldo + d, v);
+            }
+        }
     }
-    if (out_len && tid == 0) *out_len = nout;
+    if (out_len && tid == 0) *out_len = c.valid ? nstart : len;
 }
 
 __global__ __launch_bounds__(VC_THREADS) void vad_mask_kernel(const float* __restrict__ feats, int64_t T, int D,
@@ -195,20 +226,23 @@ __global__ __launch_bounds__(VC_THREADS) void vad_index_kernel(const float* __re
     __shared__ int scan[VC_WAVES + 1];
     const float* f = feats + (int64_t)blockIdx.x * T * D;
     const float thr = vad_threshold(f, T, D, c, red);
-    const int n = vad_compact(f, T, D, c, thr, idx + (int64_t)blockIdx.x * T, scan);
+    const int n = vad_compact(f, T, D, c, thr, idx + (int64_t)blockIdx.x * T, nullptr, scan);
     if (threadIdx.x == 0) lens[blockIdx.x] = n;
 }
 
 __global__ __launch_bounds__(VC_THREADS) void cmvn_kernel(const float* __restrict__ x, int64_t T, int D, int64_t ldx,
                                                           const int32_t* __restrict__ lens, KtfCmvnCfg c,
                                                           float* __restrict__ out, int64_t ldo,
-                                                          int32_t* __restrict__ out_lens, float* __restrict__ work) {
-    __shared__ float red[VC_WAVES];
+                                                          int32_t* __restrict__ out_lens, float* __restrict__ work,
+                                                          int64_t stage_floats) {
+    extern __shared__ __attribute__((aligned(16))) float vc_lds[];
+    float* gm = vc_lds;                      // VC_GM floats
+    float* stage = vc_lds + VC_GM;
     const int b = blockIdx.x;
     const int len = lens ? lens[b] : (int)T;
     int* ol = out_lens ? out_lens + b : nullptr;
-    cmvn_block<float>(x + (int64_t)b * T * ldx, ldx, nullptr, len, D, c, out + (int64_t)b * T * ldo, ldo,
-                      work + (int64_t)b * T * 2 * D, red, ol);
+    float* xs = ((int64_t)len * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
+    cmvn_block<float>(x + (int64_t)b * T * ldx, ldx, nullptr, len, len, D, c, out + (int64_t)b * T * ldo, ldo, xs, gm, ol);
 }
 
 template <typename OutT>
@@ -216,17 +250,22 @@ __global__ __launch_bounds__(VC_THREADS) void vad_cmvn_kernel(const float* __res
                                                               KtfVadCfg vc, KtfCmvnCfg cc, OutT* __restrict__ out,
                                                               int64_t ldo, int32_t* __restrict__ lens,
                                                               int32_t* __restrict__ idx_work,
-                                                              float* __restrict__ work) {
-    __shared__ float red[VC_WAVES];
-    __shared__ int scan[VC_WAVES + 1];
+                                                              float* __restrict__ work, int64_t stage_floats) {
+    extern __shared__ __attribute__((aligned(16))) float vc_lds[];
+    float* gm = vc_lds;                      // VC_GM floats (also the reduction scratch of the VAD phase)
+    int* pos = reinterpret_cast<int*>(vc_lds + VC_GM);        // T ints: frame -> compacted row (-1 = dropped)
+    float* stage = vc_lds + VC_GM + ((T + 3) & ~3ll);
+    float* red = gm;
+    int* scan = reinterpret_cast<int*>(gm + 64);
     const int b = blockIdx.x;
     const float* f = feats + (int64_t)b * T * D;
     int32_t* idx = idx_work + (int64_t)b * T;
     const float thr = vad_threshold(f, T, D, vc, red);
-    const int n = vad_compact(f, T, D, vc, thr, idx, scan);
-    __syncthreads();  // idx[] written by this workgroup is read below by other threads of it
+    const int n = vad_compact(f, T, D, vc, thr, idx, pos, scan);
+    __syncthreads();  // pos[] written by this workgroup is read below by other threads of it
     int* ol = lens + b;
-    cmvn_block<OutT>(f, D, idx, n, D, cc, out + (int64_t)b * T * ldo, ldo, work + (int64_t)b * T * 2 * D, red, ol);
+    float* xs = ((int64_t)n * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
+    cmvn_block<OutT>(f, D, pos, (int)T, n, D, cc, out + (int64_t)b * T * ldo, ldo, xs, gm, ol);
 }
 
 static int check_vad(const char* who, const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* c) {
@@ -262,6 +301,12 @@ extern "C" int ktf_vad_index(const float* feats, int64_t B, int64_t T, int32_t D
     return KTF_OK;
 }
 
+// floats of LDS used to stage one utterance (0 = stage in the global workspace): whole utterances up to 150 KiB
+static int64_t vc_stage_floats(int64_t T, int32_t D) {
+    const int64_t need = T * D;
+    return (need * 4 <= 148 * 1024) ? need : 0;
+}
+
 static int check_cmvn(const char* who, const KtfCmvnCfg* c) {
     KTF_REQUIRE(c, "%s: null cmvn config", who);
     KTF_REQUIRE(c->window > 0, "%s: window must be > 0", who);
@@ -277,8 +322,11 @@ extern "C" int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int
     KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ldx >= D && ldo >= D, "ktf_cmvn_f32: bad sizes");
     KTF_REQUIRE(T < (1ll << 31) / (ldo > 0 ? ldo : 1), "ktf_cmvn_f32: T*ldo too large");
     if (B * T == 0) return KTF_OK;
-    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)B), dim3(VC_THREADS), 0, (hipStream_t)stream, x, T, D, ldx, lens, *cfg,
-                       out, ldo, out_lens, work);
+    const int64_t stage_floats = vc_stage_floats(T, D);
+    const size_t lds = (VC_GM + (size_t)stage_floats) * sizeof(float);
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)cmvn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)B), dim3(VC_THREADS), lds, (hipStream_t)stream, x, T, D, ldx, lens, *cfg,
+                       out, ldo, out_lens, work, stage_floats);
     KTF_CHECK_LAUNCH("ktf_cmvn_f32");
     return KTF_OK;
 }
@@ -300,12 +348,19 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
         return KTF_OK;
     }
     hipStream_t st = (hipStream_t)stream;
-    if (out_dtype == KTF_F32)
-        hipLaunchKernelGGL(vad_cmvn_kernel<float>, dim3((unsigned)B), dim3(VC_THREADS), 0, st, feats, T, D, *vad, *cmvn,
-                           (float*)out, ldo, lens, idx_work, work);
-    else
-        hipLaunchKernelGGL(vad_cmvn_kernel<unsigned short>, dim3((unsigned)B), dim3(VC_THREADS), 0, st, feats, T, D, *vad,
-                           *cmvn, (unsigned short*)out, ldo, lens, idx_work, work);
+    KTF_REQUIRE(T <= 8192, "ktf_vad_cmvn: T > 8192 frames per utterance is not supported by the fused kernel");
+    int64_t stage_floats = vc_stage_floats(T, D);
+    if ((VC_GM + ((T + 3) & ~3ll) + stage_floats) * 4 > 158 * 1024) stage_floats = 0;
+    const size_t lds = (VC_GM + (size_t)((T + 3) & ~3ll) + (size_t)stage_floats) * sizeof(float);
+    if (out_dtype == KTF_F32) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vad_cmvn_kernel<float>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad, *cmvn,
+                           (float*)out, ldo, lens, idx_work, work, stage_floats);
+    } else {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vad_cmvn_kernel<unsigned short>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
+                           *cmvn, (unsigned short*)out, ldo, lens, idx_work, work, stage_floats);
+    }
     KTF_CHECK_LAUNCH("ktf_vad_cmvn");
     return KTF_OK;
 }
