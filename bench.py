@@ -120,6 +120,15 @@ def main():
         "algorithmic_flop_per_step": flops_per_step,
         "note": "bf16x3 issues 3 MFMA passes per algorithmic FLOP" if args.gemm == "bf16x3" else "",
     }
+    # HBM traffic of those launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE),
+    # committed under profiles/: it cannot be collected from inside this process
+    tpath = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if args.gemm == "bf16" and B == 1024 and os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        out["roofline"]["traffic"] = tj["tdnn_gemm_bytes_per_step_corrected"]
+        out["roofline"]["traffic_note"] = ("HBM bytes per step summed over the 5 GEMM launches (profiles/r1_traffic.json); "
+                                           f"algorithmic bytes {tj['tdnn_gemm_algorithmic_bytes_per_step']}")
     out["mfcc"] = _bench_mfcc(mdl, wav, ops)
     if not args.no_extra:
         out["parity"] = _parity_sample(ktf, synth, cfg, w, args.gemm, dev)
