@@ -197,9 +197,11 @@ int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* le
 /* ktf_tdnn fused with the reducing StatsPooling that follows it (sequential.py:68-79 order "tdnn5 -> stats"): the layer
  * output is never written; instead sums[b, 0, u] += sum_t y[b,t,u] and sums[b, 1, u] += sum_t y[b,t,u]^2 (fp64, over
  * the valid rows). `sums` (B, 2, units) must be zeroed by the caller before the call. Only the bf16 256x256 kernel
- * implements it: d->gemm == KTF_GEMM_BF16, bf16 activations, units > 128, SAME padding, subsampling 1. */
+ * the 256x256 kernels implement it: KTF_GEMM_BF16 (bf16 x) or KTF_GEMM_BF16X3 (fp32 x, w_lo given), units > 128, SAME
+ * padding, subsampling 1. */
 int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
-                   const void* w, const float* bias, const float* scale, const float* shift, double* sums, void* stream);
+                   const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift, double* sums,
+                   void* stream);
 /* finishes the fused pooling: out[b, c] = sums[b,0,c]/n_b, out[b, D+c] = sqrt(max(sums[b,1,c]/n_b - mean^2, 0) + eps)
  * with n_b = lens[b] (or T when lens is NULL); stats_pooling.py:231-240. */
 int ktf_stats_finalize(const double* sums, const int32_t* lens, int64_t T, int64_t B, int32_t D, int32_t include_std,

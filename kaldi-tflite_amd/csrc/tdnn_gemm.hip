@@ -522,6 +522,105 @@ __global__ __launch_bounds__(256) void tdnn_bf16g_kernel(TdnnParams p, int mtile
 #define R_EPI_PITCH 260
 #define R_LDS_BYTES (R_NSTAGE * R_STAGE_BYTES)  // 131,072 B (epilogue staging needs 64*260*4 = 66,560 B)
 
+// Epilogue shared by the 256x256 kernels: bias -> activation -> BatchNorm affine on the 4x2 accumulator tiles of each wave,
+// then either (STATS) fp64 column sums / sums of squares into stats[b][0|1][unit], or four passes of LDS-staged,
+// fully coalesced row stores (one 256-column row per wave-instruction).
+template <int ACT, bool STATS>
+__device__ __forceinline__ void ring_epilogue(f32x16 (&acc)[4][2], const TdnnParams& p, double* __restrict__ stats,
+                                              unsigned char* rsm, int b, int t0, int n0, int out_len, int wm, int wn,
+                                              int wave, int lane) {
+    // ---- epilogue: four passes of 64 staged rows (wave (wm, wn) contributes its 32 x 64 block of pass i)
+    float* et = reinterpret_cast<float*>(rsm);
+    float bias[2], sc[2], sh[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        const bool nv = n < p.units;
+        bias[j] = (nv && p.bias) ? p.bias[n] : 0.0f;
+        sc[j] = (nv && p.scale) ? p.scale[n] : 1.0f;
+        sh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
+    }
+    const int rows_valid = out_len - t0;
+    if (STATS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    float v = acc[i][j][r] + bias[j];
+                    if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                    else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                    v = v * sc[j] + sh[j];
+                    if (m < rows_valid) {
+                        s += (double)v;
+                        q += (double)v * (double)v;
+                    }
+                }
+            }
+            s += __shfl_xor(s, 32, 64);      // the two half-waves hold the same column
+            q += __shfl_xor(q, 32, 64);
+            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+            if (lane < 32 && n < p.units) {
+                double* dst = stats + ((int64_t)b * 2) * p.units + n;
+                atomicAdd(dst, s);
+                atomicAdd(dst + p.units, q);
+            }
+        }
+        return;
+    }
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+    const int nl = lane * 4;                      // this lane's 4 columns of the 256-wide staged row
+    const int n = n0 + nl;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int srow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r] + bias[j];
+                if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                v = v * sc[j] + sh[j];
+                et[srow * R_EPI_PITCH + col] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sp = 0; sp < 8; ++sp) {
+            const int srow = sp * 8 + wave;          // one staged row per wave: 256 contiguous columns
+            const int m = (srow >> 5) * 128 + i * 32 + (srow & 31);
+            if (m < rows_valid) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + nl);
+                const int64_t off = (out_row0 + m) * p.ldy + n;
+                if (n + 4 <= p.units) {
+                    if (p.y_dtype == KTF_F32) {
+                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + off) = v;
+                    } else {
+                        uint2 pk;
+                        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
+                        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e < p.units) {
+                            if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off + e] = v[e];
+                            else reinterpret_cast<unsigned short*>(p.y)[off + e] = f2bf(v[e]);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // STATS: instead of storing y, the epilogue adds every column's sum and sum of squares over the tile's valid rows (fp64)
 // into stats[b][0|1][unit] — statistics pooling fused into the producing GEMM, the (B,T,units) activation never exists.
 template <int ACT, bool STATS, int DBG = 0>
@@ -691,96 +790,155 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
 #undef R_STAGE
     __syncthreads();   // all fragment reads done before the LDS is reused by the epilogue
 
-    // ---- epilogue: four passes of 64 staged rows (wave (wm, wn) contributes its 32 x 64 block of pass i)
-    float* et = reinterpret_cast<float*>(rsm);
-    float bias[2], sc[2], sh[2];
+    ring_epilogue<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------ BF16X3, 256x256 tile
+// Split-bf16 on the 256x256 structure: fp32 activations are staged RAW (256 rows x 32 k x 4 B = 128-byte rows, chunk
+// permutation c ^ ((row>>1)&7)) and split into bf16 hi/lo parts in registers when the fragments are read; the weights are
+// pre-split on the host into two bf16 planes. acc += hi*hi + lo*hi + hi*lo: 48 MFMAs per wave per K-step against 8 DMA
+// instructions, so a plain double buffer (2 x 64 KiB) with one stage in flight covers the DMA latency.
+#define X_STAGE_BYTES (32768 + 2 * R_TILE_BYTES)    // A fp32 + W hi + W lo = 64 KiB
+#define X_LDS_BYTES (2 * X_STAGE_BYTES)             // 128 KiB (epilogue staging 66,560 B fits)
+
+__device__ __forceinline__ void split_bf16x8(const f32x4& v0, const f32x4& v1, bfrag8& hi, bfrag8& lo) {
+    union { bfrag8 f; unsigned u[4]; } H, Lw;
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-        const bool nv = n < p.units;
-        bias[j] = (nv && p.bias) ? p.bias[n] : 0.0f;
-        sc[j] = (nv && p.scale) ? p.scale[n] : 1.0f;
-        sh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
+    for (int e = 0; e < 4; ++e) {
+        const unsigned short h0 = f2bf(x[2 * e]), h1 = f2bf(x[2 * e + 1]);
+        H.u[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+        const unsigned short l0 = f2bf(x[2 * e] - bf2f(h0)), l1 = f2bf(x[2 * e + 1] - bf2f(h1));
+        Lw.u[e] = (unsigned)l0 | ((unsigned)l1 << 16);
     }
-    const int rows_valid = out_len - t0;
-    if (STATS) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            double s = 0.0, q = 0.0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    float v = acc[i][j][r] + bias[j];
-                    if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
-                    else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
-                    v = v * sc[j] + sh[j];
-                    if (m < rows_valid) {
-                        s += (double)v;
-                        q += (double)v * (double)v;
-                    }
-                }
-            }
-            s += __shfl_xor(s, 32, 64);      // the two half-waves hold the same column
-            q += __shfl_xor(q, 32, 64);
-            const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (lane < 32 && n < p.units) {
-                double* dst = stats + ((int64_t)b * 2) * p.units + n;
-                atomicAdd(dst, s);
-                atomicAdd(dst + p.units, q);
-            }
-        }
-        return;
-    }
-    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
-    const int nl = lane * 4;                      // this lane's 4 columns of the 256-wide staged row
-    const int n = n0 + nl;
+    hi = H.f;
+    lo = Lw.f;
+}
+
+template <int ACT, bool STATS>
+__global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
+                                                       double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = (slot / ntiles) * 8 + xcd;
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * R_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = nt * R_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 4;
+    const char* wb = reinterpret_cast<const char*>(p.w);
+    const char* wl = reinterpret_cast<const char*>(p.w_lo);
+    const unsigned ldxb = (unsigned)p.ldx * 4u;
+
+    // A staging: chunk q = i*512 + tid (i < 4) -> row q/8, LDS position q%8, global chunk (q%8) ^ ((row>>1)&7)
+    int a_t[4];
+    unsigned a_cb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = wn * 64 + j * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int srow = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = acc[i][j][r] + bias[j];
-                if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
-                else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
-                v = v * sc[j] + sh[j];
-                et[srow * R_EPI_PITCH + col] = v;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sp = 0; sp < 8; ++sp) {
-            const int srow = sp * 8 + wave;          // one staged row per wave: 256 contiguous columns
-            const int m = (srow >> 5) * 128 + i * 32 + (srow & 31);
-            if (m < rows_valid) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + nl);
-                const int64_t off = (out_row0 + m) * p.ldy + n;
-                if (n + 4 <= p.units) {
-                    if (p.y_dtype == KTF_F32) {
-                        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + off) = v;
-                    } else {
-                        uint2 pk;
-                        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-                        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
-                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (n + e < p.units) {
-                            if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off + e] = v[e];
-                            else reinterpret_cast<unsigned short*>(p.y)[off + e] = f2bf(v[e]);
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
+        const int q = i * 512 + tid;
+        const int row = q >> 3;
+        a_cb[i] = (unsigned)(((q & 7) ^ ((row >> 1) & 7)) * 16);
+        a_t[i] = start + (t0 + row) * p.sub;
     }
+    // W staging (both planes): chunk q = i*512 + tid (i < 2) -> row q/4, position q%4, global chunk (q%4) ^ ((row>>2)&3)
+    unsigned w_ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q >> 2;
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + (unsigned)(((q & 3) ^ ((row >> 2) & 3)) * 16);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / R_BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 4;
+#define X_STAGE()                                                                                                      \
+    {                                                                                                                  \
+        unsigned char* st_ = rsm + (is_ks & 1) * X_STAGE_BYTES + wave * 1024;                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+            int r_ = a_t[i] + is_off;                                                                                  \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                      \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                             \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_), (lds_ptr_t*)(st_ + 32768 + i * 8192), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + 32768 + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+        ++is_ks;                                                                                                       \
+        is_db += R_BK * 4;                                                                                             \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
+    }
+
+    X_STAGE()
+    const int rswa = ((lane & 31) >> 1) & 7;               // A: 128-B rows
+    const int rswb = ((lane & 31) >> 2) & 3;               // W: 64-B rows
+    const int a_row_off = (wm * 128 + (lane & 31)) * 128;
+    const int b_row_off = (wn * 64 + (lane & 31)) * 64;
+    const int hsel = lane >> 5;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage ks landed (nothing else is in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (is_ks < nk) X_STAGE()                            // stage ks+1 -> the buffer every wave finished reading (stage ks-1)
+        const unsigned char* sa = rsm + (ks & 1) * X_STAGE_BYTES;
+        const unsigned char* sh = sa + 32768;
+        const unsigned char* sl = sh + R_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bfrag8 ah[4], al[4], bh[2], bl[2];
+            const int ca = kk * 4 + 2 * hsel;                // first of the two 16-B chunks holding k = 16kk + 8h .. +7
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned char* row = sa + a_row_off + i * 32 * 128;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + ((ca ^ rswa) << 4));
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + (((ca + 1) ^ rswa) << 4));
+                split_bf16x8(v0, v1, ah[i], al[i]);
+            }
+            const int cb = ((kk * 2 + hsel) ^ rswb) << 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const bfrag8*>(sh + b_row_off + j * 32 * 64 + cb);
+                bl[j] = *reinterpret_cast<const bfrag8*>(sl + b_row_off + j * 32 * 64 + cb);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#undef X_STAGE
+    __syncthreads();
+    ring_epilogue<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ elementwise helpers
@@ -829,8 +987,9 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream) {
     KTF_REQUIRE(x && d && w && (y || stats_sums), "ktf_tdnn: null argument");
     if (stats_sums) {
-        KTF_REQUIRE(d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16 && d->units > 128 && !d->valid && d->subsampling == 1,
-                    "ktf_tdnn_stats: needs the bf16 256x256 kernel (bf16 activations, units > 128, SAME padding, no subsampling)");
+        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32)) &&
+                        d->units > 128 && !d->valid && d->subsampling == 1,
+                    "ktf_tdnn_stats: needs a 256x256 kernel (bf16 or bf16x3 gemm, units > 128, SAME padding, no subsampling)");
         ldy = (d->units + 3) / 4 * 4;
     }
     KTF_REQUIRE(B >= 0 && T >= 0, "ktf_tdnn: negative size");
@@ -878,7 +1037,27 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             (void)hipFuncSetAttribute((const void*)tdnn_bf16_kernel<BK, XF, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((tdnn_bf16_kernel<BK, XF, X3>), grid, dim3(256), lds, st, p);                     \
     } while (0)
-        if (x3) {
+        if (x3 && d->units > 128 && ldy % 4 == 0) {
+            const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
+            const int64_t gtiles = B * (int64_t)mtiles;
+            const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
+            KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
+#define X_LAUNCH(A)                                                                                                    \
+    do {                                                                                                               \
+        if (stats_sums) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)tdnn_x3r_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_x3r_kernel<A, true>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        } else {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)tdnn_x3r_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_x3r_kernel<A, false>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr); \
+        }                                                                                                              \
+    } while (0)
+            if (d->act == KTF_ACT_NONE) X_LAUNCH(KTF_ACT_NONE);
+            else if (d->act == KTF_ACT_RELU) X_LAUNCH(KTF_ACT_RELU);
+            else if (d->act == KTF_ACT_SIGMOID) X_LAUNCH(KTF_ACT_SIGMOID);
+            else X_LAUNCH(KTF_ACT_TANH);
+#undef X_LAUNCH
+        } else if (x3) {
             if (k64) BF_LAUNCH(64, true, true); else BF_LAUNCH(32, true, true);
         } else if (d->x_dtype == KTF_F32) {
             if (k64) BF_LAUNCH(64, true, false); else BF_LAUNCH(32, true, false);
@@ -945,10 +1124,10 @@ extern "C" int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const 
 }
 
 extern "C" int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
-                              const void* w, const float* bias, const float* scale, const float* shift, double* sums,
-                              void* stream) {
+                              const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
+                              double* sums, void* stream) {
     KTF_REQUIRE(sums, "ktf_tdnn_stats: null sums");
-    return tdnn_launch(x, B, T, ldx, lens, d, w, nullptr, bias, scale, shift, nullptr, 0, nullptr, sums, stream);
+    return tdnn_launch(x, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream);
 }
 
 // mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)

@@ -142,24 +142,25 @@ class Sequential:
                 skip = False
                 continue
             nxt = steps[si + 1] if si + 1 < len(steps) else None
-            if (self.fuse_stats and st[0] == "tdnn" and not pooled and gemm == L.GEMM_BF16 and nxt is not None
+            if (self.fuse_stats and st[0] == "tdnn" and not pooled and gemm in (L.GEMM_BF16, L.GEMM_BF16X3) and nxt is not None
                     and nxt[0] == "stats" and nxt[1].inputPeriod == 1 and st[1].units > 128 and st[1].padding == "SAME"
                     and st[1].subsamplingFactor == 1):
                 # [affine, relu, batchnorm] -> reducing StatsPooling: pooled inside the GEMM epilogue, y is never written
                 _, l, relu, bn = st
                 sp = nxt[1]
-                if x.dtype != torch.bfloat16 or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
-                    x = _padded_copy(x, torch.bfloat16)
+                xdt = torch.bfloat16 if gemm == L.GEMM_BF16 else torch.float32
+                if x.dtype != xdt or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
+                    x = _padded_copy(x, xdt)
                 B, T, _ = x.shape
                 D = l.units
                 od = 2 * D if sp.includeStd else D
                 ld = ops.round_up(od, 32)
                 sums = self._buffer(("sum", id(l), B, D, str(x.device)), (B, 2, D), torch.float64, x.device)
                 sbuf = self._buffer(("s", id(sp), B, ld, str(x.device)), (B, ld), torch.float32, x.device)
-                w, _, bias = l.device_weights(x.device, gemm)
-                d = l.desc(gemm, x.dtype, torch.bfloat16, act="relu" if relu else None)
+                w, w_lo, bias = l.device_weights(x.device, gemm)
+                d = l.desc(gemm, x.dtype, xdt, act="relu" if relu else None)
                 scale, shift = bn.affine_device(x.device) if bn is not None else (None, None)
-                ops.tdnn_stats(x, lens, d, w, bias, scale, shift, sums)
+                ops.tdnn_stats(x, lens, d, w, w_lo, bias, scale, shift, sums)
                 ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf)
                 x = sbuf[:, :od].unsqueeze(0)
                 lens = None

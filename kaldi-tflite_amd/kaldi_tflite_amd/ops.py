@@ -304,14 +304,14 @@ def tdnn(x, lens, desc, w, w_lo, bias, scale, shift, y, out_lens=None):
     return y
 
 
-def tdnn_stats(x, lens, desc, w, bias, scale, shift, sums):
+def tdnn_stats(x, lens, desc, w, w_lo, bias, scale, shift, sums):
     """Fused TDNN + reducing stats pooling: accumulates fp64 column sums / sums of squares into `sums` (B,2,units)."""
     lib = L.load()
     B, T = x.shape[0], x.shape[1]
     with torch.cuda.device(x.device):
         sums.zero_()
-        rc = lib.ktf_tdnn_stats(L.ptr(x), B, T, x.stride(1), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(bias), L.ptr(scale),
-                                L.ptr(shift), L.ptr(sums), L.stream_ptr())
+        rc = lib.ktf_tdnn_stats(L.ptr(x), B, T, x.stride(1), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo), L.ptr(bias),
+                                L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
     L.check(rc, "ktf_tdnn_stats")
     return sums
 
