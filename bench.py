@@ -132,6 +132,7 @@ def main():
     out["mfcc"] = _bench_mfcc(mdl, wav, ops)
     if not args.no_extra:
         out["parity"] = _parity_sample(ktf, synth, cfg, w, args.gemm, dev)
+        out["other_configs"] = _other_configs(ktf, synth, cfg, w, wav, args.gemm, dev)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = _cpu_baseline(synth, cfg, w, args.cpu_utts, N)
     print(json.dumps(out))
@@ -218,6 +219,42 @@ def _parity_sample(ktf, synth, cfg, w, gemm, dev):
     for g in sorted({gemm, "f32"}):
         got = synth.build_extractor(ktf, cfg, w, gemm=g)(torch.as_tensor(wav, device=dev)).cpu().numpy()
         res[f"max_abs_dev_{g}"] = float(np.abs(got - want).max())
+    return res
+
+
+def _time_ms(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / iters
+
+
+def _other_configs(ktf, synth, cfg, w, wav, gemm, dev):
+    """Side measurements of the remaining BASELINE.json configs on the same GPU (not part of `value`):
+    the same 1024-utterance step in the other GEMM arithmetic modes, batch-1 latency (config 2) and the
+    1024 x 1024 PLDA trial matrix (config 5)."""
+    res = {}
+    B = wav.shape[0]
+    for g in ("bf16x3", "f32"):
+        if g == gemm:
+            continue
+        m = synth.build_extractor(ktf, cfg, w, gemm=g)
+        ms = _time_ms(lambda: m(wav), 2)
+        res[f"x_vectors_per_s_{g}"] = B / (ms * 1e-3)
+        del m
+        torch.cuda.empty_cache()
+    m1 = synth.build_extractor(ktf, cfg, w, gemm="f32")
+    one = wav[:1].contiguous()
+    res["batch1_fp32_latency_ms"] = _time_ms(lambda: m1(one), 10)
+    rng = np.random.default_rng(31)
+    dim, nb = 128, 1024
+    A = rng.standard_normal((dim, dim)) / np.sqrt(dim) + np.eye(dim)
+    plda = ktf.layers.PLDA(dim, rng.standard_normal(dim) * 0.1, A, np.sort(rng.uniform(0.05, 30.0, dim))[::-1].copy())
+    xv = torch.as_tensor(rng.standard_normal((nb, dim)), device=dev)
+    res["plda_1024x1024_fp64_ms"] = _time_ms(lambda: plda(xv), 5)
     return res
 
 
