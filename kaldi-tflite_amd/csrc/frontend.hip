@@ -383,7 +383,8 @@ extern "C" int ktf_frontend_f32(const float* in, int64_t B, int64_t n, int32_t i
     const int64_t rows = B * T;
     if (rows == 0) return KTF_OK;
     if (cfg->nfft == 512 && out_stage >= KTF_OUT_FBANK && tab->fast_tw && tab->fast_mel_meta && tab->fast_mel_w &&
-        cfg->num_mels <= 32 && (out_stage == KTF_OUT_FBANK || cfg->num_ceps <= 64))
+        cfg->num_mels <= 32 && (out_stage == KTF_OUT_FBANK || cfg->num_ceps <= 64) && B < 65536 &&
+        T * (int64_t)512 < (1ll << 31) && n < (1ll << 31))
         return ktf_frontend512_launch(in, B, n, in_kind, cfg, tab, out_stage, out, seed, T, (hipStream_t)stream);
     FeLds L = fe_layout(*cfg, *tab, out_stage);
     const size_t lds_bytes = (size_t)L.total * sizeof(float);

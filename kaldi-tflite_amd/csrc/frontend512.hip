@@ -181,21 +181,21 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const float* __
     const float invM = 1.0f / (float)M;
     __syncthreads();
 
-    const int64_t rows = B * T;
-    const int64_t row_step = (int64_t)gridDim.x * F5_WAVES;
-    for (int64_t row0 = (int64_t)blockIdx.x * F5_WAVES; row0 < rows; row0 += row_step) {
-        const int64_t row = row0 + wave;
-        const bool valid = row < rows;   // wave-uniform
+    // grid = (frame groups per utterance, B): no division in the frame loop, 32-bit offsets from per-utterance bases
+    const int b = blockIdx.y;
+    const int Ti = (int)T;
+    const float* in_b = in + (int64_t)b * ((in_kind == KTF_IN_WAV) ? n : T * (int64_t)M);
+    const int src_step = (in_kind == KTF_IN_WAV) ? cfg.frame_shift : M;
+    const int64_t row_base = (int64_t)b * T;
+    const int t_step = gridDim.x * F5_WAVES;
+    for (int t0 = blockIdx.x * F5_WAVES; t0 < Ti; t0 += t_step) {
+        const int t = t0 + wave;
+        const bool valid = t < Ti;   // wave-uniform
+        const int64_t row = row_base + t;
         float v[NV];
         float logE = 0.0f;
         if (valid) {
-            const float* src;
-            if (in_kind == KTF_IN_WAV) {
-                const int64_t b = row / T, t = row - b * T;
-                src = in + b * n + t * (int64_t)cfg.frame_shift;
-            } else {
-                src = in + row * (int64_t)M;
-            }
+            const float* src = in_b + t * src_step;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = lane + KTF_WAVE * j;
@@ -339,15 +339,19 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const float* __
 int ktf_frontend512_launch(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
                            const KtfFrontendTables* tab, int32_t out_stage, float* out, uint64_t seed, int64_t T,
                            hipStream_t st) {
-    const int64_t rows = B * T;
-    int blocks = ktf_cdiv(rows, F5_WAVES);
-    if (blocks > 256 * 8) blocks = 256 * 8;
+    // ~2048 workgroups in total: gx frame groups per utterance x B utterances
+    KTF_REQUIRE(B < 65536 && T * (int64_t)512 < (1ll << 31) && n < (1ll << 31), "ktf_frontend_f32(fast512): B, T or n too large");
+    int gx = (int)(2048 / (B > 0 ? B : 1));
+    const int gmax = ktf_cdiv(T, F5_WAVES);
+    if (gx < 1) gx = 1;
+    if (gx > gmax) gx = gmax;
+    const dim3 grid((unsigned)gx, (unsigned)B);
     const size_t lds = sizeof(float) * (512 + F5_WAVES * (512 + 256 + 64));
     if (cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED)
-        hipLaunchKernelGGL(frontend512_kernel<true>, dim3(blocks), dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
+        hipLaunchKernelGGL(frontend512_kernel<true>, grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
                            out_stage, out, seed, T);
     else
-        hipLaunchKernelGGL(frontend512_kernel<false>, dim3(blocks), dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
+        hipLaunchKernelGGL(frontend512_kernel<false>, grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
                            out_stage, out, seed, T);
     KTF_CHECK_LAUNCH("ktf_frontend_f32(fast512)");
     return KTF_OK;
