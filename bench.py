@@ -113,7 +113,7 @@ def main():
     achieved = flops_per_step / (gemm_ms_per_step * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.gemm]
     out["roofline"] = {
-        "bound": "mfma", "kernel": {"bf16": "tdnn_bf16r_kernel", "bf16x3": "tdnn_x3r_kernel", "f32": "tdnn_f32_kernel"}[args.gemm],
+        "bound": "mfma", "kernel": {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=768 layers)", "bf16x3": "tdnn_x3r_kernel", "f32": "tdnn_f32_kernel"}[args.gemm],
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
         "launches_per_step": gemm_stats["launches"] // args.steps, "avg_launch_ms": gemm_stats["total_ms"] / max(gemm_stats["launches"], 1),
         "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],

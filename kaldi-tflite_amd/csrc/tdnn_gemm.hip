@@ -868,6 +868,34 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
             }
         }
         __syncthreads();
+        if (p.y_dtype != KTF_F32) {
+            // bf16 output: 16-byte stores (8 columns per lane, two staged rows per wave instruction)
+            const int n8 = n0 + (lane & 31) * 8;
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                const int srow = sp * 16 + wave * 2 + (lane >> 5);
+                const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
+                if (m < rows_valid) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + (lane & 31) * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + (lane & 31) * 8 + 4);
+                    const int64_t off = (out_row0 + m) * p.ldy + n8;
+                    unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + off;
+                    if (n8 + 8 <= p.units) {
+                        u32x4 pk;
+                        pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
+                        pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
+                        pk.z = (unsigned)f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16);
+                        pk.w = (unsigned)f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
+                        *reinterpret_cast<u32x4*>(yp) = pk;
+                    } else {
+                        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (n8 + e < p.units) yp[e] = f2bf(vv[e]);
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int sp = 0; sp < 8; ++sp) {
             const int srow = sp * 8 + wave;
@@ -899,11 +927,140 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
     }
 }
 
+// Non-reducing epilogue of the 16x16x32 kernel. The MFMA operands are swapped there (W fragment as A, x fragment as B), so
+// a lane's four accumulator values are four CONSECUTIVE output columns of one output row:
+//   acc[i][j][r] = out[row wm*128 + i*16 + (lane&15)][col wn*64 + j*16 + (lane>>4)*4 + r]
+// bias/ReLU/BatchNorm, the bf16 pack and the store therefore need no LDS staging and no barrier; the four stores of one i
+// (j = 0..3) complete a 128-byte line of each of the 16 rows.
+template <int ACT>
+__device__ __forceinline__ void ring_epilogue16_direct(f32x4v (&acc)[8][4], const TdnnParams& p, int b, int t0, int n0,
+                                                       int out_len, int wm, int wn, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    f32x4v bias[4], sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4 + e;
+            const bool nv = n < p.units;
+            bias[j][e] = (nv && p.bias) ? p.bias[n] : 0.0f;
+            sc[j][e] = (nv && p.scale) ? p.scale[n] : 1.0f;
+            sh[j][e] = (nv && p.shift) ? p.shift[n] : 0.0f;
+        }
+    }
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = wm * 128 + i * 16 + c;
+        if (m >= rows_valid) continue;
+        const int64_t rowoff = (out_row0 + m) * p.ldy;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4;
+            f32x4v v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[i][j][e] + bias[j][e];
+                if (ACT == KTF_ACT_RELU) t = fmaxf(t, 0.0f);
+                else if (ACT != KTF_ACT_NONE) t = apply_act(t, ACT);
+                v[e] = t * sc[j][e] + sh[j][e];
+            }
+            const int64_t off = rowoff + n;
+            if (n + 4 <= p.units) {
+                if (p.y_dtype == KTF_F32) {
+                    *reinterpret_cast<f32x4v*>(reinterpret_cast<float*>(p.y) + off) = v;
+                } else {
+                    uint2 pk;
+                    pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                    pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (n + e < p.units) {
+                        if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off + e] = v[e];
+                        else reinterpret_cast<unsigned short*>(p.y)[off + e] = f2bf(v[e]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// bf16-output epilogue of the 16x16x32 kernel (swapped operands, see ring_epilogue16_direct): bias/ReLU/BatchNorm and the
+// bf16 pack happen in registers, each lane stages its four consecutive columns with one ds_write_b64 (row pitch 520 B: the
+// 16 lanes of a store group cover all 32 banks), and after ONE barrier every wave streams 32 staged rows out with 16-byte
+// stores (two 512-byte rows per wave instruction). The stores are issue-bound per instruction (T21), hence the wide form.
+#define R16_PK_PITCH 520
+#define R16_LDS_BYTES (R_BM * R16_PK_PITCH > R_LDS_BYTES ? R_BM * R16_PK_PITCH : R_LDS_BYTES)
+template <int ACT>
+__device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const TdnnParams& p, unsigned char* rsm, int b,
+                                                   int t0, int n0, int out_len, int wm, int wn, int wave, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    f32x4v bias[4], sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + wn * 64 + j * 16 + g * 4 + e;
+            const bool nv = n < p.units;
+            bias[j][e] = (nv && p.bias) ? p.bias[n] : 0.0f;
+            sc[j][e] = (nv && p.scale) ? p.scale[n] : 1.0f;
+            sh[j][e] = (nv && p.shift) ? p.shift[n] : 0.0f;
+        }
+    }
+    unsigned char* stg = rsm + (wm * 128 + c) * R16_PK_PITCH + (wn * 64 + g * 4) * 2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4v v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t = acc[i][j][e] + bias[j][e];
+                if (ACT == KTF_ACT_RELU) t = fmaxf(t, 0.0f);
+                else if (ACT != KTF_ACT_NONE) t = apply_act(t, ACT);
+                v[e] = t * sc[j][e] + sh[j][e];
+            }
+            uint2 pk;
+            pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            *reinterpret_cast<uint2*>(stg + i * 16 * R16_PK_PITCH + j * 32) = pk;
+        }
+    }
+    __syncthreads();
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+    const int n8 = n0 + (lane & 31) * 8;
+    const bool wide = (n8 + 8 <= p.units) && ((p.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+    unsigned short* ybase = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll 4
+    for (int sp = 0; sp < 16; ++sp) {
+        const int m = wave * 32 + sp * 2 + (lane >> 5);
+        if (m < rows_valid) {
+            const unsigned char* src = rsm + m * R16_PK_PITCH + (lane & 31) * 16;
+            const uint2 lo = *reinterpret_cast<const uint2*>(src);
+            const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+            unsigned short* yp = ybase + (out_row0 + m) * p.ldy + n8;
+            if (wide) {
+                u32x4 o;
+                o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+                *reinterpret_cast<u32x4*>(yp) = o;
+            } else {
+                const unsigned w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n8 + e < p.units) yp[e] = (unsigned short)(w4[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+    }
+}
+
 template <int ACT, bool STATS>
-__global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
-                                                           double* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-    const int id = blockIdx.x;
+__device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int ntiles, int gtiles,
+                                         double* __restrict__ stats, unsigned char* rsm, const int id) {
     const int xcd = id & 7, slot = id >> 3;
     const int g = (slot / ntiles) * 8 + xcd;
     const int nt = slot - (slot / ntiles) * ntiles;
@@ -1002,7 +1159,8 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0) {
 #pragma unroll
@@ -1017,7 +1175,8 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 #pragma unroll
         for (int i = 4; i < 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0)
+                                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 4 && ks + 1 < nk) {
                 // next stage (certified by this K-step's barrier): first-half A fragments; a[0..3] are no longer needed
@@ -1042,8 +1201,335 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 #undef S_DMA_A
 #undef S_DMA_B
 #undef S_ADVANCE
+    if (STATS) {
+        ring_epilogue16<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+    } else if (p.y_dtype == KTF_F32) {
+        ring_epilogue16_direct<ACT>(acc, p, b, t0, n0, out_len, wm, wn, lane);
+    } else {
+        __syncthreads();          // every wave's fragment reads are done before the ring is reused as staging
+        ring_epilogue16_pk<ACT>(acc, p, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+    }
+}
+
+template <int ACT, bool STATS>
+__global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
+                                                           double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    r16_tile<ACT, STATS>(p, mtiles, ntiles, gtiles, stats, rsm, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------ BF16, 128x256 tile, 2 workgroups/CU
+// The 256x256 kernel keeps one workgroup per CU, so its fixed per-tile phases (address setup, first-stage latency,
+// epilogue: ~11 us against 16 us of K-loop at K = 512) leave the MFMA pipe idle. Here a workgroup is FOUR waves on a
+// 128 x 256 tile (the same 128 x 64 block of 16x16x32 MFMAs per wave) with a 3-stage ring of 24 KiB stages: 76,800 B of
+// LDS and <= 256 VGPRs let TWO workgroups share a CU, out of phase, so one's epilogue / prologue overlaps the other's
+// K-loop and the two waves of a SIMD are no longer barrier-locked to each other.
+//  * bias is preloaded into the accumulators, BatchNorm scale/shift sit in LDS (no global loads in the epilogue);
+//  * non-reducing epilogue: operands swapped (W fragment as A) so a lane owns 4 consecutive columns -> packed bf16
+//    ds_write_b64 staging, one barrier, 16-byte global stores (store issue is per instruction, T21);
+//  * reducing (fused StatsPooling) epilogue: natural operand order, fp64 column sums, fp64 atomics.
+#define H_BM 128
+#define H_BN 256
+#define H_NSTAGE 3
+#define H_A_BYTES (H_BM * R_BK * 2)                  // 8 KiB
+#define H_B_BYTES (H_BN * R_BK * 2)                  // 16 KiB
+#define H_STAGE_BYTES (H_A_BYTES + H_B_BYTES)        // 24 KiB
+#define H_RING_BYTES (H_NSTAGE * H_STAGE_BYTES)      // 72 KiB (bf16 staging of the tile: 128 x 520 B = 66,560 B)
+#define H_LDS_BYTES (H_RING_BYTES + 3 * H_BN * 4)    // + bias | scale | shift of the tile's columns = 76,800 B
+#define H_PK_PITCH 520
+
+#ifdef KTF_TILE_PROBE
+#define H_PROBE(k) if (dbgp && threadIdx.x == 0) dbgp[k] = wall_clock64();
+#define H_PROBE_HW()                                                                  \
+    if (dbgp && threadIdx.x == 0) {                                                   \
+        unsigned hw_, xcc_;                                                           \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));             \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));           \
+        dbgp[5] = hw_; dbgp[6] = xcc_; dbgp[7] = nk;                                  \
+    }
+#else
+#define H_PROBE_HW()
+#define H_PROBE(k)
+#endif
+
+template <int ACT, bool STATS>
+__global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
+                                                            double* __restrict__ stats, long long* __restrict__ dbg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int id = blockIdx.x;
+#ifdef KTF_TILE_PROBE
+    long long* dbgp = dbg ? dbg + (int64_t)id * 16 : nullptr;
+#endif
+    H_PROBE(0)
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = (slot / ntiles) * 8 + xcd;
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * H_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = nt * H_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wn = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g4 = lane >> 4;
+
+    float* prm = reinterpret_cast<float*>(rsm + H_RING_BYTES);
+    {
+        const int n = n0 + tid;
+        const bool nv = n < p.units;
+        prm[tid] = (nv && p.bias) ? p.bias[n] : 0.0f;
+        prm[H_BN + tid] = (nv && p.scale) ? p.scale[n] : 1.0f;
+        prm[2 * H_BN + tid] = (nv && p.shift) ? p.shift[n] : 0.0f;
+    }
+
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;
+    const char* wb = reinterpret_cast<const char*>(p.w);
+    const unsigned ldxb = (unsigned)p.ldx * 2u;
+
+    // LDS-DMA chunk q = i*256 + tid -> tile row q/4, LDS position q%4, global chunk (q%4) ^ f(row) (f as in the r16 kernel)
+    int a_t[2];
+    unsigned a_cb[2], w_ob[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * 256 + tid;
+        const int row = q >> 2;
+        const unsigned chunk = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
+        if (i < 2) {
+            a_cb[i] = chunk;
+            a_t[i] = start + (t0 + row) * p.sub;
+        }
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + chunk;
+    }
+
+    const int nk = p.ktot / R_BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_slot = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 2;
+#define H_DMA_A(i)                                                                                                     \
+    {                                                                                                                  \
+        int r_ = a_t[i] + is_off;                                                                                      \
+        r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
+        const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                          \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_),                                                       \
+            (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);                           \
+    }
+#define H_DMA_B(i)                                                                                                     \
+    {                                                                                                                  \
+        const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                                 \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_),                                                       \
+            (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + H_A_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);               \
+    }
+#define H_ADVANCE()                                                                                                    \
+    {                                                                                                                  \
+        ++is_ks;                                                                                                       \
+        is_slot = (is_slot == H_NSTAGE - 1) ? 0 : is_slot + 1;                                                         \
+        is_db += R_BK * 2;                                                                                             \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
+    }
+    for (int s_ = 0; s_ < 2 && s_ < nk; ++s_) {
+        H_DMA_A(0) H_DMA_A(1) H_DMA_B(0) H_DMA_B(1) H_DMA_B(2) H_DMA_B(3)
+        H_ADVANCE()
+    }
+    H_PROBE(1)
+    __syncthreads();                                  // prm[] visible
+
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4v bj;
+        if (STATS) {
+            const float bv = prm[wn * 64 + j * 16 + c];
+            bj[0] = bv; bj[1] = bv; bj[2] = bv; bj[3] = bv;
+        } else {
+            bj = *reinterpret_cast<const f32x4v*>(prm + wn * 64 + j * 16 + g4 * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i][j] = bj;
+    }
+
+    const int fr = (4 - ((c >> 2) & 3)) & 3;
+    const int coff = ((g4 ^ fr) << 4);
+    const int a_row_off = c * 64 + coff;
+    const int b_row_off = (wn * 64 + c) * 64 + coff;
+    bfrag8 a[8], bq[4];
+    int cs = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef KTF_TILE_PROBE
+        if (ks == 0) { H_PROBE(2) }
+#endif
+        const bool refill = is_ks < nk;
+        const unsigned char* sa = rsm + cs * H_STAGE_BYTES;
+        const unsigned char* sb = sa + H_A_BYTES;
+        cs = (cs == H_NSTAGE - 1) ? 0 : cs + 1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 16 * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + j * 16 * 64);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = STATS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) {
+#pragma unroll
+                for (int i2 = 4; i2 < 8; ++i2) a[i2] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i2 * 16 * 64);
+            }
+            if (refill) {
+                if (i == 1) H_DMA_A(0)
+                if (i == 2) H_DMA_A(1)
+                if (i == 3) H_DMA_B(0)
+                if (i == 4) H_DMA_B(1)
+                if (i == 5) H_DMA_B(2)
+                if (i == 6) H_DMA_B(3)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (refill) H_ADVANCE()
+    }
+#undef H_DMA_A
+#undef H_DMA_B
+#undef H_ADVANCE
+    H_PROBE(3)
+    const int rows_valid = out_len - t0;
+    if (STATS) {
+        // acc[i][j][r] = out[row i*16 + g4*4 + r][col wn*64 + j*16 + c]
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + c;
+            const float scj = prm[H_BN + nl], shj = prm[2 * H_BN + nl];
+            double sm = 0.0, sq = 0.0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = i * 16 + g4 * 4 + r;
+                    float v = acc[i][j][r];
+                    if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                    else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                    v = v * scj + shj;
+                    if (m < rows_valid) {
+                        sm += (double)v;
+                        sq += (double)v * (double)v;
+                    }
+                }
+            }
+            sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
+            const int n = n0 + nl;
+            if (lane < 16 && n < p.units) {
+                double* dst = stats + ((int64_t)b * 2) * p.units + n;
+                atomicAdd(dst, sm);
+                atomicAdd(dst + p.units, sq);
+            }
+        }
+        H_PROBE(4)
+        H_PROBE_HW()
+        return;
+    }
+    // acc[i][j][e] = out[row i*16 + c][col wn*64 + j*16 + g4*4 + e]
+    f32x4v sc[4], sh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sc[j] = *reinterpret_cast<const f32x4v*>(prm + H_BN + wn * 64 + j * 16 + g4 * 4);
+        sh[j] = *reinterpret_cast<const f32x4v*>(prm + 2 * H_BN + wn * 64 + j * 16 + g4 * 4);
+    }
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+    if (p.y_dtype == KTF_F32) {
+        float* ybase = reinterpret_cast<float*>(p.y);
+        const bool vec_ok = ((p.ldy & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int m = i * 16 + c;
+            if (m >= rows_valid) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4v v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ACT == KTF_ACT_RELU) v[e] = fmaxf(v[e], 0.0f);
+                    else if (ACT != KTF_ACT_NONE) v[e] = apply_act(v[e], ACT);
+                }
+                v = v * sc[j] + sh[j];
+                const int n = n0 + wn * 64 + j * 16 + g4 * 4;
+                float* yp = ybase + (out_row0 + m) * p.ldy + n;
+                if (vec_ok && n + 4 <= p.units) {
+                    *reinterpret_cast<f32x4v*>(yp) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.units) yp[e] = v[e];
+                }
+            }
+        }
+        return;
+    }
+    __syncthreads();                                  // all fragment reads done: the ring becomes the staging buffer
+    H_PROBE(8)
+    {
+        unsigned char* stg = rsm + c * H_PK_PITCH + (wn * 64 + g4 * 4) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4v v = acc[i][j];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (ACT == KTF_ACT_RELU) v[e] = fmaxf(v[e], 0.0f);
+                    else if (ACT != KTF_ACT_NONE) v[e] = apply_act(v[e], ACT);
+                }
+                v = v * sc[j] + sh[j];
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(stg + i * 16 * H_PK_PITCH + j * 32) = pk;
+            }
+        }
+    }
+    H_PROBE(9)
     __syncthreads();
-    ring_epilogue16<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+    H_PROBE(10)
+    {
+        const int n8 = n0 + (lane & 31) * 8;
+        const bool wide = (n8 + 8 <= p.units) && ((p.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+        unsigned short* ybase = reinterpret_cast<unsigned short*>(p.y);
+#pragma unroll 4
+        for (int sp = 0; sp < 16; ++sp) {
+            const int m = wn * 32 + sp * 2 + (lane >> 5);
+            if (m < rows_valid) {
+                const unsigned char* src = rsm + m * H_PK_PITCH + (lane & 31) * 16;
+                const uint2 lo = *reinterpret_cast<const uint2*>(src);
+                const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+                unsigned short* yp = ybase + (out_row0 + m) * p.ldy + n8;
+                if (wide) {
+                    u32x4 o;
+                    o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+                    *reinterpret_cast<u32x4*>(yp) = o;
+                } else {
+                    const unsigned w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (n8 + e < p.units) yp[e] = (unsigned short)(w4[e >> 1] >> ((e & 1) * 16));
+                }
+            }
+        }
+    }
+    H_PROBE(4)
+    H_PROBE_HW()
 }
 
 // ------------------------------------------------------------------------------------ BF16X3, 256x256 tile
@@ -1332,12 +1818,33 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             hipLaunchKernelGGL((tdnn_bf16r_kernel<A, false>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr); \
         }                                                                                                              \
     } while (0)
+                // 128x256 tiles with two workgroups per CU win while the fixed per-tile phases are comparable to the K-loop
+                // (K <= 768); deeper K amortises them and the 256x256 tile moves fewer bytes per flop. KTF_HTILE=0/1 forces.
+                static const int htile_env = getenv("KTF_HTILE") ? atoi(getenv("KTF_HTILE")) : -1;
+                const bool htile = htile_env >= 0 ? (htile_env != 0) : (p.ktot <= 768);
+                if (htile && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE)) {
+                    const int mt_h = ktf_cdiv(Tout, H_BM);
+                    const int64_t gt_h = B * (int64_t)mt_h;
+                    const int64_t nb_h = ((gt_h + 7) / 8) * 8 * ntiles_r;
+                    KTF_REQUIRE(nb_h < (1ll << 31), "ktf_tdnn: grid too large");
+                    static long long* dbgptr = getenv("KTF_DBG_PTR") ? (long long*)strtoull(getenv("KTF_DBG_PTR"), nullptr, 10) : nullptr;
+#define H_LAUNCH(A, ST)                                                                                                \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)tdnn_bf16h_kernel<A, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); \
+        hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums, dbgptr); \
+    } while (0)
+                    if (d->act == KTF_ACT_RELU) { if (stats_sums) H_LAUNCH(KTF_ACT_RELU, true); else H_LAUNCH(KTF_ACT_RELU, false); }
+                    else { if (stats_sums) H_LAUNCH(KTF_ACT_NONE, true); else H_LAUNCH(KTF_ACT_NONE, false); }
+#undef H_LAUNCH
+                    KTF_CHECK_LAUNCH("ktf_tdnn");
+                    return KTF_OK;
+                }
                 static const int mfma16 = getenv("KTF_MFMA16") ? atoi(getenv("KTF_MFMA16")) : 1;     // default: 16x16x32 variant (0 = 32x32x16, A/B)
                 if (mfma16 && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE)) {
 #define S_LAUNCH(A, ST)                                                                                                \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)tdnn_bf16r16_kernel<A, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
-        hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        (void)hipFuncSetAttribute((const void*)tdnn_bf16r16_kernel<A, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, R16_LDS_BYTES); \
+        hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
                     if (d->act == KTF_ACT_RELU) { if (stats_sums) S_LAUNCH(KTF_ACT_RELU, true); else S_LAUNCH(KTF_ACT_RELU, false); }
                     else { if (stats_sums) S_LAUNCH(KTF_ACT_NONE, true); else S_LAUNCH(KTF_ACT_NONE, false); }
