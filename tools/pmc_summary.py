@@ -15,4 +15,6 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             n[(k, r["Counter_Name"])] += 1
     for k, v in agg.items():
-        print(k, {c: (x, n[(k, c)]) for c, x in v.items()})
+        print(k)
+        for c, x in v.items():
+            print(f"    {c:42s} per launch {x / n[(k, c)]:16.1f}   launches {n[(k, c)]}")

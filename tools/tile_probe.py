@@ -32,6 +32,8 @@ for name, din, units, ctx in [("tdnn2", 512, 512, [-2, 0, 2]), ("tdnn4", 512, 51
     print(f"  setup {np.mean(t1-t0):.2f}  first-stage wait {np.mean(t2-t1):.2f}  loop {np.mean(t3-t2):.2f}  epilogue {np.mean(t4-t3):.2f}  total {np.mean(t4-t0):.2f} us")
     e = [d[:, k].astype(np.float64) * 0.01 for k in (8, 9, 10, 11)]
     print(f"  epi: sync-before {np.mean(e[0]-t3):.2f}  valu+ds_write {np.mean(e[1]-e[0]):.2f}  barrier {np.mean(e[2]-e[1]):.2f}  read+store {np.mean(t4-e[2]):.2f}")
+    cyc = (d[:, 13] - d[:, 12]).astype(np.float64) / d[:, 7]
+    print(f"  K-loop: {np.mean(cyc):.0f} shader cycles per K-step ({np.mean(t3-t2)/d[0,7]*1000:.0f} ns -> {np.mean(cyc)/(np.mean(t3-t2)/d[0,7]*1000):.2f} GHz); ideal 1024 with two workgroups per CU")
     # per-CU gaps
     key = (d[:, 6] & 0xf) * 65536 + (d[:, 5] & 0xff00)       # xcc, (se, sh, cu)
     gaps, busy = [], []
