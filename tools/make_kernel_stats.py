@@ -15,3 +15,19 @@ with open(out, "w") as f:
     for r in rows:
         f.write(f"| `{r['Name'][:90]}` | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {float(r['Percentage']):.2f} |\n")
 print(open(out).read())
+
+# optional 4th argument: the kernel_trace.csv of the same run -> a second table without each kernel's first launch
+if len(sys.argv) > 4:
+    import collections
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(sys.argv[4])):
+        d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(out, "a") as f:
+        f.write("\n## Steady state (same run, kernel_trace.csv, first launch of every kernel dropped)\n\n")
+        f.write("The first launch of `tdnn_bf16h_kernel<1, true>` (warm-up step 1) takes ~30 ms once per process; the table above "
+                "averages it in, this one does not.\n\n| kernel | calls | average ns | min ns | max ns |\n|---|---:|---:|---:|---:|\n")
+        for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1][1:])):
+            v = v[1:]
+            if v and not k.startswith("void at::") and not k.startswith("__amd"):
+                f.write(f"| `{k[:90]}` | {len(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} |\n")
+    print(open(out).read()[-1500:])
