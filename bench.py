@@ -246,6 +246,14 @@ def _other_configs(ktf, synth, cfg, w, wav, gemm, dev):
         res[f"x_vectors_per_s_{g}"] = B / (ms * 1e-3)
         del m
         torch.cuda.empty_cache()
+    # int16 PCM input: same step, half the input bytes; and the PCIe-inclusive rate of a host-fed step
+    mi = synth.build_extractor(ktf, cfg, w, gemm=gemm)
+    wav16 = wav.to(torch.int16)
+    res[f"x_vectors_per_s_{gemm}_int16_input"] = B / (_time_ms(lambda: mi(wav16), 3) * 1e-3)
+    host16 = wav16.cpu().pin_memory()
+    res[f"x_vectors_per_s_{gemm}_int16_from_pinned_host"] = B / (_time_ms(lambda: mi(host16.to(dev, non_blocking=True)), 3) * 1e-3)
+    del mi, wav16, host16
+    torch.cuda.empty_cache()
     m1 = synth.build_extractor(ktf, cfg, w, gemm="f32")
     one = wav[:1].contiguous()
     res["batch1_fp32_latency_ms"] = _time_ms(lambda: m1(one), 10)

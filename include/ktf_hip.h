@@ -79,6 +79,10 @@ typedef struct KtfFrontendCfg {
     float dither;          /* 0 disables; else x += N(0,1)*dither (counter-based RNG, `seed`)    */
     float energy_floor;    /* clip of the LOG energy from below (windowing.py:177)               */
     float eps;             /* epsilon inside both logs                                           */
+    int32_t pad_mode;      /* KTF_IN_WAV* only. 0: Framing as the reference (no padding, T = 1+(n-size)/shift).
+                            * 1: Kaldi snip-edges=false framing: the waveform is mirror-padded as by the reference's
+                            *    kaldi_numpy PadWaveform (kaldi_numpy/frame_extraction.py:28-89) -- fused into the frame
+                            *    gather, nothing is materialised; T = (n + shift/2) / shift                             */
 } KtfFrontendCfg;
 
 typedef struct KtfFrontendTables {   /* all DEVICE pointers, built once by the host */
@@ -104,6 +108,7 @@ typedef struct KtfFrontendTables {   /* all DEVICE pointers, built once by the h
 #define KTF_IN_WAV 0         /* in = (B, N) samples; frames are gathered on the fly (Framing fused)   */
 #define KTF_IN_FRAMES 1      /* in = (B, T, frame_size) frames                                        */
 #define KTF_IN_WINDOWED 2    /* in = (B, T, frame_size) already-windowed frames (FilterBank alone)     */
+#define KTF_IN_WAV_I16 3     /* in = (B, N) int16 PCM samples (half the HBM / PCIe bytes of KTF_IN_WAV) */
 #define KTF_OUT_FRAMES 0     /* out (B,T,frame_size): Framing.call                                    */
 #define KTF_OUT_WINDOWED 1   /* out (B,T,frame_size) [+ energy (B,T)]: Windowing.call                 */
 #define KTF_OUT_FBANK 2      /* out (B,T,num_mels): FilterBank.call                                    */
@@ -111,11 +116,13 @@ typedef struct KtfFrontendTables {   /* all DEVICE pointers, built once by the h
 
 /* Number of frames Framing produces from n samples: 1 + (n - frame_size) / frame_shift (0 if n < size). */
 int64_t ktf_num_frames(int64_t n_samples, int32_t frame_size, int32_t frame_shift);
+/* The same for a given KtfFrontendCfg.pad_mode (1: (n + shift/2) / shift; -1 if the mirror padding is undefined for n). */
+int64_t ktf_num_frames_padded(int64_t n_samples, int32_t frame_size, int32_t frame_shift, int32_t pad_mode);
 
 /* One launch for any prefix/suffix of Framing -> Windowing -> FilterBank -> DCT/lifter/C0.
  * `n` is the number of samples per row for KTF_IN_WAV, else the number of frames T.
  * `energy` (B,T) may be NULL unless out_stage == KTF_OUT_WINDOWED and cfg->use_energy. */
-int ktf_frontend_f32(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
+int ktf_frontend_f32(const void* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
                      const KtfFrontendTables* tab, int32_t out_stage, float* out, float* energy,
                      uint64_t seed, void* stream);
 

@@ -54,4 +54,12 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return *reinterpret_cast<unsigned short*>(&h);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// Sample g of an utterance's waveform in "frame coordinates" (frame t starts at t*shift - pad_left): outside [0, n) the
+// waveform is mirrored with the edge sample repeated, as kaldi_numpy MirrorPad does (frame_extraction.py:28-51).
+__device__ __forceinline__ float ktf_wav_sample(const void* wav_b, int i16, int n, int g) {
+    if (g < 0) g = -g - 1;
+    else if (g >= n) g = 2 * n - 1 - g;
+    return i16 ? (float)reinterpret_cast<const short*>(wav_b)[g] : reinterpret_cast<const float*>(wav_b)[g];
+}
 #endif

@@ -103,7 +103,7 @@ __device__ __forceinline__ void fft_stage(const float2* __restrict__ x, float2* 
 }
 
 template <int LOG2NF>
-__global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __restrict__ in, int64_t B, int64_t n,
+__global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                               int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                               FeLds L, int out_stage, float* __restrict__ out,
                                                               float* __restrict__ energy_out, uint64_t seed,
@@ -116,6 +116,10 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = cfg.frame_size;
     const int nm = cfg.num_mels, nc = cfg.num_ceps;
+    const float* in = reinterpret_cast<const float*>(in_v);
+    const int i16 = in_kind == KTF_IN_WAV_I16;
+    if (i16) in_kind = KTF_IN_WAV;
+    const int pad_left = (in_kind == KTF_IN_WAV && cfg.pad_mode) ? (M - cfg.frame_shift) / 2 : 0;
 
     // ---- block-shared tables -> LDS (once per block)
     if (in_kind != KTF_IN_WINDOWED && out_stage >= KTF_OUT_WINDOWED)
@@ -155,7 +159,17 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
         float logE = 0.0f;
 
         // ---- load the frame (Framing fused: frame t of utterance b starts at sample t*shift)
-        if (valid) {
+        if (valid && in_kind == KTF_IN_WAV && (i16 || cfg.pad_mode)) {
+            // int16 samples and/or mirrored edges (KtfFrontendCfg.pad_mode): n < 2^31 checked by the host
+            const int64_t b = row / T, t = row - b * T;
+            const void* wav_b = i16 ? (const void*)(reinterpret_cast<const short*>(in_v) + b * n) : (const void*)(in + b * n);
+            const int g0 = (int)t * cfg.frame_shift - pad_left;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + KTF_WAVE * j;
+                v[j] = (i < M) ? ktf_wav_sample(wav_b, i16, (int)n, g0 + i) : 0.0f;
+            }
+        } else if (valid) {
             const float* src;
             if (in_kind == KTF_IN_WAV) {
                 const int64_t b = row / T, t = row - b * T;
@@ -309,14 +323,20 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const float* __res
 }
 
 // Framing.call on its own (any frame size): out[b, t, i] = in[b, t*shift + i]
-__global__ void framing_kernel(const float* __restrict__ in, int64_t B, int64_t n, int M, int shift, int64_t T,
-                               float* __restrict__ out) {
+__global__ void framing_kernel(const void* __restrict__ in_v, int i16, int pad_left, int64_t B, int64_t n, int M,
+                               int shift, int64_t T, float* __restrict__ out) {
     const int64_t total = B * T * M;
+    const float* in = reinterpret_cast<const float*>(in_v);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(e % M);
         const int64_t bt = e / M;
         const int64_t t = bt % T, b = bt / T;
-        out[e] = in[b * n + t * shift + i];
+        if (i16 || pad_left >= 0) {        // pad_left < 0: plain reference Framing on fp32 samples
+            const void* wav_b = i16 ? (const void*)(reinterpret_cast<const short*>(in_v) + b * n) : (const void*)(in + b * n);
+            out[e] = ktf_wav_sample(wav_b, i16, (int)n, (int)t * shift - (pad_left < 0 ? 0 : pad_left) + i);
+        } else {
+            out[e] = in[b * n + t * shift + i];
+        }
     }
 }
 
@@ -334,7 +354,7 @@ __global__ void rowmat_kernel(const float* __restrict__ x, int64_t rows, int in_
     }
 }
 
-int ktf_frontend512_launch(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
+int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
                            const KtfFrontendTables* tab, int32_t out_stage, float* out, uint64_t seed, int64_t T,
                            hipStream_t st);   // frontend512.hip
 
@@ -343,25 +363,46 @@ extern "C" int64_t ktf_num_frames(int64_t n_samples, int32_t frame_size, int32_t
     return 1 + (n_samples - frame_size) / frame_shift;
 }
 
-extern "C" int ktf_frontend_f32(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
+extern "C" int64_t ktf_num_frames_padded(int64_t n_samples, int32_t frame_size, int32_t frame_shift, int32_t pad_mode) {
+    if (!pad_mode) return ktf_num_frames(n_samples, frame_size, frame_shift);
+    if (frame_size <= 0 || frame_shift <= 0 || n_samples <= 0) return 0;
+    // kaldi_numpy PadWaveform (frame_extraction.py:71-89): M frames, padded length Nv = (M-1)*shift + size
+    const int64_t M = (n_samples + frame_shift / 2) / frame_shift;
+    const int64_t Nv = (M - 1) * frame_shift + frame_size;
+    const int64_t left = (frame_size - frame_shift) / 2, right = (Nv - n_samples) - left;
+    if (M < 1 || Nv < n_samples || left < 0 || right < 0 || left > n_samples || right > n_samples) return -1;
+    return M;
+}
+
+extern "C" int ktf_frontend_f32(const void* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
                                 const KtfFrontendTables* tab, int32_t out_stage, float* out, float* energy,
                                 uint64_t seed, void* stream) {
     KTF_REQUIRE(in && out && cfg && tab, "ktf_frontend_f32: null argument");
     KTF_REQUIRE(B >= 0 && n >= 0, "ktf_frontend_f32: negative size");
-    KTF_REQUIRE(in_kind >= KTF_IN_WAV && in_kind <= KTF_IN_WINDOWED, "ktf_frontend_f32: bad in_kind %d", in_kind);
+    KTF_REQUIRE(in_kind >= KTF_IN_WAV && in_kind <= KTF_IN_WAV_I16, "ktf_frontend_f32: bad in_kind %d", in_kind);
+    const bool wav = in_kind == KTF_IN_WAV || in_kind == KTF_IN_WAV_I16;
+    const int pad_mode = wav ? cfg->pad_mode : 0;
+    KTF_REQUIRE(pad_mode == 0 || pad_mode == 1, "ktf_frontend_f32: bad pad_mode %d", pad_mode);
+    if (wav && (pad_mode || in_kind == KTF_IN_WAV_I16)) KTF_REQUIRE(n < (1ll << 31) - 4096, "ktf_frontend_f32: int16 / padded input needs n < 2^31");
+    int64_t Tw = 0;
+    if (wav) {
+        Tw = ktf_num_frames_padded(n, cfg->frame_size, cfg->frame_shift, pad_mode);
+        KTF_REQUIRE(Tw >= 0, "ktf_frontend_f32: mirror padding undefined for %lld samples (frame %d, shift %d)", (long long)n, cfg->frame_size, cfg->frame_shift);
+    }
     KTF_REQUIRE(out_stage >= KTF_OUT_FRAMES && out_stage <= KTF_OUT_MFCC, "ktf_frontend_f32: bad out_stage %d", out_stage);
     KTF_REQUIRE(cfg->frame_size > 0 && cfg->frame_shift > 0, "ktf_frontend_f32: frame size/shift must be > 0");
     KTF_REQUIRE(!(in_kind == KTF_IN_WINDOWED && out_stage < KTF_OUT_FBANK), "ktf_frontend_f32: windowed input needs a FBANK/MFCC stage");
     if (out_stage == KTF_OUT_FRAMES) {
-        KTF_REQUIRE(in_kind == KTF_IN_WAV, "ktf_frontend_f32: KTF_OUT_FRAMES needs KTF_IN_WAV");
-        KTF_REQUIRE(B == 0 || n >= cfg->frame_size, "ktf_frontend_f32: input of %lld samples is shorter than a frame (%d)", (long long)n, cfg->frame_size);
-        const int64_t Tf = ktf_num_frames(n, cfg->frame_size, cfg->frame_shift);
+        KTF_REQUIRE(wav, "ktf_frontend_f32: KTF_OUT_FRAMES needs KTF_IN_WAV");
+        KTF_REQUIRE(B == 0 || pad_mode || n >= cfg->frame_size, "ktf_frontend_f32: input of %lld samples is shorter than a frame (%d)", (long long)n, cfg->frame_size);
+        const int64_t Tf = Tw;
         const int64_t total = B * Tf * cfg->frame_size;
         if (total == 0) return KTF_OK;
         int blk = ktf_cdiv(total, 256);
         if (blk > 4096) blk = 4096;
-        hipLaunchKernelGGL(framing_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, in, B, n, cfg->frame_size,
-                           cfg->frame_shift, Tf, out);
+        hipLaunchKernelGGL(framing_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, in, (int)(in_kind == KTF_IN_WAV_I16),
+                           pad_mode ? (cfg->frame_size - cfg->frame_shift) / 2 : (in_kind == KTF_IN_WAV_I16 ? 0 : -1), B, n,
+                           cfg->frame_size, cfg->frame_shift, Tf, out);
         KTF_CHECK_LAUNCH("ktf_frontend_f32(framing)");
         return KTF_OK;
     }
@@ -378,8 +419,8 @@ extern "C" int ktf_frontend_f32(const float* in, int64_t B, int64_t n, int32_t i
         KTF_REQUIRE(tab->dct, "ktf_frontend_f32: missing DCT table");
     }
     if (in_kind != KTF_IN_WINDOWED && out_stage >= KTF_OUT_WINDOWED) KTF_REQUIRE(tab->window, "ktf_frontend_f32: missing window table");
-    const int64_t T = (in_kind == KTF_IN_WAV) ? ktf_num_frames(n, cfg->frame_size, cfg->frame_shift) : n;
-    if (in_kind == KTF_IN_WAV) KTF_REQUIRE(B == 0 || n >= cfg->frame_size, "ktf_frontend_f32: input of %lld samples is shorter than a frame (%d)", (long long)n, cfg->frame_size);
+    const int64_t T = wav ? Tw : n;
+    if (wav) KTF_REQUIRE(B == 0 || pad_mode || n >= cfg->frame_size, "ktf_frontend_f32: input of %lld samples is shorter than a frame (%d)", (long long)n, cfg->frame_size);
     const int64_t rows = B * T;
     if (rows == 0) return KTF_OK;
     if (cfg->nfft == 512 && out_stage >= KTF_OUT_FBANK && tab->fast_tw && tab->fast_mel_meta && tab->fast_mel_w &&

@@ -125,7 +125,7 @@ __device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t
     } while (0)
 
 template <bool DITHER>
-__global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const float* __restrict__ in, int64_t B, int64_t n,
+__global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                                  int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                                  int out_stage, float* __restrict__ out,
                                                                  uint64_t seed, int64_t T) {
@@ -184,8 +184,13 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const float* __
     // grid = (frame groups per utterance, B): no division in the frame loop, 32-bit offsets from per-utterance bases
     const int b = blockIdx.y;
     const int Ti = (int)T;
-    const float* in_b = in + (int64_t)b * ((in_kind == KTF_IN_WAV) ? n : T * (int64_t)M);
+    const int i16 = in_kind == KTF_IN_WAV_I16;
+    if (i16) in_kind = KTF_IN_WAV;
+    const float* in_b = reinterpret_cast<const float*>(in_v) + (int64_t)b * ((in_kind == KTF_IN_WAV) ? n : T * (int64_t)M);
+    const short* in_b16 = reinterpret_cast<const short*>(in_v) + (int64_t)b * n;
     const int src_step = (in_kind == KTF_IN_WAV) ? cfg.frame_shift : M;
+    const int pad_left = (in_kind == KTF_IN_WAV && cfg.pad_mode) ? (M - cfg.frame_shift) / 2 : 0;
+    const int ni = (int)n;
     const int64_t row_base = (int64_t)b * T;
     const int t_step = gridDim.x * F5_WAVES;
     for (int t0 = blockIdx.x * F5_WAVES; t0 < Ti; t0 += t_step) {
@@ -194,8 +199,23 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const float* __
         const int64_t row = row_base + t;
         float v[NV];
         float logE = 0.0f;
-        if (valid) {
-            const float* src = in_b + t * src_step;
+        const int g0 = t * src_step - pad_left;          // first sample of the frame (wav kinds)
+        if (valid && in_kind == KTF_IN_WAV && (g0 < 0 || g0 + M > ni)) {
+            // edge frame of KtfFrontendCfg.pad_mode 1: mirrored samples
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + KTF_WAVE * j;
+                v[j] = (i < M) ? ktf_wav_sample(i16 ? (const void*)in_b16 : (const void*)in_b, i16, ni, g0 + i) : 0.0f;
+            }
+        } else if (valid && i16) {
+            const short* src = in_b16 + g0;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + KTF_WAVE * j;
+                v[j] = (i < M) ? (float)src[i] : 0.0f;
+            }
+        } else if (valid) {
+            const float* src = in_b + g0;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = lane + KTF_WAVE * j;
@@ -336,7 +356,7 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const float* __
 }
 
 // launcher used by ktf_frontend_f32 (frontend.hip) when the fast tables are present and the configuration qualifies
-int ktf_frontend512_launch(const float* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
+int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
                            const KtfFrontendTables* tab, int32_t out_stage, float* out, uint64_t seed, int64_t T,
                            hipStream_t st) {
     // ~2048 workgroups in total: gx frame groups per utterance x B utterances

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libktf_hip.so")
 KTF_F32, KTF_BF16 = 0, 1
 GEMM_F32, GEMM_BF16, GEMM_BF16X3 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
-IN_WAV, IN_FRAMES, IN_WINDOWED = 0, 1, 2
+IN_WAV, IN_FRAMES, IN_WINDOWED, IN_WAV_I16 = 0, 1, 2, 3
 OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
 
 
@@ -28,7 +28,7 @@ class FrontendCfg(C.Structure):
         ("frame_size", C.c_int32), ("frame_shift", C.c_int32), ("nfft", C.c_int32), ("num_mels", C.c_int32),
         ("num_ceps", C.c_int32), ("remove_dc", C.c_int32), ("raw_energy", C.c_int32), ("use_energy", C.c_int32),
         ("use_power", C.c_int32), ("use_log", C.c_int32), ("use_lifter", C.c_int32), ("preemph", C.c_float),
-        ("dither", C.c_float), ("energy_floor", C.c_float), ("eps", C.c_float),
+        ("dither", C.c_float), ("energy_floor", C.c_float), ("eps", C.c_float), ("pad_mode", C.c_int32),
     ]
 
 
@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ktf_version": (_i32, []),
     "ktf_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
     "ktf_num_frames": (_i64, [_i64, _i32, _i32]),
+    "ktf_num_frames_padded": (_i64, [_i64, _i32, _i32, _i32]),
     "ktf_frontend_f32": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(FrontendCfg), C.POINTER(FrontendTables), _i32, _P, _P, _u64, _P]),
     "ktf_dct_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P]),
     "ktf_vad_mask_f32": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(VadCfg), _P, _P]),

@@ -93,11 +93,16 @@ class Layer:
 
 # =============================================================================== dsp
 class Framing(Layer):
-    """layers/dsp/framing.py:25 — frames of `frame_length_ms` every `frame_shift_ms`, no padding."""
+    """layers/dsp/framing.py:25 — frames of `frame_length_ms` every `frame_shift_ms`, no padding.
+
+    Extensions (not in the reference): `snip_edges=False` frames the waveform as Kaldi's --snip-edges=false does, i.e. as
+    if it had been mirror-padded with the reference's `kaldi_numpy.PadWaveform` (frame_extraction.py:54-89) first — done
+    inside the frame gather on the device; int16 tensors are consumed as they are (no fp32 copy)."""
 
     def __init__(self, frame_length_ms=25.0, frame_shift_ms=10.0, sample_frequency=16000.0, name=None,
-                 dynamic_input_shape=False, **kwargs):
+                 dynamic_input_shape=False, snip_edges=True, **kwargs):
         super().__init__(trainable=False, name=name, **kwargs)
+        self.snipEdges = bool(snip_edges)
         self.sampleFreq = sample_frequency
         self.frameSizeMs = frame_length_ms
         self.frameShiftMs = frame_shift_ms
@@ -120,15 +125,42 @@ class Framing(Layer):
         if n is None and not self.dynamicInputShape:
             raise ValueError("input_shape must not be unknown if dynamic_input_shape set to False")
         if n is not None:
-            if n < self.frameSize:
+            if n < self.minSamples():
                 raise ValueError(f"input sample size (axis={self.sampleAxis}) must be >= frame size ({self.frameSize})")
             self.numInputSamples = n
         self.built = True
 
     def numFrames(self, n):
+        if not self.snipEdges:
+            # kaldi_numpy PadWaveform + Framing: M = round(n / shift) frames over the mirror-padded waveform
+            M = (n + self.frameShift // 2) // self.frameShift
+            Nv = (M - 1) * self.frameShift + self.frameWidth
+            left = (self.frameWidth - self.frameShift) // 2
+            right = (Nv - n) - left
+            if M < 1 or Nv < n or left < 0 or right < 0 or left > n or right > n:
+                raise ValueError(f"snip_edges=False: mirror padding is undefined for {n} samples")
+            return M
         # centres = range(half, n - half + 1, shift)
         span = n - 2 * self.halfFrameSize
         return 0 if span < 0 else 1 + span // self.frameShift
+
+    def minSamples(self):
+        return self.frameSize if self.snipEdges else 1
+
+    @staticmethod
+    def device_samples(inputs):
+        """(tensor, in_kind) the kernels read: int16 PCM stays int16, everything else becomes fp32."""
+        x = inputs
+        if not (isinstance(x, torch.Tensor) and x.is_cuda):
+            if isinstance(x, np.ndarray) and x.dtype == np.int16:
+                x = torch.as_tensor(x).to(ops.default_device())
+            elif isinstance(x, torch.Tensor) and x.dtype == torch.int16:
+                x = x.to(ops.default_device())
+            else:
+                x = ops.to_device_f32(x)
+        if x.dtype == torch.int16:
+            return x.contiguous(), L.IN_WAV_I16
+        return x.to(torch.float32).contiguous(), L.IN_WAV
 
     def compute_output_shape(self, input_shape):
         n = input_shape[self.sampleAxis]
@@ -142,18 +174,21 @@ class Framing(Layer):
         c = super().get_config()
         c.update({"frame_length": self.frameSizeMs, "frame_shift": self.frameShiftMs,
                   "sample_frequency": self.sampleFreq, "dynamic_input_shape": self.dynamicInputShape})
+        if not self.snipEdges:
+            c["snip_edges"] = False
         return c
 
     def _cfg(self):
         return L.FrontendCfg(frame_size=self.frameWidth, frame_shift=self.frameShift,
-                             nfft=max(64, ops.next_power_of_2(self.frameWidth)), num_mels=1, num_ceps=1)
+                             nfft=max(64, ops.next_power_of_2(self.frameWidth)), num_mels=1, num_ceps=1,
+                             pad_mode=0 if self.snipEdges else 1)
 
     def call(self, inputs):
-        x = inputs.to(torch.float32).contiguous()
+        x, kind = self.device_samples(inputs)
         n = x.shape[-1]
         if not self.dynamicInputShape and self.numInputSamples is not None and n != self.numInputSamples:
             raise ValueError(f"layer was built for {self.numInputSamples} samples, got {n}")
-        if n < self.frameSize:
+        if n < self.minSamples():
             raise ValueError(f"input sample size (axis={self.sampleAxis}) must be >= frame size ({self.frameSize})")
         lead = x.shape[:-1]
         B = int(np.prod(lead)) if len(lead) else 1
@@ -161,7 +196,7 @@ class Framing(Layer):
         cfg = self._cfg()
         if not hasattr(self, "_tables"):
             self._tables = ops.FrontendTables(self.frameWidth, device=x.device)
-        out = ops.frontend(x.reshape(B, n), L.IN_WAV, cfg, self._tables, L.OUT_FRAMES, n, B, T)
+        out = ops.frontend(x.reshape(B, n), kind, cfg, self._tables, L.OUT_FRAMES, n, B, T)
         if self.dynamicInputShape:
             return out.reshape(lead[0] if len(lead) else 1, -1, self.frameWidth)
         return out.reshape(*lead, T, self.frameWidth)

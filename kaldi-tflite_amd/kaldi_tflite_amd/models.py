@@ -356,15 +356,12 @@ class XvectorExtractor:
 
     def features(self, inputs):
         """wav -> (mfcc (B,T,C), cmvn'd voiced features view (B,T,C), lens (B,)) — the front half of call()."""
-        x = inputs
-        if not (isinstance(x, torch.Tensor) and x.is_cuda):
-            x = ops.to_device_f32(x)
-        x = x.to(torch.float32).contiguous()
+        fr, mf = self.framing, self.mfcc
+        x, kind = fr.device_samples(inputs)          # fp32, or int16 PCM as it is
         if x.dim() == 1:
             x = x.unsqueeze(0)
         B, N = x.shape
-        fr, mf = self.framing, self.mfcc
-        if N < fr.frameSize:
+        if N < fr.minSamples():
             raise ValueError(f"input sample size (axis=-1) must be >= frame size ({fr.frameSize})")
         if not mf.built or mf._M != fr.frameWidth:
             mf.build((None, None, fr.frameWidth))
@@ -375,7 +372,8 @@ class XvectorExtractor:
         ws = self._workspace(B, T, D, x.device, feat_dtype)
         cfg = L.FrontendCfg.from_buffer_copy(mf._cfg)
         cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift
-        ops.frontend(x, L.IN_WAV, cfg, mf.tables(x.device), L.OUT_MFCC, N, B, T, seed=mf.next_seed(), out=ws["mfcc"])
+        cfg.pad_mode = 0 if fr.snipEdges else 1
+        ops.frontend(x, kind, cfg, mf.tables(x.device), L.OUT_MFCC, N, B, T, seed=mf.next_seed(), out=ws["mfcc"])
         ops.vad_cmvn(ws["mfcc"], self.vad.cfg(), self.cmvn.cfg(), ws["feats"], ws["lens"], ws["idx"], ws["work"])
         return ws["mfcc"], ws["feats"][:, :, :D], ws["lens"]
 

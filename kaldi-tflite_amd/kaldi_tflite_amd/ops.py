@@ -21,6 +21,10 @@ def _dev(device=None):
     return torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
 
 
+def default_device():
+    return _dev(None)
+
+
 def to_device_f32(x, device=None):
     """numpy / tensor -> contiguous fp32 tensor on the GPU."""
     dev = _dev(device)
@@ -220,7 +224,7 @@ def num_frames(n_samples, frame_size, frame_shift):
 
 
 def frontend(x, in_kind, cfg, tables, out_stage, n, B, T, seed=0, want_energy=False, out=None):
-    """x: fp32 device tensor. Returns out (B,T,last) [, energy (B,T)]."""
+    """x: fp32 device tensor (int16 for L.IN_WAV_I16). Returns out (B,T,last) [, energy (B,T)]."""
     lib = L.load()
     last = {L.OUT_FRAMES: cfg.frame_size, L.OUT_WINDOWED: cfg.frame_size, L.OUT_FBANK: cfg.num_mels,
             L.OUT_MFCC: cfg.num_ceps}[out_stage]

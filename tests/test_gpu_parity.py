@@ -55,6 +55,55 @@ def test_framing_exact():
         fr(np.zeros((1, 399), np.float32))
 
 
+def test_input_side_int16_and_device_side_padding():
+    """int16 PCM ingestion and Kaldi snip-edges=false framing (the reference's NumPy PadWaveform,
+    kaldi_numpy/frame_extraction.py:54-89) done inside the frame gather equal the host-side forms bit for bit."""
+    z = G.load("kaldi_numpy.npz")
+    rng = np.random.default_rng(99)
+    for fl, fs, sf in z["framing_configs"]:
+        N = int(1.37 * sf) + 13
+        m, k = int(sf * fl / 1000.0), int(sf * fs / 1000.0)
+        x16 = rng.integers(-32768, 32767, size=(3, N), dtype=np.int16)
+        x = x16.astype(np.float32)
+        fr = Ls.Framing(fl, fs, sf, snip_edges=False)
+        if k > m:                       # shift > frame: PadWaveform's "left padding" is negative; rejected here
+            with pytest.raises(ValueError):
+                fr(x)
+            continue
+        want = host(Ls.Framing(fl, fs, sf)(ktf.kaldi_numpy.PadWaveform(x, m, k)))
+        assert fr.numFrames(N) == want.shape[1]
+        assert np.array_equal(host(fr(x)), want)
+        assert np.array_equal(host(fr(x16)), want)                                   # int16 numpy
+        assert np.array_equal(host(fr(torch.as_tensor(x16, device="cuda"))), want)     # int16 device tensor
+        if N >= m:
+            assert np.array_equal(host(Ls.Framing(fl, fs, sf)(x16)), host(Ls.Framing(fl, fs, sf)(x)))
+    # Kaldi MFCC goldens generated with --snip-edges=false, padded on the device instead of by PadWaveform
+    n_checked = 0
+    for name in G.mfcc_case_names():
+        cfg, wav, want = G.mfcc_case(name)
+        if cfg["snip_edges"]:
+            continue
+        fr = Ls.Framing(**cfg["framing"], snip_edges=False)
+        got = host(Ls.MFCC(**cfg["mfcc"])(fr(wav)))
+        assert got.shape == want.shape, name
+        assert G.rmse(want, got) < 2.25e-4, name
+        n_checked += 1
+    assert n_checked >= 10
+    # whole extractor (fused wav -> MFCC launch, register-resident nfft-512 kernel): both options against the host forms
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=1, narrow=True)
+    wav = synth.make_wav(3, 48000 + 77, seed=5, ragged=True)
+    base = synth.build_extractor(ktf, cfg, w)
+    a = host(base(dev(wav)))
+    assert np.array_equal(host(base(torch.as_tensor(wav.astype(np.int16), device="cuda"))), a)
+    cfg2 = synth.extractor_cfg()
+    cfg2["framing"]["snip_edges"] = False
+    padded = synth.build_extractor(ktf, cfg2, w)
+    want = host(base(dev(ktf.kaldi_numpy.PadWaveform(wav, 400, 160))))
+    assert np.array_equal(host(padded(dev(wav))), want)
+    assert np.array_equal(host(padded(wav.astype(np.int16))), want)
+
+
 # ----------------------------------------------------------------------------- a2 Windowing
 def test_windowing_vs_process_frames():
     z = G.load("kaldi_numpy.npz")

@@ -55,6 +55,21 @@ def test_host_side_size_helpers():
     assert lib.ktf_num_frames(160000, 400, 160) == 998          # 10 s @ 16 kHz (Framing does not pad)
     assert lib.ktf_num_frames(48000, 400, 160) == 298
     assert lib.ktf_num_frames(399, 400, 160) == 0
+    # pad_mode 1 = the reference's kaldi_numpy PadWaveform followed by Framing (frame_extraction.py:54-89)
+    for n, m, k in [(160000, 400, 160), (48077, 400, 160), (8013, 200, 80), (1000, 400, 160), (23, 400, 160)]:
+        fr = ktf.layers.Framing(1000.0 * m / 16000, 1000.0 * k / 16000, 16000, snip_edges=False)
+        try:
+            want = ktf.layers.Framing(1000.0 * m / 16000, 1000.0 * k / 16000, 16000).numFrames(
+                ktf.kaldi_numpy.PadWaveform(np.zeros(n, np.float32), m, k).shape[-1])
+        except ValueError:
+            want = None
+        got = lib.ktf_num_frames_padded(n, m, k, 1)
+        if got >= 0:
+            assert got == want == fr.numFrames(n), (n, m, k)
+        else:
+            with pytest.raises(ValueError):
+                fr.numFrames(n)
+    assert lib.ktf_num_frames_padded(160000, 400, 160, 0) == 998
     d = L.TdnnDesc(units=8, din=3, din_pad=32, nctx=3, subsampling=1, valid=1)
     d.ctx[0], d.ctx[1], d.ctx[2] = -2, 0, 2
     assert lib.ktf_tdnn_out_len(10, C.byref(d)) == 6
