@@ -29,25 +29,35 @@ def extractor_cfg(dither=0.0):
     }
 
 
-def model_config(narrow=False):
+def extractor_cfg_8k():
+    """Front-end of the reference's second shipped model, data/kaldi_models/configs/0006_callhome_diarization_v2_1a.yml
+    (8 kHz, 23-dim MFCC: 200-sample frames -> nfft 256, i.e. the generic front-end kernel, not the nfft-512 fast path)."""
+    c = extractor_cfg()
+    c["framing"]["sample_frequency"] = 8000
+    c["mfcc"].update({"num_mfccs": 23, "num_mels": 23, "sample_frequency": 8000.0, "high_freq_cutoff": 3700.0})
+    return c
+
+
+def model_config(narrow=False, feat_dim=30, out_dim=512):
     h, p = (64, 96) if narrow else (512, 1500)
     dims = {"h": h, "p": p}
-    layers = [{"name": "input", "type": "input", "shape": [None, None, 30]}]
+    layers = [{"name": "input", "type": "input", "shape": [None, None, feat_dim]}]
     for name, ctx, d in TOPOLOGY:
         layers.append({"name": name, "type": ["affine", "relu", "batchnorm"], "cfg": {"units": dims[d], "context": list(ctx)}})
     layers.append({"name": "stats", "type": "stats_pooling",
                    "cfg": {"left_context": 0, "right_context": 10000, "include_std": True, "reduce_time_axis": True}})
-    layers.append({"name": "tdnn6", "type": "affine", "cfg": {"units": 512, "context": [0]}})
+    layers.append({"name": "tdnn6", "type": "affine", "cfg": {"units": out_dim, "context": [0]}})
     return {"type": "sequential", "layers": layers}
 
 
-def make_weights(seed=4321, narrow=False):
-    """W ~ N(0, 1/(K*D)), b ~ N(0, 0.1), BN mean ~ U(0.2,1), var ~ U(0.5,2), target-rms 1; real LDA/mean."""
+def make_weights(seed=4321, narrow=False, feat_dim=30, out_dim=512):
+    """W ~ N(0, 1/(K*D)), b ~ N(0, 0.1), BN mean ~ U(0.2,1), var ~ U(0.5,2), target-rms 1; real LDA/mean
+    (synthetic mean / LDA when the embedding is not 512-dimensional)."""
     rng = np.random.default_rng(seed)
     h, p = (64, 96) if narrow else (512, 1500)
     dims = {"h": h, "p": p}
-    w = {}
-    din = 30
+    w = {"feat_dim": feat_dim, "out_dim": out_dim}
+    din = feat_dim
     for name, ctx, d in TOPOLOGY:
         u, K = dims[d], len(ctx)
         w[f"{name}.affine"] = ((rng.standard_normal((u, K * din)) / np.sqrt(K * din)).astype(np.float32),
@@ -55,10 +65,14 @@ def make_weights(seed=4321, narrow=False):
         w[f"{name}.batchnorm"] = (np.float32(1.0), rng.uniform(0.2, 1.0, u).astype(np.float32),
                                   rng.uniform(0.5, 2.0, u).astype(np.float32))
         din = u
-    w["tdnn6.affine"] = ((rng.standard_normal((512, 2 * din)) / np.sqrt(2 * din)).astype(np.float32),
-                         (rng.standard_normal(512) * 0.1).astype(np.float32))
-    w["mean"] = _read_text_vec(os.path.join(GOLDEN, "xvectors_train_combined_200k.mean.vec.txt"))
-    w["lda"] = _read_bin_mat(os.path.join(GOLDEN, "xvectors_train_combined_200k.transform.mat"))
+    w["tdnn6.affine"] = ((rng.standard_normal((out_dim, 2 * din)) / np.sqrt(2 * din)).astype(np.float32),
+                         (rng.standard_normal(out_dim) * 0.1).astype(np.float32))
+    if out_dim == 512:
+        w["mean"] = _read_text_vec(os.path.join(GOLDEN, "xvectors_train_combined_200k.mean.vec.txt"))
+        w["lda"] = _read_bin_mat(os.path.join(GOLDEN, "xvectors_train_combined_200k.transform.mat"))
+    else:
+        w["mean"] = (rng.standard_normal(out_dim) * 0.1).astype(np.float32)
+        w["lda"] = (rng.standard_normal((out_dim // 2, out_dim + 1)) / np.sqrt(out_dim)).astype(np.float32)
     w["narrow"] = narrow
     return w
 
@@ -91,7 +105,8 @@ def oracle_layers(w):
 
 
 def build_sequential(ktf, w, gemm="f32"):
-    mdl = ktf.models.SequentialFromConfig(model_config(w["narrow"]), None, "cmvn2xvec", gemm=gemm)
+    mdl = ktf.models.SequentialFromConfig(model_config(w["narrow"], w.get("feat_dim", 30), w.get("out_dim", 512)), None,
+                                          "cmvn2xvec", gemm=gemm)
     for layer in mdl.layers:
         if layer.name in w:
             layer.set_weights(list(w[layer.name]))

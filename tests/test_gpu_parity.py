@@ -458,6 +458,22 @@ def test_extractor_edge_cases():
     assert np.array_equal(a, b[::-1])
 
 
+@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("bf16", 5e-2)])
+def test_extractor_8khz_callhome_topology(gemm, tol):
+    """The reference's second model family (0006_callhome_diarization_v2_1a.yml: 8 kHz, 23-dim MFCC, 128-dim embedding):
+    200-sample frames -> nfft 256 takes the generic front-end kernel, tdnn6 has 128 units."""
+    cfg = synth.extractor_cfg_8k()
+    w = synth.make_weights(seed=11, narrow=False, feat_dim=23, out_dim=128)
+    wav = synth.make_wav(3, 8000 * 4 + 41, seed=3, ragged=True)
+    want, lens = _extract_oracle(wav, cfg, w)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
+    assert (mdl.framing.frameSize, mdl.mfcc.numMfccs) == (200, 23)
+    got = host(mdl(dev(wav)))
+    assert got.shape == want.shape == (3, 64)
+    assert np.abs(got - want).max() <= tol
+    assert np.array_equal(host(mdl(wav.astype(np.int16))), got)
+
+
 def test_sequential_from_config_dense_input_equals_oracle():
     w = synth.make_weights(seed=5, narrow=True)
     mdl = synth.build_sequential(ktf, w)
