@@ -124,7 +124,9 @@ __device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t
         asm volatile("" ::: "memory");           \
     } while (0)
 
-template <bool DITHER>
+// PLAIN: fp32 input without mirror padding (the hot path keeps its scalar-register budget); !PLAIN adds int16 samples
+// and KtfFrontendCfg.pad_mode.
+template <bool DITHER, bool PLAIN>
 __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                                  int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                                  int out_stage, float* __restrict__ out,
@@ -184,12 +186,12 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
     // grid = (frame groups per utterance, B): no division in the frame loop, 32-bit offsets from per-utterance bases
     const int b = blockIdx.y;
     const int Ti = (int)T;
-    const int i16 = in_kind == KTF_IN_WAV_I16;
-    if (i16) in_kind = KTF_IN_WAV;
+    const int i16 = !PLAIN && in_kind == KTF_IN_WAV_I16;
+    if (in_kind == KTF_IN_WAV_I16) in_kind = KTF_IN_WAV;
     const float* in_b = reinterpret_cast<const float*>(in_v) + (int64_t)b * ((in_kind == KTF_IN_WAV) ? n : T * (int64_t)M);
     const short* in_b16 = reinterpret_cast<const short*>(in_v) + (int64_t)b * n;
     const int src_step = (in_kind == KTF_IN_WAV) ? cfg.frame_shift : M;
-    const int pad_left = (in_kind == KTF_IN_WAV && cfg.pad_mode) ? (M - cfg.frame_shift) / 2 : 0;
+    const int pad_left = (!PLAIN && in_kind == KTF_IN_WAV && cfg.pad_mode) ? (M - cfg.frame_shift) / 2 : 0;
     const int ni = (int)n;
     const int64_t row_base = (int64_t)b * T;
     const int t_step = gridDim.x * F5_WAVES;
@@ -200,19 +202,37 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
         float v[NV];
         float logE = 0.0f;
         const int g0 = t * src_step - pad_left;          // first sample of the frame (wav kinds)
-        if (valid && in_kind == KTF_IN_WAV && (g0 < 0 || g0 + M > ni)) {
+        if (!PLAIN && valid && in_kind == KTF_IN_WAV && (g0 < 0 || g0 + M > ni)) {
             // edge frame of KtfFrontendCfg.pad_mode 1: mirrored samples
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = lane + KTF_WAVE * j;
                 v[j] = (i < M) ? ktf_wav_sample(i16 ? (const void*)in_b16 : (const void*)in_b, i16, ni, g0 + i) : 0.0f;
             }
-        } else if (valid && i16) {
+        } else if (!PLAIN && valid && i16) {
             const short* src = in_b16 + g0;
+            if (((reinterpret_cast<uintptr_t>(src) | (unsigned)M) & 3u) == 0 || ((reinterpret_cast<uintptr_t>(src) & 3u) == 0 && (M & 1) == 0)) {
+                // dword loads: lanes 2k, 2k+1 fetch the same word. All loads are issued before the first conversion (a
+                // conversion inside the predicated load would put an s_waitcnt vmcnt(0) behind every load).
+                const unsigned* src32 = reinterpret_cast<const unsigned*>(src);
+                const int sh = 16 - (lane & 1) * 16;
+                unsigned wd[NV];
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = lane + KTF_WAVE * j;
-                v[j] = (i < M) ? (float)src[i] : 0.0f;
+                for (int j = 0; j < NV; ++j) {
+                    const int i = lane + KTF_WAVE * j;
+                    wd[j] = (i < M) ? src32[i >> 1] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[j] = (float)((int)(wd[j] << sh) >> 16);
+            } else {
+                int raw[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = lane + KTF_WAVE * j;
+                    raw[j] = (i < M) ? (int)src[i] : 0;
+                }
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[j] = (float)raw[j];
             }
         } else if (valid) {
             const float* src = in_b + g0;
@@ -367,12 +387,14 @@ int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind
     if (gx > gmax) gx = gmax;
     const dim3 grid((unsigned)gx, (unsigned)B);
     const size_t lds = sizeof(float) * (512 + F5_WAVES * (512 + 256 + 64));
-    if (cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED)
-        hipLaunchKernelGGL(frontend512_kernel<true>, grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
-                           out_stage, out, seed, T);
-    else
-        hipLaunchKernelGGL(frontend512_kernel<false>, grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,
-                           out_stage, out, seed, T);
+    const bool dither = cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED;
+    const bool plain = in_kind != KTF_IN_WAV_I16 && !(in_kind == KTF_IN_WAV && cfg->pad_mode);
+#define F5_LAUNCH(DI, PL)                                                                                              \
+    hipLaunchKernelGGL((frontend512_kernel<DI, PL>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,  \
+                       out_stage, out, seed, T)
+    if (dither) { if (plain) F5_LAUNCH(true, true); else F5_LAUNCH(true, false); }
+    else { if (plain) F5_LAUNCH(false, true); else F5_LAUNCH(false, false); }
+#undef F5_LAUNCH
     KTF_CHECK_LAUNCH("ktf_frontend_f32(fast512)");
     return KTF_OK;
 }

@@ -23,11 +23,12 @@ __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float load1<unsigned short>(const unsigned short* p) { return bf2f(*p); }
 
+#define SP_RG 16      // row groups per workgroup (1024 threads): a single utterance still has 16 loads in flight per column pair
 template <typename T, bool VEC2>
-__global__ __launch_bounds__(256) void stats_pool_kernel(const T* __restrict__ x, int64_t Tmax, int D, int64_t ldx,
+__global__ __launch_bounds__(64 * SP_RG) void stats_pool_kernel(const T* __restrict__ x, int64_t Tmax, int D, int64_t ldx,
                                                          const int32_t* __restrict__ lens, int period, int include_std,
                                                          float eps, float* __restrict__ out, int64_t ldo) {
-    __shared__ double red[4][2][128];   // fp64 sums: E[x^2]-mean^2 of a (near-)constant channel must not cancel to noise
+    __shared__ double red[SP_RG][2][128];   // fp64 sums: E[x^2]-mean^2 of a (near-)constant channel must not cancel to noise
     const int b = blockIdx.y;
     const int len = lens ? lens[b] : (int)Tmax;
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -37,8 +38,10 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const T* __restrict__ x
     const int nrows = len <= 0 ? 0 : (len + period - 1) / period;
     if (c0 < D) {
         const bool two = (c0 + 1 < D);
-        for (int j = rg; j < nrows; j += 4) {
-            const T* p = xb + (int64_t)j * period * ldx + c0;
+        const int64_t rstep = (int64_t)period * ldx;
+#pragma unroll 4
+        for (int j = rg; j < nrows; j += SP_RG) {
+            const T* p = xb + (int64_t)j * rstep + c0;
             float2 v;
             if (VEC2 && two) v = load2<T>(p);
             else { v.x = load1<T>(p); v.y = two ? load1<T>(p + 1) : 0.f; }
@@ -52,8 +55,12 @@ __global__ __launch_bounds__(256) void stats_pool_kernel(const T* __restrict__ x
     if (threadIdx.x < 128) {
         const int c = blockIdx.x * 128 + threadIdx.x;
         if (c < D) {
-            const double s = red[0][0][threadIdx.x] + red[1][0][threadIdx.x] + red[2][0][threadIdx.x] + red[3][0][threadIdx.x];
-            const double q = red[0][1][threadIdx.x] + red[1][1][threadIdx.x] + red[2][1][threadIdx.x] + red[3][1][threadIdx.x];
+            double s = 0., q = 0.;
+#pragma unroll
+            for (int g = 0; g < SP_RG; ++g) {
+                s += red[g][0][threadIdx.x];
+                q += red[g][1][threadIdx.x];
+            }
             const double n = (double)nrows;
             const double mean = s / n;
             out[(int64_t)b * ldo + c] = (float)mean;
@@ -263,11 +270,11 @@ extern "C" int ktf_stats_pool(const void* x, int32_t x_dtype, int64_t B, int64_t
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
     if (x_dtype == KTF_F32) {
-        if (vec) hipLaunchKernelGGL((stats_pool_kernel<float, true>), grid, dim3(256), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-        else hipLaunchKernelGGL((stats_pool_kernel<float, false>), grid, dim3(256), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+        if (vec) hipLaunchKernelGGL((stats_pool_kernel<float, true>), grid, dim3(64 * SP_RG), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+        else hipLaunchKernelGGL((stats_pool_kernel<float, false>), grid, dim3(64 * SP_RG), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
     } else if (x_dtype == KTF_BF16) {
-        if (vec) hipLaunchKernelGGL((stats_pool_kernel<unsigned short, true>), grid, dim3(256), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-        else hipLaunchKernelGGL((stats_pool_kernel<unsigned short, false>), grid, dim3(256), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+        if (vec) hipLaunchKernelGGL((stats_pool_kernel<unsigned short, true>), grid, dim3(64 * SP_RG), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+        else hipLaunchKernelGGL((stats_pool_kernel<unsigned short, false>), grid, dim3(64 * SP_RG), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
     } else {
         KTF_REQUIRE(false, "ktf_stats_pool: bad dtype");
     }

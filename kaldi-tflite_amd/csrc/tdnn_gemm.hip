@@ -81,54 +81,57 @@ __device__ __forceinline__ void store_tile32(const f32x16& acc, const TdnnParams
 }
 
 // ------------------------------------------------------------------------------------ F32
-// 128x128 block tile, K-step 16, 4 waves as 2x2, each wave a 64x64 sub-tile = 2x2 MFMA 32x32 tiles.
-#define F32_BM 128
-#define F32_BN 128
+// (64*MT) x (64*MT) block tile, K-step 16, 4 waves as 2x2, each wave MT x MT MFMA 32x32 tiles. MT = 2 (128x128) is the
+// throughput shape; MT = 1 (64x64) is used when the 128-tiles would fill fewer workgroups than the chip has CUs (one
+// utterance: M = 998 -> 32 workgroups; tdnn6: one row per utterance): four times the workgroups, a quarter of the
+// serial MFMA chain per wave.
 #define F32_BK 16
 #define F32_PITCH (F32_BK + 1)
 
+template <int MT>
 __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
-    __shared__ float As[2][F32_BM * F32_PITCH];
-    __shared__ float Bs[2][F32_BN * F32_PITCH];
+    constexpr int BM = 64 * MT, BN = 64 * MT;
+    __shared__ float As[2][BM * F32_PITCH];
+    __shared__ float Bs[2][BN * F32_PITCH];
     const int b = blockIdx.z;
     const int len = p.lens ? p.lens[b] : (int)p.T;
     int start;
     const int out_len = tdnn_out_len(len, p, start);
     if (p.out_lens && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
-    const int t0 = blockIdx.y * F32_BM;
+    const int t0 = blockIdx.y * BM;
     if (t0 >= out_len || len <= 0) return;
-    const int n0 = blockIdx.x * F32_BN;
+    const int n0 = blockIdx.x * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
     const float* xb = reinterpret_cast<const float*>(p.x) + (int64_t)b * p.T * p.ldx;
     const float* wb = reinterpret_cast<const float*>(p.w);
 
-    // staging map: thread loads 2 float4 of A and 2 of B per K-step
+    // staging map: thread loads MT float4 of A and MT of B per K-step
     const int ld_row = tid >> 2;          // 0..63 (+64)
     const int ld_col = (tid & 3) * 4;     // 0,4,8,12
-    int a_t[2];
+    int a_t[MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a_t[i] = start + (t0 + ld_row + 64 * i) * p.sub;
+    for (int i = 0; i < MT; ++i) a_t[i] = start + (t0 + ld_row + 64 * i) * p.sub;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][MT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = p.ktot / F32_BK;
     const int steps_per_ctx = p.din_pad / F32_BK;
-    float4 ra[2], rb[2];
+    float4 ra[MT], rb[MT];
 
     auto load_global = [&](int ks) {
         const int c = ks / steps_per_ctx;
         const int d0 = (ks - c * steps_per_ctx) * F32_BK;
         const int off = p.ctx[c];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             int r = a_t[i] + off;
             r = r < 0 ? 0 : (r > len - 1 ? len - 1 : r);
             ra[i] = *reinterpret_cast<const float4*>(xb + (int64_t)r * p.ldx + d0 + ld_col);
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < MT; ++i) {
             float* a = &As[buf][(ld_row + 64 * i) * F32_PITCH + ld_col];
             a[0] = ra[i].x; a[1] = ra[i].y; a[2] = ra[i].z; a[3] = ra[i].w;
             float* bb = &Bs[buf][(ld_row + 64 * i) * F32_PITCH + ld_col];
@@ -151,16 +154,21 @@ __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
     for (int ks = 0; ks < nk; ++ks) {
         const int buf = ks & 1;
         if (ks + 1 < nk) load_global(ks + 1);
-        const float* a_base = &As[buf][(wm * 64 + (lane & 31)) * F32_PITCH + (lane >> 5)];
-        const float* b_base = &Bs[buf][(wn * 64 + (lane & 31)) * F32_PITCH + (lane >> 5)];
+        const float* a_base = &As[buf][(wm * 32 * MT + (lane & 31)) * F32_PITCH + (lane >> 5)];
+        const float* b_base = &Bs[buf][(wn * 32 * MT + (lane & 31)) * F32_PITCH + (lane >> 5)];
 #pragma unroll
         for (int kk = 0; kk < F32_BK; kk += 2) {
-            const float a0 = a_base[kk], a1 = a_base[32 * F32_PITCH + kk];
-            const float b0 = b_base[kk], b1 = b_base[32 * F32_PITCH + kk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[MT], bv[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                av[i] = a_base[i * 32 * F32_PITCH + kk];
+                bv[i] = b_base[i * 32 * F32_PITCH + kk];
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (ks + 1 < nk) store_lds(buf ^ 1);
         __syncthreads();
@@ -169,10 +177,10 @@ __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
     const int rows_valid = out_len - t0;
     const int64_t out_row0 = (int64_t)b * p.Tout + t0;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            store_tile32(acc[i][j], p, out_row0, rows_valid, wm * 64 + i * 32, n0 + wn * 64 + j * 32, lane);
+        for (int j = 0; j < MT; ++j)
+            store_tile32(acc[i][j], p, out_row0, rows_valid, wm * 32 * MT + i * 32, n0 + wn * 32 * MT + j * 32, lane);
 }
 
 // ------------------------------------------------------------------------------------ BF16 / BF16X3
@@ -1760,8 +1768,15 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     const unsigned ntiles = (unsigned)ktf_cdiv(d->units, 128);
     if (d->gemm == KTF_GEMM_F32) {
         KTF_REQUIRE(d->x_dtype == KTF_F32 && d->w_dtype == KTF_F32, "ktf_tdnn: F32 gemm needs fp32 x and w");
-        dim3 grid(ntiles, (unsigned)ktf_cdiv(Tout, F32_BM), (unsigned)B);
-        hipLaunchKernelGGL(tdnn_f32_kernel, grid, dim3(256), 0, st, p);
+        // W must cover round_up(units, 128) rows (the host pads to 256)
+        const int64_t wg128 = (int64_t)ktf_cdiv(d->units, 128) * ktf_cdiv(Tout, 128) * B;
+        if (wg128 >= 256) {
+            dim3 grid((unsigned)ktf_cdiv(d->units, 128), (unsigned)ktf_cdiv(Tout, 128), (unsigned)B);
+            hipLaunchKernelGGL(tdnn_f32_kernel<2>, grid, dim3(256), 0, st, p);
+        } else {
+            dim3 grid((unsigned)ktf_cdiv(d->units, 64), (unsigned)ktf_cdiv(Tout, 64), (unsigned)B);
+            hipLaunchKernelGGL(tdnn_f32_kernel<1>, grid, dim3(256), 0, st, p);
+        }
     } else if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3) {
         KTF_REQUIRE(d->w_dtype == KTF_BF16, "ktf_tdnn: bf16 gemm needs bf16 weights");
         const bool x3 = d->gemm == KTF_GEMM_BF16X3;
