@@ -100,30 +100,50 @@ __global__ void stats_pool_windowed_kernel(const float* __restrict__ x, int64_t 
 
 // ------------------------------------------------------------------------------------ x-vector post-processing
 // one workgroup per embedding: LDS holds (x - mean); thread j owns output column j.
-__global__ __launch_bounds__(256) void xvec_post_kernel(const float* __restrict__ x, int in_dim, int out_dim,
-                                                        const float* __restrict__ mean, const float* __restrict__ A,
-                                                        const float* __restrict__ off, float* __restrict__ y) {
-    extern __shared__ float sm[];  // in_dim + out_dim + 4
+#define XP_THREADS 1024
+__global__ __launch_bounds__(XP_THREADS) void xvec_post_kernel(const float* __restrict__ x, int in_dim, int out_dim,
+                                                               const float* __restrict__ mean, const float* __restrict__ A,
+                                                               const float* __restrict__ off, float* __restrict__ y) {
+    // one workgroup per embedding; thread = (output column j, slice `part` of the input dimension): the 512-long dot
+    // products are split into P partial sums (fixed order -> deterministic) so a single embedding is not a serial chain
+    extern __shared__ float sm[];  // in_dim | out_dim | XP_THREADS partials | 16
     float* xc = sm;
     float* yo = sm + in_dim;
-    float* red = yo + out_dim;
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < in_dim; i += 256) xc[i] = x[(int64_t)b * in_dim + i] - (mean ? mean[i] : 0.f);
+    float* part_s = yo + out_dim;
+    float* red = part_s + XP_THREADS;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < in_dim; i += XP_THREADS) xc[i] = x[(int64_t)b * in_dim + i] - (mean ? mean[i] : 0.f);
     __syncthreads();
+    int J = (out_dim + 63) & ~63;
+    if (J > XP_THREADS) J = XP_THREADS;
+    const int P = XP_THREADS / J;
+    const int jl = tid % J, part = tid / J;
+    const int chunk = (in_dim + P - 1) / P;
+    const int i_lo = part * chunk, i_hi = (i_lo + chunk < in_dim) ? i_lo + chunk : in_dim;
     float ss = 0.f;
-    for (int j = threadIdx.x; j < out_dim; j += 256) {
+    for (int j0 = 0; j0 < out_dim; j0 += J) {
+        const int j = j0 + jl;
         float acc = 0.f;
-        for (int i = 0; i < in_dim; ++i) acc += xc[i] * A[(int64_t)i * out_dim + j];
-        acc += off ? off[j] : 0.f;
-        yo[j] = acc;
-        ss += acc * acc;
+        if (part < P && j < out_dim)
+            for (int i = i_lo; i < i_hi; ++i) acc += xc[i] * A[(int64_t)i * out_dim + j];
+        part_s[tid] = acc;
+        __syncthreads();
+        if (part == 0 && j < out_dim) {
+            float t = 0.f;
+            for (int q = 0; q < P; ++q) t += part_s[q * J + jl];
+            t += off ? off[j] : 0.f;
+            yo[j] = t;
+            ss += t * t;
+        }
+        __syncthreads();
     }
     ss = wave_sum(ss);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
-    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
-    const float ratio = norm / sqrtf((float)out_dim);   // xvector_extractor.py:178-181
-    for (int j = threadIdx.x; j < out_dim; j += 256) y[(int64_t)b * out_dim + j] = yo[j] / ratio;
+    float tot = 0.f;
+    for (int w = 0; w < XP_THREADS / 64; ++w) tot += red[w];
+    const float ratio = sqrtf(tot) / sqrtf((float)out_dim);   // xvector_extractor.py:178-181
+    for (int j = tid; j < out_dim; j += XP_THREADS) y[(int64_t)b * out_dim + j] = yo[j] / ratio;
 }
 
 // ------------------------------------------------------------------------------------ PLDA
@@ -304,9 +324,9 @@ extern "C" int ktf_xvec_post_f32(const float* x, int64_t B, int32_t in_dim, int3
     KTF_REQUIRE(x && A && y, "ktf_xvec_post_f32: null argument");
     KTF_REQUIRE(B >= 0 && in_dim > 0 && out_dim > 0, "ktf_xvec_post_f32: bad sizes");
     if (B == 0) return KTF_OK;
-    const size_t lds = sizeof(float) * ((size_t)in_dim + out_dim + 4);
+    const size_t lds = sizeof(float) * ((size_t)in_dim + out_dim + XP_THREADS + 16);
     KTF_REQUIRE(lds <= 64 * 1024, "ktf_xvec_post_f32: dims too large");
-    hipLaunchKernelGGL(xvec_post_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, x, in_dim, out_dim, mean, A, off, y);
+    hipLaunchKernelGGL(xvec_post_kernel, dim3((unsigned)B), dim3(XP_THREADS), lds, (hipStream_t)stream, x, in_dim, out_dim, mean, A, off, y);
     KTF_CHECK_LAUNCH("ktf_xvec_post_f32");
     return KTF_OK;
 }

@@ -85,12 +85,13 @@ __device__ __forceinline__ void store_tile32(const f32x16& acc, const TdnnParams
 // throughput shape; MT = 1 (64x64) is used when the 128-tiles would fill fewer workgroups than the chip has CUs (one
 // utterance: M = 998 -> 32 workgroups; tdnn6: one row per utterance): four times the workgroups, a quarter of the
 // serial MFMA chain per wave.
-#define F32_BK 16
-#define F32_PITCH (F32_BK + 1)
-
-template <int MT>
+// K-step BK: 16 for the big tile; 32 for the small one, whose MFMA time per K-step is too short to cover a global load.
+template <int MT, int BK>
 __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
     constexpr int BM = 64 * MT, BN = 64 * MT;
+    constexpr int F32_BK = BK, F32_PITCH = BK + 1;
+    constexpr int C4 = BK / 4;                       // float4 per staged row
+    constexpr int NLD = BM * C4 / 256;               // float4 per thread and operand
     __shared__ float As[2][BM * F32_PITCH];
     __shared__ float Bs[2][BN * F32_PITCH];
     const int b = blockIdx.z;
@@ -107,12 +108,15 @@ __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
     const float* xb = reinterpret_cast<const float*>(p.x) + (int64_t)b * p.T * p.ldx;
     const float* wb = reinterpret_cast<const float*>(p.w);
 
-    // staging map: thread loads MT float4 of A and MT of B per K-step
-    const int ld_row = tid >> 2;          // 0..63 (+64)
-    const int ld_col = (tid & 3) * 4;     // 0,4,8,12
-    int a_t[MT];
+    // staging map: float4 q = i*256 + tid of the (BM x BK) slice -> row q / C4, column 4*(q % C4)
+    int ld_row[NLD], ld_col[NLD], a_t[NLD];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a_t[i] = start + (t0 + ld_row + 64 * i) * p.sub;
+    for (int i = 0; i < NLD; ++i) {
+        const int q = i * 256 + tid;
+        ld_row[i] = q / C4;
+        ld_col[i] = (q % C4) * 4;
+        a_t[i] = start + (t0 + ld_row[i]) * p.sub;
+    }
 
     f32x16 acc[MT][MT];
 #pragma unroll
@@ -124,26 +128,26 @@ __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
 
     const int nk = p.ktot / F32_BK;
     const int steps_per_ctx = p.din_pad / F32_BK;
-    float4 ra[MT], rb[MT];
+    float4 ra[NLD], rb[NLD];
 
     auto load_global = [&](int ks) {
         const int c = ks / steps_per_ctx;
         const int d0 = (ks - c * steps_per_ctx) * F32_BK;
         const int off = p.ctx[c];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < NLD; ++i) {
             int r = a_t[i] + off;
             r = r < 0 ? 0 : (r > len - 1 ? len - 1 : r);
-            ra[i] = *reinterpret_cast<const float4*>(xb + (int64_t)r * p.ldx + d0 + ld_col);
-            rb[i] = *reinterpret_cast<const float4*>(wb + (int64_t)(n0 + ld_row + 64 * i) * p.ktot + ks * F32_BK + ld_col);
+            ra[i] = *reinterpret_cast<const float4*>(xb + (int64_t)r * p.ldx + d0 + ld_col[i]);
+            rb[i] = *reinterpret_cast<const float4*>(wb + (int64_t)(n0 + ld_row[i]) * p.ktot + ks * F32_BK + ld_col[i]);
         }
     };
     auto store_lds = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            float* a = &As[buf][(ld_row + 64 * i) * F32_PITCH + ld_col];
+        for (int i = 0; i < NLD; ++i) {
+            float* a = &As[buf][ld_row[i] * F32_PITCH + ld_col[i]];
             a[0] = ra[i].x; a[1] = ra[i].y; a[2] = ra[i].z; a[3] = ra[i].w;
-            float* bb = &Bs[buf][(ld_row + 64 * i) * F32_PITCH + ld_col];
+            float* bb = &Bs[buf][ld_row[i] * F32_PITCH + ld_col[i]];
             bb[0] = rb[i].x; bb[1] = rb[i].y; bb[2] = rb[i].z; bb[3] = rb[i].w;
         }
     };
@@ -1772,10 +1776,10 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         const int64_t wg128 = (int64_t)ktf_cdiv(d->units, 128) * ktf_cdiv(Tout, 128) * B;
         if (wg128 >= 256) {
             dim3 grid((unsigned)ktf_cdiv(d->units, 128), (unsigned)ktf_cdiv(Tout, 128), (unsigned)B);
-            hipLaunchKernelGGL(tdnn_f32_kernel<2>, grid, dim3(256), 0, st, p);
+            hipLaunchKernelGGL((tdnn_f32_kernel<2, 16>), grid, dim3(256), 0, st, p);
         } else {
             dim3 grid((unsigned)ktf_cdiv(d->units, 64), (unsigned)ktf_cdiv(Tout, 64), (unsigned)B);
-            hipLaunchKernelGGL(tdnn_f32_kernel<1>, grid, dim3(256), 0, st, p);
+            hipLaunchKernelGGL((tdnn_f32_kernel<1, 32>), grid, dim3(256), 0, st, p);
         }
     } else if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3) {
         KTF_REQUIRE(d->w_dtype == KTF_BF16, "ktf_tdnn: bf16 gemm needs bf16 weights");
