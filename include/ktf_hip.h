@@ -83,6 +83,9 @@ typedef struct KtfFrontendCfg {
                             * 1: Kaldi snip-edges=false framing: the waveform is mirror-padded as by the reference's
                             *    kaldi_numpy PadWaveform (kaldi_numpy/frame_extraction.py:28-89) -- fused into the frame
                             *    gather, nothing is materialised; T = (n + shift/2) / shift                             */
+    int32_t row_stride;    /* KTF_IN_WAV* only: samples between the starts of consecutive rows of `in`; 0 = n (dense).
+                            * A stride < n describes OVERLAPPING windows of one long recording (sliding-window /
+                            * diarization extraction, torch `wav.unfold(-1, n, hop)`) without copying them            */
 } KtfFrontendCfg;
 
 typedef struct KtfFrontendTables {   /* all DEVICE pointers, built once by the host */
@@ -250,6 +253,14 @@ int ktf_plda_f64(const double* x, int64_t B, int32_t dim, const double* A, const
 int ktf_plda_f32(const float* x, int64_t B, int32_t dim, const float* A, const float* offset, const float* psi,
                  int32_t normalize_length, int32_t simple_length_norm, float* transformed, float* scores,
                  void* stream);
+
+/* Rectangular trial blocks (plda.py:198-245 logLikelihoodRatio on two sets; the reference only scores a batch against
+ * itself): scores[i, j] (N x M, row-major) = LLR(test_tr[i] | class of enroll_tr[j]); both inputs are TRANSFORMED vectors
+ * (ktf_plda_* with scores == NULL produces them). Lets a large trial matrix be cut into row blocks, one per GPU. */
+int ktf_plda_score_f64(const double* test_tr, int64_t N, const double* enroll_tr, int64_t M, int32_t dim,
+                       const double* psi, double* scores, void* stream);
+int ktf_plda_score_f32(const float* test_tr, int64_t N, const float* enroll_tr, int64_t M, int32_t dim, const float* psi,
+                       float* scores, void* stream);
 
 #ifdef __cplusplus
 }

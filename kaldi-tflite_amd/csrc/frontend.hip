@@ -120,6 +120,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const void* __rest
     const int i16 = in_kind == KTF_IN_WAV_I16;
     if (i16) in_kind = KTF_IN_WAV;
     const int pad_left = (in_kind == KTF_IN_WAV && cfg.pad_mode) ? (M - cfg.frame_shift) / 2 : 0;
+    const int64_t rstride = cfg.row_stride > 0 ? (int64_t)cfg.row_stride : n;
 
     // ---- block-shared tables -> LDS (once per block)
     if (in_kind != KTF_IN_WINDOWED && out_stage >= KTF_OUT_WINDOWED)
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const void* __rest
         if (valid && in_kind == KTF_IN_WAV && (i16 || cfg.pad_mode)) {
             // int16 samples and/or mirrored edges (KtfFrontendCfg.pad_mode): n < 2^31 checked by the host
             const int64_t b = row / T, t = row - b * T;
-            const void* wav_b = i16 ? (const void*)(reinterpret_cast<const short*>(in_v) + b * n) : (const void*)(in + b * n);
+            const void* wav_b = i16 ? (const void*)(reinterpret_cast<const short*>(in_v) + b * rstride) : (const void*)(in + b * rstride);
             const int g0 = (int)t * cfg.frame_shift - pad_left;
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const void* __rest
             const float* src;
             if (in_kind == KTF_IN_WAV) {
                 const int64_t b = row / T, t = row - b * T;
-                src = in + b * n + t * (int64_t)cfg.frame_shift;
+                src = in + b * rstride + t * (int64_t)cfg.frame_shift;
             } else {
                 src = in + row * (int64_t)M;
             }
@@ -323,8 +324,8 @@ __global__ __launch_bounds__(FE_THREADS) void frontend_kernel(const void* __rest
 }
 
 // Framing.call on its own (any frame size): out[b, t, i] = in[b, t*shift + i]
-__global__ void framing_kernel(const void* __restrict__ in_v, int i16, int pad_left, int64_t B, int64_t n, int M,
-                               int shift, int64_t T, float* __restrict__ out) {
+__global__ void framing_kernel(const void* __restrict__ in_v, int i16, int pad_left, int64_t B, int64_t n, int64_t rstride,
+                               int M, int shift, int64_t T, float* __restrict__ out) {
     const int64_t total = B * T * M;
     const float* in = reinterpret_cast<const float*>(in_v);
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -332,10 +333,10 @@ __global__ void framing_kernel(const void* __restrict__ in_v, int i16, int pad_l
         const int64_t bt = e / M;
         const int64_t t = bt % T, b = bt / T;
         if (i16 || pad_left >= 0) {        // pad_left < 0: plain reference Framing on fp32 samples
-            const void* wav_b = i16 ? (const void*)(reinterpret_cast<const short*>(in_v) + b * n) : (const void*)(in + b * n);
+            const void* wav_b = i16 ? (const void*)(reinterpret_cast<const short*>(in_v) + b * rstride) : (const void*)(in + b * rstride);
             out[e] = ktf_wav_sample(wav_b, i16, (int)n, (int)t * shift - (pad_left < 0 ? 0 : pad_left) + i);
         } else {
-            out[e] = in[b * n + t * shift + i];
+            out[e] = in[b * rstride + t * shift + i];
         }
     }
 }
@@ -383,6 +384,7 @@ extern "C" int ktf_frontend_f32(const void* in, int64_t B, int64_t n, int32_t in
     const bool wav = in_kind == KTF_IN_WAV || in_kind == KTF_IN_WAV_I16;
     const int pad_mode = wav ? cfg->pad_mode : 0;
     KTF_REQUIRE(pad_mode == 0 || pad_mode == 1, "ktf_frontend_f32: bad pad_mode %d", pad_mode);
+    KTF_REQUIRE(cfg->row_stride >= 0, "ktf_frontend_f32: negative row_stride");
     if (wav && (pad_mode || in_kind == KTF_IN_WAV_I16)) KTF_REQUIRE(n < (1ll << 31) - 4096, "ktf_frontend_f32: int16 / padded input needs n < 2^31");
     int64_t Tw = 0;
     if (wav) {
@@ -402,7 +404,7 @@ extern "C" int ktf_frontend_f32(const void* in, int64_t B, int64_t n, int32_t in
         if (blk > 4096) blk = 4096;
         hipLaunchKernelGGL(framing_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, in, (int)(in_kind == KTF_IN_WAV_I16),
                            pad_mode ? (cfg->frame_size - cfg->frame_shift) / 2 : (in_kind == KTF_IN_WAV_I16 ? 0 : -1), B, n,
-                           cfg->frame_size, cfg->frame_shift, Tf, out);
+                           cfg->row_stride > 0 ? (int64_t)cfg->row_stride : n, cfg->frame_size, cfg->frame_shift, Tf, out);
         KTF_CHECK_LAUNCH("ktf_frontend_f32(framing)");
         return KTF_OK;
     }

@@ -188,8 +188,9 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
     const int Ti = (int)T;
     const int i16 = !PLAIN && in_kind == KTF_IN_WAV_I16;
     if (in_kind == KTF_IN_WAV_I16) in_kind = KTF_IN_WAV;
-    const float* in_b = reinterpret_cast<const float*>(in_v) + (int64_t)b * ((in_kind == KTF_IN_WAV) ? n : T * (int64_t)M);
-    const short* in_b16 = reinterpret_cast<const short*>(in_v) + (int64_t)b * n;
+    const int64_t rstride = cfg.row_stride > 0 ? (int64_t)cfg.row_stride : n;
+    const float* in_b = reinterpret_cast<const float*>(in_v) + (int64_t)b * ((in_kind == KTF_IN_WAV) ? rstride : T * (int64_t)M);
+    const short* in_b16 = reinterpret_cast<const short*>(in_v) + (int64_t)b * rstride;
     const int src_step = (in_kind == KTF_IN_WAV) ? cfg.frame_shift : M;
     const int pad_left = (!PLAIN && in_kind == KTF_IN_WAV && cfg.pad_mode) ? (M - cfg.frame_shift) / 2 : 0;
     const int ni = (int)n;

@@ -199,8 +199,10 @@ __global__ __launch_bounds__(256) void plda_transform_kernel(const R* __restrict
 
 // logLikelihoodRatio (plda.py:198-245): 16x16 (i, j) tile per workgroup, d-loop over LDS-staged rows.
 template <typename R>
-__global__ __launch_bounds__(256) void plda_score_kernel(const R* __restrict__ y, int64_t B, int dim,
-                                                         const R* __restrict__ psi, R* __restrict__ scores) {
+__global__ __launch_bounds__(256) void plda_score_kernel(const R* __restrict__ y, int64_t B, const R* __restrict__ yc,
+                                                         int64_t Bc, int dim, const R* __restrict__ psi,
+                                                         R* __restrict__ scores) {
+    // rows i: vectors y (B of them, "test"); columns j: vectors yc (Bc of them, the classes); PLDA.call uses y == yc
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     R* yi = reinterpret_cast<R*>(smraw);       // 16 x dim
     R* yj = yi + 16 * dim;                     // 16 x dim
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void plda_score_kernel(const R* __restrict__ y
     for (int e = threadIdx.x; e < 16 * dim; e += 256) {
         const int r = e / dim, d = e - r * dim;
         yi[e] = (i0 + r < B) ? y[(i0 + r) * dim + d] : (R)0;
-        yj[e] = (j0 + r < B) ? y[(j0 + r) * dim + d] : (R)0;
+        yj[e] = (j0 + r < Bc) ? yc[(j0 + r) * dim + d] : (R)0;
     }
     for (int d = threadIdx.x; d < dim; d += 256) ps[d] = psi[d];
     __syncthreads();
@@ -236,8 +238,8 @@ __global__ __launch_bounds__(256) void plda_score_kernel(const R* __restrict__ y
         a += diff * diff / ((R)1 + p / (p + (R)1));
         c += v * v / ((R)1 + p);
     }
-    if (i0 + ti < B && j0 + tj < B)
-        scores[(i0 + ti) * B + (j0 + tj)] = (R)(-0.5) * (logdet1 + a) - (R)(-0.5) * (logdet2 + c);
+    if (i0 + ti < B && j0 + tj < Bc)
+        scores[(i0 + ti) * Bc + (j0 + tj)] = (R)(-0.5) * (logdet1 + a) - (R)(-0.5) * (logdet2 + c);
 }
 
 template <typename R>
@@ -258,10 +260,36 @@ static int plda_launch(const char* who, const R* x, int64_t B, int32_t dim, cons
         if (lds2 > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)plda_score_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         dim3 grid((unsigned)ktf_cdiv(B, 16), (unsigned)ktf_cdiv(B, 16));
-        hipLaunchKernelGGL(plda_score_kernel<R>, grid, dim3(256), lds2, st, transformed, B, dim, psi, scores);
+        hipLaunchKernelGGL(plda_score_kernel<R>, grid, dim3(256), lds2, st, transformed, B, transformed, B, dim, psi, scores);
         KTF_CHECK_LAUNCH(who);
     }
     return KTF_OK;
+}
+
+template <typename R>
+static int plda_score_launch(const char* who, const R* test, int64_t N, const R* enroll, int64_t M, int32_t dim,
+                             const R* psi, R* scores, void* stream) {
+    KTF_REQUIRE(test && enroll && psi && scores, "%s: null argument", who);
+    KTF_REQUIRE(N >= 0 && M >= 0 && dim > 0, "%s: bad sizes", who);
+    if (N == 0 || M == 0) return KTF_OK;
+    const size_t lds2 = sizeof(R) * (33 * (size_t)dim + 8);
+    KTF_REQUIRE(lds2 <= 160 * 1024, "%s: dim %d too large for the score tile", who, dim);
+    KTF_REQUIRE(ktf_cdiv(N, 16) < 65536, "%s: too many rows (shard them)", who);
+    if (lds2 > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)plda_score_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+    dim3 grid((unsigned)ktf_cdiv(M, 16), (unsigned)ktf_cdiv(N, 16));
+    hipLaunchKernelGGL(plda_score_kernel<R>, grid, dim3(256), lds2, (hipStream_t)stream, test, N, enroll, M, dim, psi, scores);
+    KTF_CHECK_LAUNCH(who);
+    return KTF_OK;
+}
+
+extern "C" int ktf_plda_score_f64(const double* test_tr, int64_t N, const double* enroll_tr, int64_t M, int32_t dim,
+                                  const double* psi, double* scores, void* stream) {
+    return plda_score_launch<double>("ktf_plda_score_f64", test_tr, N, enroll_tr, M, dim, psi, scores, stream);
+}
+extern "C" int ktf_plda_score_f32(const float* test_tr, int64_t N, const float* enroll_tr, int64_t M, int32_t dim,
+                                  const float* psi, float* scores, void* stream) {
+    return plda_score_launch<float>("ktf_plda_score_f32", test_tr, N, enroll_tr, M, dim, psi, scores, stream);
 }
 
 extern "C" int ktf_plda_f64(const double* x, int64_t B, int32_t dim, const double* A, const double* offset,

@@ -5,7 +5,7 @@ reference exposes as `import kaldi_tflite as ktf` for that path: ktf.layers, ktf
 ktf.io, ktf.kaldi_numpy.
 """
 
-from . import io, kaldi_numpy, layers, models  # noqa: F401
+from . import io, kaldi_numpy, layers, models, parallel  # noqa: F401
 from ._lib import KtfBackendError  # noqa: F401
 
 __version__ = "0.1.0"

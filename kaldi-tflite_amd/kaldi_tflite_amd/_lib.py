@@ -28,7 +28,7 @@ class FrontendCfg(C.Structure):
         ("frame_size", C.c_int32), ("frame_shift", C.c_int32), ("nfft", C.c_int32), ("num_mels", C.c_int32),
         ("num_ceps", C.c_int32), ("remove_dc", C.c_int32), ("raw_energy", C.c_int32), ("use_energy", C.c_int32),
         ("use_power", C.c_int32), ("use_log", C.c_int32), ("use_lifter", C.c_int32), ("preemph", C.c_float),
-        ("dither", C.c_float), ("energy_floor", C.c_float), ("eps", C.c_float), ("pad_mode", C.c_int32),
+        ("dither", C.c_float), ("energy_floor", C.c_float), ("eps", C.c_float), ("pad_mode", C.c_int32), ("row_stride", C.c_int32),
     ]
 
 
@@ -83,6 +83,8 @@ PROTOTYPES = {
     "ktf_xvec_post_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P, _P]),
     "ktf_plda_f64": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
     "ktf_plda_f32": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
+    "ktf_plda_score_f64": (C.c_int, [_P, _i64, _P, _i64, _i32, _P, _P, _P]),
+    "ktf_plda_score_f32": (C.c_int, [_P, _i64, _P, _i64, _i32, _P, _P, _P]),
 }
 
 _lib = None

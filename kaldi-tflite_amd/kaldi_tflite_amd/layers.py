@@ -158,9 +158,14 @@ class Framing(Layer):
                 x = x.to(ops.default_device())
             else:
                 x = ops.to_device_f32(x)
-        if x.dtype == torch.int16:
-            return x.contiguous(), L.IN_WAV_I16
-        return x.to(torch.float32).contiguous(), L.IN_WAV
+        kind = L.IN_WAV_I16 if x.dtype == torch.int16 else L.IN_WAV
+        if x.dtype != torch.int16:
+            x = x.to(torch.float32)
+        # (B, N) views with unit sample stride are read in place: overlapping windows of one recording
+        # (`wav.unfold(-1, N, hop)`, sliding-window / diarization extraction) are not materialised
+        if not (x.dim() == 2 and x.stride(1) == 1 and 0 < x.stride(0) < 2**31):
+            x = x.contiguous()
+        return x, kind
 
     def compute_output_shape(self, input_shape):
         n = input_shape[self.sampleAxis]
@@ -196,7 +201,11 @@ class Framing(Layer):
         cfg = self._cfg()
         if not hasattr(self, "_tables"):
             self._tables = ops.FrontendTables(self.frameWidth, device=x.device)
-        out = ops.frontend(x.reshape(B, n), kind, cfg, self._tables, L.OUT_FRAMES, n, B, T)
+        if x.dim() == 2 and not x.is_contiguous():
+            cfg.row_stride = x.stride(0)
+        else:
+            x = x.reshape(B, n)
+        out = ops.frontend(x, kind, cfg, self._tables, L.OUT_FRAMES, n, B, T)
         if self.dynamicInputShape:
             return out.reshape(lead[0] if len(lead) else 1, -1, self.frameWidth)
         return out.reshape(*lead, T, self.frameWidth)
@@ -982,8 +991,10 @@ class PLDA(Layer):
         assert r == self.dim, f"plda_transform_mat dimension size ({r}) != input dim ({self.dim})"
         assert r == c, f"plda_transform_mat ({r} x {c}) is not a square matrix"
 
-    def call(self, inputs):
+    def _prepare(self, inputs):
         x = inputs
+        if not isinstance(x, torch.Tensor):
+            x = torch.as_tensor(np.ascontiguousarray(x), device=ops.default_device())
         if x.dim() == 3:
             if x.shape[1] != 1:
                 raise ValueError(f"expected (batch, 1, dim) input, got {tuple(x.shape)}")
@@ -992,8 +1003,28 @@ class PLDA(Layer):
             raise ValueError(f"expected input tensor rank to be 2 or 3, got {x.dim()}")
         x = x.to(self.paramDtype).contiguous()
         if self._dev is None or self._dev[0].device != x.device:
-            f = lambda a: torch.as_tensor(np.ascontiguousarray(a), device=x.device)  # noqa: E731
+            f = lambda a: torch.as_tensor(np.ascontiguousarray(a).copy(), device=x.device)  # noqa: E731
             self._dev = (f(self.transformMat), f(self.offset), f(self.psi))
+        return x
+
+    def transform(self, inputs):
+        """Extension: transformVector alone (plda.py:163-196) -> (B, dim) transformed vectors."""
+        x = self._prepare(inputs)
+        A, off, psi = self._dev
+        return ops.plda(x, A, off, psi, self.normalizeLength, self.simpleLengthNorm, want_scores=False)[1]
+
+    def score(self, test_transformed, enroll_transformed):
+        """Extension: rectangular trial block, scores[i, j] = LLR(test_i | class of enroll_j) on TRANSFORMED vectors
+        (the reference scores a batch against itself only); row blocks of a large trial matrix shard across GPUs
+        (parallel.plda_trials)."""
+        t = test_transformed.reshape(test_transformed.shape[0], -1).to(self.paramDtype).contiguous()
+        e = enroll_transformed.reshape(enroll_transformed.shape[0], -1).to(self.paramDtype).contiguous()
+        if self._dev is None or self._dev[0].device != t.device:
+            self._prepare(t)
+        return ops.plda_score(t, e, self._dev[2])
+
+    def call(self, inputs):
+        x = self._prepare(inputs)
         A, off, psi = self._dev
         scores, tr = ops.plda(x, A, off, psi, self.normalizeLength, self.simpleLengthNorm)
         if self.returnTransformed:

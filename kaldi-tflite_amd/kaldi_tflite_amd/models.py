@@ -373,6 +373,7 @@ class XvectorExtractor:
         cfg = L.FrontendCfg.from_buffer_copy(mf._cfg)
         cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift
         cfg.pad_mode = 0 if fr.snipEdges else 1
+        cfg.row_stride = 0 if x.is_contiguous() else x.stride(0)
         ops.frontend(x, kind, cfg, mf.tables(x.device), L.OUT_MFCC, N, B, T, seed=mf.next_seed(), out=ws["mfcc"])
         ops.vad_cmvn(ws["mfcc"], self.vad.cfg(), self.cmvn.cfg(), ws["feats"], ws["lens"], ws["idx"], ws["work"])
         return ws["mfcc"], ws["feats"][:, :, :D], ws["lens"]

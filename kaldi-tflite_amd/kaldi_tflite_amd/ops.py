@@ -320,6 +320,19 @@ def tdnn_stats(x, lens, desc, w, w_lo, bias, scale, shift, sums):
     return sums
 
 
+def plda_score(test_tr, enroll_tr, psi):
+    """scores (N, M) of transformed test vectors against transformed enrollment vectors."""
+    lib = L.load()
+    N, dim = test_tr.shape
+    M = enroll_tr.shape[0]
+    scores = torch.empty((N, M), dtype=test_tr.dtype, device=test_tr.device)
+    fn = lib.ktf_plda_score_f64 if test_tr.dtype == torch.float64 else lib.ktf_plda_score_f32
+    with torch.cuda.device(test_tr.device):
+        rc = fn(L.ptr(test_tr), N, L.ptr(enroll_tr), M, dim, L.ptr(psi), L.ptr(scores), L.stream_ptr())
+    L.check(rc, "ktf_plda_score")
+    return scores
+
+
 def stats_finalize(sums, lens, T, D, include_std, eps, out):
     lib = L.load()
     B = sums.shape[0]

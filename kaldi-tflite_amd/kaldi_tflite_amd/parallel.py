@@ -60,6 +60,17 @@ def gather_ragged_embeddings(local, world):
     return torch.cat([p[:s] for p, s in zip(parts, sizes)], 0)
 
 
+def plda_trials(score_block, test, enroll, rank, world, gather=True):
+    """Row-sharded N x M trial matrix: rank r scores rows shard_range(N, r, world) of `test` against ALL of `enroll`
+    with `score_block(test_rows, enroll) -> (n_r, M)` (e.g. `PLDA.score` on transformed vectors). No collective on the
+    scoring path; `gather=True` all-gathers the row blocks so every rank ends with the full (N, M) matrix."""
+    lo, hi = shard_range(test.shape[0], rank, world)
+    block = score_block(test[lo:hi], enroll)
+    if not gather or world == 1:
+        return block
+    return gather_ragged_embeddings(block, world)
+
+
 def max_over_ranks(seconds, world, device):
     if world == 1:
         return seconds

@@ -42,6 +42,10 @@ def _worker(rank, world, port, total, out_dir):
         allv = P.gather_embeddings(local, world)
     else:
         allv = P.gather_ragged_embeddings(local, world)
+    # row-sharded trial matrix (plda_trials): a bilinear stand-in scorer, every rank ends with the full matrix
+    enroll = torch.randn(5, 16, generator=g)
+    trials = P.plda_trials(lambda a, b: a @ b.T, full, enroll, rank, world)
+    assert trials.shape == (total, 5) and torch.equal(trials, full @ enroll.T)
     t = P.max_over_ranks(1.0 + rank, world, torch.device("cpu"))
     np.save(os.path.join(out_dir, f"r{rank}.npy"), allv.numpy())
     assert t == float(world)

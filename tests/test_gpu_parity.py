@@ -374,6 +374,45 @@ def test_plda_1024_trial_matrix_properties():
     assert np.abs(s[:48, :48] - want).max() < 1e-8
 
 
+def test_sliding_window_extraction_is_zero_copy_and_exact():
+    """overlapping windows of one long recording (`wav.unfold`: row stride < window length) are
+    read in place by the front-end (KtfFrontendCfg.row_stride) and give exactly the x-vectors of the copied windows."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=1, narrow=True)
+    mdl = synth.build_extractor(ktf, cfg, w)
+    rec = synth.make_wav(1, 16000 * 9 + 57, seed=8, ragged=True)[0]
+    for dt in (torch.float32, torch.int16):
+        x = torch.as_tensor(rec, device="cuda").to(dt)
+        win = x.unfold(0, 24000, 12007)                 # 1.5 s windows, odd hop
+        assert not win.is_contiguous() and win.shape[0] == 10
+        ptr = x.data_ptr()
+        a = host(mdl(win))
+        assert x.data_ptr() == ptr
+        assert np.array_equal(a, host(mdl(win.contiguous())))
+        assert np.array_equal(host(Ls.Framing(25, 10, 16000)(win)), host(Ls.Framing(25, 10, 16000)(win.contiguous())))
+
+
+def test_plda_rectangular_trial_blocks():
+    """N x M trial blocks (rows shard across GPUs). A block of the square matrix PLDA.call returns
+    must be reproduced bit for bit by transform() + score() on the two row sets."""
+    rng = np.random.default_rng(17)
+    dim, n = 128, 300
+    A = rng.standard_normal((dim, dim)) / np.sqrt(dim) + np.eye(dim)
+    for dt in (torch.float64, torch.float32):
+        plda = Ls.PLDA(dim, rng.standard_normal(dim) * 0.1, A, np.sort(rng.uniform(0.05, 30.0, dim))[::-1].copy(), dtype=dt)
+        x = torch.as_tensor(rng.standard_normal((n, dim)), device="cuda").to(dt)
+        full, tr = plda(x)
+        t = plda.transform(x)
+        assert torch.equal(t, tr.reshape(n, dim))
+        blk = plda.score(t[37:181], t[5:250])
+        assert blk.shape == (144, 245) and torch.equal(blk, full[37:181, 5:250])
+        rows = ktf.parallel.plda_trials(plda.score, t, t, rank=1, world=3, gather=False)
+        assert torch.equal(rows, full[100:200])
+        # oracle on a corner
+        want, _ = O.plda(host(x).astype(np.float64), plda.mean, plda.transformMat, plda.psi)
+        assert np.abs(host(blk) - want[37:181, 5:250]).max() < (1e-9 if dt == torch.float64 else 5e-3)
+
+
 # ----------------------------------------------------------------------------- whole pipeline
 def _extract_oracle(wav, cfg, w):
     return O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64, return_intermediates=True)

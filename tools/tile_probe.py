@@ -16,12 +16,19 @@ os.environ.setdefault("KTF_HTILE", "1")
 import kaldi_tflite_amd as ktf
 from kaldi_tflite_amd import _lib as L
 B, T = 1024, 998
-for name, din, units, ctx in [("tdnn2", 512, 512, [-2, 0, 2]), ("tdnn4", 512, 512, [0]), ("tdnn5", 512, 1500, [0])]:
+from kaldi_tflite_amd import ops
+for name, din, units, ctx in [("tdnn2", 512, 512, [-2, 0, 2]), ("tdnn4", 512, 512, [0]), ("tdnn5", 512, 1500, [0]),
+                              ("tdnn5+stats", 512, 1500, [0])]:
     t = ktf.layers.TDNN(units, context=ctx, gemm="bf16")
     t.build((B, T, din))
     x = torch.randn((B, T, din), device=dev).to(torch.bfloat16)
     y = torch.zeros((B, T, (units + 31) // 32 * 32), dtype=torch.bfloat16, device=dev)
     f = lambda: t.forward(x, relu=True, bn=None, gemm=L.GEMM_BF16, out_dtype=torch.bfloat16, ldy=y.shape[-1], out=y)
+    if name.endswith("+stats"):
+        sums = torch.zeros((B, 2, units), dtype=torch.float64, device=dev)
+        w, w_lo, bias = t.device_weights(dev, L.GEMM_BF16)
+        dsc = t.desc(L.GEMM_BF16, torch.bfloat16, torch.bfloat16, act="relu")
+        f = lambda: ops.tdnn_stats(x, None, dsc, w, w_lo, bias, None, None, sums)
     f(); f(); torch.cuda.synchronize()
     dbg.zero_(); torch.cuda.synchronize()
     f(); torch.cuda.synchronize()
