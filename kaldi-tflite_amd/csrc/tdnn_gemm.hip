@@ -1250,6 +1250,10 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 #define H_LDS_BYTES (H_RING_BYTES + 3 * H_BN * 4)    // + bias | scale | shift of the tile's columns = 76,800 B
 #define H_PK_PITCH 520
 
+#ifndef KTF_H_ABL
+#define KTF_H_ABL 0   // timing-only ablations of the K-loop (tools/tile_probe.py; results are garbage): 1 no refill DMA,
+                    // 2 also no LDS reads, 3 no MFMA, 5 DMA issued but never waited for, 6 DMA from one small hot region (7: W only, 8: A only)
+#endif
 #ifdef KTF_TILE_PROBE
 #define H_PROBE(k) if (dbgp && threadIdx.x == 0) dbgp[k] = wall_clock64();
 #define H_PROBE_HW()                                                                  \
@@ -1325,13 +1329,15 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
     {                                                                                                                  \
         int r_ = a_t[i] + is_off;                                                                                      \
         r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
-        const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                          \
+        const unsigned vo_ = (KTF_H_ABL == 6 || KTF_H_ABL == 8) ? a_cb[i] + (unsigned)(tid >> 2) * 64u                                   \
+                                              : (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                       \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_),                                                       \
             (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);                           \
     }
 #define H_DMA_B(i)                                                                                                     \
     {                                                                                                                  \
-        const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                                 \
+        const unsigned vo_ = (KTF_H_ABL == 6 || KTF_H_ABL == 7) ? (unsigned)((i) * 256 + tid) * 16u                                      \
+                                              : w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                              \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_),                                                       \
             (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + H_A_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);               \
     }
@@ -1374,30 +1380,35 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
     bfrag8 a[8], bq[4];
     int cs = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (KTF_H_ABL != 5) {
+            if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 #ifdef KTF_TILE_PROBE
-        if (ks == 0) { H_PROBE(2) }
+        if (ks == 0) { H_PROBE(2) if (dbgp && threadIdx.x == 0) dbgp[12] = clock64(); }
 #endif
-        const bool refill = is_ks < nk;
+        const bool refill = is_ks < nk && (KTF_H_ABL == 0 || KTF_H_ABL >= 3);
         const unsigned char* sa = rsm + cs * H_STAGE_BYTES;
         const unsigned char* sb = sa + H_A_BYTES;
         cs = (cs == H_NSTAGE - 1) ? 0 : cs + 1;
+        if (KTF_H_ABL != 2 || ks == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 16 * 64);
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 16 * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + j * 16 * 64);
+            for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bfrag8*>(sb + b_row_off + j * 16 * 64);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
+                if (KTF_H_ABL != 3)
                 acc[i][j] = STATS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0)
                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (i == 0) {
+            if (i == 0 && (KTF_H_ABL != 2 || ks == 0)) {
 #pragma unroll
                 for (int i2 = 4; i2 < 8; ++i2) a[i2] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i2 * 16 * 64);
             }
@@ -1416,7 +1427,11 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
 #undef H_DMA_A
 #undef H_DMA_B
 #undef H_ADVANCE
+    if (KTF_H_ABL == 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     H_PROBE(3)
+#ifdef KTF_TILE_PROBE
+    if (dbgp && threadIdx.x == 0) dbgp[13] = clock64();
+#endif
     const int rows_valid = out_len - t0;
     if (STATS) {
         // acc[i][j][r] = out[row i*16 + g4*4 + r][col wn*64 + j*16 + c]
