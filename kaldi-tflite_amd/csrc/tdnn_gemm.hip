@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 
 #ifndef KTF_H_ABL
 #define KTF_H_ABL 0   // timing-only ablations of the K-loop (tools/tile_probe.py; results are garbage): 1 no refill DMA,
-                    // 2 also no LDS reads, 3 no MFMA, 5 DMA issued but never waited for, 6 DMA from one small hot region (7: W only, 8: A only)
+                    // 2 also no LDS reads, 3 no MFMA, 5 DMA issued but never waited for, 6 DMA from one small hot region (7: W only, 8: A only), 9 real addresses but 128-byte pieces (what a 64-deep K-step would fetch)
 #endif
 #ifdef KTF_TILE_PROBE
 #define H_PROBE(k) if (dbgp && threadIdx.x == 0) dbgp[k] = wall_clock64();
@@ -1329,15 +1329,26 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
     {                                                                                                                  \
         int r_ = a_t[i] + is_off;                                                                                      \
         r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
-        const unsigned vo_ = (KTF_H_ABL == 6 || KTF_H_ABL == 8) ? a_cb[i] + (unsigned)(tid >> 2) * 64u                                   \
+        unsigned vo_ = (KTF_H_ABL == 6 || KTF_H_ABL == 8) ? a_cb[i] + (unsigned)(tid >> 2) * 64u                                   \
                                               : (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                       \
+        if (KTF_H_ABL == 9) {                                                                                          \
+            const int q_ = (i) * 256 + tid;                                                                            \
+            int r9_ = start + t0 + (q_ >> 3) + ((is_ks & 1) ? 64 : 0) + is_off;                                        \
+            r9_ = r9_ < 0 ? 0 : (r9_ > lenm1 ? lenm1 : r9_);                                                           \
+            vo_ = (unsigned)r9_ * ldxb + ((unsigned)is_db & ~127u) + (unsigned)(q_ & 7) * 16u;                         \
+        }                                                                                                              \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_),                                                       \
             (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);                           \
     }
 #define H_DMA_B(i)                                                                                                     \
     {                                                                                                                  \
-        const unsigned vo_ = (KTF_H_ABL == 6 || KTF_H_ABL == 7) ? (unsigned)((i) * 256 + tid) * 16u                                      \
+        unsigned vo_ = (KTF_H_ABL == 6 || KTF_H_ABL == 7) ? (unsigned)((i) * 256 + tid) * 16u                                      \
                                               : w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                              \
+        if (KTF_H_ABL == 9) {                                                                                          \
+            const int q_ = (i) * 256 + tid;                                                                            \
+            vo_ = (unsigned)(n0 + (q_ >> 3) + ((is_ks & 1) ? 128 : 0)) * (unsigned)p.ktot * 2u +                       \
+                  ((unsigned)(is_ks * (R_BK * 2)) & ~127u) + (unsigned)(q_ & 7) * 16u;                                 \
+        }                                                                                                              \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_),                                                       \
             (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + H_A_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);               \
     }
