@@ -378,6 +378,32 @@ class XvectorExtractor:
         ops.vad_cmvn(ws["mfcc"], self.vad.cfg(), self.cmvn.cfg(), ws["feats"], ws["lens"], ws["idx"], ws["work"])
         return ws["mfcc"], ws["feats"][:, :, :D], ws["lens"]
 
+    def extract_stream(self, host_batches, depth=2):
+        """Extension: x-vectors of a sequence of HOST batches (pinned (B,N) int16 / fp32 tensors) with the upload of batch
+        i+1 on a separate HIP stream under the compute of batch i (`depth` device input buffers). Yields one (B, dim)
+        device tensor per batch, in order. The compute path is the same as __call__; only the copies overlap."""
+        L.require_gpu()
+        dev = ops.default_device()
+        compute = torch.cuda.current_stream(dev)
+        copy = torch.cuda.Stream(device=dev)
+        bufs, free = [None] * depth, [None] * depth
+        for i, hb in enumerate(host_batches):
+            hb = hb if isinstance(hb, torch.Tensor) else torch.as_tensor(hb)
+            k = i % depth
+            with torch.cuda.stream(copy):
+                if free[k] is not None:
+                    copy.wait_event(free[k])                      # the compute that read this buffer has finished
+                if bufs[k] is None or bufs[k].shape != hb.shape or bufs[k].dtype != hb.dtype:
+                    bufs[k] = torch.empty(hb.shape, dtype=hb.dtype, device=dev)
+                bufs[k].copy_(hb, non_blocking=True)
+                ready = torch.cuda.Event()
+                ready.record(copy)
+            compute.wait_event(ready)
+            y = self(bufs[k])
+            free[k] = torch.cuda.Event()
+            free[k].record(compute)
+            yield y
+
     def __call__(self, inputs, training=False):
         _, feats, lens = self.features(inputs)
         h = self.xvec.run_ragged(feats, lens)                      # (B, 1, 512)

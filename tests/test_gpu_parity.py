@@ -392,6 +392,17 @@ def test_sliding_window_extraction_is_zero_copy_and_exact():
         assert np.array_equal(host(Ls.Framing(25, 10, 16000)(win)), host(Ls.Framing(25, 10, 16000)(win.contiguous())))
 
 
+def test_extract_stream_overlapped_upload_matches_direct_calls():
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=1, narrow=True)
+    mdl = synth.build_extractor(ktf, cfg, w)
+    batches = [torch.as_tensor(synth.make_wav(2, 32000 + 160 * i, seed=20 + i, ragged=True).astype(np.int16)).pin_memory()
+               for i in range(5)]
+    want = [host(mdl(b.cuda())) for b in batches]
+    got = [host(y) for y in mdl.extract_stream(batches)]
+    assert len(got) == 5 and all(np.array_equal(a, b) for a, b in zip(got, want))
+
+
 def test_plda_rectangular_trial_blocks():
     """N x M trial blocks (rows shard across GPUs). A block of the square matrix PLDA.call returns
     must be reproduced bit for bit by transform() + score() on the two row sets."""
