@@ -118,6 +118,7 @@ def main():
         "launches_per_step": gemm_stats["launches"] // args.steps, "avg_launch_ms": gemm_stats["total_ms"] / max(gemm_stats["launches"], 1),
         "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],
         "algorithmic_flop_per_step": flops_per_step,
+        "per_layer_tflops": {k: _layer_flops(k, B, T) / (v * 1e-3) / 1e12 for k, v in gemm_stats["per_layer_ms"].items()},
         "note": "bf16x3 issues 3 MFMA passes per algorithmic FLOP" if args.gemm == "bf16x3" else "",
     }
     # HBM traffic of those launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE),
@@ -126,9 +127,11 @@ def main():
     if args.gemm == "bf16" and B == 1024 and os.path.exists(tpath):
         with open(tpath) as f:
             tj = json.load(f)
-        out["roofline"]["traffic"] = tj["tdnn_gemm_bytes_per_step_corrected"]
-        out["roofline"]["traffic_note"] = ("HBM bytes per step summed over the 5 GEMM launches (profiles/r1_traffic.json); "
-                                           f"algorithmic bytes {tj['tdnn_gemm_algorithmic_bytes_per_step']}")
+        nl = max(out["roofline"]["launches_per_step"], 1)
+        out["roofline"]["traffic"] = tj["tdnn_gemm_bytes_per_step_corrected"] / nl
+        out["roofline"]["traffic_note"] = ("HBM bytes per launch = PMC bytes per step (profiles/r1_traffic.json: "
+                                           f"{tj['tdnn_gemm_bytes_per_step_corrected']:.4g}) / {nl} GEMM launches; algorithmic "
+                                           f"{tj['tdnn_gemm_algorithmic_bytes_per_step'] / nl:.4g} per launch")
     out["mfcc"] = _bench_mfcc(mdl, wav, ops)
     if not args.no_extra:
         out["parity"] = _parity_sample(ktf, synth, cfg, w, args.gemm, dev)
@@ -220,6 +223,14 @@ def _parity_sample(ktf, synth, cfg, w, gemm, dev):
         got = synth.build_extractor(ktf, cfg, w, gemm=g)(torch.as_tensor(wav, device=dev)).cpu().numpy()
         res[f"max_abs_dev_{g}"] = float(np.abs(got - want).max())
     return res
+
+
+def _layer_flops(key, B, T):
+    """FLOPs of all launches filed under a per_layer_ms key 'KxD->U[+stats]' (layers of equal shape share a key)."""
+    kd, u = key.split("->")
+    k, d = kd.split("x")
+    n = {"3x512->512": 2}.get(key.replace("+stats", ""), 1)      # tdnn2 and tdnn3
+    return 2.0 * B * T * int(k) * int(d) * int(u.replace("+stats", "")) * n
 
 
 def _time_ms(fn, iters):
