@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 
 #ifndef KTF_H_ABL
 #define KTF_H_ABL 0   // timing-only ablations of the K-loop (tools/tile_probe.py; results are garbage): 1 no refill DMA,
-                    // 2 also no LDS reads, 3 no MFMA, 5 DMA issued but never waited for, 6 DMA from one small hot region (7: W only, 8: A only), 9 real addresses but 128-byte pieces (what a 64-deep K-step would fetch)
+                    // 2 also no LDS reads, 3 no MFMA, 5 DMA issued but never waited for, 6 DMA from one small hot region (7: W only, 8: A only), 9 real addresses but 128-byte pieces (what a 64-deep K-step would fetch), 10 activation DMAs only in N-tile 0
 #endif
 #ifdef KTF_TILE_PROBE
 #define H_PROBE(k) if (dbgp && threadIdx.x == 0) dbgp[k] = wall_clock64();
@@ -1392,7 +1392,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
     int cs = 0;
     for (int ks = 0; ks < nk; ++ks) {
         if (KTF_H_ABL != 5) {
-            if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (KTF_H_ABL == 10 && nt != 0 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -1424,8 +1425,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
                 for (int i2 = 4; i2 < 8; ++i2) a[i2] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i2 * 16 * 64);
             }
             if (refill) {
-                if (i == 1) H_DMA_A(0)
-                if (i == 2) H_DMA_A(1)
+                if (i == 1 && (KTF_H_ABL != 10 || nt == 0)) H_DMA_A(0)
+                if (i == 2 && (KTF_H_ABL != 10 || nt == 0)) H_DMA_A(1)
                 if (i == 3) H_DMA_B(0)
                 if (i == 4) H_DMA_B(1)
                 if (i == 5) H_DMA_B(2)
