@@ -208,7 +208,7 @@ int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* le
  * output is never written; instead sums[b, 0, u] += sum_t y[b,t,u] and sums[b, 1, u] += sum_t y[b,t,u]^2 (fp64, over
  * the valid rows). `sums` (B, 2, units) must be zeroed by the caller before the call. Implemented by the bf16 ring
  * kernels only: KTF_GEMM_BF16 (bf16 x) or KTF_GEMM_BF16X3 (fp32 x, w_lo given), units > 128, SAME padding,
- * subsampling 1, ReLU or no activation. */
+ * subsampling 1. */
 int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                    const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift, double* sums,
                    void* stream);
