@@ -357,6 +357,15 @@ __global__ __launch_bounds__(256) void tdnn_bf16_kernel(TdnnParams p) {
 // 1-D grid, XCD-aware: block id -> (xcd = id % 8, slot = id / 8); an XCD walks its own M-tiles and runs all N-tiles of
 // one M-tile back to back, so the gathered activation rows are fetched into that XCD's L2 once.
 // The epilogue stages the fp32 accumulators through LDS and writes whole 256-B row segments.
+// cache policy bits of the operand DMAs (aux of global_load_lds: 1 = sc0, 2 = nt, 16 = sc1); A = activations, W = weights.
+// Measured (tools/gemm_layers.py): nt on the activations -10..-20 %, nt on the weights -10..-40 %, sc0 no change: both
+// streams live on L2 hits (other N-tiles / context offsets re-read the activations, every CU re-reads the weights).
+#ifndef KTF_AUX_A
+#define KTF_AUX_A 0
+#endif
+#ifndef KTF_AUX_W
+#define KTF_AUX_W 0
+#endif
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef __attribute__((address_space(1))) const void glb_ptr_t;
 
@@ -695,14 +704,14 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
         r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
         const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                          \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_),                                                       \
-            (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + wave * 1024 + (i) * 8192), 16, 0, 0);        \
+            (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + wave * 1024 + (i) * 8192), 16, 0, KTF_AUX_A);\
     }
 #define R_DMA_B(i)                                                                                                     \
     {                                                                                                                  \
         const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                                 \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_),                                                       \
             (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + R_TILE_BYTES + wave * 1024 + (i) * 8192),    \
-            16, 0, 0);                                                                                                 \
+            16, 0, KTF_AUX_W);                                                                                            \
     }
 #define R_ADVANCE()                                                                                                    \
     {                                                                                                                  \
@@ -1123,14 +1132,14 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
         r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
         const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                          \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_),                                                       \
-            (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + wave * 1024 + (i) * 8192), 16, 0, 0);        \
+            (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + wave * 1024 + (i) * 8192), 16, 0, KTF_AUX_A);\
     }
 #define S_DMA_B(i)                                                                                                     \
     {                                                                                                                  \
         const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                                 \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_),                                                       \
             (lds_ptr_t*)(rsm + (is_ks & (R_NSTAGE - 1)) * R_STAGE_BYTES + R_TILE_BYTES + wave * 1024 + (i) * 8192),    \
-            16, 0, 0);                                                                                                 \
+            16, 0, KTF_AUX_W);                                                                                            \
     }
 #define S_ADVANCE()                                                                                                    \
     {                                                                                                                  \
@@ -1338,7 +1347,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
             vo_ = (unsigned)r9_ * ldxb + ((unsigned)is_db & ~127u) + (unsigned)(q_ & 7) * 16u;                         \
         }                                                                                                              \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_),                                                       \
-            (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);                           \
+            (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + wn * 1024 + (i) * 4096), 16, 0, KTF_AUX_A);                   \
     }
 #define H_DMA_B(i)                                                                                                     \
     {                                                                                                                  \
@@ -1350,7 +1359,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
                   ((unsigned)(is_ks * (R_BK * 2)) & ~127u) + (unsigned)(q_ & 7) * 16u;                                 \
         }                                                                                                              \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_),                                                       \
-            (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + H_A_BYTES + wn * 1024 + (i) * 4096), 16, 0, 0);               \
+            (lds_ptr_t*)(rsm + is_slot * H_STAGE_BYTES + H_A_BYTES + wn * 1024 + (i) * 4096), 16, 0, KTF_AUX_W);       \
     }
 #define H_ADVANCE()                                                                                                    \
     {                                                                                                                  \
