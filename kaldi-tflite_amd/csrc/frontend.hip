@@ -378,8 +378,10 @@ extern "C" int64_t ktf_num_frames_padded(int64_t n_samples, int32_t frame_size, 
 extern "C" int ktf_frontend_f32(const void* in, int64_t B, int64_t n, int32_t in_kind, const KtfFrontendCfg* cfg,
                                 const KtfFrontendTables* tab, int32_t out_stage, float* out, float* energy,
                                 uint64_t seed, void* stream) {
-    KTF_REQUIRE(in && out && cfg && tab, "ktf_frontend_f32: null argument");
     KTF_REQUIRE(B >= 0 && n >= 0, "ktf_frontend_f32: negative size");
+    KTF_REQUIRE(cfg && tab, "ktf_frontend_f32: null argument");
+    if (B == 0) return KTF_OK;                       // empty batch: nothing to read or write (pointers may be NULL)
+    KTF_REQUIRE(in && out, "ktf_frontend_f32: null argument");
     KTF_REQUIRE(in_kind >= KTF_IN_WAV && in_kind <= KTF_IN_WAV_I16, "ktf_frontend_f32: bad in_kind %d", in_kind);
     const bool wav = in_kind == KTF_IN_WAV || in_kind == KTF_IN_WAV_I16;
     const int pad_mode = wav ? cfg->pad_mode : 0;

@@ -405,6 +405,9 @@ class XvectorExtractor:
             yield y
 
     def __call__(self, inputs, training=False):
+        if hasattr(inputs, "shape") and len(inputs.shape) == 2 and inputs.shape[0] == 0:
+            L.require_gpu()
+            return torch.empty((0, self.ldaMat.shape[1]), dtype=torch.float32, device=ops.default_device())
         _, feats, lens = self.features(inputs)
         h = self.xvec.run_ragged(feats, lens)                      # (B, 1, 512)
         B = h.shape[0]

@@ -501,6 +501,15 @@ def test_extractor_edge_cases():
         assert np.abs(got - want).max() <= 1e-4, n
     with pytest.raises(ValueError):
         mdl(dev(np.zeros((1, 399), np.float32)))
+    # an utterance without a single voiced frame: NaN embedding for it (the reference pools over zero frames), the
+    # other utterances of the batch bit-identical; an empty batch gives an empty result
+    wav = synth.make_wav(3, 32000, seed=5, ragged=True)
+    ref = host(mdl(dev(wav)))
+    wav[1] = 0.0
+    out = host(mdl(dev(wav)))
+    assert np.array_equal(out[[0, 2]], ref[[0, 2]]) and np.isnan(out[1]).all()
+    assert int(mdl.features(dev(wav))[2][1]) == 0
+    assert tuple(mdl(torch.zeros((0, 32000), device="cuda")).shape) == (0, 128)
     # permutation equivariance over the batch at the full 10 s size
     wav = synth.make_wav(4, 160000, seed=7, ragged=True)
     a = host(mdl(dev(wav)))
