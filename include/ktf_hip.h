@@ -166,7 +166,8 @@ int ktf_vad_index(const float* feats, int64_t B, int64_t T, int32_t D, const Ktf
 int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int64_t ldx, const int32_t* lens,
                  const KtfCmvnCfg* cfg, float* out, int64_t ldo, int32_t* out_lens, float* work, void* stream);
 /* Fused hot path: VAD -> per-utterance compaction -> CMVN (xvector_extractor.py:162-166).
- * out_dtype KTF_F32 or KTF_BF16. idx_work = B*T int32, work = B*T*2*D floats. */
+ * out_dtype KTF_F32 or KTF_BF16. idx_work = B*T int32, work = B*T*2*D floats. T <= 38,400 frames per utterance
+ * (the frame -> row map of an utterance lives in LDS); longer recordings: ktf_vad_index + ktf_cmvn_f32, or split. */
 int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* vad, const KtfCmvnCfg* cmvn,
                  void* out, int32_t out_dtype, int64_t ldo, int32_t* lens, int32_t* idx_work, float* work,
                  void* stream);

@@ -348,7 +348,8 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
         return KTF_OK;
     }
     hipStream_t st = (hipStream_t)stream;
-    KTF_REQUIRE(T <= 8192, "ktf_vad_cmvn: T > 8192 frames per utterance is not supported by the fused kernel");
+    // the frame -> compacted-row map lives in LDS: (T + VC_GM) * 4 B <= 158 KiB, i.e. utterances up to ~6.5 min at 10 ms
+    KTF_REQUIRE((VC_GM + ((T + 3) & ~3ll)) * 4 <= 158 * 1024, "ktf_vad_cmvn: %lld frames per utterance exceed the fused kernel's limit (38,400): split the recording", (long long)T);
     int64_t stage_floats = vc_stage_floats(T, D);
     if ((VC_GM + ((T + 3) & ~3ll) + stage_floats) * 4 > 158 * 1024) stage_floats = 0;
     const size_t lds = (VC_GM + (size_t)((T + 3) & ~3ll) + (size_t)stage_floats) * sizeof(float);

@@ -501,6 +501,10 @@ def test_extractor_edge_cases():
         assert np.abs(got - want).max() <= 1e-4, n
     with pytest.raises(ValueError):
         mdl(dev(np.zeros((1, 399), np.float32)))
+    # a 150 s recording (14,998 frames: the whole-utterance LDS staging of VAD/CMVN no longer fits, workspace path)
+    wav = synth.make_wav(1, 16000 * 150, seed=77, ragged=True)
+    want, _ = _extract_oracle(wav, cfg, w)
+    assert np.abs(host(mdl(dev(wav))) - want).max() <= 1e-4
     # an utterance without a single voiced frame: NaN embedding for it (the reference pools over zero frames), the
     # other utterances of the batch bit-identical; an empty batch gives an empty result
     wav = synth.make_wav(3, 32000, seed=5, ragged=True)
