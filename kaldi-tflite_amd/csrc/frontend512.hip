@@ -126,7 +126,9 @@ __device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t
 
 // PLAIN: fp32 input without mirror padding (the hot path keeps its scalar-register budget); !PLAIN adds int16 samples
 // and KtfFrontendCfg.pad_mode.
-template <bool DITHER, bool PLAIN>
+// MFIX: frame size known at compile time (400 = 25 ms at 16 kHz, the shipped configuration) or 0 = cfg.frame_size: with
+// a constant M the `sample index < M` predicates of the loads, DC removal and pre-emphasis fold away.
+template <bool DITHER, bool PLAIN, int MFIX>
 __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                                  int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                                  int out_stage, float* __restrict__ out,
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
     constexpr int NF = 512, N2 = 256, NV = 8;
     extern __shared__ __attribute__((aligned(16))) float lds5[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int M = cfg.frame_size;
+    const int M = MFIX ? MFIX : cfg.frame_size;
     const int nm = cfg.num_mels, nc = cfg.num_ceps;
     const int maxw = tab.reserved;          // bins per mel work item actually used (<= F5_MAXW)
 
@@ -390,11 +392,12 @@ int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind
     const size_t lds = sizeof(float) * (512 + F5_WAVES * (512 + 256 + 64));
     const bool dither = cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED;
     const bool plain = in_kind != KTF_IN_WAV_I16 && !(in_kind == KTF_IN_WAV && cfg->pad_mode);
-#define F5_LAUNCH(DI, PL)                                                                                              \
-    hipLaunchKernelGGL((frontend512_kernel<DI, PL>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab,  \
-                       out_stage, out, seed, T)
-    if (dither) { if (plain) F5_LAUNCH(true, true); else F5_LAUNCH(true, false); }
-    else { if (plain) F5_LAUNCH(false, true); else F5_LAUNCH(false, false); }
+#define F5_LAUNCH(DI, PL, MF)                                                                                          \
+    hipLaunchKernelGGL((frontend512_kernel<DI, PL, MF>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg,    \
+                       *tab, out_stage, out, seed, T)
+    if (dither) { if (plain) F5_LAUNCH(true, true, 0); else F5_LAUNCH(true, false, 0); }
+    else if (cfg->frame_size == 400) { if (plain) F5_LAUNCH(false, true, 400); else F5_LAUNCH(false, false, 400); }
+    else { if (plain) F5_LAUNCH(false, true, 0); else F5_LAUNCH(false, false, 0); }
 #undef F5_LAUNCH
     KTF_CHECK_LAUNCH("ktf_frontend_f32(fast512)");
     return KTF_OK;
