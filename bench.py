@@ -30,7 +30,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 FLOP_PER_FRAME_TDNN = 2 * 2_679_808          # 5 frame-level layers
-PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
 def main():
@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--gemm", default="bf16", choices=["bf16", "bf16x3", "f32"])
+    ap.add_argument("--gemm", default="bf16", choices=["bf16", "f16", "bf16x3", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-utts", type=int, default=200)
     ap.add_argument("--no-gather", action="store_true")
@@ -99,7 +99,7 @@ def main():
     out = {
         "metric": "x-vectors/sec (10 s @16 kHz)", "value": value, "unit": "x-vectors/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": {"bf16": "bf16", "bf16x3": "bf16x3", "f32": "f32"}[args.gemm],
+        "scaling": "weak", "vs_baseline": None, "dtype": args.gemm,
         "data": "synthetic",
         "config": {"workload": "0008_sitw_v2_1a wav->x-vector, 10 s @16 kHz utterances, 1024 per GPU "
                                "(BASELINE config: 8192 utterances batch-sharded over 8 GPUs), dither 0, all 998 frames voiced",
@@ -113,7 +113,8 @@ def main():
     achieved = flops_per_step / (gemm_ms_per_step * 1e-3) / 1e12
     peak = PEAK_TFLOPS[args.gemm]
     out["roofline"] = {
-        "bound": "mfma", "kernel": {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=768 layers)", "bf16x3": "tdnn_x3r_kernel", "f32": "tdnn_f32_kernel"}[args.gemm],
+        "bound": "mfma", "kernel": {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=768 layers)", "bf16x3": "tdnn_x3r_kernel", "f32": "tdnn_f32_kernel",
+                                       "f16": "tdnn_bf16r16_kernel<.., F16> + tdnn_bf16h_kernel<.., F16>"}[args.gemm],
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
         "launches_per_step": gemm_stats["launches"] // args.steps, "avg_launch_ms": gemm_stats["total_ms"] / max(gemm_stats["launches"], 1),
         "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],
@@ -219,7 +220,7 @@ def _parity_sample(ktf, synth, cfg, w, gemm, dev):
     wav = synth.make_wav(2, 16000 * 3, seed=4242, ragged=True)
     want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
     res = {}
-    for g in sorted({gemm, "f32"}):
+    for g in sorted({gemm, "f32", "f16", "bf16x3"}):
         got = synth.build_extractor(ktf, cfg, w, gemm=g)(torch.as_tensor(wav, device=dev)).cpu().numpy()
         res[f"max_abs_dev_{g}"] = float(np.abs(got - want).max())
     return res
@@ -249,7 +250,7 @@ def _other_configs(ktf, synth, cfg, w, wav, gemm, dev):
     1024 x 1024 PLDA trial matrix (config 5)."""
     res = {}
     B = wav.shape[0]
-    for g in ("bf16x3", "f32"):
+    for g in ("f16", "bf16x3", "f32"):
         if g == gemm:
             continue
         m = synth.build_extractor(ktf, cfg, w, gemm=g)

@@ -40,11 +40,15 @@ extern "C" {
 /* element types of activation / weight buffers */
 #define KTF_F32 0
 #define KTF_BF16 1
+#define KTF_F16 2           /* IEEE half: same 16-bit MFMA rate as bf16, 3 more mantissa bits (activations of this
+                             * network are BatchNorm-scaled, far inside the half range) */
 
 /* GEMM arithmetic of ktf_tdnn */
 #define KTF_GEMM_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity path) */
 #define KTF_GEMM_BF16 1     /* v_mfma_f32_*_bf16: bf16 operands, fp32 accumulate */
 #define KTF_GEMM_BF16X3 2   /* split-bf16: x=hi+lo, w=hi+lo, 3 bf16 MFMA passes, fp32 accumulate */
+#define KTF_GEMM_F16 3      /* v_mfma_f32_16x16x32_f16: half operands (x, w of KTF_F16), fp32 accumulate; ring kernels only
+                             * (units > 128, ReLU or no activation) */
 
 /* activations fused into the ktf_tdnn epilogue */
 #define KTF_ACT_NONE 0

@@ -22,6 +22,13 @@ template <>
 __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float load1<unsigned short>(const unsigned short* p) { return bf2f(*p); }
+template <>
+__device__ __forceinline__ float2 load2<_Float16>(const _Float16* p) {
+    const unsigned v = *reinterpret_cast<const unsigned*>(p);
+    return make_float2(h2f((unsigned short)(v & 0xffffu)), h2f((unsigned short)(v >> 16)));
+}
+template <>
+__device__ __forceinline__ float load1<_Float16>(const _Float16* p) { return (float)*p; }
 
 #define SP_RG 16      // row groups per workgroup (1024 threads): a single utterance still has 16 loads in flight per column pair
 template <typename T, bool VEC2>
@@ -323,6 +330,9 @@ extern "C" int ktf_stats_pool(const void* x, int32_t x_dtype, int64_t B, int64_t
     } else if (x_dtype == KTF_BF16) {
         if (vec) hipLaunchKernelGGL((stats_pool_kernel<unsigned short, true>), grid, dim3(64 * SP_RG), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
         else hipLaunchKernelGGL((stats_pool_kernel<unsigned short, false>), grid, dim3(64 * SP_RG), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+    } else if (x_dtype == KTF_F16) {
+        if (vec) hipLaunchKernelGGL((stats_pool_kernel<_Float16, true>), grid, dim3(64 * SP_RG), 0, st, (const _Float16*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
+        else hipLaunchKernelGGL((stats_pool_kernel<_Float16, false>), grid, dim3(64 * SP_RG), 0, st, (const _Float16*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
     } else {
         KTF_REQUIRE(false, "ktf_stats_pool: bad dtype");
     }

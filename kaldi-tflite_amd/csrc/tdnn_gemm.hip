@@ -820,6 +820,15 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
 // shape under load (MI355X_MICROARCH.md, DVFS item 7). Fragment lane map: row = lane&15, 16-B chunk = lane>>4, so the
 // conflict-free chunk permutation is c ^ ((4 - (row>>2)) & 3) (each ds_read_b128 lane group then covers all 16 slots).
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
+typedef __attribute__((ext_vector_type(8))) _Float16 hfrag8;
+// one 16x16x32 MFMA on 16-bit fragments held as raw 16 bytes: bf16 or (F16) IEEE half operands
+template <bool F16>
+__device__ __forceinline__ f32x4v mfma16x16x32(const bfrag8& a, const bfrag8& b, const f32x4v& c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hfrag8, a), __builtin_bit_cast(hfrag8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
 
 template <int ACT, bool STATS>
 __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats,
@@ -1016,7 +1025,7 @@ __device__ __forceinline__ void ring_epilogue16_direct(f32x4v (&acc)[8][4], cons
 // stores (two 512-byte rows per wave instruction). The stores are issue-bound per instruction (T21), hence the wide form.
 #define R16_PK_PITCH 520
 #define R16_LDS_BYTES (R_BM * R16_PK_PITCH > R_LDS_BYTES ? R_BM * R16_PK_PITCH : R_LDS_BYTES)
-template <int ACT>
+template <int ACT, bool F16>
 __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const TdnnParams& p, unsigned char* rsm, int b,
                                                    int t0, int n0, int out_len, int wm, int wn, int wave, int lane) {
     const int c = lane & 15, g = lane >> 4;
@@ -1046,8 +1055,8 @@ __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const Td
                 v[e] = t * sc[j][e] + sh[j][e];
             }
             uint2 pk;
-            pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-            pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+            pk.x = (unsigned)f2x16<F16>(v[0]) | ((unsigned)f2x16<F16>(v[1]) << 16);
+            pk.y = (unsigned)f2x16<F16>(v[2]) | ((unsigned)f2x16<F16>(v[3]) << 16);
             *reinterpret_cast<uint2*>(stg + i * 16 * R16_PK_PITCH + j * 32) = pk;
         }
     }
@@ -1079,7 +1088,7 @@ __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const Td
     }
 }
 
-template <int ACT, bool STATS>
+template <int ACT, bool STATS, bool F16>
 __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int ntiles, int gtiles,
                                          double* __restrict__ stats, unsigned char* rsm, const int id) {
     const int xcd = id & 7, slot = id >> 3;
@@ -1180,8 +1189,7 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0)
-                                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? mfma16x16x32<F16>(a[i], bq[j], acc[i][j]) : mfma16x16x32<F16>(bq[j], a[i], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0) {
 #pragma unroll
@@ -1196,8 +1204,7 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
 #pragma unroll
         for (int i = 4; i < 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0)
-                                                   : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? mfma16x16x32<F16>(a[i], bq[j], acc[i][j]) : mfma16x16x32<F16>(bq[j], a[i], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 4 && ks + 1 < nk) {
                 // next stage (certified by this K-step's barrier): first-half A fragments; a[0..3] are no longer needed
@@ -1228,15 +1235,15 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
         ring_epilogue16_direct<ACT>(acc, p, b, t0, n0, out_len, wm, wn, lane);
     } else {
         __syncthreads();          // every wave's fragment reads are done before the ring is reused as staging
-        ring_epilogue16_pk<ACT>(acc, p, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+        ring_epilogue16_pk<ACT, F16>(acc, p, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
     }
 }
 
-template <int ACT, bool STATS>
+template <int ACT, bool STATS, bool F16>
 __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                            double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-    r16_tile<ACT, STATS>(p, mtiles, ntiles, gtiles, stats, rsm, blockIdx.x);
+    r16_tile<ACT, STATS, F16>(p, mtiles, ntiles, gtiles, stats, rsm, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ BF16, 128x256 tile, 2 workgroups/CU
@@ -1277,7 +1284,7 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 #define H_PROBE(k)
 #endif
 
-template <int ACT, bool STATS>
+template <int ACT, bool STATS, bool F16>
 __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                             double* __restrict__ stats, long long* __restrict__ dbg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -1426,8 +1433,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (KTF_H_ABL != 3)
-                acc[i][j] = STATS ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[i][j], 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq[j], a[i], acc[i][j], 0, 0, 0);
+                acc[i][j] = STATS ? mfma16x16x32<F16>(a[i], bq[j], acc[i][j]) : mfma16x16x32<F16>(bq[j], a[i], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0 && (KTF_H_ABL != 2 || ks == 0)) {
 #pragma unroll
@@ -1542,8 +1548,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
                 }
                 v = v * sc[j] + sh[j];
                 uint2 pk;
-                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                pk.x = (unsigned)f2x16<F16>(v[0]) | ((unsigned)f2x16<F16>(v[1]) << 16);
+                pk.y = (unsigned)f2x16<F16>(v[2]) | ((unsigned)f2x16<F16>(v[3]) << 16);
                 *reinterpret_cast<uint2*>(stg + i * 16 * H_PK_PITCH + j * 32) = pk;
             }
         }
@@ -1741,6 +1747,17 @@ __global__ void affine_act_kernel(const float* __restrict__ x, int64_t total, in
     }
 }
 
+template <typename S>
+__device__ __forceinline__ float cp_load(const S* p);
+template <> __device__ __forceinline__ float cp_load<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float cp_load<unsigned short>(const unsigned short* p) { return bf2f(*p); }
+template <> __device__ __forceinline__ float cp_load<_Float16>(const _Float16* p) { return (float)*p; }
+template <typename Dd>
+__device__ __forceinline__ void cp_store(Dd* p, float v);
+template <> __device__ __forceinline__ void cp_store<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void cp_store<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
+template <> __device__ __forceinline__ void cp_store<_Float16>(_Float16* p, float v) { *p = (_Float16)v; }
+
 template <typename S, typename Dd>
 __global__ void convert_pad_kernel(const S* __restrict__ src, int64_t rows, int D, int64_t lds_, Dd* __restrict__ dst,
                                    int64_t ldd) {
@@ -1748,13 +1765,7 @@ __global__ void convert_pad_kernel(const S* __restrict__ src, int64_t rows, int 
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / ldd;
         const int d = (int)(e - r * ldd);
-        float v = 0.0f;
-        if (d < D) {
-            if constexpr (sizeof(S) == 4) v = (float)src[r * lds_ + d];
-            else v = bf2f((unsigned short)src[r * lds_ + d]);
-        }
-        if constexpr (sizeof(Dd) == 4) dst[e] = v;
-        else dst[e] = f2bf(v);
+        cp_store<Dd>(dst + e, d < D ? cp_load<S>(src + r * lds_ + d) : 0.0f);
     }
 }
 
@@ -1774,9 +1785,10 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream) {
     KTF_REQUIRE(x && d && w && (y || stats_sums), "ktf_tdnn: null argument");
     if (stats_sums) {
-        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32)) &&
+        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) ||
+                     (d->gemm == KTF_GEMM_F16 && d->x_dtype == KTF_F16)) &&
                         d->units > 128 && !d->valid && d->subsampling == 1,
-                    "ktf_tdnn_stats: needs a 256x256 kernel (bf16 or bf16x3 gemm, units > 128, SAME padding, no subsampling)");
+                    "ktf_tdnn_stats: needs a ring kernel (bf16, f16 or bf16x3 gemm, units > 128, SAME padding, no subsampling)");
         ldy = (d->units + 3) / 4 * 4;
     }
     KTF_REQUIRE(B >= 0 && T >= 0, "ktf_tdnn: negative size");
@@ -1788,7 +1800,8 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     KTF_REQUIRE(ldx % 8 == 0, "ktf_tdnn: ldx must be a multiple of 8");
     KTF_REQUIRE(ldy >= d->units, "ktf_tdnn: ldy < units");
     KTF_REQUIRE(d->act >= KTF_ACT_NONE && d->act <= KTF_ACT_TANH, "ktf_tdnn: bad activation %d", d->act);
-    KTF_REQUIRE(d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16, "ktf_tdnn: bad y_dtype");
+    KTF_REQUIRE(d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F16, "ktf_tdnn: bad y_dtype");
+    KTF_REQUIRE(d->y_dtype != KTF_F16 || d->gemm == KTF_GEMM_F16, "ktf_tdnn: half output needs KTF_GEMM_F16");
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_tdnn: scale and shift go together");
     KTF_REQUIRE(T < (1ll << 30) && B < 65536, "ktf_tdnn: T or B too large");
     const int64_t Tout = ktf_tdnn_out_len(T, d);
@@ -1817,8 +1830,17 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             dim3 grid((unsigned)ktf_cdiv(d->units, 64), (unsigned)ktf_cdiv(Tout, 64), (unsigned)B);
             hipLaunchKernelGGL((tdnn_f32_kernel<1, 32>), grid, dim3(256), 0, st, p);
         }
-    } else if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3) {
-        KTF_REQUIRE(d->w_dtype == KTF_BF16, "ktf_tdnn: bf16 gemm needs bf16 weights");
+    } else if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3 || d->gemm == KTF_GEMM_F16) {
+        const bool f16 = d->gemm == KTF_GEMM_F16;
+        if (f16) {
+            KTF_REQUIRE(d->w_dtype == KTF_F16 && d->x_dtype == KTF_F16, "ktf_tdnn: F16 gemm needs half x and w");
+            KTF_REQUIRE(d->y_dtype == KTF_F16 || d->y_dtype == KTF_F32, "ktf_tdnn: F16 gemm writes half or fp32");
+            KTF_REQUIRE(d->units > 128 && ldy % 4 == 0 && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE),
+                        "ktf_tdnn: F16 gemm runs on the ring kernels only (units > 128, ldy %% 4 == 0, ReLU or no activation)");
+        } else {
+            KTF_REQUIRE(d->w_dtype == KTF_BF16, "ktf_tdnn: bf16 gemm needs bf16 weights");
+            KTF_REQUIRE(d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F32, "ktf_tdnn: bf16 gemm writes bf16 or fp32");
+        }
         const bool x3 = d->gemm == KTF_GEMM_BF16X3;
         if (x3) KTF_REQUIRE(d->x_dtype == KTF_F32 && w_lo, "ktf_tdnn: BF16X3 needs fp32 activations and w_lo");
         dim3 grid(ntiles, (unsigned)ktf_cdiv(Tout, BF_BM), (unsigned)B);
@@ -1856,7 +1878,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         } else if (d->x_dtype == KTF_F32) {
             if (k64) BF_LAUNCH(64, true, false); else BF_LAUNCH(32, true, false);
         } else {
-            KTF_REQUIRE(d->x_dtype == KTF_BF16, "ktf_tdnn: bad x_dtype");
+            KTF_REQUIRE(d->x_dtype == (f16 ? KTF_F16 : KTF_BF16), "ktf_tdnn: bad x_dtype");
             if (d->units > 128 && ldy % 4 == 0) {
                 // W must be padded to a multiple of 256 rows for this kernel (documented in ktf_hip.h)
                 const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
@@ -1885,8 +1907,13 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                     static long long* dbgptr = getenv("KTF_DBG_PTR") ? (long long*)strtoull(getenv("KTF_DBG_PTR"), nullptr, 10) : nullptr;
 #define H_LAUNCH(A, ST)                                                                                                \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)tdnn_bf16h_kernel<A, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); \
-        hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums, dbgptr); \
+        if (f16) {                                                                                                     \
+            (void)hipFuncSetAttribute((const void*)tdnn_bf16h_kernel<A, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST, true>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums, dbgptr); \
+        } else {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)tdnn_bf16h_kernel<A, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST, false>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums, dbgptr); \
+        }                                                                                                              \
     } while (0)
                     if (d->act == KTF_ACT_RELU) { if (stats_sums) H_LAUNCH(KTF_ACT_RELU, true); else H_LAUNCH(KTF_ACT_RELU, false); }
                     else { if (stats_sums) H_LAUNCH(KTF_ACT_NONE, true); else H_LAUNCH(KTF_ACT_NONE, false); }
@@ -1895,11 +1922,16 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                     return KTF_OK;
                 }
                 static const int mfma16 = getenv("KTF_MFMA16") ? atoi(getenv("KTF_MFMA16")) : 1;     // default: 16x16x32 variant (0 = 32x32x16, A/B)
-                if (mfma16 && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE)) {
+                if ((mfma16 || f16) && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE)) {
 #define S_LAUNCH(A, ST)                                                                                                \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)tdnn_bf16r16_kernel<A, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, R16_LDS_BYTES); \
-        hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        if (f16) {                                                                                                     \
+            (void)hipFuncSetAttribute((const void*)tdnn_bf16r16_kernel<A, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R16_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST, true>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        } else {                                                                                                       \
+            (void)hipFuncSetAttribute((const void*)tdnn_bf16r16_kernel<A, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R16_LDS_BYTES); \
+            hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST, false>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        }                                                                                                              \
     } while (0)
                     if (d->act == KTF_ACT_RELU) { if (stats_sums) S_LAUNCH(KTF_ACT_RELU, true); else S_LAUNCH(KTF_ACT_RELU, false); }
                     else { if (stats_sums) S_LAUNCH(KTF_ACT_NONE, true); else S_LAUNCH(KTF_ACT_NONE, false); }
@@ -2010,16 +2042,18 @@ extern "C" int ktf_convert_pad(const void* src, int32_t src_dtype, int64_t rows,
     int blocks = ktf_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;
-    if (src_dtype == KTF_F32 && dst_dtype == KTF_F32)
-        hipLaunchKernelGGL((convert_pad_kernel<float, float>), dim3(blocks), dim3(256), 0, st, (const float*)src, rows, D, ld_src, (float*)dst, ld_dst);
-    else if (src_dtype == KTF_F32 && dst_dtype == KTF_BF16)
-        hipLaunchKernelGGL((convert_pad_kernel<float, unsigned short>), dim3(blocks), dim3(256), 0, st, (const float*)src, rows, D, ld_src, (unsigned short*)dst, ld_dst);
-    else if (src_dtype == KTF_BF16 && dst_dtype == KTF_F32)
-        hipLaunchKernelGGL((convert_pad_kernel<unsigned short, float>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)src, rows, D, ld_src, (float*)dst, ld_dst);
-    else if (src_dtype == KTF_BF16 && dst_dtype == KTF_BF16)
-        hipLaunchKernelGGL((convert_pad_kernel<unsigned short, unsigned short>), dim3(blocks), dim3(256), 0, st, (const unsigned short*)src, rows, D, ld_src, (unsigned short*)dst, ld_dst);
-    else
-        KTF_REQUIRE(false, "ktf_convert_pad: bad dtype");
+#define CP_CASE(SD, ST, DD, DT)                                                                                        \
+    if (src_dtype == SD && dst_dtype == DD) {                                                                          \
+        hipLaunchKernelGGL((convert_pad_kernel<ST, DT>), dim3(blocks), dim3(256), 0, st, (const ST*)src, rows, D, ld_src, \
+                           (DT*)dst, ld_dst);                                                                          \
+        launched = true;                                                                                               \
+    }
+    bool launched = false;
+    CP_CASE(KTF_F32, float, KTF_F32, float) CP_CASE(KTF_F32, float, KTF_BF16, unsigned short) CP_CASE(KTF_F32, float, KTF_F16, _Float16)
+    CP_CASE(KTF_BF16, unsigned short, KTF_F32, float) CP_CASE(KTF_BF16, unsigned short, KTF_BF16, unsigned short)
+    CP_CASE(KTF_F16, _Float16, KTF_F32, float) CP_CASE(KTF_F16, _Float16, KTF_F16, _Float16)
+#undef CP_CASE
+    KTF_REQUIRE(launched, "ktf_convert_pad: unsupported dtype pair %d -> %d", src_dtype, dst_dtype);
     KTF_CHECK_LAUNCH("ktf_convert_pad");
     return KTF_OK;
 }

@@ -94,6 +94,8 @@ template <>
 __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void store_out<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
+template <>
+__device__ __forceinline__ void store_out<_Float16>(_Float16* p, float v) { *p = (_Float16)v; }
 
 // CMVN of one utterance: rows r < len, row r read at x[(idx ? idx[r] : r) * ldx + d].
 // The (compacted) rows are first staged contiguously into `xs` (len*D floats: LDS when the utterance fits, else the
@@ -340,7 +342,7 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     if (rc) return rc;
     KTF_REQUIRE(out && lens && idx_work && work, "ktf_vad_cmvn: null argument");
     KTF_REQUIRE(ldo >= D, "ktf_vad_cmvn: ldo < D");
-    KTF_REQUIRE(out_dtype == KTF_F32 || out_dtype == KTF_BF16, "ktf_vad_cmvn: bad out_dtype");
+    KTF_REQUIRE(out_dtype == KTF_F32 || out_dtype == KTF_BF16 || out_dtype == KTF_F16, "ktf_vad_cmvn: bad out_dtype");
     KTF_REQUIRE(T < (1ll << 31) / (ldo > 0 ? ldo : 1), "ktf_vad_cmvn: T*ldo too large");
     if (B == 0) return KTF_OK;
     if (T == 0) {
@@ -357,6 +359,10 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(vad_cmvn_kernel<float>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad, *cmvn,
                            (float*)out, ldo, lens, idx_work, work, stage_floats);
+    } else if (out_dtype == KTF_F16) {
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(vad_cmvn_kernel<_Float16>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
+                           *cmvn, (_Float16*)out, ldo, lens, idx_work, work, stage_floats);
     } else {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(vad_cmvn_kernel<unsigned short>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,

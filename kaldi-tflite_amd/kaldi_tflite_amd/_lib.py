@@ -12,8 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libktf_hip.so")
 
-KTF_F32, KTF_BF16 = 0, 1
-GEMM_F32, GEMM_BF16, GEMM_BF16X3 = 0, 1, 2
+KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
+GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 IN_WAV, IN_FRAMES, IN_WINDOWED, IN_WAV_I16 = 0, 1, 2, 3
 OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
@@ -21,6 +21,18 @@ OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
 
 class KtfBackendError(RuntimeError):
     pass
+
+
+def ktf_dtype(t):
+    """torch dtype -> KTF_* element type of an activation / weight buffer."""
+    import torch
+    return {torch.float32: KTF_F32, torch.bfloat16: KTF_BF16, torch.float16: KTF_F16}[t]
+
+
+def act_torch_dtype(gemm):
+    """Storage dtype of the frame-level activations for a GEMM mode."""
+    import torch
+    return {GEMM_BF16: torch.bfloat16, GEMM_F16: torch.float16}.get(gemm, torch.float32)
 
 
 class FrontendCfg(C.Structure):

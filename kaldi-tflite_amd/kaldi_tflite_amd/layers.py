@@ -33,7 +33,7 @@ def _to_device(x):
     if isinstance(x, torch.Tensor):
         if not x.is_cuda:
             x = x.to(dev)
-        if x.dtype not in (torch.float32, torch.float64, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.float64, torch.bfloat16, torch.float16):
             x = x.to(torch.float32)
         return x
     a = np.asarray(x)
@@ -654,7 +654,8 @@ def reshapeKaldiTdnnWeights(weights, units, kernel_width):
 
 
 _ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
-_GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat16": L.GEMM_BF16, "bf16x3": L.GEMM_BF16X3}
+_GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat16": L.GEMM_BF16, "bf16x3": L.GEMM_BF16X3,
+         "f16": L.GEMM_F16, "float16": L.GEMM_F16}
 
 
 class TDNN(Layer):
@@ -758,7 +759,7 @@ class TDNN(Layer):
         if gemm == L.GEMM_F32:
             w = W
         else:
-            w = W.to(torch.bfloat16)
+            w = W.to(torch.float16 if gemm == L.GEMM_F16 else torch.bfloat16)
             if gemm == L.GEMM_BF16X3:
                 w_lo = (W - w.to(torch.float32)).to(torch.bfloat16)
         bias = ops.to_device_f32(self.bias, device) if self.useBias else None
@@ -774,9 +775,9 @@ class TDNN(Layer):
         a = self.activation if act is None else act
         d.act = _ACTS[a.lower() if isinstance(a, str) else a]
         d.gemm = gemm
-        d.x_dtype = L.KTF_BF16 if x_dtype == torch.bfloat16 else L.KTF_F32
-        d.w_dtype = L.KTF_F32 if gemm == L.GEMM_F32 else L.KTF_BF16
-        d.y_dtype = L.KTF_BF16 if y_dtype == torch.bfloat16 else L.KTF_F32
+        d.x_dtype = L.ktf_dtype(x_dtype)
+        d.w_dtype = {L.GEMM_F32: L.KTF_F32, L.GEMM_F16: L.KTF_F16}.get(gemm, L.KTF_BF16)
+        d.y_dtype = L.ktf_dtype(y_dtype)
         return d
 
     def getStartEndSteps(self, T):
@@ -824,14 +825,23 @@ class TDNN(Layer):
             ops.tdnn(x, lens, d, w, w_lo, bias, scale, shift, out, out_lens)
         return out
 
+    def effective_gemm(self, gemm, relu=False):
+        """The half-precision mode runs on the ring kernels only (units > 128, ReLU or no activation); any other layer
+        of an "f16" model is evaluated by the exact fp32 kernel instead."""
+        if gemm != L.GEMM_F16:
+            return gemm
+        a = self.activation.lower() if isinstance(self.activation, str) else self.activation
+        ok = self.units > 128 and (a in (None, "linear") or (a == "relu" and not relu))
+        return gemm if ok else L.GEMM_F32
+
     def prepare_input(self, x, gemm):
         """Dense user tensor (B,T,D) -> operand the GEMM can read (padded to a multiple of 32 columns, right dtype)."""
         D = x.shape[-1]
         Dp = ops.round_up(D, 32)
-        want = torch.float32 if gemm in (L.GEMM_F32, L.GEMM_BF16X3) else torch.bfloat16
+        want = L.act_torch_dtype(gemm)
         if D == Dp and x.dtype == want and x.is_contiguous():
             return x
-        if x.dtype not in (torch.float32, torch.bfloat16):
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or (x.dtype != torch.float32 and x.dtype != want):
             x = x.to(torch.float32)
         dst = torch.empty((*x.shape[:-1], Dp), dtype=want, device=x.device)
         return ops.convert_pad(x.contiguous(), D, dst)
@@ -842,7 +852,7 @@ class TDNN(Layer):
             raise ValueError(f"expected a (batch, time, feat) input, got shape {tuple(x.shape)}")
         if x.shape[-1] != self.inputDim:
             raise ValueError(f"expected input feature dim {self.inputDim}, got {x.shape[-1]}")
-        gemm = _GEMM[self.gemm]
+        gemm = self.effective_gemm(_GEMM[self.gemm])
         B, T, D = x.shape
         if T == 1 and self.kernelWidth == 1 and self.padding == "SAME" and self.subsamplingFactor == 1 and B > 1:
             # one row per utterance (e.g. the affine after stats pooling): run as ONE B-row GEMM
@@ -918,7 +928,7 @@ class StatsPooling(Layer):
         return out
 
     def call(self, inputs):
-        x = inputs if inputs.dtype in (torch.float32, torch.bfloat16) else inputs.to(torch.float32)
+        x = inputs if inputs.dtype in (torch.float32, torch.bfloat16, torch.float16) else inputs.to(torch.float32)
         x = x.contiguous()
         B, T, D = x.shape
         od = 2 * D if self.includeStd else D

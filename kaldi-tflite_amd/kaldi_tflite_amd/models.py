@@ -134,7 +134,7 @@ class Sequential:
         if steps is None:
             raise NotImplementedError("this layer stack is not supported by the fused ragged runner")
         gemm = _GEMM[self.gemm]
-        act_dtype = torch.bfloat16 if gemm == L.GEMM_BF16 else torch.float32
+        act_dtype = L.act_torch_dtype(gemm)
         pooled = False
         skip = False
         for si, st in enumerate(steps):
@@ -142,13 +142,14 @@ class Sequential:
                 skip = False
                 continue
             nxt = steps[si + 1] if si + 1 < len(steps) else None
-            if (self.fuse_stats and st[0] == "tdnn" and not pooled and gemm in (L.GEMM_BF16, L.GEMM_BF16X3) and nxt is not None
+            if (self.fuse_stats and st[0] == "tdnn" and not pooled and gemm in (L.GEMM_BF16, L.GEMM_BF16X3, L.GEMM_F16) and nxt is not None
+                    and st[1].effective_gemm(gemm, st[2]) == gemm
                     and nxt[0] == "stats" and nxt[1].inputPeriod == 1 and st[1].units > 128 and st[1].padding == "SAME"
                     and st[1].subsamplingFactor == 1):
                 # [affine, relu, batchnorm] -> reducing StatsPooling: pooled inside the GEMM epilogue, y is never written
                 _, l, relu, bn = st
                 sp = nxt[1]
-                xdt = torch.bfloat16 if gemm == L.GEMM_BF16 else torch.float32
+                xdt = L.act_torch_dtype(gemm)
                 if x.dtype != xdt or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
                     x = _padded_copy(x, xdt)
                 B, T, _ = x.shape
@@ -169,11 +170,11 @@ class Sequential:
                 continue
             if st[0] == "tdnn":
                 _, l, relu, bn = st
-                g = L.GEMM_F32 if pooled else gemm
-                ydt = torch.float32 if pooled else act_dtype
-                if x.dtype != (torch.bfloat16 if g == L.GEMM_BF16 else torch.float32) or x.stride(2) != 1 or \
+                g = L.GEMM_F32 if pooled else l.effective_gemm(gemm, relu)
+                ydt = torch.float32 if (pooled or g != gemm) else act_dtype
+                if x.dtype != L.act_torch_dtype(g) or x.stride(2) != 1 or \
                         x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
-                    x = _padded_copy(x, torch.bfloat16 if g == L.GEMM_BF16 else torch.float32)
+                    x = _padded_copy(x, L.act_torch_dtype(g))
                 B, T, _ = x.shape
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
@@ -237,7 +238,7 @@ def _padded_copy(x, dtype):
     B, T, D = x.shape
     Dp = ops.round_up(D, 32)
     src = x.contiguous()
-    if src.dtype not in (torch.float32, torch.bfloat16):
+    if src.dtype not in (torch.float32, torch.bfloat16, torch.float16) or (src.dtype != torch.float32 and src.dtype != dtype):
         src = src.to(torch.float32)
     dst = torch.empty((B, T, Dp), dtype=dtype, device=x.device)
     ops.convert_pad(src, D, dst)
@@ -368,7 +369,7 @@ class XvectorExtractor:
         T = fr.numFrames(N)
         D = mf.numMfccs
         gemm = _GEMM[self.xvec.gemm]
-        feat_dtype = torch.bfloat16 if gemm == L.GEMM_BF16 else torch.float32
+        feat_dtype = L.act_torch_dtype(gemm)
         ws = self._workspace(B, T, D, x.device, feat_dtype)
         cfg = L.FrontendCfg.from_buffer_copy(mf._cfg)
         cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift

@@ -286,7 +286,7 @@ def cmvn(x, cfg, lens=None, ldo=None, want_lens=False):
 def vad_cmvn(feats, vad_cfg, cmvn_cfg, out, lens, idx_work, work):
     lib = L.load()
     B, T, D = feats.shape
-    dt = L.KTF_BF16 if out.dtype == torch.bfloat16 else L.KTF_F32
+    dt = L.ktf_dtype(out.dtype)
     with torch.cuda.device(feats.device):
         rc = lib.ktf_vad_cmvn(L.ptr(feats), B, T, D, C.byref(vad_cfg), C.byref(cmvn_cfg), L.ptr(out), dt, out.stride(1),
                               L.ptr(lens), L.ptr(idx_work), L.ptr(work), L.stream_ptr())
@@ -358,8 +358,7 @@ def convert_pad(src, D, dst):
     """src (..., ld_src) / dst (..., ld_dst) 2-D-viewable row-major tensors; copies D columns, zero-fills the pad."""
     lib = L.load()
     rows = src.numel() // src.shape[-1]
-    sd = L.KTF_BF16 if src.dtype == torch.bfloat16 else L.KTF_F32
-    dd = L.KTF_BF16 if dst.dtype == torch.bfloat16 else L.KTF_F32
+    sd, dd = L.ktf_dtype(src.dtype), L.ktf_dtype(dst.dtype)
     with torch.cuda.device(src.device):
         rc = lib.ktf_convert_pad(L.ptr(src), sd, rows, D, src.shape[-1], L.ptr(dst), dd, dst.shape[-1], L.stream_ptr())
     L.check(rc, "ktf_convert_pad")
@@ -370,7 +369,7 @@ def stats_pool(x, D, lens, input_period, include_std, eps, out):
     """x (B,T,ldx) fp32/bf16; out (B, ld_out) fp32 preallocated."""
     lib = L.load()
     B, T = x.shape[0], x.shape[1]
-    dt = L.KTF_BF16 if x.dtype == torch.bfloat16 else L.KTF_F32
+    dt = L.ktf_dtype(x.dtype)
     with torch.cuda.device(x.device):
         rc = lib.ktf_stats_pool(L.ptr(x), dt, B, T, D, x.stride(1), L.ptr(lens), input_period, int(include_std), eps,
                                 L.ptr(out), out.stride(0), L.stream_ptr())

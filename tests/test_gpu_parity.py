@@ -263,7 +263,7 @@ def test_tdnn_narrow_golden_fused_and_layerwise():
     assert np.abs(got - O.sequential_forward(layers, x, dtype=np.float64)).max() < 1e-5
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2), ("f16", 8e-3)])
 def test_tdnn_options_vs_oracle(gemm, tol):
     rng = np.random.default_rng(11)
     for (B, T, D, U, ctx, sub, pad, act) in [
@@ -456,7 +456,7 @@ def test_extractor_f32_vs_oracle(narrow):
         assert np.array_equal(host(one), got[b])
 
 
-@pytest.mark.parametrize("gemm,tol", [("bf16x3", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("gemm,tol", [("bf16x3", 1e-4), ("bf16", 5e-2), ("f16", 1e-3)])
 def test_extractor_reduced_precision_modes(gemm, tol):
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
@@ -466,6 +466,21 @@ def test_extractor_reduced_precision_modes(gemm, tol):
     err = np.abs(got - want).max()
     print(f"extractor {gemm}: max-abs dev vs fp64 oracle {err:.3e}")
     assert err <= tol, (gemm, err)
+
+
+def test_half_mode_fused_stats_and_batch_independence():
+    # "f16": IEEE-half operands on the same MFMA rate as bf16; fused pooling vs separate kernels, and batch == single
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=False)
+    wav = synth.make_wav(3, 16000 * 3 + 77, seed=5, ragged=True)
+    want, _ = _extract_oracle(wav, cfg, w)
+    fused = synth.build_extractor(ktf, cfg, w, gemm="f16")
+    plain = synth.build_extractor(ktf, cfg, w, gemm="f16")
+    plain.xvec.fuse_stats = False
+    a, b = host(fused(dev(wav))), host(plain(dev(wav)))
+    assert np.abs(a - want).max() < 1e-3 and np.abs(b - want).max() < 1e-3
+    assert np.abs(a - b).max() < 5e-4
+    assert np.array_equal(host(fused(dev(wav[1:2]))), a[1])
 
 
 def test_fused_stats_pooling_matches_unfused():
@@ -521,7 +536,7 @@ def test_extractor_edge_cases():
     assert np.array_equal(a, b[::-1])
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("bf16", 5e-2)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("bf16", 5e-2), ("f16", 1e-3)])
 def test_extractor_8khz_callhome_topology(gemm, tol):
     """The reference's second model family (0006_callhome_diarization_v2_1a.yml: 8 kHz, 23-dim MFCC, 128-dim embedding):
     200-sample frames -> nfft 256 takes the generic front-end kernel, tdnn6 has 128 units."""
