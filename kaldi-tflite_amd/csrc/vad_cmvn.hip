@@ -106,7 +106,7 @@ __device__ __forceinline__ void store_out<_Float16>(_Float16* p, float v) { *p =
 template <typename OutT>
 __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* __restrict__ pos, int Tsrc, int len, int D,
                            const KtfCmvnCfg& c, OutT* __restrict__ out, int64_t ldo, float* __restrict__ xs, float* gm,
-                           int* out_len) {
+                           int* out_len, float* __restrict__ bs = nullptr) {
     const int N = c.window;
     const int tid = threadIdx.x;
     const int ldo_i = (int)ldo;
@@ -116,9 +116,21 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         for (int d0 = 0; d0 < D; d0 += 32) {
             const int d = d0 + dl;
             if (d < D)
-                for (int t = rs; t < Tsrc; t += VC_RG) {
-                    const int pr = pos ? pos[t] : (t < len ? t : -1);
-                    if (pr >= 0) xs[pr * D + d] = x[(int64_t)t * ldx + d];
+                for (int t = rs; t < Tsrc; t += VC_RG * 8) {
+                    // eight independent global loads in flight per thread (a load behind each conditional store would
+                    // serialise the ~1 us latencies: 31 of them per thread at T = 998)
+                    float v[8];
+                    int pr[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int tt = t + u * VC_RG;
+                        const bool ok = tt < Tsrc;
+                        pr[u] = ok ? (pos ? pos[tt] : (tt < len ? tt : -1)) : -1;
+                        v[u] = ok ? x[(int64_t)tt * ldx + d] : 0.0f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (pr[u] >= 0) xs[pr[u] * D + d] = v[u];
                 }
         }
     }
@@ -169,6 +181,29 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
     const int nchunk = (nstart + CMVN_CHUNK - 1) / CMVN_CHUNK;
     const int half = N / 2;
     const float fN = (float)N;
+    // sums of the CMVN_CHUNK-row blocks of every column (bs: [2][nblk][32] floats of LDS, when the launcher found room):
+    // the first window of a chunk starts on a block boundary, so its sum is N/CMVN_CHUNK block sums plus a short tail
+    // instead of a chain of N dependent LDS reads per item
+    const int nblk = len / CMVN_CHUNK;                 // complete blocks
+    if (bs) {
+        float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
+        for (int item = tid; item < nblk * 32; item += VC_THREADS) {
+            const int k = item >> 5, d = item & 31;
+            float a = 0.0f, a2 = 0.0f;
+            if (d < D) {
+                const float* p = xs + k * CMVN_CHUNK * D + d;
+#pragma unroll 8
+                for (int i = 0; i < CMVN_CHUNK; ++i) {
+                    const float v = p[i * D];
+                    a += v;
+                    a2 += v * v;
+                }
+            }
+            bs[item] = a;
+            bs2[item] = a2;
+        }
+        __syncthreads();
+    }
     for (int item = tid; item < nchunk * ldo_i; item += VC_THREADS) {
         const int ch = item / ldo_i, d = item - ch * ldo_i;
         const int s0 = ch * CMVN_CHUNK;
@@ -176,9 +211,19 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         const bool real = d < D;
         float a = 0.0f, a2 = 0.0f;
         if (real) {
+            int i = 0;
+            if (bs) {
+                const float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
+                const int nb = N / CMVN_CHUNK;       // whole blocks inside the window (all complete: s0 + N <= len)
+                for (int k = 0; k < nb; ++k) {
+                    a += bs[(ch + k) * 32 + d];
+                    a2 += bs2[(ch + k) * 32 + d];
+                }
+                i = nb * CMVN_CHUNK;
+            }
             const float* p = xs + s0 * D + d;
 #pragma unroll 4
-            for (int i = 0; i < N; ++i) {
+            for (; i < N; ++i) {
                 const float v = p[i * D];
                 a += v;
                 a2 += v * v;
@@ -192,13 +237,15 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
             }
             const float mean = a / fN;
             const float sd = (real && c.norm_vars) ? sqrtf(a2 / fN - mean * mean) : 1.0f;
-            // frames served by this window start
-            int t_lo = s + half, t_hi = s + half;
+            // the frame centred on this window; the first / last window also serve the N/2 edge frames before / after
+            // it (SAME): their statistics are parked in LDS and those ~N frames are written by the whole workgroup below
+            // (one thread per column walking 150 frames was the critical path of the kernel)
             if (!c.valid) {
-                if (s == 0) t_lo = 0;
-                if (s == nstart - 1) t_hi = len - 1;
+                if (s == 0) { gm[d] = mean; gm[32 + d] = sd; }
+                if (s == nstart - 1) { gm[64 + d] = mean; gm[96 + d] = sd; }
             }
-            for (int t = t_lo; t <= t_hi; ++t) {
+            {
+                const int t = s + half;
                 float v = 0.0f;
                 if (real) {
                     v = xs[t * D + d] - mean;
@@ -207,6 +254,23 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
                 const int j = c.valid ? t - half : t;
                 store_out<OutT>(out + (int64_t)j * ldo + d, v);
             }
+        }
+    }
+    if (!c.valid) {
+        __syncthreads();
+        const int n_head = half;                              // frames [0, half) use the first window
+        const int t_tail = nstart + half;                     // frames [t_tail, len) use the last window
+        const int n_edge = n_head + (len - t_tail);
+        for (int e = tid; e < n_edge * ldo_i; e += VC_THREADS) {
+            const int k = e / ldo_i, d = e - k * ldo_i;
+            const bool tail = k >= n_head;
+            const int t = tail ? t_tail + (k - n_head) : k;
+            float v = 0.0f;
+            if (d < D) {
+                v = xs[t * D + d] - gm[(tail ? 64 : 0) + d];
+                if (c.norm_vars) v = v / gm[(tail ? 96 : 32) + d];
+            }
+            store_out<OutT>(out + (int64_t)t * ldo + d, v);
         }
     }
     if (out_len && tid == 0) *out_len = c.valid ? nstart : len;
@@ -236,15 +300,16 @@ __global__ __launch_bounds__(VC_THREADS) void cmvn_kernel(const float* __restric
                                                           const int32_t* __restrict__ lens, KtfCmvnCfg c,
                                                           float* __restrict__ out, int64_t ldo,
                                                           int32_t* __restrict__ out_lens, float* __restrict__ work,
-                                                          int64_t stage_floats) {
+                                                          int64_t stage_floats, int64_t bs_floats) {
     extern __shared__ __attribute__((aligned(16))) float vc_lds[];
     float* gm = vc_lds;                      // VC_GM floats
-    float* stage = vc_lds + VC_GM;
+    float* bsp = bs_floats ? vc_lds + VC_GM : nullptr;
+    float* stage = vc_lds + VC_GM + bs_floats;
     const int b = blockIdx.x;
     const int len = lens ? lens[b] : (int)T;
     int* ol = out_lens ? out_lens + b : nullptr;
     float* xs = ((int64_t)len * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
-    cmvn_block<float>(x + (int64_t)b * T * ldx, ldx, nullptr, len, len, D, c, out + (int64_t)b * T * ldo, ldo, xs, gm, ol);
+    cmvn_block<float>(x + (int64_t)b * T * ldx, ldx, nullptr, len, len, D, c, out + (int64_t)b * T * ldo, ldo, xs, gm, ol, bsp);
 }
 
 template <typename OutT>
@@ -252,11 +317,13 @@ __global__ __launch_bounds__(VC_THREADS) void vad_cmvn_kernel(const float* __res
                                                               KtfVadCfg vc, KtfCmvnCfg cc, OutT* __restrict__ out,
                                                               int64_t ldo, int32_t* __restrict__ lens,
                                                               int32_t* __restrict__ idx_work,
-                                                              float* __restrict__ work, int64_t stage_floats) {
+                                                              float* __restrict__ work, int64_t stage_floats,
+                                                              int64_t bs_floats) {
     extern __shared__ __attribute__((aligned(16))) float vc_lds[];
     float* gm = vc_lds;                      // VC_GM floats (also the reduction scratch of the VAD phase)
     int* pos = reinterpret_cast<int*>(vc_lds + VC_GM);        // T ints: frame -> compacted row (-1 = dropped)
-    float* stage = vc_lds + VC_GM + ((T + 3) & ~3ll);
+    float* bsp = bs_floats ? vc_lds + VC_GM + ((T + 3) & ~3ll) : nullptr;
+    float* stage = vc_lds + VC_GM + ((T + 3) & ~3ll) + bs_floats;
     float* red = gm;
     int* scan = reinterpret_cast<int*>(gm + 64);
     const int b = blockIdx.x;
@@ -267,7 +334,7 @@ __global__ __launch_bounds__(VC_THREADS) void vad_cmvn_kernel(const float* __res
     __syncthreads();  // pos[] written by this workgroup is read below by other threads of it
     int* ol = lens + b;
     float* xs = ((int64_t)n * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
-    cmvn_block<OutT>(f, D, pos, (int)T, n, D, cc, out + (int64_t)b * T * ldo, ldo, xs, gm, ol);
+    cmvn_block<OutT>(f, D, pos, (int)T, n, D, cc, out + (int64_t)b * T * ldo, ldo, xs, gm, ol, bsp);
 }
 
 static int check_vad(const char* who, const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* c) {
@@ -324,11 +391,13 @@ extern "C" int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int
     KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ldx >= D && ldo >= D, "ktf_cmvn_f32: bad sizes");
     KTF_REQUIRE(T < (1ll << 31) / (ldo > 0 ? ldo : 1), "ktf_cmvn_f32: T*ldo too large");
     if (B * T == 0) return KTF_OK;
-    const int64_t stage_floats = vc_stage_floats(T, D);
-    const size_t lds = (VC_GM + (size_t)stage_floats) * sizeof(float);
+    int64_t stage_floats = vc_stage_floats(T, D);
+    int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
+    if ((VC_GM + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;     // block sums only when they fit beside the staged utterance
+    const size_t lds = (VC_GM + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)cmvn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)B), dim3(VC_THREADS), lds, (hipStream_t)stream, x, T, D, ldx, lens, *cfg,
-                       out, ldo, out_lens, work, stage_floats);
+                       out, ldo, out_lens, work, stage_floats, bs_floats);
     KTF_CHECK_LAUNCH("ktf_cmvn_f32");
     return KTF_OK;
 }
@@ -354,19 +423,21 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     KTF_REQUIRE((VC_GM + ((T + 3) & ~3ll)) * 4 <= 158 * 1024, "ktf_vad_cmvn: %lld frames per utterance exceed the fused kernel's limit (38,400): split the recording", (long long)T);
     int64_t stage_floats = vc_stage_floats(T, D);
     if ((VC_GM + ((T + 3) & ~3ll) + stage_floats) * 4 > 158 * 1024) stage_floats = 0;
-    const size_t lds = (VC_GM + (size_t)((T + 3) & ~3ll) + (size_t)stage_floats) * sizeof(float);
+    int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
+    if ((VC_GM + ((T + 3) & ~3ll) + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;
+    const size_t lds = (VC_GM + (size_t)((T + 3) & ~3ll) + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
     if (out_dtype == KTF_F32) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(vad_cmvn_kernel<float>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad, *cmvn,
-                           (float*)out, ldo, lens, idx_work, work, stage_floats);
+                           (float*)out, ldo, lens, idx_work, work, stage_floats, bs_floats);
     } else if (out_dtype == KTF_F16) {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(vad_cmvn_kernel<_Float16>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
-                           *cmvn, (_Float16*)out, ldo, lens, idx_work, work, stage_floats);
+                           *cmvn, (_Float16*)out, ldo, lens, idx_work, work, stage_floats, bs_floats);
     } else {
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(vad_cmvn_kernel<unsigned short>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
-                           *cmvn, (unsigned short*)out, ldo, lens, idx_work, work, stage_floats);
+                           *cmvn, (unsigned short*)out, ldo, lens, idx_work, work, stage_floats, bs_floats);
     }
     KTF_CHECK_LAUNCH("ktf_vad_cmvn");
     return KTF_OK;
