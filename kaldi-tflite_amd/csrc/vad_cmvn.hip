@@ -181,14 +181,14 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
     const int nchunk = (nstart + CMVN_CHUNK - 1) / CMVN_CHUNK;
     const int half = N / 2;
     const float fN = (float)N;
-    // sums of the CMVN_CHUNK-row blocks of every column (bs: [2][nblk][32] floats of LDS, when the launcher found room):
+    // sums of the CMVN_CHUNK-row blocks of every column (bs: [2][nblk][ldo] floats of LDS, when the launcher found room):
     // the first window of a chunk starts on a block boundary, so its sum is N/CMVN_CHUNK block sums plus a short tail
     // instead of a chain of N dependent LDS reads per item
     const int nblk = len / CMVN_CHUNK;                 // complete blocks
     if (bs) {
-        float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
-        for (int item = tid; item < nblk * 32; item += VC_THREADS) {
-            const int k = item >> 5, d = item & 31;
+        float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo_i;
+        for (int item = tid; item < nblk * ldo_i; item += VC_THREADS) {
+            const int k = item / ldo_i, d = item - k * ldo_i;
             float a = 0.0f, a2 = 0.0f;
             if (d < D) {
                 const float* p = xs + k * CMVN_CHUNK * D + d;
@@ -213,11 +213,11 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         if (real) {
             int i = 0;
             if (bs) {
-                const float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
+                const float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo_i;
                 const int nb = N / CMVN_CHUNK;       // whole blocks inside the window (all complete: s0 + N <= len)
                 for (int k = 0; k < nb; ++k) {
-                    a += bs[(ch + k) * 32 + d];
-                    a2 += bs2[(ch + k) * 32 + d];
+                    a += bs[(ch + k) * ldo_i + d];
+                    a2 += bs2[(ch + k) * ldo_i + d];
                 }
                 i = nb * CMVN_CHUNK;
             }
@@ -241,8 +241,8 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
             // it (SAME): their statistics are parked in LDS and those ~N frames are written by the whole workgroup below
             // (one thread per column walking 150 frames was the critical path of the kernel)
             if (!c.valid) {
-                if (s == 0) { gm[d] = mean; gm[32 + d] = sd; }
-                if (s == nstart - 1) { gm[64 + d] = mean; gm[96 + d] = sd; }
+                if (s == 0) { gm[d] = mean; gm[ldo_i + d] = sd; }
+                if (s == nstart - 1) { gm[2 * ldo_i + d] = mean; gm[3 * ldo_i + d] = sd; }
             }
             {
                 const int t = s + half;
@@ -267,8 +267,8 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
             const int t = tail ? t_tail + (k - n_head) : k;
             float v = 0.0f;
             if (d < D) {
-                v = xs[t * D + d] - gm[(tail ? 64 : 0) + d];
-                if (c.norm_vars) v = v / gm[(tail ? 96 : 32) + d];
+                v = xs[t * D + d] - gm[(tail ? 2 * ldo_i : 0) + d];
+                if (c.norm_vars) v = v / gm[(tail ? 3 * ldo_i : ldo_i) + d];
             }
             store_out<OutT>(out + (int64_t)t * ldo + d, v);
         }
@@ -389,10 +389,11 @@ extern "C" int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int
     if (rc) return rc;
     KTF_REQUIRE(x && out && work, "ktf_cmvn_f32: null argument");
     KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ldx >= D && ldo >= D, "ktf_cmvn_f32: bad sizes");
+    KTF_REQUIRE(ldo <= VC_GM / 4, "ktf_cmvn_f32: ldo > %d", VC_GM / 4);
     KTF_REQUIRE(T < (1ll << 31) / (ldo > 0 ? ldo : 1), "ktf_cmvn_f32: T*ldo too large");
     if (B * T == 0) return KTF_OK;
     int64_t stage_floats = vc_stage_floats(T, D);
-    int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
+    int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo;
     if ((VC_GM + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;     // block sums only when they fit beside the staged utterance
     const size_t lds = (VC_GM + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)cmvn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -410,7 +411,7 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     rc = check_cmvn("ktf_vad_cmvn", cmvn);
     if (rc) return rc;
     KTF_REQUIRE(out && lens && idx_work && work, "ktf_vad_cmvn: null argument");
-    KTF_REQUIRE(ldo >= D, "ktf_vad_cmvn: ldo < D");
+    KTF_REQUIRE(ldo >= D && ldo <= VC_GM / 4, "ktf_vad_cmvn: ldo must be in [D, %d]", VC_GM / 4);
     KTF_REQUIRE(out_dtype == KTF_F32 || out_dtype == KTF_BF16 || out_dtype == KTF_F16, "ktf_vad_cmvn: bad out_dtype");
     KTF_REQUIRE(T < (1ll << 31) / (ldo > 0 ? ldo : 1), "ktf_vad_cmvn: T*ldo too large");
     if (B == 0) return KTF_OK;
@@ -423,7 +424,7 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     KTF_REQUIRE((VC_GM + ((T + 3) & ~3ll)) * 4 <= 158 * 1024, "ktf_vad_cmvn: %lld frames per utterance exceed the fused kernel's limit (38,400): split the recording", (long long)T);
     int64_t stage_floats = vc_stage_floats(T, D);
     if ((VC_GM + ((T + 3) & ~3ll) + stage_floats) * 4 > 158 * 1024) stage_floats = 0;
-    int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * 32;
+    int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo;
     if ((VC_GM + ((T + 3) & ~3ll) + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;
     const size_t lds = (VC_GM + (size_t)((T + 3) & ~3ll) + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
     if (out_dtype == KTF_F32) {

@@ -217,6 +217,13 @@ def test_cmvn_vs_oracle_batched():
         want = O.cmvn(x, window=w, norm_vars=nv, padding=pad, dtype=np.float64)
         assert got.shape == want.shape
         assert np.abs(got - want).max() < 2e-5, (w, nv, pad, np.abs(got - want).max())
+    # feature dims beyond one 32-column group (block sums / edge-frame scratch are per output column) and odd windows
+    for D, T, w in [(40, 500, 151), (80, 333, 100), (23, 1200, 300)]:
+        x = (rng.standard_normal((2, T, D)) * 4 - 1).astype(np.float32)
+        for nv, pad in [(False, "SAME"), (True, "SAME"), (True, "VALID")]:
+            got = host(Ls.CMVN(window=w, norm_vars=nv, padding=pad)(x))
+            want = O.cmvn(x, window=w, norm_vars=nv, padding=pad, dtype=np.float64)
+            assert got.shape == want.shape and np.abs(got - want).max() < 3e-5, (D, T, w, nv, pad, np.abs(got - want).max())
 
 
 # ----------------------------------------------------------------------------- a9/a10 TDNN
