@@ -78,6 +78,23 @@ def test_host_side_size_helpers():
     assert lib.ktf_tdnn_out_len(10, C.byref(d)) == 4
 
 
+def test_gemm_mode_selection_host_logic():
+    import torch
+    assert L.ktf_dtype(torch.float16) == L.KTF_F16 and L.ktf_dtype(torch.bfloat16) == L.KTF_BF16
+    assert L.act_torch_dtype(L.GEMM_F16) == torch.float16 and L.act_torch_dtype(L.GEMM_BF16X3) == torch.float32
+    big = ktf.layers.TDNN(512, context=[-2, 0, 2], gemm="f16")
+    assert big.effective_gemm(L.GEMM_F16, relu=True) == L.GEMM_F16 and big.effective_gemm(L.GEMM_BF16) == L.GEMM_BF16
+    # the half mode runs on the ring kernels only: narrow layers and sigmoid / tanh layers are evaluated in fp32
+    assert ktf.layers.TDNN(64, context=[0], gemm="f16").effective_gemm(L.GEMM_F16) == L.GEMM_F32
+    assert ktf.layers.TDNN(512, context=[0], activation="tanh", gemm="f16").effective_gemm(L.GEMM_F16) == L.GEMM_F32
+    assert ktf.layers.TDNN(512, context=[0], activation="relu", gemm="f16").effective_gemm(L.GEMM_F16, relu=False) == L.GEMM_F16
+    big.build((None, None, 512))
+    d = big.desc(L.GEMM_F16, torch.float16, torch.float16, act="relu")
+    assert (d.x_dtype, d.w_dtype, d.y_dtype, d.gemm) == (L.KTF_F16, L.KTF_F16, L.KTF_F16, L.GEMM_F16)
+    with pytest.raises(ValueError):
+        ktf.layers.TDNN(8, context=[0], gemm="fp8")
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
