@@ -134,10 +134,11 @@ def main():
                                            f"{tj['tdnn_gemm_bytes_per_step_corrected']:.4g}) / {nl} GEMM launches; algorithmic "
                                            f"{tj['tdnn_gemm_algorithmic_bytes_per_step'] / nl:.4g} per launch")
     out["mfcc"] = _bench_mfcc(mdl, wav, ops)
-    if not args.no_extra:
+    # side measurements and the CPU baseline belong to the single-GPU run only (rank 0 at N = 1)
+    if not args.no_extra and world == 1:
         out["parity"] = _parity_sample(ktf, synth, cfg, w, args.gemm, dev)
         out["other_configs"] = _other_configs(ktf, synth, cfg, w, wav, args.gemm, dev)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = _cpu_baseline(synth, cfg, w, args.cpu_utts, N)
     print(json.dumps(out))
     if world > 1:
