@@ -854,11 +854,14 @@ class TDNN(Layer):
             raise ValueError(f"expected input feature dim {self.inputDim}, got {x.shape[-1]}")
         gemm = self.effective_gemm(_GEMM[self.gemm])
         B, T, D = x.shape
+        # the 16-bit ring kernels want an output row stride that is a multiple of 8 (16-byte stores); the pad columns
+        # are sliced off again
+        ldy = ops.round_up(self.units, 8) if gemm in (L.GEMM_BF16, L.GEMM_F16) else self.units
         if T == 1 and self.kernelWidth == 1 and self.padding == "SAME" and self.subsamplingFactor == 1 and B > 1:
             # one row per utterance (e.g. the affine after stats pooling): run as ONE B-row GEMM
-            y = self.forward(self.prepare_input(x.reshape(1, B, D), gemm), gemm=gemm)
-            return y.reshape(B, 1, self.units)
-        return self.forward(self.prepare_input(x, gemm), gemm=gemm)
+            y = self.forward(self.prepare_input(x.reshape(1, B, D), gemm), gemm=gemm, ldy=ldy)
+            return y[:, :, : self.units].reshape(B, 1, self.units)
+        return self.forward(self.prepare_input(x, gemm), gemm=gemm, ldy=ldy)[:, :, : self.units]
 
 
 # =============================================================================== stats

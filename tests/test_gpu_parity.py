@@ -295,6 +295,35 @@ def test_tdnn_options_vs_oracle(gemm, tol):
         assert err < tol, (gemm, B, T, D, U, ctx, sub, pad, act, err)
 
 
+@pytest.mark.parametrize("gemm", ["bf16", "f16"])
+def test_tdnn_ring_kernels_random_shapes(gemm):
+    """Seeded sweep over shapes that reach the 256x256 / 128x256 ring kernels with awkward tails: units not a multiple of
+    8 (scalar store tail), K on both sides of the 768 switch, ragged batches, VALID padding, subsampling, ReLU on/off.
+    Inputs and weights are pre-rounded to the operand format, so only the fp32 accumulation order differs from the oracle."""
+    rng = np.random.default_rng(2024)
+    rnd = (lambda a: torch.as_tensor(a).to(torch.bfloat16).float().numpy()) if gemm == "bf16" else \
+          (lambda a: a.astype(np.float16).astype(np.float32))
+    for trial in range(10):
+        U = int(rng.choice([129, 200, 255, 256, 257, 300, 512, 770, 1500]))
+        D = int(rng.choice([32, 40, 96, 160, 256, 512]))
+        ctx = [[0], [-1, 0, 1], [-2, 0, 2], [-3, 0, 3], [-2, -1, 0, 1, 2], [-4, 1]][int(rng.integers(6))]
+        sub = int(rng.choice([1, 1, 1, 2, 3]))
+        pad = "VALID" if rng.random() < 0.3 else "SAME"
+        act = "relu" if rng.random() < 0.5 else None
+        B, T = int(rng.integers(1, 4)), int(rng.integers(20, 700))
+        x = rnd(rng.standard_normal((B, T, D)).astype(np.float32))
+        W = rnd((rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32))
+        b = rng.standard_normal(U).astype(np.float32)
+        t = Ls.TDNN(U, context=list(ctx), subsampling_factor=sub, padding=pad, activation=act, gemm=gemm)
+        t.build(x.shape)
+        t.set_weights([W, b])
+        got = host(t(x))
+        want = O.tdnn(x, W, b, ctx, sub, pad, act, dtype=np.float64)
+        assert got.shape == want.shape, (trial, got.shape, want.shape)
+        err = np.abs(got - want).max()
+        assert err < 2e-4, (gemm, trial, B, T, D, U, ctx, sub, pad, act, err)
+
+
 def test_tdnn_gemm_is_linear_at_full_size():
     # size-independent property at the BASELINE shape (998 frames x 1536 -> 512): f(a*x1 + x2) - f(0) is linear
     rng = np.random.default_rng(17)
