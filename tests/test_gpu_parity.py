@@ -519,6 +519,38 @@ def test_half_mode_fused_stats_and_batch_independence():
     assert np.array_equal(host(fused(dev(wav[1:2]))), a[1])
 
 
+@pytest.mark.parametrize("gemm,tol", [("bf16", 2e-4), ("f16", 2e-4), ("bf16x3", 2e-5)])
+def test_fused_tdnn_stats_random_shapes(gemm, tol):
+    """[affine, relu, batchnorm] -> reducing StatsPooling, pooled inside the GEMM epilogue (ktf_tdnn_stats), over shapes
+    with awkward widths and ragged utterance lengths; operands pre-rounded so only accumulation order differs."""
+    rng = np.random.default_rng(77)
+    rnd = {"bf16": lambda a: torch.as_tensor(a).to(torch.bfloat16).float().numpy(),
+           "f16": lambda a: a.astype(np.float16).astype(np.float32), "bf16x3": lambda a: a}[gemm]
+    for U, D, ctx in [(129, 64, [0]), (300, 96, [-1, 0, 1]), (1500, 512, [0]), (257, 40, [-2, 0, 2])]:
+        cfg = {"type": "sequential", "layers": [
+            {"name": "input", "type": "input", "shape": [None, None, D]},
+            {"name": "t", "type": ["affine", "relu", "batchnorm"], "cfg": {"units": U, "context": ctx}},
+            {"name": "stats", "type": "stats_pooling", "cfg": {"left_context": 0, "right_context": 5, "include_std": True,
+                                                               "reduce_time_axis": True}}]}
+        mdl = ktf.models.SequentialFromConfig(cfg, None, "m", gemm=gemm)
+        W = rnd((rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32))
+        b = rng.standard_normal(U).astype(np.float32) * 0.1
+        bn = (np.float32(1.0), rng.uniform(0.2, 1.0, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
+        mdl.get_layer("t.affine").set_weights([W, b])
+        mdl.get_layer("t.batchnorm").set_weights(list(bn))
+        B, T = 3, 397
+        x = rnd(rng.standard_normal((B, T, D)).astype(np.float32))
+        lens = np.array([T, 131, 260], np.int32)
+        layers = [{"kind": "tdnn", "W": W, "b": b, "context": ctx}, {"kind": "relu"},
+                  {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]},
+                  {"kind": "stats", "left_context": 0, "right_context": 5, "include_std": True, "reduce_time_axis": True}]
+        got = host(mdl.run_ragged(dev(x), torch.as_tensor(lens, device="cuda")))
+        assert got.shape == (B, 1, 2 * U)
+        for i in range(B):
+            want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)
+            assert np.abs(got[i] - want[0]).max() < tol, (gemm, U, D, ctx, i, np.abs(got[i] - want[0]).max())
+
+
 def test_fused_stats_pooling_matches_unfused():
     # bf16 mode pools tdnn5's output inside the GEMM epilogue (ktf_tdnn_stats); it must agree with the separate
     # TDNN -> StatsPooling kernels up to the bf16 rounding of the (otherwise materialised) activations
