@@ -22,10 +22,13 @@ if len(sys.argv) > 4:
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(sys.argv[4])):
         d[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    slow_first = [k for k, v in d.items() if len(v) > 2 and v[0] > 5 * sorted(v[1:])[len(v[1:]) // 2]]
     with open(out, "a") as f:
         f.write("\n## Steady state (same run, kernel_trace.csv, first launch of every kernel dropped)\n\n")
-        f.write("The first launch of `tdnn_bf16h_kernel<1, true>` (warm-up step 1) takes ~30 ms once per process; the table above "
-                "averages it in, this one does not.\n\n| kernel | calls | average ns | min ns | max ns |\n|---|---:|---:|---:|---:|\n")
+        if slow_first:
+            f.write("First launches more than 5x slower than the kernel's median in this run (one-off, inside the warm-up): "
+                    + ", ".join(f"`{k[:50]}`" for k in slow_first) + "; the table above averages them in, this one does not.\n\n")
+        f.write("| kernel | calls | average ns | min ns | max ns |\n|---|---:|---:|---:|---:|\n")
         for k, v in sorted(d.items(), key=lambda kv: -sum(kv[1][1:])):
             v = v[1:]
             if v and not k.startswith("void at::") and not k.startswith("__amd"):
