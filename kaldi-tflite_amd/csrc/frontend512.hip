@@ -36,14 +36,19 @@ __device__ __forceinline__ float dpp_merge(float old, float src) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xF, BANK_MASK, false));
 }
 
+#define DPP_ROW_BCAST15 0x142   // lane 15 of each row -> every lane of the next row (gfx9 wave64 DPP)
+#define DPP_ROW_BCAST31 0x143   // lane 31 -> every lane of rows 2 and 3
+// wave-wide sum, returned wave-uniform (an SGPR operand for the consumers): four row-local DPP steps, then the classic
+// row_bcast:15 / row_bcast:31 combine (rows 1,3 += row 0,2; rows 2,3 += lane 31) and one v_readlane of lane 63 -- no
+// ds_bpermute and none of its address arithmetic
 __device__ __forceinline__ float wave_sum_f(float v) {
     v += dpp_mov<DPP_QUAD_XOR1>(v);
     v += dpp_mov<DPP_QUAD_XOR2>(v);
     v += dpp_mov<DPP_ROW_ROR4>(v);
     v += dpp_mov<DPP_ROW_ROR8>(v);           // every lane: sum of its row of 16
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST15, 0xA, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST31, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
         for (int r = 0; r < 4; ++r) Zb[mo + 64 * r] = z[r];
         F5_WAVE_SYNC();
         // ---- split the packed spectrum, |X[k]|(^2)  (filterbank.py:232-235; bin 256 carries no mel weight)
+        float pw[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = lane + 64 * j;
@@ -335,9 +341,16 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
             const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
             const float xr = er + rw[j].x * orr - rw[j].y * oi;
             const float xi = ei + rw[j].x * oi + rw[j].y * orr;
-            const float mag = sqrtf(xr * xr + xi * xi);
-            Pb[k] = cfg.use_power ? mag * mag : mag;
+            // |X|^2 directly (what Kaldi's ComputePowerSpectrum does; the reference's abs-then-square differs by an ulp)
+            pw[j] = xr * xr + xi * xi;
         }
+        if (!cfg.use_power) {                        // wave-uniform branch: the magnitude spectrum pays for its sqrt only when asked
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pw[j] = sqrtf(pw[j]);
+            asm volatile("" ::: "memory");
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Pb[lane + 64 * j] = pw[j];
         F5_WAVE_SYNC();
         // ---- sparse mel bank: this lane's slice of one filter (weights are zero beyond the slice; the reads stay inside
         //      the wave's own P/feat area), then a segmented reduction over <= 4 adjacent lanes
