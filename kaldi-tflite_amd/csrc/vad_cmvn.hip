@@ -233,10 +233,11 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
             if (s > s0 && real) {
                 const float vn = xs[(s + N - 1) * D + d], vo = xs[(s - 1) * D + d];
                 a += vn - vo;
-                a2 += vn * vn - vo * vo;
+                if (c.norm_vars) a2 += vn * vn - vo * vo;        // wave-uniform: the variance path costs nothing when off
             }
             const float mean = a / fN;
-            const float sd = (real && c.norm_vars) ? sqrtf(a2 / fN - mean * mean) : 1.0f;
+            float sd = 1.0f;
+            if (c.norm_vars && real) sd = sqrtf(a2 / fN - mean * mean);
             // the frame centred on this window; the first / last window also serve the N/2 edge frames before / after
             // it (SAME): their statistics are parked in LDS and those ~N frames are written by the whole workgroup below
             // (one thread per column walking 150 frames was the critical path of the kernel)
