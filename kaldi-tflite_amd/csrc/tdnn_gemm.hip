@@ -1467,18 +1467,33 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
             const int nl = wn * 64 + j * 16 + c;
             const float scj = prm[H_BN + nl], shj = prm[2 * H_BN + nl];
             double sm = 0.0, sq = 0.0;
+            if (rows_valid >= H_BM) {                 // wave-uniform: full tiles carry no row predicate
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = i * 16 + g4 * 4 + r;
-                    float v = acc[i][j][r];
-                    if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
-                    else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
-                    v = v * scj + shj;
-                    if (m < rows_valid) {
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[i][j][r];
+                        if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                        else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                        v = v * scj + shj;
                         sm += (double)v;
                         sq += (double)v * (double)v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = i * 16 + g4 * 4 + r;
+                        float v = acc[i][j][r];
+                        if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                        else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                        v = v * scj + shj;
+                        if (m < rows_valid) {
+                            sm += (double)v;
+                            sq += (double)v * (double)v;
+                        }
                     }
                 }
             }
