@@ -1462,11 +1462,22 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
     const int rows_valid = out_len - t0;
     if (STATS) {
         // acc[i][j][r] = out[row i*16 + g4*4 + r][col wn*64 + j*16 + c]
+        // Column sums with a PIVOT: every lane accumulates sum(v - p) and sum((v - p)^2) in fp32, where p is the column's
+        // value in the tile's first row (the same for the four lanes that share a column), and converts to the absolute
+        // sums in fp64 once per tile: sum v = s + n p, sum v^2 = q + 2 p s + n p^2. A constant channel (dead ReLU, zero
+        // weight row) gives v - p == 0 exactly, hence var == 0 exactly as with fp64 accumulation of v, v^2 -- at 5 fp32
+        // operations per element instead of 2 fp32 + 3 fp64.
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int nl = wn * 64 + j * 16 + c;
             const float scj = prm[H_BN + nl], shj = prm[2 * H_BN + nl];
-            double sm = 0.0, sq = 0.0;
+            float v0 = acc[0][j][0];
+            if (ACT == KTF_ACT_RELU) v0 = fmaxf(v0, 0.0f);
+            else if (ACT != KTF_ACT_NONE) v0 = apply_act(v0, ACT);
+            v0 = v0 * scj + shj;
+            const float pv = __shfl(v0, c, 64);       // row 0 of the tile lives in the g4 == 0 lane of this column
+            float s32 = 0.0f, q32 = 0.0f;
+            int cnt = 0;
             if (rows_valid >= H_BM) {                 // wave-uniform: full tiles carry no row predicate
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -1476,10 +1487,12 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
                         if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
                         else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
                         v = v * scj + shj;
-                        sm += (double)v;
-                        sq += (double)v * (double)v;
+                        const float u = v - pv;
+                        s32 += u;
+                        q32 = fmaf(u, u, q32);
                     }
                 }
+                cnt = 32;
             } else {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -1491,12 +1504,17 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
                         else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
                         v = v * scj + shj;
                         if (m < rows_valid) {
-                            sm += (double)v;
-                            sq += (double)v * (double)v;
+                            const float u = v - pv;
+                            s32 += u;
+                            q32 = fmaf(u, u, q32);
+                            ++cnt;
                         }
                     }
                 }
             }
+            const double pd = (double)pv, sd = (double)s32, nd = (double)cnt;
+            double sm = sd + nd * pd;
+            double sq = (double)q32 + 2.0 * pd * sd + nd * pd * pd;
             sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
             sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
             const int n = n0 + nl;

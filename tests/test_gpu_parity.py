@@ -535,6 +535,10 @@ def test_fused_tdnn_stats_random_shapes(gemm, tol):
         mdl = ktf.models.SequentialFromConfig(cfg, None, "m", gemm=gemm)
         W = rnd((rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32))
         b = rng.standard_normal(U).astype(np.float32) * 0.1
+        # constant channels: a dead ReLU (std must come out as sqrt(eps) = 1e-5, not as cancellation noise) and a
+        # constant positive one
+        W[5], b[5] = 0.0, -1.0
+        W[6], b[6] = 0.0, 0.7
         bn = (np.float32(1.0), rng.uniform(0.2, 1.0, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
         mdl.get_layer("t.affine").set_weights([W, b])
         mdl.get_layer("t.batchnorm").set_weights(list(bn))
@@ -549,6 +553,7 @@ def test_fused_tdnn_stats_random_shapes(gemm, tol):
         for i in range(B):
             want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)
             assert np.abs(got[i] - want[0]).max() < tol, (gemm, U, D, ctx, i, np.abs(got[i] - want[0]).max())
+            assert np.abs(got[i, 0, U + 5] - 1e-5) < 1e-7 and np.abs(got[i, 0, U + 6] - 1e-5) < 1e-7, got[i, 0, U + 5:U + 7]
 
 
 def test_fused_stats_pooling_matches_unfused():
