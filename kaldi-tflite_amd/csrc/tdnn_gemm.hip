@@ -1024,22 +1024,21 @@ __device__ __forceinline__ void ring_epilogue16_direct(f32x4v (&acc)[8][4], cons
 // 16 lanes of a store group cover all 32 banks), and after ONE barrier every wave streams 32 staged rows out with 16-byte
 // stores (two 512-byte rows per wave instruction). The stores are issue-bound per instruction (T21), hence the wide form.
 #define R16_PK_PITCH 520
-#define R16_LDS_BYTES (R_BM * R16_PK_PITCH > R_LDS_BYTES ? R_BM * R16_PK_PITCH : R_LDS_BYTES)
+#define R16_PRM_OFF (R_BM * R16_PK_PITCH)              // bias | scale | shift of the tile's 256 columns, behind the staging image
+#define R16_LDS_BYTES (R16_PRM_OFF + 3 * R_BN * 4)      // 136,192 B
 template <int ACT, bool F16>
 __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const TdnnParams& p, unsigned char* rsm, int b,
                                                    int t0, int n0, int out_len, int wm, int wn, int wave, int lane) {
     const int c = lane & 15, g = lane >> 4;
+    // column constants were parked in LDS when the tile started (no global loads, and no latency, at this point)
+    const float* prm = reinterpret_cast<const float*>(rsm + R16_PRM_OFF);
     f32x4v bias[4], sc[4], sh[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wn * 64 + j * 16 + g * 4 + e;
-            const bool nv = n < p.units;
-            bias[j][e] = (nv && p.bias) ? p.bias[n] : 0.0f;
-            sc[j][e] = (nv && p.scale) ? p.scale[n] : 1.0f;
-            sh[j][e] = (nv && p.shift) ? p.shift[n] : 0.0f;
-        }
+        const int nl = wn * 64 + j * 16 + g * 4;
+        bias[j] = *reinterpret_cast<const f32x4v*>(prm + nl);
+        sc[j] = *reinterpret_cast<const f32x4v*>(prm + R_BN + nl);
+        sh[j] = *reinterpret_cast<const f32x4v*>(prm + 2 * R_BN + nl);
     }
     unsigned char* stg = rsm + (wm * 128 + c) * R16_PK_PITCH + (wn * 64 + g * 4) * 2;
 #pragma unroll
@@ -1106,6 +1105,14 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
+    if (!STATS && tid < R_BN) {
+        float* prm = reinterpret_cast<float*>(rsm + R16_PRM_OFF);
+        const int n = n0 + tid;
+        const bool nv = n < p.units;
+        prm[tid] = (nv && p.bias) ? p.bias[n] : 0.0f;
+        prm[R_BN + tid] = (nv && p.scale) ? p.scale[n] : 1.0f;
+        prm[2 * R_BN + tid] = (nv && p.shift) ? p.shift[n] : 0.0f;
+    }
 
     const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;
     const char* wb = reinterpret_cast<const char*>(p.w);
