@@ -577,6 +577,34 @@ def test_fused_stats_pooling_matches_unfused():
     assert np.abs(h_f - h_p).max() < 2e-2 * max(1.0, np.abs(h_p).max())
 
 
+def test_full_size_batch_equals_single_utterances():
+    """BASELINE size (per-GPU share of config 4: 1024 utterances x 10 s): every utterance of the big batch must give the
+    x-vector it gives alone — bitwise on the exact fp32 path, within the bf16 accumulation-order noise (fp64 atomics of the
+    fused pooling) in bf16 mode. Utterances with quiet blocks make the batch ragged."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=False)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    wav = torch.clamp(torch.round(1000.0 * torch.randn((1024, 160000), generator=g, device="cuda")), -32767, 32767)
+    wav[5, 16000:56000] *= 0.001          # ragged: two utterances lose frames to the VAD
+    wav[777, 80000:] *= 0.001
+    wav = torch.round(wav)
+    picks = [0, 5, 511, 777, 1023]
+    for gemm, exact, tol in [("f32", True, 0.0), ("bf16", False, 2e-4)]:
+        mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
+        full = mdl(wav)
+        lens = mdl.features(wav)[2].cpu().numpy()
+        assert lens[0] == 998 and lens[5] < 998 and lens[777] < 998
+        assert bool(torch.isfinite(full).all())
+        for i in picks:
+            one = mdl(wav[i:i + 1])
+            if exact:
+                assert torch.equal(one, full[i]), (gemm, i)
+            else:
+                assert float((one - full[i]).abs().max()) < tol, (gemm, i)
+        del mdl
+        torch.cuda.empty_cache()
+
+
 def test_extractor_edge_cases():
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=1, narrow=True)
