@@ -174,12 +174,33 @@ class _GemmProfiler:
             prof.events.append(((int(desc.units), int(desc.nctx), int(desc.din), "+stats"), s, e))
             return r
 
+        self.orig_split, self.orig_split_stats = ops.tdnn_split, ops.tdnn_split_stats
+
+        def wrapped_split(xp, lens, desc, *a, **k):      # bf16x3 with hi/lo activation planes (xp: (2,B,T,ld))
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = prof.orig_split(xp, lens, desc, *a, **k)
+            e.record()
+            prof.events.append(((int(desc.units), int(desc.nctx), int(desc.din)), s, e))
+            return r
+
+        def wrapped_split_stats(xp, lens, desc, *a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = prof.orig_split_stats(xp, lens, desc, *a, **k)
+            e.record()
+            prof.events.append(((int(desc.units), int(desc.nctx), int(desc.din), "+stats"), s, e))
+            return r
+
         ops.tdnn = wrapped
         ops.tdnn_stats = wrapped_stats
+        ops.tdnn_split = wrapped_split
+        ops.tdnn_split_stats = wrapped_split_stats
 
     def finish(self):
         self.ops.tdnn = self.orig
         self.ops.tdnn_stats = self.orig_stats
+        self.ops.tdnn_split, self.ops.tdnn_split_stats = self.orig_split, self.orig_split_stats
         total, per = 0.0, {}
         for key, s, e in self.events:
             ms = s.elapsed_time(e)

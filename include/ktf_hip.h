@@ -217,6 +217,19 @@ int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* le
 int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                    const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift, double* sums,
                    void* stream);
+/* Split-bf16 activations kept as TWO bf16 planes (hi = bf16(v), lo = bf16(v - hi)) instead of fp32: same bytes, but the
+ * GEMM stages them as they are and its K-loop carries no fp32 -> (hi, lo) conversion (28 % shorter on MI355X). desc->gemm
+ * must be KTF_GEMM_BF16X3 with x_dtype KTF_BF16; units > 128. y_dtype KTF_BF16 with y_lo != NULL writes the output as
+ * planes again (the next layer's input); y_dtype KTF_F32 (y_lo NULL) writes plain fp32. ktf_split_bf16 produces the planes
+ * of the first layer's input from fp32 rows (columns [D, ld_dst) are zeroed). */
+int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* lens,
+                   const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                   const float* shift, void* y, void* y_lo, int64_t ldy, int32_t* out_lens, void* stream);
+int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* lens,
+                         const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                         const float* shift, double* sums, void* stream);
+int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, void* hi, void* lo, int64_t ld_dst,
+                   void* stream);
 /* finishes the fused pooling: out[b, c] = sums[b,0,c]/n_b, out[b, D+c] = sqrt(max(sums[b,1,c]/n_b - mean^2, 0) + eps)
  * with n_b = lens[b] (or T when lens is NULL); stats_pooling.py:231-240. */
 int ktf_stats_finalize(const double* sums, const int32_t* lens, int64_t T, int64_t B, int32_t D, int32_t include_std,

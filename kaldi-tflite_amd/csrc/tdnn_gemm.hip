@@ -35,6 +35,8 @@ struct TdnnParams {
     const float* scale;
     const float* shift;
     void* y;
+    const void* x_lo;       // split-bf16 planes (KTF_GEMM_BF16X3 with bf16 x): x = hi plane, x_lo = lo plane
+    void* y_lo;             // ... and the same for the output (y = hi plane) when non-null
     int32_t* out_lens;
     int64_t T, ldx, ldy, Tout;
     int32_t units, din_pad, nctx, sub, valid, act, y_dtype, ktot;
@@ -622,17 +624,29 @@ __device__ __forceinline__ void ring_epilogue(f32x16 (&acc)[4][2], const TdnnPar
                     if (p.y_dtype == KTF_F32) {
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + off) = v;
                     } else {
+                        const unsigned short h0 = f2bf(v.x), h1 = f2bf(v.y), h2 = f2bf(v.z), h3 = f2bf(v.w);
                         uint2 pk;
-                        pk.x = (unsigned)f2bf(v.x) | ((unsigned)f2bf(v.y) << 16);
-                        pk.y = (unsigned)f2bf(v.z) | ((unsigned)f2bf(v.w) << 16);
+                        pk.x = (unsigned)h0 | ((unsigned)h1 << 16);
+                        pk.y = (unsigned)h2 | ((unsigned)h3 << 16);
                         *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
+                        if (p.y_lo) {            // split-bf16 output: the residual plane, the next layer's lo operand
+                            uint2 pl;
+                            pl.x = (unsigned)f2bf(v.x - bf2f(h0)) | ((unsigned)f2bf(v.y - bf2f(h1)) << 16);
+                            pl.y = (unsigned)f2bf(v.z - bf2f(h2)) | ((unsigned)f2bf(v.w - bf2f(h3)) << 16);
+                            *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(p.y_lo) + off) = pl;
+                        }
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (n + e < p.units) {
-                            if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off + e] = v[e];
-                            else reinterpret_cast<unsigned short*>(p.y)[off + e] = f2bf(v[e]);
+                            if (p.y_dtype == KTF_F32) {
+                                reinterpret_cast<float*>(p.y)[off + e] = v[e];
+                            } else {
+                                const unsigned short h = f2bf(v[e]);
+                                reinterpret_cast<unsigned short*>(p.y)[off + e] = h;
+                                if (p.y_lo) reinterpret_cast<unsigned short*>(p.y_lo)[off + e] = f2bf(v[e] - bf2f(h));
+                            }
                         }
                     }
                 }
@@ -1648,7 +1662,11 @@ __device__ __forceinline__ void split_bf16x8(const f32x4& v0, const f32x4& v1, b
     lo = Lw.f;
 }
 
-template <int ACT, bool STATS>
+// SPLIT: the activations arrive as two bf16 planes (hi, lo) written by the producing layer's epilogue (or by
+// ktf_split_bf16): the A tile is then two 16 KiB bf16 images in the W layout and the K-loop carries no conversion at
+// all -- the in-register split costs ~190 VALU instructions per wave per K-step, four times redundantly per A tile
+// (measured: the K-loop is 28 % shorter without it).
+template <int ACT, bool STATS, bool SPLIT>
 __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -1669,10 +1687,12 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 4;
+    constexpr int XB = SPLIT ? 2 : 4;                  // bytes per activation element
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * XB;
+    const char* xl = SPLIT ? reinterpret_cast<const char*>(p.x_lo) + ((int64_t)b * p.T * p.ldx) * XB : nullptr;
     const char* wb = reinterpret_cast<const char*>(p.w);
     const char* wl = reinterpret_cast<const char*>(p.w_lo);
-    const unsigned ldxb = (unsigned)p.ldx * 4u;
+    const unsigned ldxb = (unsigned)p.ldx * XB;
 
     // A staging: chunk q = i*512 + tid (i < 4) -> row q/8, LDS position q%8, global chunk (q%8) ^ ((row>>1)&7)
     int a_t[4];
@@ -1680,9 +1700,16 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int q = i * 512 + tid;
-        const int row = q >> 3;
-        a_cb[i] = (unsigned)(((q & 7) ^ ((row >> 1) & 7)) * 16);
-        a_t[i] = start + (t0 + row) * p.sub;
+        if (SPLIT) {
+            // two bf16 planes, each 256 rows x 4 chunks (the W layout): i = 0,1 -> hi plane rows 0-127 / 128-255, i = 2,3 -> lo
+            const int row = (q & 1023) >> 2;
+            a_cb[i] = (unsigned)(((q & 3) ^ ((row >> 2) & 3)) * 16);
+            a_t[i] = start + (t0 + row) * p.sub;
+        } else {
+            const int row = q >> 3;
+            a_cb[i] = (unsigned)(((q & 7) ^ ((row >> 1) & 7)) * 16);
+            a_t[i] = start + (t0 + row) * p.sub;
+        }
     }
     // W staging (both planes): chunk q = i*512 + tid (i < 2) -> row q/4, position q%4, global chunk (q%4) ^ ((row>>2)&3)
     unsigned w_ob[2];
@@ -1704,7 +1731,7 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
     const int nk = p.ktot / R_BK;
     const int lenm1 = len - 1;
     int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
-    const int dpad_b = p.din_pad * 4;
+    const int dpad_b = p.din_pad * XB;
 #define X_STAGE()                                                                                                      \
     {                                                                                                                  \
         unsigned char* st_ = rsm + (is_ks & 1) * X_STAGE_BYTES + wave * 1024;                                          \
@@ -1712,7 +1739,7 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
             int r_ = a_t[i] + is_off;                                                                                  \
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
             const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                      \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(((SPLIT && i >= 2) ? xl : xb) + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                             \
@@ -1720,7 +1747,7 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + 32768 + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         ++is_ks;                                                                                                       \
-        is_db += R_BK * 4;                                                                                             \
+        is_db += R_BK * XB;                                                                                            \
         if (is_db == dpad_b) {                                                                                         \
             is_db = 0;                                                                                                 \
             ++is_c;                                                                                                    \
@@ -1731,7 +1758,7 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
     X_STAGE()
     const int rswa = ((lane & 31) >> 1) & 7;               // A: 128-B rows
     const int rswb = ((lane & 31) >> 2) & 3;               // W: 64-B rows
-    const int a_row_off = (wm * 128 + (lane & 31)) * 128;
+    const int a_row_off = (wm * 128 + (lane & 31)) * (SPLIT ? 64 : 128);
     const int b_row_off = (wn * 64 + (lane & 31)) * 64;
     const int hsel = lane >> 5;
     for (int ks = 0; ks < nk; ++ks) {
@@ -1745,15 +1772,23 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bfrag8 ah[4], al[4], bh[2], bl[2];
-            const int ca = kk * 4 + 2 * hsel;                // first of the two 16-B chunks holding k = 16kk + 8h .. +7
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const unsigned char* row = sa + a_row_off + i * 32 * 128;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + ((ca ^ rswa) << 4));
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + (((ca + 1) ^ rswa) << 4));
-                split_bf16x8(v0, v1, ah[i], al[i]);
-            }
             const int cb = ((kk * 2 + hsel) ^ rswb) << 4;
+            if (SPLIT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 32 * 64 + cb);
+                    al[i] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + i * 32 * 64 + cb);
+                }
+            } else {
+                const int ca = kk * 4 + 2 * hsel;            // first of the two 16-B chunks holding k = 16kk + 8h .. +7
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned char* row = sa + a_row_off + i * 32 * 128;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + ((ca ^ rswa) << 4));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + (((ca + 1) ^ rswa) << 4));
+                    split_bf16x8(v0, v1, ah[i], al[i]);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 bh[j] = *reinterpret_cast<const bfrag8*>(sh + b_row_off + j * 32 * 64 + cb);
@@ -1822,10 +1857,14 @@ extern "C" int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d) {
 
 static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
-                       void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream) {
+                       void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,
+                       const void* x_lo = nullptr, void* y_lo = nullptr) {
     KTF_REQUIRE(x && d && w && (y || stats_sums), "ktf_tdnn: null argument");
+    const bool split_in = d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16;     // activations as hi/lo bf16 planes
+    if (split_in) KTF_REQUIRE(x_lo, "ktf_tdnn_split: null lo plane");
+    if (y_lo) KTF_REQUIRE(split_in && d->y_dtype == KTF_BF16, "ktf_tdnn_split: a split output needs split input and y_dtype bf16");
     if (stats_sums) {
-        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) ||
+        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) || split_in ||
                      (d->gemm == KTF_GEMM_F16 && d->x_dtype == KTF_F16)) &&
                         d->units > 128 && !d->valid && d->subsampling == 1,
                     "ktf_tdnn_stats: needs a ring kernel (bf16, f16 or bf16x3 gemm, units > 128, SAME padding, no subsampling)");
@@ -1853,6 +1892,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     TdnnParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.lens = lens; p.w = w; p.w_lo = w_lo; p.bias = bias; p.scale = scale; p.shift = shift; p.y = y;
+    p.x_lo = x_lo; p.y_lo = y_lo;
     p.out_lens = out_lens; p.T = T; p.ldx = ldx; p.ldy = ldy; p.Tout = Tout;
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
     p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
@@ -1882,7 +1922,8 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             KTF_REQUIRE(d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F32, "ktf_tdnn: bf16 gemm writes bf16 or fp32");
         }
         const bool x3 = d->gemm == KTF_GEMM_BF16X3;
-        if (x3) KTF_REQUIRE(d->x_dtype == KTF_F32 && w_lo, "ktf_tdnn: BF16X3 needs fp32 activations and w_lo");
+        if (x3) KTF_REQUIRE((d->x_dtype == KTF_F32 || split_in) && w_lo, "ktf_tdnn: BF16X3 needs fp32 activations (or hi/lo planes) and w_lo");
+        if (split_in) KTF_REQUIRE(d->units > 128 && ldy % 4 == 0, "ktf_tdnn_split: runs on the 256x256 kernel only (units > 128, ldy %% 4 == 0)");
         dim3 grid(ntiles, (unsigned)ktf_cdiv(Tout, BF_BM), (unsigned)B);
         // K-step: 64 when the per-context width allows it, else 32
         const bool k64 = (d->din_pad % 64) == 0;
@@ -1898,21 +1939,22 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             const int64_t gtiles = B * (int64_t)mtiles;
             const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
             KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
+#define X_LAUNCH1(A, ST, SP)                                                                                           \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)tdnn_x3r_kernel<A, ST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES); \
+        hipLaunchKernelGGL((tdnn_x3r_kernel<A, ST, SP>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+    } while (0)
 #define X_LAUNCH(A)                                                                                                    \
     do {                                                                                                               \
-        if (stats_sums) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)tdnn_x3r_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES); \
-            hipLaunchKernelGGL((tdnn_x3r_kernel<A, true>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
-        } else {                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)tdnn_x3r_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES); \
-            hipLaunchKernelGGL((tdnn_x3r_kernel<A, false>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr); \
-        }                                                                                                              \
+        if (stats_sums) { if (split_in) X_LAUNCH1(A, true, true); else X_LAUNCH1(A, true, false); }                    \
+        else { if (split_in) X_LAUNCH1(A, false, true); else X_LAUNCH1(A, false, false); }                            \
     } while (0)
             if (d->act == KTF_ACT_NONE) X_LAUNCH(KTF_ACT_NONE);
             else if (d->act == KTF_ACT_RELU) X_LAUNCH(KTF_ACT_RELU);
             else if (d->act == KTF_ACT_SIGMOID) X_LAUNCH(KTF_ACT_SIGMOID);
             else X_LAUNCH(KTF_ACT_TANH);
 #undef X_LAUNCH
+#undef X_LAUNCH1
         } else if (x3) {
             if (k64) BF_LAUNCH(64, true, true); else BF_LAUNCH(32, true, true);
         } else if (d->x_dtype == KTF_F32) {
@@ -2028,6 +2070,50 @@ extern "C" int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, 
                               double* sums, void* stream) {
     KTF_REQUIRE(sums, "ktf_tdnn_stats: null sums");
     return tdnn_launch(x, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream);
+}
+
+extern "C" int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* lens,
+                              const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                              const float* shift, void* y, void* y_lo, int64_t ldy, int32_t* out_lens, void* stream) {
+    KTF_REQUIRE(y && d, "ktf_tdnn_split: null argument");
+    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes)");
+    return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, y, ldy, out_lens, nullptr, stream, x_lo, y_lo);
+}
+
+extern "C" int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx,
+                                    const int32_t* lens, const KtfTdnnDesc* d, const void* w, const void* w_lo,
+                                    const float* bias, const float* scale, const float* shift, double* sums, void* stream) {
+    KTF_REQUIRE(sums && d, "ktf_tdnn_split_stats: null argument");
+    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_stats: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes)");
+    return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream, x_lo, nullptr);
+}
+
+// fp32 rows -> the two bf16 planes of the split representation (hi = bf16(v), lo = bf16(v - hi)); pad columns zero
+__global__ void split_bf16_kernel(const float* __restrict__ src, int64_t rows, int D, int64_t lds_, unsigned short* __restrict__ hi,
+                                  unsigned short* __restrict__ lo, int64_t ldd) {
+    const int64_t total = rows * ldd;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / ldd;
+        const int d = (int)(e - r * ldd);
+        const float v = d < D ? src[r * lds_ + d] : 0.0f;
+        const unsigned short h = f2bf(v);
+        hi[e] = h;
+        lo[e] = f2bf(v - bf2f(h));
+    }
+}
+
+extern "C" int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, void* hi, void* lo, int64_t ld_dst,
+                              void* stream) {
+    KTF_REQUIRE(src && hi && lo, "ktf_split_bf16: null argument");
+    KTF_REQUIRE(rows >= 0 && D > 0 && ld_src >= D && ld_dst >= D, "ktf_split_bf16: bad sizes");
+    if (rows == 0) return KTF_OK;
+    const int64_t total = rows * ld_dst;
+    int blocks = ktf_cdiv(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(split_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, rows, D, ld_src,
+                       (unsigned short*)hi, (unsigned short*)lo, ld_dst);
+    KTF_CHECK_LAUNCH("ktf_split_bf16");
+    return KTF_OK;
 }
 
 // mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)

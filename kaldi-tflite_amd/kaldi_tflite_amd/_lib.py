@@ -87,6 +87,9 @@ PROTOTYPES = {
     "ktf_tdnn_out_len": (_i64, [_i64, C.POINTER(TdnnDesc)]),
     "ktf_tdnn": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
     "ktf_tdnn_stats": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ktf_tdnn_split": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
+    "ktf_tdnn_split_stats": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ktf_split_bf16": (C.c_int, [_P, _i64, _i32, _i64, _P, _P, _i64, _P]),
     "ktf_stats_finalize": (C.c_int, [_P, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_affine_act_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P]),
     "ktf_convert_pad": (C.c_int, [_P, _i32, _i64, _i32, _i64, _P, _i32, _i64, _P]),

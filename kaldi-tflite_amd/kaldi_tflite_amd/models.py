@@ -126,6 +126,8 @@ class Sequential:
                 return None
         return steps
 
+    split_planes = os.environ.get("KTF_X3_SPLIT", "1") != "0"     # bf16x3: hi/lo activation planes between wide layers
+
     def run_ragged(self, x, lens=None):
         """x: (B, T, D) view of an utterance-strided buffer whose row stride is a multiple of 8 and >= round_up(D, 32)
         (pad columns finite); lens: int32 (B,) valid rows per utterance or None. Returns (B, T', units) for frame-level
@@ -137,11 +139,65 @@ class Sequential:
         act_dtype = L.act_torch_dtype(gemm)
         pooled = False
         skip = False
+        # split-bf16 mode: frame-level activations travel between the wide layers as hi/lo bf16 planes (2,B,T,ld) instead
+        # of fp32, so the GEMM K-loop carries no conversion (ktf_tdnn_split); `planes` holds them while they exist
+        use_planes = gemm == L.GEMM_BF16X3 and self.split_planes
+        planes = None
         for si, st in enumerate(steps):
             if skip:
                 skip = False
                 continue
             nxt = steps[si + 1] if si + 1 < len(steps) else None
+            if use_planes and st[0] == "tdnn" and not pooled and st[1].units > 128:
+                _, l, relu, bn = st
+                if relu and l.activation not in (None, "linear"):
+                    raise ValueError("cannot fuse a ReLU after a TDNN that already has an activation")
+                if planes is None:                                   # first wide layer: split its fp32 input once
+                    B, T, D = x.shape
+                    planes = self._buffer(("xp", id(l), B, T, str(x.device)), (2, B, T, ops.round_up(D, 32)), torch.bfloat16, x.device)
+                    src = x if (x.dtype == torch.float32 and x.stride(2) == 1 and x.stride(0) == T * x.stride(1)) else x.to(torch.float32).contiguous()
+                    ops.split_bf16(src, D, planes)
+                B, T = planes.shape[1], planes.shape[2]
+                w, w_lo, bias = l.device_weights(x.device, gemm)
+                scale, shift = bn.affine_device(x.device) if bn is not None else (None, None)
+                fuse = (self.fuse_stats and nxt is not None and nxt[0] == "stats" and nxt[1].inputPeriod == 1 and
+                        l.padding == "SAME" and l.subsamplingFactor == 1)
+                if fuse:
+                    sp = nxt[1]
+                    D = l.units
+                    od = 2 * D if sp.includeStd else D
+                    ld = ops.round_up(od, 32)
+                    sums = self._buffer(("sum", id(l), B, D, str(x.device)), (B, 2, D), torch.float64, x.device)
+                    sbuf = self._buffer(("s", id(sp), B, ld, str(x.device)), (B, ld), torch.float32, x.device)
+                    d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None)
+                    ops.tdnn_split_stats(planes, lens, d, w, w_lo, bias, scale, shift, sums)
+                    ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf)
+                    x = sbuf[:, :od].unsqueeze(0)
+                    lens, pooled, skip, planes = None, True, True, None
+                    continue
+                Tout = l.outputTimesteps(T)
+                ldy = ops.round_up(l.units, 32)
+                out_lens = None
+                if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
+                    out_lens = torch.empty_like(lens)
+                keep = nxt is not None and nxt[0] == "tdnn" and nxt[1].units > 128        # the consumer reads planes too
+                if keep:
+                    ybuf = self._buffer(("yp", id(l), B, Tout, ldy, str(x.device)), (2, B, Tout, ldy), torch.bfloat16, x.device)
+                    d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None)
+                    ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf[0], ybuf[1], out_lens)
+                    planes = ybuf
+                    x = ybuf[0][:, :, : l.units]                     # shape carrier only (the values live in `planes`)
+                else:
+                    ybuf = self._buffer(("y", id(l), B, Tout, ldy, torch.float32, str(x.device)), (B, Tout, ldy), torch.float32, x.device)
+                    d = l.desc(gemm, torch.bfloat16, torch.float32, act="relu" if relu else None)
+                    ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
+                    planes = None
+                    x = ybuf[:, :, : l.units]
+                if out_lens is not None:
+                    lens = out_lens
+                continue
+            if planes is not None:
+                raise RuntimeError("internal: split planes reached a layer that cannot read them")
             if (self.fuse_stats and st[0] == "tdnn" and not pooled and gemm in (L.GEMM_BF16, L.GEMM_BF16X3, L.GEMM_F16) and nxt is not None
                     and st[1].effective_gemm(gemm, st[2]) == gemm
                     and nxt[0] == "stats" and nxt[1].inputPeriod == 1 and st[1].units > 128 and st[1].padding == "SAME"

@@ -333,6 +333,40 @@ def plda_score(test_tr, enroll_tr, psi):
     return scores
 
 
+def split_bf16(src, D, planes):
+    """fp32 (B,T,ld_src) rows -> planes (2,B,T,ld) bf16: hi = bf16(v), lo = bf16(v - hi); pad columns zero."""
+    lib = L.load()
+    rows = src.shape[0] * src.shape[1]
+    with torch.cuda.device(src.device):
+        rc = lib.ktf_split_bf16(L.ptr(src), rows, D, src.stride(1), L.ptr(planes[0]), L.ptr(planes[1]), planes.shape[-1],
+                                L.stream_ptr())
+    L.check(rc, "ktf_split_bf16")
+    return planes
+
+
+def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_lens=None):
+    """xp: (2,B,T,ldx) bf16 planes. y: (B,Tout,ldy) bf16 hi plane (+ y_lo) or fp32."""
+    lib = L.load()
+    B, T = xp.shape[1], xp.shape[2]
+    with torch.cuda.device(xp.device):
+        rc = lib.ktf_tdnn_split(L.ptr(xp[0]), L.ptr(xp[1]), B, T, xp.stride(2), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo),
+                                L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(y_lo), y.stride(1), L.ptr(out_lens),
+                                L.stream_ptr())
+    L.check(rc, "ktf_tdnn_split")
+    return y
+
+
+def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums):
+    lib = L.load()
+    B, T = xp.shape[1], xp.shape[2]
+    with torch.cuda.device(xp.device):
+        sums.zero_()
+        rc = lib.ktf_tdnn_split_stats(L.ptr(xp[0]), L.ptr(xp[1]), B, T, xp.stride(2), L.ptr(lens), C.byref(desc), L.ptr(w),
+                                      L.ptr(w_lo), L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_split_stats")
+    return sums
+
+
 def stats_finalize(sums, lens, T, D, include_std, eps, out):
     lib = L.load()
     B = sums.shape[0]

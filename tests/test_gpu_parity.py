@@ -556,6 +556,46 @@ def test_fused_tdnn_stats_random_shapes(gemm, tol):
             assert np.abs(got[i, 0, U + 5] - 1e-5) < 1e-7 and np.abs(got[i, 0, U + 6] - 1e-5) < 1e-7, got[i, 0, U + 5:U + 7]
 
 
+def test_bf16x3_split_planes_equal_fp32_activation_path():
+    """bf16x3 carries activations between wide layers as hi/lo bf16 planes (ktf_tdnn_split); the split is the same two
+    roundings the fp32-activation kernel performs in registers, so both routes see identical MFMA operands. Stack with
+    VALID padding, subsampling, a narrow (<=128 units: fp32 hand-over) layer in the middle and a frame-level output."""
+    rng = np.random.default_rng(31)
+    D = 40
+    spec = [(300, [-2, 0, 2], "VALID", 1, True), (260, [-1, 0, 1], "SAME", 2, True), (96, [0], "SAME", 1, True),
+            (520, [-3, 0, 3], "VALID", 1, True), (200, [0], "SAME", 1, False)]
+    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
+    for i, (U, ctx, pad, sub, act) in enumerate(spec):
+        lcfg.append({"name": f"t{i}", "type": ["affine", "relu", "batchnorm"] if act else "affine",
+                     "cfg": {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}})
+    cfg = {"type": "sequential", "layers": lcfg}
+    mdl = ktf.models.SequentialFromConfig(cfg, None, "m", gemm="bf16x3")
+    layers, din = [], D
+    for i, (U, ctx, pad, sub, act) in enumerate(spec):
+        W = (rng.standard_normal((U, len(ctx) * din)) / np.sqrt(len(ctx) * din)).astype(np.float32)
+        b = (rng.standard_normal(U) * 0.1).astype(np.float32)
+        mdl.get_layer(f"t{i}.affine").set_weights([W, b])
+        layers.append({"kind": "tdnn", "W": W, "b": b, "context": ctx, "padding": pad, "subsampling_factor": sub})
+        if act:
+            bn = (np.float32(1.0), rng.uniform(-0.2, 0.4, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
+            mdl.get_layer(f"t{i}.batchnorm").set_weights(list(bn))
+            layers += [{"kind": "relu"}, {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]}]
+        din = U
+    B, T = 3, 301
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    lens = np.array([T, 97, 222], np.int32)
+    dl = torch.as_tensor(lens, device="cuda")
+    assert mdl.split_planes
+    a = host(mdl.run_ragged(dev(x), dl))
+    mdl.split_planes = False
+    b = host(mdl.run_ragged(dev(x), dl))
+    for i in range(B):
+        want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)[0]
+        n = want.shape[0]
+        assert n > 0 and np.array_equal(a[i, :n], b[i, :n])
+        assert np.abs(a[i, :n] - want).max() < 2e-5, np.abs(a[i, :n] - want).max()
+
+
 def test_fused_stats_pooling_matches_unfused():
     # bf16 mode pools tdnn5's output inside the GEMM epilogue (ktf_tdnn_stats); it must agree with the separate
     # TDNN -> StatsPooling kernels up to the bf16 rounding of the (otherwise materialised) activations
