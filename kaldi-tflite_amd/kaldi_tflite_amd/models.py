@@ -435,7 +435,7 @@ class XvectorExtractor:
         ops.vad_cmvn(ws["mfcc"], self.vad.cfg(), self.cmvn.cfg(), ws["feats"], ws["lens"], ws["idx"], ws["work"])
         return ws["mfcc"], ws["feats"][:, :, :D], ws["lens"]
 
-    def extract_stream(self, host_batches, depth=2):
+    def extract_stream(self, host_batches, depth=3):
         """Extension: x-vectors of a sequence of HOST batches (pinned (B,N) int16 / fp32 tensors) with the upload of batch
         i+1 on a separate HIP stream under the compute of batch i (`depth` device input buffers). Yields one (B, dim)
         device tensor per batch, in order. The compute path is the same as __call__; only the copies overlap."""
