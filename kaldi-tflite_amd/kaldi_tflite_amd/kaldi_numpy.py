@@ -69,6 +69,22 @@ def ProcessFrames(frames, dither=0.0, remove_dc_offset=True, preemphasis_coeffic
     return win, np.log(energy)
 
 
+def GetWindowFunction(window_type, window_size):
+    """frame_extraction.py:141-187: hamming | hanning | rectangular | blackman | povey | sine; ValueError for a zero
+    size or an unknown name."""
+    if window_size == 0:
+        raise ValueError("window_size must be > 0")
+    if window_type not in ("hamming", "hanning", "rectangular", "blackman", "povey", "sine"):
+        raise ValueError(f"invalid window type {window_type}")
+    return window_function(window_type, window_size)
+
+
+def getWindowedSums(frames, N, padding):
+    """frame_extraction.py:268-322: sums over sliding windows of N frames along axis -2 of a zero-prefixed array; with
+    "SAME" padding the edge outputs repeat the first / last full window."""
+    return _windowed_sums(frames, N, padding)
+
+
 def _windowed_sums(frames, N, padding):
     T = frames.shape[-2] - 1
     cs = np.cumsum(frames, axis=-2)

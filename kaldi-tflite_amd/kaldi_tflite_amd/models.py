@@ -324,12 +324,12 @@ def SequentialFromConfig(cfg, nnet3Path=None, name=None, gemm="f32"):
     return mdl
 
 
-def downloadModel(link, downloadDir, tarHash):
+def downloadModel(link, outPath, sha256=None):
     """models/kaldi/download.py:28-100 fetches the Kaldi tarball; there is no network on the target machines, so
     only the "already present -> nothing to do" half of that contract is kept."""
     raise FileNotFoundError(
-        f"pretrained Kaldi model not found under '{downloadDir}' and cannot be downloaded here (wanted {link}, "
-        f"sha256 {tarHash}); place the extracted tarball there")
+        f"pretrained Kaldi model not found under '{outPath}' and cannot be downloaded here (wanted {link}, "
+        f"sha256 {sha256}); place the extracted tarball there")
 
 
 def XvectorExtractorFromConfig(cfgPath, name=None, gemm="f32"):

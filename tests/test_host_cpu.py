@@ -203,6 +203,19 @@ def test_kaldi_numpy_matches_reference_outputs():
         assert np.allclose(got, z[f"cmvn_np_out_{j}"], rtol=0, atol=1e-6)
     with pytest.raises(NotImplementedError):
         ktf.kaldi_numpy.ApplyCMVN(x)
+    # window helper (frame_extraction.py:141-187): the windowed frames above pin "povey"; names and errors here
+    n = np.arange(400)
+    assert np.allclose(ktf.kaldi_numpy.GetWindowFunction("povey", 400), (0.5 - 0.5 * np.cos(2 * np.pi * n / 399)) ** 0.85)
+    assert np.array_equal(ktf.kaldi_numpy.GetWindowFunction("hamming", 25), np.hamming(25))
+    for bad in [("povey", 0), ("triangle", 25)]:
+        with pytest.raises(ValueError):
+            ktf.kaldi_numpy.GetWindowFunction(*bad)
+    x2 = x.reshape(-1, x.shape[-1])
+    xp = np.pad(x2, [[1, 0], [0, 0]])
+    s = ktf.kaldi_numpy.getWindowedSums(xp, 11, "VALID")
+    assert s.shape[0] == x2.shape[0] - 10 and np.allclose(s[3], x2[3:14].sum(0))
+    ss = ktf.kaldi_numpy.getWindowedSums(xp, 11, "SAME")
+    assert ss.shape == x2.shape and np.array_equal(ss[0], ss[5]) and np.allclose(ss[5], s[0]) and np.array_equal(ss[-1], ss[-6])
 
 
 # ----------------------------------------------------------------------------- layer constructors / config errors
