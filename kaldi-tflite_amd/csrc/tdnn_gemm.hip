@@ -1040,6 +1040,35 @@ __device__ __forceinline__ void ring_epilogue16_direct(f32x4v (&acc)[8][4], cons
 #define R16_PK_PITCH 520
 #define R16_PRM_OFF (R_BM * R16_PK_PITCH)              // bias | scale | shift of the tile's 256 columns, behind the staging image
 #define R16_LDS_BYTES (R16_PRM_OFF + 3 * R_BN * 4)      // 136,192 B
+
+// every wave streams 32 rows of the staged 256 x 256 16-bit image out with 16-byte stores (two 512-byte rows per instruction)
+__device__ __forceinline__ void r16_store_staged(const TdnnParams& p, const unsigned char* rsm, unsigned short* ybase, int b,
+                                                 int t0, int n0, int out_len, int wave, int lane) {
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+    const int n8 = n0 + (lane & 31) * 8;
+    const bool wide = (n8 + 8 <= p.units) && ((p.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(ybase) & 15) == 0);
+#pragma unroll 4
+    for (int sp = 0; sp < 16; ++sp) {
+        const int m = wave * 32 + sp * 2 + (lane >> 5);
+        if (m < rows_valid) {
+            const unsigned char* src = rsm + m * R16_PK_PITCH + (lane & 31) * 16;
+            const uint2 lo = *reinterpret_cast<const uint2*>(src);
+            const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
+            unsigned short* yp = ybase + (out_row0 + m) * p.ldy + n8;
+            if (wide) {
+                u32x4 o;
+                o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
+                *reinterpret_cast<u32x4*>(yp) = o;
+            } else {
+                const unsigned w4[4] = {lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (n8 + e < p.units) yp[e] = (unsigned short)(w4[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+    }
+}
 template <int ACT, bool F16>
 __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const TdnnParams& p, unsigned char* rsm, int b,
                                                    int t0, int n0, int out_len, int wm, int wn, int wave, int lane) {
@@ -1074,31 +1103,7 @@ __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const Td
         }
     }
     __syncthreads();
-    const int rows_valid = out_len - t0;
-    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
-    const int n8 = n0 + (lane & 31) * 8;
-    const bool wide = (n8 + 8 <= p.units) && ((p.ldy & 7) == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
-    unsigned short* ybase = reinterpret_cast<unsigned short*>(p.y);
-#pragma unroll 4
-    for (int sp = 0; sp < 16; ++sp) {
-        const int m = wave * 32 + sp * 2 + (lane >> 5);
-        if (m < rows_valid) {
-            const unsigned char* src = rsm + m * R16_PK_PITCH + (lane & 31) * 16;
-            const uint2 lo = *reinterpret_cast<const uint2*>(src);
-            const uint2 hi = *reinterpret_cast<const uint2*>(src + 8);
-            unsigned short* yp = ybase + (out_row0 + m) * p.ldy + n8;
-            if (wide) {
-                u32x4 o;
-                o.x = lo.x; o.y = lo.y; o.z = hi.x; o.w = hi.y;
-                *reinterpret_cast<u32x4*>(yp) = o;
-            } else {
-                const unsigned w4[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (n8 + e < p.units) yp[e] = (unsigned short)(w4[e >> 1] >> ((e & 1) * 16));
-            }
-        }
-    }
+    r16_store_staged(p, rsm, reinterpret_cast<unsigned short*>(p.y), b, t0, n0, out_len, wave, lane);
 }
 
 template <int ACT, bool STATS, bool F16>
@@ -1809,6 +1814,129 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
     ring_epilogue<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------ BF16X3 on 16x16x32, split planes
+// Split-bf16 with hi/lo activation planes and fused pooling on the 16x16x32 MFMA (the chip holds a higher clock on this
+// shape than on 32x32x16: the K-loop is 8-10 % shorter): 256x256 tile, 8 waves of 128x64, a stage = A hi | A lo | W hi | W lo
+// (4 x 16 KiB, the chunk permutation of the 16x16x32 bf16 kernel), double buffered -- 96 MFMAs per wave per K-step cover one
+// stage of DMA latency. Only the reducing (fused StatsPooling) form exists: a 16x16-layout epilogue that writes hi/lo planes
+// (two staged passes) measured 10 us per tile slower than the 32x32 kernel's, which cancels the K-loop gain at K <= 1536.
+#define XS_STAGE_BYTES (4 * R_TILE_BYTES)                // 64 KiB
+#define XS_LDS_BYTES (2 * XS_STAGE_BYTES)                // 128 KiB
+template <int ACT>
+__global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
+                                                       double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = (slot / ntiles) * 8 + xcd;
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * R_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = nt * R_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const char* xh = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;
+    const char* xl = reinterpret_cast<const char*>(p.x_lo) + ((int64_t)b * p.T * p.ldx) * 2;
+    const char* wh = reinterpret_cast<const char*>(p.w);
+    const char* wl = reinterpret_cast<const char*>(p.w_lo);
+    const unsigned ldxb = (unsigned)p.ldx * 2u;
+
+    int a_t[2];
+    unsigned a_cb[2], w_ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q >> 2;
+        const unsigned chunk = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
+        a_cb[i] = chunk;
+        a_t[i] = start + (t0 + row) * p.sub;
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + chunk;
+    }
+
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / R_BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 2;
+#define XS_STAGE()                                                                                                     \
+    {                                                                                                                  \
+        unsigned char* st_ = rsm + (is_ks & 1) * XS_STAGE_BYTES + wave * 1024;                                         \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            int r_ = a_t[i] + is_off;                                                                                  \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                      \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                             \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + 2 * R_TILE_BYTES + i * 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + 3 * R_TILE_BYTES + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+        ++is_ks;                                                                                                       \
+        is_db += R_BK * 2;                                                                                             \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
+    }
+    XS_STAGE()
+    const int fr = (4 - (((lane & 15) >> 2) & 3)) & 3;
+    const int coff = (((lane >> 4) ^ fr) << 4);
+    const int a_row_off = (wm * 128 + (lane & 15)) * 64 + coff;
+    const int b_row_off = (wn * 64 + (lane & 15)) * 64 + coff;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage ks landed (nothing else is in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (is_ks < nk) XS_STAGE()                           // stage ks+1 -> the buffer every wave finished reading
+        const unsigned char* sa = rsm + (ks & 1) * XS_STAGE_BYTES;
+        const unsigned char* sw = sa + 2 * R_TILE_BYTES;
+        bfrag8 bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
+            bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            bfrag8 ah[4], al[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ah[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + (half * 4 + i) * 16 * 64);
+                al[i] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + (half * 4 + i) * 16 * 64);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4v(&c)[4] = acc[half * 4 + i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = mfma16x16x32<false>(ah[i], bh[j], c[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = mfma16x16x32<false>(al[i], bh[j], c[j]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c[j] = mfma16x16x32<false>(ah[i], bl[j], c[j]);
+            }
+        }
+    }
+#undef XS_STAGE
+    ring_epilogue16<ACT, true>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+}
+
 // ------------------------------------------------------------------------------------ elementwise helpers
 __global__ void affine_act_kernel(const float* __restrict__ x, int64_t total, int D, int act,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
@@ -1949,10 +2077,23 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         if (stats_sums) { if (split_in) X_LAUNCH1(A, true, true); else X_LAUNCH1(A, true, false); }                    \
         else { if (split_in) X_LAUNCH1(A, false, true); else X_LAUNCH1(A, false, false); }                            \
     } while (0)
+#define XS_LAUNCH(A)                                                                                                   \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)tdnn_x3s_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS_BYTES); \
+        hipLaunchKernelGGL((tdnn_x3s_kernel<A>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+    } while (0)
+            static const int x3s_env = getenv("KTF_X3S") ? atoi(getenv("KTF_X3S")) : 1;      // 0: 32x32x16 kernel (A/B)
+            if (split_in && stats_sums && x3s_env) {
+                if (d->act == KTF_ACT_NONE) XS_LAUNCH(KTF_ACT_NONE);
+                else if (d->act == KTF_ACT_RELU) XS_LAUNCH(KTF_ACT_RELU);
+                else if (d->act == KTF_ACT_SIGMOID) XS_LAUNCH(KTF_ACT_SIGMOID);
+                else XS_LAUNCH(KTF_ACT_TANH);
+            } else
             if (d->act == KTF_ACT_NONE) X_LAUNCH(KTF_ACT_NONE);
             else if (d->act == KTF_ACT_RELU) X_LAUNCH(KTF_ACT_RELU);
             else if (d->act == KTF_ACT_SIGMOID) X_LAUNCH(KTF_ACT_SIGMOID);
             else X_LAUNCH(KTF_ACT_TANH);
+#undef XS_LAUNCH
 #undef X_LAUNCH
 #undef X_LAUNCH1
         } else if (x3) {

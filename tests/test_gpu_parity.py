@@ -558,7 +558,8 @@ def test_fused_tdnn_stats_random_shapes(gemm, tol):
 
 def test_bf16x3_split_planes_equal_fp32_activation_path():
     """bf16x3 carries activations between wide layers as hi/lo bf16 planes (ktf_tdnn_split); the split is the same two
-    roundings the fp32-activation kernel performs in registers, so both routes see identical MFMA operands. Stack with
+    roundings the fp32-activation kernel performs in registers, so both routes see identical MFMA operands (the plane
+    kernel uses the 16x16x32 MFMA, so only the fp32 summation order differs). Stack with
     VALID padding, subsampling, a narrow (<=128 units: fp32 hand-over) layer in the middle and a frame-level output."""
     rng = np.random.default_rng(31)
     D = 40
@@ -592,7 +593,7 @@ def test_bf16x3_split_planes_equal_fp32_activation_path():
     for i in range(B):
         want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)[0]
         n = want.shape[0]
-        assert n > 0 and np.array_equal(a[i, :n], b[i, :n])
+        assert n > 0 and np.abs(a[i, :n] - b[i, :n]).max() < 1e-5       # same operands; MFMA shape / summation order differ
         assert np.abs(a[i, :n] - want).max() < 2e-5, np.abs(a[i, :n] - want).max()
 
 
