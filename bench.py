@@ -16,6 +16,7 @@ bounded sample of the same workload on this box's host cores.
 """
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -74,6 +75,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # a full Python GC pass over torch's ~170k long-lived objects stalls the host for 30-40 ms (measured: it landed in
+    # one call of a side measurement and doubled its time): collect now and park the survivors in the permanent generation
+    gc.collect()
+    gc.freeze()
     # ---- timed region: exactly K steps between barrier + synchronize
     ops_prof = _GemmProfiler(ops)
     parallel.barrier(world)
