@@ -55,6 +55,8 @@ def main():
     rank, local_rank, world = parallel.init_from_env()
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    if os.environ.get("KTF_SHARE_GPU"):          # test hook: several ranks on one GPU (with KTF_DIST_BACKEND=gloo)
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -106,8 +108,8 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.gemm,
         "data": "synthetic",
-        "config": {"workload": "0008_sitw_v2_1a wav->x-vector, 10 s @16 kHz utterances, 1024 per GPU "
-                               "(BASELINE config: 8192 utterances batch-sharded over 8 GPUs), dither 0, all 998 frames voiced",
+        "config": {"workload": f"0008_sitw_v2_1a wav->x-vector, {args.seconds:g} s @16 kHz utterances, {B} per GPU "
+                               f"(BASELINE config: 8192 utterances batch-sharded over 8 GPUs = 1024 per GPU), dither 0, all {T} frames voiced",
                    "utterances_per_gpu": B, "samples_per_utterance": N, "frames_per_utterance": T,
                    "tdnn_gemm": args.gemm, "weights": "synthetic seed 4321 (pretrained final.raw not shipped)",
                    "gather": bool(world > 1 and not args.no_gather)},
