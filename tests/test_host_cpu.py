@@ -48,6 +48,23 @@ def test_abi_argument_validation_without_gpu():
     assert rc == -1 and "ascending" in L.last_error()
     v = L.VadCfg(energy_threshold=5, energy_mean_scale=0.5, proportion_threshold=0.6, frames_context=2, energy_coeff=40)
     assert lib.ktf_vad_mask_f32(buf, 1, 10, 30, C.byref(v), buf, None) == -1
+    # split-bf16 plane entry points: mode / dtype / plane checks happen before any launch
+    d = L.TdnnDesc(units=512, din=64, din_pad=64, nctx=1, subsampling=1, gemm=L.GEMM_BF16, x_dtype=L.KTF_BF16,
+                   w_dtype=L.KTF_BF16, y_dtype=L.KTF_BF16)
+    rc = lib.ktf_tdnn_split(buf, buf, 1, 8, 64, None, C.byref(d), buf, buf, None, None, None, buf, buf, 512, None, None)
+    assert rc == -1 and "KTF_GEMM_BF16X3" in L.last_error()
+    d.gemm = L.GEMM_BF16X3
+    rc = lib.ktf_tdnn_split(buf, None, 1, 8, 64, None, C.byref(d), buf, buf, None, None, None, buf, buf, 512, None, None)
+    assert rc == -1 and "lo plane" in L.last_error()
+    d.units = 64                                                    # the plane route runs on the 256x256 kernels only
+    rc = lib.ktf_tdnn_split(buf, buf, 1, 8, 64, None, C.byref(d), buf, buf, None, None, None, buf, buf, 64, None, None)
+    assert rc == -1 and "units > 128" in L.last_error()
+    d.units, d.valid = 512, 1
+    rc = lib.ktf_tdnn_split_stats(buf, buf, 1, 8, 64, None, C.byref(d), buf, buf, None, None, None, buf, None)
+    assert rc == -1 and "SAME" in L.last_error()
+    assert lib.ktf_split_bf16(buf, 4, 0, 8, buf, buf, 8, None) == -1 and "bad sizes" in L.last_error()
+    assert lib.ktf_split_bf16(buf, 4, 4, 8, buf, None, 8, None) == -1 and "null" in L.last_error()
+    assert lib.ktf_split_bf16(buf, 0, 4, 8, buf, buf, 8, None) == 0   # nothing to do
 
 
 def test_host_side_size_helpers():
