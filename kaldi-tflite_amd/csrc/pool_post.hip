@@ -30,43 +30,74 @@ __device__ __forceinline__ float2 load2<_Float16>(const _Float16* p) {
 template <>
 __device__ __forceinline__ float load1<_Float16>(const _Float16* p) { return (float)*p; }
 
-#define SP_RG 16      // row groups per workgroup (1024 threads): a single utterance still has 16 loads in flight per column pair
-template <typename T, bool VEC2>
-__global__ __launch_bounds__(64 * SP_RG) void stats_pool_kernel(const T* __restrict__ x, int64_t Tmax, int D, int64_t ldx,
-                                                         const int32_t* __restrict__ lens, int period, int include_std,
-                                                         float eps, float* __restrict__ out, int64_t ldo) {
-    __shared__ double red[SP_RG][2][128];   // fp64 sums: E[x^2]-mean^2 of a (near-)constant channel must not cancel to noise
+// Column statistics of one utterance. Rows are summed in 64 interleaved groups (row j -> group j mod 64, fp64), the
+// groups are combined in ONE fixed association ((g + g+16) + g+32) + g+48 for g = 0..15, then over g -- independent of how
+// threads map to groups. Two mappings of the 1024 threads share it and therefore give bit-identical results:
+//   CW = 128 columns per workgroup, 16 row groups of 64 lanes, four groups per thread (throughput shape);
+//   CW = 32 columns per workgroup, 64 row groups of 16 lanes, one group per thread: four times the workgroups and a
+//   quarter of the serial chain per thread when only a few utterances are in flight (single-utterance latency).
+#define SP_THREADS 1024
+template <typename T, bool VEC2, int CW>
+__global__ __launch_bounds__(SP_THREADS) void stats_pool_kernel(const T* __restrict__ x, int64_t Tmax, int D, int64_t ldx,
+                                                                const int32_t* __restrict__ lens, int period, int include_std,
+                                                                float eps, float* __restrict__ out, int64_t ldo) {
+    constexpr int LPR = CW / 2;                  // lanes per row group (two columns per thread)
+    constexpr int RG = SP_THREADS / LPR;         // row groups per workgroup: 16 or 64
+    constexpr int NG = 64 / RG;                  // canonical groups per thread: 4 or 1
+    __shared__ double red[RG][2][CW];            // fp64 sums: E[x^2]-mean^2 of a (near-)constant channel must not cancel to noise
     const int b = blockIdx.y;
     const int len = lens ? lens[b] : (int)Tmax;
-    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c0 = blockIdx.x * 128 + lane * 2;
+    const int lc = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    const int c0 = blockIdx.x * CW + lc * 2;
     const T* xb = x + (int64_t)b * Tmax * ldx;
-    double s0 = 0., s1 = 0., q0 = 0., q1 = 0.;
+    double s0[NG], s1[NG], q0[NG], q1[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) s0[g] = s1[g] = q0[g] = q1[g] = 0.;
     const int nrows = len <= 0 ? 0 : (len + period - 1) / period;
     if (c0 < D) {
         const bool two = (c0 + 1 < D);
         const int64_t rstep = (int64_t)period * ldx;
-#pragma unroll 4
-        for (int j = rg; j < nrows; j += SP_RG) {
-            const T* p = xb + (int64_t)j * rstep + c0;
-            float2 v;
-            if (VEC2 && two) v = load2<T>(p);
-            else { v.x = load1<T>(p); v.y = two ? load1<T>(p + 1) : 0.f; }
-            s0 += (double)v.x; s1 += (double)v.y;
-            q0 += (double)v.x * (double)v.x; q1 += (double)v.y * (double)v.y;
+#pragma unroll 2
+        for (int j0 = rg; j0 < nrows; j0 += 64) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int j = j0 + g * RG;
+                if (j < nrows) {
+                    const T* p = xb + (int64_t)j * rstep + c0;
+                    float2 v;
+                    if (VEC2 && two) v = load2<T>(p);
+                    else { v.x = load1<T>(p); v.y = two ? load1<T>(p + 1) : 0.f; }
+                    s0[g] += (double)v.x; s1[g] += (double)v.y;
+                    q0[g] += (double)v.x * (double)v.x; q1[g] += (double)v.y * (double)v.y;
+                }
+            }
         }
     }
-    red[rg][0][lane * 2] = s0; red[rg][0][lane * 2 + 1] = s1;
-    red[rg][1][lane * 2] = q0; red[rg][1][lane * 2 + 1] = q1;
+    if (NG == 4) {
+        red[rg][0][lc * 2] = ((s0[0] + s0[1 % NG]) + s0[2 % NG]) + s0[3 % NG];
+        red[rg][0][lc * 2 + 1] = ((s1[0] + s1[1 % NG]) + s1[2 % NG]) + s1[3 % NG];
+        red[rg][1][lc * 2] = ((q0[0] + q0[1 % NG]) + q0[2 % NG]) + q0[3 % NG];
+        red[rg][1][lc * 2 + 1] = ((q1[0] + q1[1 % NG]) + q1[2 % NG]) + q1[3 % NG];
+    } else {
+        red[rg][0][lc * 2] = s0[0]; red[rg][0][lc * 2 + 1] = s1[0];
+        red[rg][1][lc * 2] = q0[0]; red[rg][1][lc * 2 + 1] = q1[0];
+    }
     __syncthreads();
-    if (threadIdx.x < 128) {
-        const int c = blockIdx.x * 128 + threadIdx.x;
+    if (threadIdx.x < CW) {
+        const int c = blockIdx.x * CW + threadIdx.x;
         if (c < D) {
             double s = 0., q = 0.;
 #pragma unroll
-            for (int g = 0; g < SP_RG; ++g) {
-                s += red[g][0][threadIdx.x];
-                q += red[g][1][threadIdx.x];
+            for (int g = 0; g < 16; ++g) {
+                if (NG == 4) {
+                    s += red[g % RG][0][threadIdx.x];
+                    q += red[g % RG][1][threadIdx.x];
+                } else {
+                    s += ((red[g % RG][0][threadIdx.x] + red[(g + 16) % RG][0][threadIdx.x]) + red[(g + 32) % RG][0][threadIdx.x]) +
+                         red[(g + 48) % RG][0][threadIdx.x];
+                    q += ((red[g % RG][1][threadIdx.x] + red[(g + 16) % RG][1][threadIdx.x]) + red[(g + 32) % RG][1][threadIdx.x]) +
+                         red[(g + 48) % RG][1][threadIdx.x];
+                }
             }
             const double n = (double)nrows;
             const double mean = s / n;
@@ -321,21 +352,23 @@ extern "C" int ktf_stats_pool(const void* x, int32_t x_dtype, int64_t B, int64_t
     KTF_REQUIRE(B < 65536, "ktf_stats_pool: B too large");
     KTF_REQUIRE(ld_out >= (include_std ? 2 : 1) * (int64_t)D, "ktf_stats_pool: ld_out too small");
     if (B == 0) return KTF_OK;
-    dim3 grid((unsigned)ktf_cdiv(D, 128), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = (ldx % 2 == 0) && ((reinterpret_cast<uintptr_t>(x) & 7) == 0);
-    if (x_dtype == KTF_F32) {
-        if (vec) hipLaunchKernelGGL((stats_pool_kernel<float, true>), grid, dim3(64 * SP_RG), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-        else hipLaunchKernelGGL((stats_pool_kernel<float, false>), grid, dim3(64 * SP_RG), 0, st, (const float*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-    } else if (x_dtype == KTF_BF16) {
-        if (vec) hipLaunchKernelGGL((stats_pool_kernel<unsigned short, true>), grid, dim3(64 * SP_RG), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-        else hipLaunchKernelGGL((stats_pool_kernel<unsigned short, false>), grid, dim3(64 * SP_RG), 0, st, (const unsigned short*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-    } else if (x_dtype == KTF_F16) {
-        if (vec) hipLaunchKernelGGL((stats_pool_kernel<_Float16, true>), grid, dim3(64 * SP_RG), 0, st, (const _Float16*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-        else hipLaunchKernelGGL((stats_pool_kernel<_Float16, false>), grid, dim3(64 * SP_RG), 0, st, (const _Float16*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out);
-    } else {
-        KTF_REQUIRE(false, "ktf_stats_pool: bad dtype");
-    }
+    // few utterances: 32-column workgroups (4x the workgroups, same results bit for bit)
+    const bool narrow = (int64_t)ktf_cdiv(D, 128) * B < 256;
+#define SP_LAUNCH(TY, CW)                                                                                              \
+    do {                                                                                                               \
+        dim3 grid((unsigned)ktf_cdiv(D, CW), (unsigned)B);                                                             \
+        if (vec) hipLaunchKernelGGL((stats_pool_kernel<TY, true, CW>), grid, dim3(SP_THREADS), 0, st, (const TY*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out); \
+        else hipLaunchKernelGGL((stats_pool_kernel<TY, false, CW>), grid, dim3(SP_THREADS), 0, st, (const TY*)x, T, D, ldx, lens, input_period, include_std, eps, out, ld_out); \
+    } while (0)
+#define SP_LAUNCH_T(TY) do { if (narrow) SP_LAUNCH(TY, 32); else SP_LAUNCH(TY, 128); } while (0)
+    if (x_dtype == KTF_F32) SP_LAUNCH_T(float);
+    else if (x_dtype == KTF_BF16) SP_LAUNCH_T(unsigned short);
+    else if (x_dtype == KTF_F16) SP_LAUNCH_T(_Float16);
+    else KTF_REQUIRE(false, "ktf_stats_pool: bad dtype");
+#undef SP_LAUNCH_T
+#undef SP_LAUNCH
     KTF_CHECK_LAUNCH("ktf_stats_pool");
     return KTF_OK;
 }

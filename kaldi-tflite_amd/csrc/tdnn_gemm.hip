@@ -1937,6 +1937,219 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     ring_epilogue16<ACT, true>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
 }
 
+// ------------------------------------------------------------------------------------ F32, few workgroups (latency)
+// A single utterance (M = 998) gives the 128-tiles 32 workgroups and even 64-tiles only one workgroup per CU: nothing
+// hides a global-load round trip, and a register-staged prefetch gets serialised by the compiler's vmcnt placement. These
+// two kernels stage through an LDS ring filled by LDS-DMA with counted waits instead. Both accumulate in K order with
+// fp32 FMAs -- the summation order of v_mfma_f32_32x32x2_f32 -- so they are bit-identical to the 128x128 tile kernel and a
+// batch still equals its single-utterance calls.
+//
+// (1) 64x64 tile, SIXTEEN waves of one 16x16 block each (v_mfma_f32_16x16x4_f32). K-step 64 when the per-context width
+//     allows it, else 32; 4-stage LDS-DMA ring (128 / 64 KiB), loads 3 steps ahead, one or two 16-byte DMAs per thread and
+//     stage. Rows are BK*4 bytes; chunk c of row r sits at position c ^ (r & (CH-1)) (2-way on the scalar fragment reads).
+//     Measured at K = 1536 on one utterance (998 x 512 outputs, 128 workgroups): 40 us; four waves of one 32x32x2 block
+//     53 us (a dependent fp32 MFMA costs ~120 cycles against 64 of issue); four waves of 2x2 16x16x4 blocks 43 us; K-step
+//     32 with this shape 44 us; 8 stages / 7 steps ahead the same. Timing-only ablations (K-step 32): without the refill
+//     DMAs 41 us, without the MFMAs 24 us -- the step is the CU's fp32 MFMA time (64x64x32 = 1024 cycles) plus about as
+//     much LDS fragment traffic (each operand block is read by four waves), which one workgroup per CU cannot overlap.
+#define FS_BM 64
+#define FS_NSTAGE 4
+template <int BK>
+__global__ __launch_bounds__(1024) void tdnn_f32s_kernel(TdnnParams p) {
+    constexpr int CH = BK / 4;                               // 16-byte chunks per row
+    constexpr int ROWB = BK * 4;                             // bytes per staged row
+    constexpr int TILE_BYTES = FS_BM * ROWB;                 // 8 / 16 KiB per operand
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int NDMA = (2 * FS_BM * CH) / 1024;            // DMAs per thread and stage: 1 / 2
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    const int b = blockIdx.z;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = blockIdx.y * FS_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = blockIdx.x * FS_BM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // staging: the 2 * 64 * CH chunks of a stage (A tile, then W tile) are dealt to the 1024 threads in order; chunk q of
+    // a tile -> row q / CH, LDS position q % CH holds global chunk (q % CH) ^ (row & (CH-1))
+    const int q = (NDMA == 1) ? (tid & 511) : tid;
+    const bool isw = (NDMA == 1) && tid >= 512;              // BK = 32: threads 512-1023 stage the W tile
+    const int srow = q / CH;
+    const unsigned scb = (unsigned)(((q % CH) ^ (srow & (CH - 1))) * 16);
+    const int a_t = start + (t0 + srow) * p.sub;
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 4;
+    const char* wrow = reinterpret_cast<const char*>(p.w) + (int64_t)(n0 + srow) * p.ktot * 4 + scb;
+    const unsigned ldxb = (unsigned)p.ldx * 4u;
+    const int nk = p.ktot / BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 4;
+#define FS_STAGE()                                                                                                     \
+    {                                                                                                                  \
+        unsigned char* st_ = fsm + (is_ks & (FS_NSTAGE - 1)) * STAGE_BYTES + wave * 1024;                              \
+        int r_ = a_t + is_off;                                                                                         \
+        r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
+        const char* xs_ = xb + ((unsigned)r_ * ldxb + scb + (unsigned)is_db);                                          \
+        const char* ws_ = wrow + is_ks * ROWB;                                                                         \
+        if (NDMA == 1) {                                     /* waves 8-15 land in the W tile: wave * 1024 >= TILE_BYTES */ \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(isw ? ws_ : xs_), (lds_ptr_t*)st_, 16, 0, 0);                \
+        } else {                                                                                                       \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)xs_, (lds_ptr_t*)st_, 16, 0, 0);                              \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)ws_, (lds_ptr_t*)(st_ + TILE_BYTES), 16, 0, 0);               \
+        }                                                                                                              \
+        ++is_ks;                                                                                                       \
+        is_db += ROWB;                                                                                                 \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
+    }
+    for (int s_ = 0; s_ < FS_NSTAGE - 1 && s_ < nk; ++s_) FS_STAGE()
+
+    f32x4v acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int a_row_off = (wm * 16 + r16) * ROWB + kq * 4;
+    const int b_row_off = TILE_BYTES + (wn * 16 + r16) * ROWB + kq * 4;
+    const int sw = r16 & (CH - 1);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int ahead = nk - 1 - ks;                       // stages issued beyond this one: min(ahead, 2), NDMA DMAs each
+        if (NDMA == 1) {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (is_ks < nk) FS_STAGE()                           // into the slot every wave finished reading last step
+        const unsigned char* st = fsm + (ks & (FS_NSTAGE - 1)) * STAGE_BYTES;
+        float av[CH], bv[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            av[c] = *reinterpret_cast<const float*>(st + a_row_off + ((c ^ sw) << 4));
+            bv[c] = *reinterpret_cast<const float*>(st + b_row_off + ((c ^ sw) << 4));
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc, 0, 0, 0);
+    }
+#undef FS_STAGE
+    // 16x16 accumulator layout: acc[r] = out[row 4*(lane>>4) + r][col lane&15]
+    const int n = n0 + wn * 16 + r16;
+    if (n < p.units) {
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+        const float sc = p.scale ? p.scale[n] : 1.0f;
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+        const int rows_valid = out_len - t0;
+        const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = wm * 16 + kq * 4 + r;
+            if (m < rows_valid) {
+                float v = apply_act(acc[r] + bias, p.act);
+                if (p.scale) v = v * sc + sh;
+                const int64_t off = (out_row0 + m) * p.ldy + n;
+                if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off] = v;
+                else reinterpret_cast<unsigned short*>(p.y)[off] = f2bf(v);
+            }
+        }
+    }
+}
+
+// (2) <= 8 output rows in all (tdnn6 of a single utterance: one 3000-long row against 512 units; the 64-tiles would run 8
+//     workgroups through a 94-step serial loop). One single-wave workgroup owns 16 units of ONE output row: all lanes
+//     issue the DMAs of a 16 x 32 weight slice and the row's 32 inputs into a 16-deep ring (loads 14 steps ahead, no
+//     barrier: one wave), lanes 0-15 run the fmaf chain.
+#define RV_UNITS 16
+#define RV_BK 32
+#define RV_NSTAGE 16
+#define RV_STAGE_BYTES (RV_UNITS * RV_BK * 4 + 256)            // 2 KiB of W + the row's 32 inputs (a 4-byte DMA writes 64 lanes x 4 B: stored twice)
+__global__ __launch_bounds__(64) void tdnn_f32_rowvec_kernel(TdnnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char rvm[RV_NSTAGE * RV_STAGE_BYTES];
+    const int b = blockIdx.z, t = blockIdx.y;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    const int tid = threadIdx.x;
+    if (p.out_lens && blockIdx.x == 0 && t == 0 && tid == 0) p.out_lens[b] = out_len;
+    if (t >= out_len || len <= 0) return;
+    const int n0 = blockIdx.x * RV_UNITS;
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 4;
+    const char* wb = reinterpret_cast<const char*>(p.w);
+    const unsigned ldxb = (unsigned)p.ldx * 4u;
+    const int at = start + t * p.sub;
+    unsigned w_ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 64 + tid;
+        const int row = q >> 3;
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 4u + (unsigned)(((q & 7) ^ ((row >> 1) & 7)) * 16);
+    }
+    const int nk = p.ktot / RV_BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 4;
+#define RV_STAGE()                                                                                                     \
+    {                                                                                                                  \
+        unsigned char* st_ = rvm + (is_ks & (RV_NSTAGE - 1)) * RV_STAGE_BYTES;                                         \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + (w_ob[0] + (unsigned)(is_ks * (RV_BK * 4)))), (lds_ptr_t*)(st_), 16, 0, 0);        \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + (w_ob[1] + (unsigned)(is_ks * (RV_BK * 4)))), (lds_ptr_t*)(st_ + 1024), 16, 0, 0); \
+        int r_ = at + is_off;                                                                                          \
+        r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + ((unsigned)r_ * ldxb + (unsigned)is_db + (unsigned)((tid & 31) * 4))), \
+                                         (lds_ptr_t*)(st_ + 2048), 4, 0, 0);                                           \
+        ++is_ks;                                                                                                       \
+        is_db += RV_BK * 4;                                                                                            \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
+    }
+    for (int s_ = 0; s_ < RV_NSTAGE - 1 && s_ < nk; ++s_) RV_STAGE()
+    float acc = 0.0f;
+    const int u = tid & 15;
+    const int sw = (u >> 1) & 7;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int ahead = nk - 1 - ks;                       // stages in flight beyond this one: min(ahead, 14), 3 DMAs each
+        if (ahead >= RV_NSTAGE - 2) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned char* st = rvm + (ks & (RV_NSTAGE - 1)) * RV_STAGE_BYTES;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const fv4 wv = *reinterpret_cast<const fv4*>(st + u * 128 + ((c ^ sw) << 4));
+            const fv4 xv = *reinterpret_cast<const fv4*>(st + 2048 + c * 16);
+            acc = fmaf(xv.x, wv.x, acc);
+            acc = fmaf(xv.y, wv.y, acc);
+            acc = fmaf(xv.z, wv.z, acc);
+            acc = fmaf(xv.w, wv.w, acc);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this stage's reads are done before its slot is refilled
+        if (is_ks < nk) RV_STAGE()
+    }
+#undef RV_STAGE
+    const int n = n0 + tid;
+    if (tid < RV_UNITS && n < p.units) {
+        const float bias = p.bias ? p.bias[n] : 0.0f;
+        const float sc = p.scale ? p.scale[n] : 1.0f;
+        const float sh = p.shift ? p.shift[n] : 0.0f;
+        float v = apply_act(acc + bias, p.act);
+        if (p.scale) v = v * sc + sh;
+        const int64_t off = ((int64_t)b * p.Tout + t) * p.ldy + n;
+        if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off] = v;
+        else reinterpret_cast<unsigned short*>(p.y)[off] = f2bf(v);
+    }
+}
+
 // ------------------------------------------------------------------------------------ elementwise helpers
 __global__ void affine_act_kernel(const float* __restrict__ x, int64_t total, int D, int act,
                                   const float* __restrict__ scale, const float* __restrict__ shift,
@@ -2031,7 +2244,23 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         KTF_REQUIRE(d->x_dtype == KTF_F32 && d->w_dtype == KTF_F32, "ktf_tdnn: F32 gemm needs fp32 x and w");
         // W must cover round_up(units, 128) rows (the host pads to 256)
         const int64_t wg128 = (int64_t)ktf_cdiv(d->units, 128) * ktf_cdiv(Tout, 128) * B;
-        if (wg128 >= 256) {
+        const char* lat_env = getenv("KTF_F32_LATENCY");                    // "0": 128x128 / register-staged tiles only (A/B, parity test)
+        const bool lat = !(lat_env && lat_env[0] == '0');
+        if (lat && B * Tout <= 8) {
+            dim3 grid((unsigned)ktf_cdiv(d->units, RV_UNITS), (unsigned)Tout, (unsigned)B);
+            hipLaunchKernelGGL(tdnn_f32_rowvec_kernel, grid, dim3(64), 0, st, p);
+        } else if (lat && wg128 < 256) {
+            dim3 grid((unsigned)ktf_cdiv(d->units, FS_BM), (unsigned)ktf_cdiv(Tout, FS_BM), (unsigned)B);
+            if (d->din_pad % 64 == 0) {
+                const int lds = FS_NSTAGE * 2 * FS_BM * 64 * 4;                 // 128 KiB
+                (void)hipFuncSetAttribute((const void*)tdnn_f32s_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(tdnn_f32s_kernel<64>, grid, dim3(1024), lds, st, p);
+            } else {
+                const int lds = FS_NSTAGE * 2 * FS_BM * 32 * 4;                 // 64 KiB
+                (void)hipFuncSetAttribute((const void*)tdnn_f32s_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(tdnn_f32s_kernel<32>, grid, dim3(1024), lds, st, p);
+            }
+        } else if (wg128 >= 256) {
             dim3 grid((unsigned)ktf_cdiv(d->units, 128), (unsigned)ktf_cdiv(Tout, 128), (unsigned)B);
             hipLaunchKernelGGL((tdnn_f32_kernel<2, 16>), grid, dim3(256), 0, st, p);
         } else {

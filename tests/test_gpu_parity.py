@@ -6,6 +6,8 @@ Tolerances: integer/index work exact; fp32 stages at the reference's RMSE bounds
 
 import json
 
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -293,6 +295,53 @@ def test_tdnn_options_vs_oracle(gemm, tol):
         assert got.shape == want.shape, (got.shape, want.shape)
         err = np.abs(got - want).max()
         assert err < tol, (gemm, B, T, D, U, ctx, sub, pad, act, err)
+
+
+def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
+    """Few workgroups (a single utterance) take the LDS-DMA-staged fp32 kernels: 64x64 MFMA tiles, and a row-vector fmaf
+    chain for <= 8 output rows (tdnn6). Both sum in K order like the fp32 MFMA tile kernels, so the outputs are
+    bit-identical (KTF_F32_LATENCY=0 forces the tile kernels) and a batch still equals its single-utterance calls."""
+    rng = np.random.default_rng(5)
+    for (B, T, D, U, ctx, sub, pad, act) in [
+        (1, 1, 3000, 512, [0], 1, "SAME", None),            # row-vector kernel
+        (5, 1, 128, 48, [0], 1, "SAME", "relu"),
+        (2, 4, 40, 70, [-1, 0, 1], 1, "SAME", "tanh"),
+        (1, 9, 33, 17, [-2, 0, 2], 1, "VALID", None),
+        (2, 7, 64, 130, [-1, 1], 2, "SAME", "sigmoid"),
+        (1, 998, 512, 512, [-2, 0, 2], 1, "SAME", "relu"),  # 64x64 DMA kernel
+        (1, 300, 512, 1500, [0], 1, "SAME", None),
+        (3, 131, 40, 33, [-1, 0, 2], 3, "SAME", "sigmoid"),
+        (2, 140, 96, 130, [-2, 0, 2], 1, "VALID", "tanh"),
+        (1, 65, 30, 64, [-2, -1, 0, 1, 2], 1, "SAME", None),
+    ]:
+        x = rng.standard_normal((B, T, D)).astype(np.float32)
+        W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+        b = rng.standard_normal(U).astype(np.float32)
+        t = Ls.TDNN(U, context=list(ctx), subsampling_factor=sub, padding=pad, activation=act)
+        t.build(x.shape)
+        t.set_weights([W, b])
+        lens = torch.as_tensor(rng.integers(max(T // 2, 1), T + 1, B).astype(np.int32), device="cuda") if T > 9 else None
+        def run():
+            if lens is None:
+                return host(t(x))
+            xin = t.prepare_input(dev(x), ktf._lib.GEMM_F32)
+            return host(t.forward(xin, lens=lens))[:, :, :U]
+        got = run()
+        os.environ["KTF_F32_LATENCY"] = "0"
+        try:
+            tile = run()
+        finally:
+            del os.environ["KTF_F32_LATENCY"]
+        if lens is None:
+            assert np.array_equal(got, tile), (B, T, D, U, np.abs(got - tile).max())
+            want = O.tdnn(x, W, b, ctx, sub, pad, act, dtype=np.float64)
+            assert got.shape == want.shape and np.abs(got - want).max() < 2e-5
+        else:                                                # ragged: rows beyond an utterance's length are unspecified
+            ol = [t.outputTimesteps(int(n)) for n in lens.cpu().numpy()]
+            for i in range(B):
+                assert np.array_equal(got[i, : ol[i]], tile[i, : ol[i]]), (B, T, D, U, i)
+                want = O.tdnn(x[i:i + 1, : int(lens[i])], W, b, ctx, sub, pad, act, dtype=np.float64)
+                assert np.abs(got[i, : ol[i]] - want[0]).max() < 2e-5
 
 
 @pytest.mark.parametrize("gemm", ["bf16", "f16"])
