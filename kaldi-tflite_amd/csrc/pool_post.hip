@@ -5,8 +5,8 @@
 #include "common.h"
 
 // ------------------------------------------------------------------------------------ stats pooling (reduce)
-// One workgroup = one utterance x 128 columns; 4 row-groups (waves) stride the time axis, each lane owns
-// two adjacent columns (8-byte fp32 / 4-byte bf16 loads, 512/256 B per wave-instruction).
+// One workgroup = one utterance x CW columns; row groups stride the time axis, each thread owns two adjacent columns
+// (8-byte fp32 / 4-byte bf16 or half loads).
 template <typename T>
 __device__ __forceinline__ float2 load2(const T* p);
 template <>
@@ -162,8 +162,11 @@ __global__ __launch_bounds__(XP_THREADS) void xvec_post_kernel(const float* __re
     for (int j0 = 0; j0 < out_dim; j0 += J) {
         const int j = j0 + jl;
         float acc = 0.f;
-        if (part < P && j < out_dim)
-            for (int i = i_lo; i < i_hi; ++i) acc += xc[i] * A[(int64_t)i * out_dim + j];
+        if (part < P && j < out_dim) {
+            const float* ap = A + (int64_t)i_lo * out_dim + j;
+#pragma unroll 16                                           // loads of 16 rows in flight; the sum stays one ordered chain
+            for (int i = i_lo; i < i_hi; ++i, ap += out_dim) acc += xc[i] * *ap;
+        }
         part_s[tid] = acc;
         __syncthreads();
         if (part == 0 && j < out_dim) {
