@@ -127,6 +127,7 @@ class Sequential:
         return steps
 
     split_planes = os.environ.get("KTF_X3_SPLIT", "1") != "0"     # bf16x3: hi/lo activation planes between wide layers
+    x3_min_tiles = 64              # bf16x3 batches with fewer 256-row tiles than this run on the exact fp32 kernels
 
     def run_ragged(self, x, lens=None):
         """x: (B, T, D) view of an utterance-strided buffer whose row stride is a multiple of 8 and >= round_up(D, 32)
@@ -136,6 +137,10 @@ class Sequential:
         if steps is None:
             raise NotImplementedError("this layer stack is not supported by the fused ragged runner")
         gemm = _GEMM[self.gemm]
+        if gemm == L.GEMM_BF16X3 and x.shape[0] * ((x.shape[1] + 255) // 256) < self.x3_min_tiles:
+            # a handful of 256-row tiles (single utterances) cannot fill the chip on the split-bf16 kernels; the exact
+            # fp32 kernels have small-tile forms and are faster there (0.22 vs 0.39 ms for one 10 s utterance)
+            gemm = L.GEMM_F32
         act_dtype = L.act_torch_dtype(gemm)
         pooled = False
         skip = False

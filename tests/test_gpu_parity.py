@@ -17,6 +17,8 @@ import synth
 import kaldi_tflite_amd as ktf
 from oracle import ktf_oracle as O
 
+ktf.models.Sequential.x3_min_tiles = 0     # the split-bf16 tests below must reach the split-bf16 kernels even at toy sizes
+
 pytestmark = pytest.mark.gpu
 Ls = ktf.layers
 
@@ -644,6 +646,21 @@ def test_bf16x3_split_planes_equal_fp32_activation_path():
         n = want.shape[0]
         assert n > 0 and np.abs(a[i, :n] - b[i, :n]).max() < 1e-5       # same operands; MFMA shape / summation order differ
         assert np.abs(a[i, :n] - want).max() < 2e-5, np.abs(a[i, :n] - want).max()
+
+
+def test_bf16x3_tiny_batches_run_on_the_fp32_kernels():
+    # a single utterance is a handful of 256-row tiles: the split-bf16 model hands it to the exact fp32 kernels
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=False)
+    wav = synth.make_wav(1, 16000 * 3, seed=8)
+    x3 = synth.build_extractor(ktf, cfg, w, gemm="bf16x3")
+    f32 = synth.build_extractor(ktf, cfg, w, gemm="f32")
+    forced = host(x3(dev(wav)))
+    x3.xvec.x3_min_tiles = 64
+    routed = host(x3(dev(wav)))
+    exact = host(f32(dev(wav)))
+    assert np.array_equal(routed, exact)
+    assert not np.array_equal(forced, exact) and np.abs(forced - exact).max() < 1e-4
 
 
 def test_fused_stats_pooling_matches_unfused():
