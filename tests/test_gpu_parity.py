@@ -760,6 +760,42 @@ def test_extractor_8khz_callhome_topology(gemm, tol):
     assert np.array_equal(host(mdl(wav.astype(np.int16))), got)
 
 
+def test_streaming_recipe_chunks_equal_the_whole_recording():
+    """The reference streams long recordings by letting the CALLER pad each chunk with context from the previous one and
+    switching the layers to padding="VALID" (cmvn.py:32-35, framing.py:227-230, README "long audio streams"). The same
+    recipe on this build: chunked results equal the corresponding interior slice of the whole-recording result."""
+    rng = np.random.default_rng(41)
+    wav = synth.make_wav(1, 16000 * 12, seed=77)
+    fcfg = dict(frame_length_ms=25.0, frame_shift_ms=10.0, sample_frequency=16000.0)
+    mfcc = Ls.MFCC(num_mfccs=30, num_mels=30, sample_frequency=16000.0, low_freq_cutoff=20.0, high_freq_cutoff=-400.0)
+    fr = Ls.Framing(**fcfg, dynamic_input_shape=True)
+    whole = host(mfcc(fr(dev(wav))))                                   # (1, T, 30)
+    T = whole.shape[1]
+    # front-end: frames [a, b) need samples [160a, 160(b-1) + 400): frames are independent -> bit-identical
+    a, b = 311, 703
+    chunk = host(mfcc(fr(dev(wav[:, 160 * a: 160 * (b - 1) + 400]))))
+    assert chunk.shape[1] == b - a and np.array_equal(chunk[0], whole[0, a:b])
+    # CMVN: output frames [a, b) of the SAME-padded whole = VALID on frames [a - N//2, b + (N-1)//2)
+    N = 300
+    cm_whole = host(Ls.CMVN(window=N, padding="SAME")(whole))
+    cm_chunk = host(Ls.CMVN(window=N, padding="VALID")(whole[:, a - N // 2: b + (N - 1) // 2]))
+    assert cm_chunk.shape[1] == b - a and np.abs(cm_chunk[0] - cm_whole[0, a:b]).max() < 2e-5
+    # TDNN stack: VALID padding consumes the context frames the caller supplied; fp32 rows are bit-identical
+    x = cm_whole
+    t1 = Ls.TDNN(64, context=[-2, -1, 0, 1, 2]); t2 = Ls.TDNN(48, context=[-3, 0, 3], activation="relu")
+    v1 = Ls.TDNN(64, context=[-2, -1, 0, 1, 2], padding="VALID"); v2 = Ls.TDNN(48, context=[-3, 0, 3], activation="relu", padding="VALID")
+    W1 = (rng.standard_normal((64, 150)) / 12).astype(np.float32); b1 = rng.standard_normal(64).astype(np.float32)
+    W2 = (rng.standard_normal((48, 192)) / 14).astype(np.float32); b2 = rng.standard_normal(48).astype(np.float32)
+    for l, Wb in ((t1, (W1, b1)), (v1, (W1, b1))):
+        l.build(x.shape); l.set_weights(list(Wb))
+    h_whole = t1(x)
+    for l, Wb in ((t2, (W2, b2)), (v2, (W2, b2))):
+        l.build(tuple(h_whole.shape)); l.set_weights(list(Wb))
+    y_whole = host(t2(h_whole))
+    y_chunk = host(v2(v1(x[:, a - 5: b + 5])))                         # 2 + 3 context frames on each side
+    assert y_chunk.shape[1] == b - a and np.array_equal(y_chunk[0], y_whole[0, a:b])
+
+
 def test_sequential_from_config_dense_input_equals_oracle():
     w = synth.make_weights(seed=5, narrow=True)
     mdl = synth.build_sequential(ktf, w)
