@@ -300,9 +300,10 @@ def test_tdnn_options_vs_oracle(gemm, tol):
 
 
 def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
-    """Few workgroups (a single utterance) take the LDS-DMA-staged fp32 kernels: 64x64 MFMA tiles, and a row-vector fmaf
-    chain for <= 8 output rows (tdnn6). Both sum in K order like the fp32 MFMA tile kernels, so the outputs are
-    bit-identical (KTF_F32_LATENCY=0 forces the tile kernels) and a batch still equals its single-utterance calls."""
+    """Few workgroups (a single utterance) take the LDS-DMA-staged fp32 kernels: 64x64 tiles of 16x16x4 MFMAs, and a
+    row-vector fmaf chain for <= 8 output rows (tdnn6). Both sum in K order like the 32x32x2 tile kernels
+    (KTF_F32_LATENCY=0 forces those), so the outputs are bit-identical and a batch still equals its single-utterance
+    calls; the two large shapes at the end check that the throughput kernel agrees with itself under the switch."""
     rng = np.random.default_rng(5)
     for (B, T, D, U, ctx, sub, pad, act) in [
         (1, 1, 3000, 512, [0], 1, "SAME", None),            # row-vector kernel
@@ -315,6 +316,8 @@ def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
         (3, 131, 40, 33, [-1, 0, 2], 3, "SAME", "sigmoid"),
         (2, 140, 96, 130, [-2, 0, 2], 1, "VALID", "tanh"),
         (1, 65, 30, 64, [-2, -1, 0, 1, 2], 1, "SAME", None),
+        (8, 1000, 64, 500, [-1, 0, 1], 1, "SAME", "relu"),  # >= 256 128-tiles: throughput kernel either way
+        (20, 300, 40, 701, [-2, 2], 2, "VALID", None),
     ]:
         x = rng.standard_normal((B, T, D)).astype(np.float32)
         W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
