@@ -1944,7 +1944,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 // fp32 FMAs -- the summation order of v_mfma_f32_32x32x2_f32 -- so they are bit-identical to the 128x128 tile kernel and a
 // batch still equals its single-utterance calls.
 //
-// (1) 64x64 tile, SIXTEEN waves of one 16x16 block each (v_mfma_f32_16x16x4_f32). K-step 64 when the per-context width
+// (1) 64 x BN tile, one 16x16 block (v_mfma_f32_16x16x4_f32) per wave: sixteen waves at BN = 64. K-step 64 when the per-context width
 //     allows it, else 32; 4-stage LDS-DMA ring (128 / 64 KiB), loads 3 steps ahead, one or two 16-byte DMAs per thread and
 //     stage. Rows are BK*4 bytes; chunk c of row r sits at position c ^ (r & (CH-1)) (2-way on the scalar fragment reads).
 //     Measured at K = 1536 on one utterance (998 x 512 outputs, 128 workgroups): 40 us; four waves of one 32x32x2 block
@@ -1952,15 +1952,24 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 //     32 with this shape 44 us; 8 stages / 7 steps ahead the same. Timing-only ablations (K-step 32): without the refill
 //     DMAs 41 us, without the MFMAs 24 us -- the step is the CU's fp32 MFMA time (64x64x32 = 1024 cycles) plus about as
 //     much LDS fragment traffic (each operand block is read by four waves), which one workgroup per CU cannot overlap.
+//     BN = 32 (64 x 32 tiles, eight waves) when 64 x 64 tiles would leave CUs idle: twice the workgroups, half the MFMA and
+//     LDS time per CU for 1.5x the L2->LDS bytes (the same layer: 26 us).
 #define FS_BM 64
 #define FS_NSTAGE 4
-template <int BK>
-__global__ __launch_bounds__(1024) void tdnn_f32s_kernel(TdnnParams p) {
+template <int BK, int BN>
+__global__ __launch_bounds__(64 * 4 * (BN / 16)) void tdnn_f32s_kernel(TdnnParams p) {
+    constexpr int WN = BN / 16;                              // waves across the tile's columns
+    constexpr int NT = 64 * 4 * WN;                          // 1024 / 512 threads
     constexpr int CH = BK / 4;                               // 16-byte chunks per row
     constexpr int ROWB = BK * 4;                             // bytes per staged row
-    constexpr int TILE_BYTES = FS_BM * ROWB;                 // 8 / 16 KiB per operand
-    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-    constexpr int NDMA = (2 * FS_BM * CH) / 1024;            // DMAs per thread and stage: 1 / 2
+    constexpr int A_BYTES = FS_BM * ROWB, W_BYTES = BN * ROWB;
+    constexpr int TILE_BYTES = A_BYTES;                      // offset of the W tile inside a stage
+    constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+    constexpr bool HALVES = (FS_BM * CH + BN * CH == NT);    // <32,64>: threads 0-511 stage A, 512-1023 stage W
+    constexpr int NA = HALVES ? 1 : (FS_BM * CH) / NT;       // DMAs per thread and stage into the A tile
+    constexpr int NW = HALVES ? 0 : (BN * CH) / NT;          // ... and into the W tile
+    constexpr int NDMA = HALVES ? 1 : NA + NW;
+    static_assert(HALVES || ((FS_BM * CH) % NT == 0 && (BN * CH) % NT == 0), "staging does not divide");
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
     const int b = blockIdx.z;
     const int len = p.lens ? p.lens[b] : (int)p.T;
@@ -1969,20 +1978,32 @@ __global__ __launch_bounds__(1024) void tdnn_f32s_kernel(TdnnParams p) {
     if (p.out_lens && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
     const int t0 = blockIdx.y * FS_BM;
     if (t0 >= out_len || len <= 0) return;
-    const int n0 = blockIdx.x * FS_BM;
+    const int n0 = blockIdx.x * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
 
-    // staging: the 2 * 64 * CH chunks of a stage (A tile, then W tile) are dealt to the 1024 threads in order; chunk q of
-    // a tile -> row q / CH, LDS position q % CH holds global chunk (q % CH) ^ (row & (CH-1))
-    const int q = (NDMA == 1) ? (tid & 511) : tid;
-    const bool isw = (NDMA == 1) && tid >= 512;              // BK = 32: threads 512-1023 stage the W tile
-    const int srow = q / CH;
-    const unsigned scb = (unsigned)(((q % CH) ^ (srow & (CH - 1))) * 16);
-    const int a_t = start + (t0 + srow) * p.sub;
+    // staging: chunk q of a tile -> row q / CH, LDS position q % CH holds global chunk (q % CH) ^ (row & (CH-1)); a DMA
+    // instruction of the workgroup covers NT consecutive chunks
+    const bool isw = HALVES && tid >= NT / 2;
+    constexpr int NAq = NA > 0 ? NA : 1, NWq = NW > 0 ? NW : 1;
+    int a_t[NAq];
+    unsigned a_cb[NAq], w_ob[NWq];
+#pragma unroll
+    for (int i = 0; i < NAq; ++i) {
+        const int q = HALVES ? (tid & (NT / 2 - 1)) : i * NT + tid;
+        const int row = q / CH;
+        a_cb[i] = (unsigned)(((q % CH) ^ (row & (CH - 1))) * 16);
+        a_t[i] = start + (t0 + row) * p.sub;
+    }
+#pragma unroll
+    for (int i = 0; i < NWq; ++i) {
+        const int q = HALVES ? (tid & (NT / 2 - 1)) : i * NT + tid;
+        const int row = q / CH;
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 4u + (unsigned)(((q % CH) ^ (row & (CH - 1))) * 16);
+    }
     const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 4;
-    const char* wrow = reinterpret_cast<const char*>(p.w) + (int64_t)(n0 + srow) * p.ktot * 4 + scb;
+    const char* wb = reinterpret_cast<const char*>(p.w);
     const unsigned ldxb = (unsigned)p.ldx * 4u;
     const int nk = p.ktot / BK;
     const int lenm1 = len - 1;
@@ -1991,15 +2012,22 @@ __global__ __launch_bounds__(1024) void tdnn_f32s_kernel(TdnnParams p) {
 #define FS_STAGE()                                                                                                     \
     {                                                                                                                  \
         unsigned char* st_ = fsm + (is_ks & (FS_NSTAGE - 1)) * STAGE_BYTES + wave * 1024;                              \
-        int r_ = a_t + is_off;                                                                                         \
-        r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
-        const char* xs_ = xb + ((unsigned)r_ * ldxb + scb + (unsigned)is_db);                                          \
-        const char* ws_ = wrow + is_ks * ROWB;                                                                         \
-        if (NDMA == 1) {                                     /* waves 8-15 land in the W tile: wave * 1024 >= TILE_BYTES */ \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(isw ? ws_ : xs_), (lds_ptr_t*)st_, 16, 0, 0);                \
+        if (HALVES) {                                        /* waves 8-15 land in the W tile: wave * 1024 >= A_BYTES */ \
+            int r_ = a_t[0] + is_off;                                                                                  \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const char* src_ = isw ? wb + (w_ob[0] + (unsigned)(is_ks * ROWB))                                         \
+                                   : xb + ((unsigned)r_ * ldxb + a_cb[0] + (unsigned)is_db);                           \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)src_, (lds_ptr_t*)st_, 16, 0, 0);                             \
         } else {                                                                                                       \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)xs_, (lds_ptr_t*)st_, 16, 0, 0);                              \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)ws_, (lds_ptr_t*)(st_ + TILE_BYTES), 16, 0, 0);               \
+            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
+                int r_ = a_t[i] + is_off;                                                                              \
+                r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                           \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + ((unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db)),\
+                                                 (lds_ptr_t*)(st_ + i * (NT * 16)), 16, 0, 0);                         \
+            }                                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                             \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + (w_ob[i] + (unsigned)(is_ks * ROWB))),              \
+                                                 (lds_ptr_t*)(st_ + TILE_BYTES + i * (NT * 16)), 16, 0, 0);            \
         }                                                                                                              \
         ++is_ks;                                                                                                       \
         is_db += ROWB;                                                                                                 \
@@ -2024,9 +2052,14 @@ __global__ __launch_bounds__(1024) void tdnn_f32s_kernel(TdnnParams p) {
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
+        } else if (NDMA == 2) {
             if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            static_assert(NDMA <= 3, "vmcnt table");
+            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
@@ -2250,16 +2283,20 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             dim3 grid((unsigned)ktf_cdiv(d->units, RV_UNITS), (unsigned)Tout, (unsigned)B);
             hipLaunchKernelGGL(tdnn_f32_rowvec_kernel, grid, dim3(64), 0, st, p);
         } else if (lat && wg128 < 256) {
-            dim3 grid((unsigned)ktf_cdiv(d->units, FS_BM), (unsigned)ktf_cdiv(Tout, FS_BM), (unsigned)B);
+            const int64_t wg64 = (int64_t)ktf_cdiv(d->units, FS_BM) * ktf_cdiv(Tout, FS_BM) * B;
+#define FS_LAUNCH(BK_, BN_)                                                                                            \
+    do {                                                                                                               \
+        const int lds = FS_NSTAGE * (FS_BM + BN_) * BK_ * 4;                                                           \
+        dim3 grid_((unsigned)ktf_cdiv(d->units, BN_), (unsigned)ktf_cdiv(Tout, FS_BM), (unsigned)B);                   \
+        (void)hipFuncSetAttribute((const void*)tdnn_f32s_kernel<BK_, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((tdnn_f32s_kernel<BK_, BN_>), grid_, dim3(64 * 4 * (BN_ / 16)), lds, st, p);                 \
+    } while (0)
             if (d->din_pad % 64 == 0) {
-                const int lds = FS_NSTAGE * 2 * FS_BM * 64 * 4;                 // 128 KiB
-                (void)hipFuncSetAttribute((const void*)tdnn_f32s_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(tdnn_f32s_kernel<64>, grid, dim3(1024), lds, st, p);
+                if (wg64 < 256) FS_LAUNCH(64, 32); else FS_LAUNCH(64, 64);
             } else {
-                const int lds = FS_NSTAGE * 2 * FS_BM * 32 * 4;                 // 64 KiB
-                (void)hipFuncSetAttribute((const void*)tdnn_f32s_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(tdnn_f32s_kernel<32>, grid, dim3(1024), lds, st, p);
+                FS_LAUNCH(32, 64);
             }
+#undef FS_LAUNCH
         } else if (wg128 >= 256) {
             dim3 grid((unsigned)ktf_cdiv(d->units, 128), (unsigned)ktf_cdiv(Tout, 128), (unsigned)B);
             hipLaunchKernelGGL((tdnn_f32_kernel<2, 16>), grid, dim3(256), 0, st, p);
