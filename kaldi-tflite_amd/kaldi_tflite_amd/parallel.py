@@ -81,4 +81,7 @@ def max_over_ranks(seconds, world, device):
 
 def barrier(world):
     if world > 1:
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])     # RCCL: name the device, do not let it guess from the rank
+        else:
+            dist.barrier()
