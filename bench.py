@@ -251,7 +251,7 @@ def _parity_sample(ktf, synth, cfg, w, gemm, dev):
     res = {}
     for g in sorted({gemm, "f32", "f16", "bf16x3"}):
         m = synth.build_extractor(ktf, cfg, w, gemm=g)
-        m.xvec.x3_min_tiles = 0        # two short utterances would be routed to the fp32 kernels: measure the split-bf16 ones
+        m.xvec.min_tiles = {}          # two short utterances would be routed to the fp32 kernels: measure the mode's own
         got = m(torch.as_tensor(wav, device=dev)).cpu().numpy()
         res[f"max_abs_dev_{g}"] = float(np.abs(got - want).max())
     return res

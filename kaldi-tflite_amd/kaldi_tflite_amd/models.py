@@ -127,7 +127,17 @@ class Sequential:
         return steps
 
     split_planes = os.environ.get("KTF_X3_SPLIT", "1") != "0"     # bf16x3: hi/lo activation planes between wide layers
-    x3_min_tiles = 64              # bf16x3 batches with fewer 256-row tiles than this run on the exact fp32 kernels
+    # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
+    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32}
+
+    def batch_gemm(self, B, T):
+        """GEMM arithmetic for a batch of B utterances of up to T frames: the model's mode, except that a handful of
+        256-row tiles (single utterances) cannot fill the chip on the 256-wide ring kernels -- the exact fp32 kernels have
+        small-tile forms and are faster there (one 10 s utterance: 0.19 ms against 0.20 bf16 / 0.39 split-bf16)."""
+        gemm = _GEMM[self.gemm]
+        if gemm != L.GEMM_F32 and B * ((T + 255) // 256) < self.min_tiles.get(self.gemm, 0):
+            gemm = L.GEMM_F32
+        return gemm
 
     def run_ragged(self, x, lens=None):
         """x: (B, T, D) view of an utterance-strided buffer whose row stride is a multiple of 8 and >= round_up(D, 32)
@@ -136,11 +146,7 @@ class Sequential:
         steps = self._plan()
         if steps is None:
             raise NotImplementedError("this layer stack is not supported by the fused ragged runner")
-        gemm = _GEMM[self.gemm]
-        if gemm == L.GEMM_BF16X3 and x.shape[0] * ((x.shape[1] + 255) // 256) < self.x3_min_tiles:
-            # a handful of 256-row tiles (single utterances) cannot fill the chip on the split-bf16 kernels; the exact
-            # fp32 kernels have small-tile forms and are faster there (0.22 vs 0.39 ms for one 10 s utterance)
-            gemm = L.GEMM_F32
+        gemm = self.batch_gemm(x.shape[0], x.shape[1])
         act_dtype = L.act_torch_dtype(gemm)
         pooled = False
         skip = False
@@ -429,7 +435,7 @@ class XvectorExtractor:
             mf.build((None, None, fr.frameWidth))
         T = fr.numFrames(N)
         D = mf.numMfccs
-        gemm = _GEMM[self.xvec.gemm]
+        gemm = self.xvec.batch_gemm(B, T)
         feat_dtype = L.act_torch_dtype(gemm)
         ws = self._workspace(B, T, D, x.device, feat_dtype)
         cfg = L.FrontendCfg.from_buffer_copy(mf._cfg)

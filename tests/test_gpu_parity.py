@@ -17,7 +17,7 @@ import synth
 import kaldi_tflite_amd as ktf
 from oracle import ktf_oracle as O
 
-ktf.models.Sequential.x3_min_tiles = 0     # the split-bf16 tests below must reach the split-bf16 kernels even at toy sizes
+ktf.models.Sequential.min_tiles = {}        # the reduced-precision tests below must reach their kernels even at toy sizes
 
 pytestmark = pytest.mark.gpu
 Ls = ktf.layers
@@ -659,7 +659,7 @@ def test_bf16x3_tiny_batches_run_on_the_fp32_kernels():
     x3 = synth.build_extractor(ktf, cfg, w, gemm="bf16x3")
     f32 = synth.build_extractor(ktf, cfg, w, gemm="f32")
     forced = host(x3(dev(wav)))
-    x3.xvec.x3_min_tiles = 64
+    x3.xvec.min_tiles = {"bf16x3": 32}
     routed = host(x3(dev(wav)))
     exact = host(f32(dev(wav)))
     assert np.array_equal(routed, exact)
