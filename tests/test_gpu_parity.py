@@ -763,6 +763,22 @@ def test_extractor_8khz_callhome_topology(gemm, tol):
     assert np.array_equal(host(mdl(wav.astype(np.int16))), got)
 
 
+def test_frontend_is_shift_equivariant_at_full_size():
+    # size-independent property at the BASELINE shape (1024 x 10 s): dropping the first frame_shift samples shifts the MFCC
+    # frames by exactly one -- frames depend on their own 400 samples only, so the match is bitwise, for fp32 and int16 input
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=False)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="bf16")
+    g = torch.Generator(device="cuda").manual_seed(99)
+    wav = torch.clamp(torch.round(1000.0 * torch.randn((1024, 160000), generator=g, device="cuda")), -32767, 32767)
+    for x in (wav, wav.to(torch.int16)):
+        a = mdl.features(x)[0]                                   # (1024, 998, 30)
+        b = mdl.features(x[:, 160:].contiguous())[0]             # (1024, 997, 30)
+        assert a.shape[1] == 998 and b.shape[1] == 997
+        assert torch.equal(a[:, 1:], b)
+        assert bool(torch.isfinite(a).all())
+
+
 def test_streaming_recipe_chunks_equal_the_whole_recording():
     """The reference streams long recordings by letting the CALLER pad each chunk with context from the previous one and
     switching the layers to padding="VALID" (cmvn.py:32-35, framing.py:227-230, README "long audio streams"). The same
