@@ -20,8 +20,6 @@ keep = []
 for s in steps:
     if s == "mfcc":
         m = synth.build_extractor(ktf, cfg, w, gemm="bf16"); m(wav); print("mfcc", bench._bench_mfcc(m, wav, ktf.ops)["ms"]); keep.append(m); continue
-    if s == "parity":
-        print("parity", bench._parity_sample(ktf, synth, cfg, w, "bf16", dev)); continue
     if s.startswith("keep:"):
         m = synth.build_extractor(ktf, cfg, w, gemm=s[5:]); print(s, t(lambda: m(wav), 3)); keep.append(m); continue
     m = synth.build_extractor(ktf, cfg, w, gemm=s)
