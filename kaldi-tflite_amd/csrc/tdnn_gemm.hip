@@ -82,6 +82,47 @@ __device__ __forceinline__ void store_tile32(const f32x16& acc, const TdnnParams
     }
 }
 
+// Same tile with the MFMA operands swapped (W block as A, x block as B): the accumulator is the transposed tile,
+//   time row = lane&31, unit = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
+// so a lane owns four CONSECUTIVE units per register quad and the store is 16 bytes instead of four 4-byte stores (the
+// 64 scalar stores per lane of store_tile32 cost the fp32 tile kernel ~20 % of its time). Products commute and the K
+// order is unchanged: bit-identical values.
+template <int ACT>
+__device__ __forceinline__ void store_tile32_t(const f32x16& acc, const TdnnParams& p, int64_t out_row0, int rows_valid,
+                                               int m_base, int n_base, int lane) {
+    const int m = m_base + (lane & 31);
+    if (m >= rows_valid) return;
+    const int64_t rowoff = (out_row0 + m) * p.ldy;
+    const bool vec_ok = (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = n_base + 8 * q + 4 * (lane >> 5);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool nv = n + e < p.units;
+            const float bias = (nv && p.bias) ? p.bias[n + e] : 0.0f;
+            v[e] = apply_act(acc[q * 4 + e] + bias, ACT);
+            if (p.scale) v[e] = v[e] * (nv ? p.scale[n + e] : 1.0f) + (nv ? p.shift[n + e] : 0.0f);
+        }
+        if (p.y_dtype == KTF_F32) {
+            float* yp = reinterpret_cast<float*>(p.y) + rowoff + n;
+            if (vec_ok && n + 4 <= p.units) {
+                *reinterpret_cast<fv4*>(yp) = fv4{v[0], v[1], v[2], v[3]};
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.units) yp[e] = v[e];
+            }
+        } else {
+            unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + rowoff + n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.units) yp[e] = f2bf(v[e]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------ F32
 // (64*MT) x (64*MT) block tile, K-step 16, 4 waves as 2x2, each wave MT x MT MFMA 32x32 tiles. MT = 2 (128x128) is the
 // throughput shape; MT = 1 (64x64) is used when the 128-tiles would fill fewer workgroups than the chip has CUs (one
@@ -174,7 +215,7 @@ __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0);   // transposed tile
         }
         if (ks + 1 < nk) store_lds(buf ^ 1);
         __syncthreads();
@@ -182,11 +223,18 @@ __global__ __launch_bounds__(256) void tdnn_f32_kernel(TdnnParams p) {
 
     const int rows_valid = out_len - t0;
     const int64_t out_row0 = (int64_t)b * p.Tout + t0;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < MT; ++j)
-            store_tile32(acc[i][j], p, out_row0, rows_valid, wm * 32 * MT + i * 32, n0 + wn * 32 * MT + j * 32, lane);
+    // the activation is a compile-time constant inside each copy: with the runtime switch inlined per value the epilogue
+    // was ~10k instructions of branches (sigmoid / tanh bodies 64 times over) and took 60-130 us per tile -- longer than
+    // the K-loop of the K = 512 layers (in-kernel s_memrealtime stamps)
+#define F32_EPILOGUE(A)                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                     \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                                 \
+            store_tile32_t<A>(acc[i][j], p, out_row0, rows_valid, wm * 32 * MT + i * 32, n0 + wn * 32 * MT + j * 32, lane);
+    if (p.act == KTF_ACT_NONE) { F32_EPILOGUE(KTF_ACT_NONE) }
+    else if (p.act == KTF_ACT_RELU) { F32_EPILOGUE(KTF_ACT_RELU) }
+    else if (p.act == KTF_ACT_SIGMOID) { F32_EPILOGUE(KTF_ACT_SIGMOID) }
+    else { F32_EPILOGUE(KTF_ACT_TANH) }
+#undef F32_EPILOGUE
 }
 
 // ------------------------------------------------------------------------------------ BF16 / BF16X3
@@ -2098,6 +2146,162 @@ __global__ __launch_bounds__(64 * 4 * (BN / 16)) void tdnn_f32s_kernel(TdnnParam
     }
 }
 
+// (3) throughput form: 128x128 tile, EIGHT waves of 2x4 blocks of v_mfma_f32_16x16x4_f32 (six scalar LDS reads feed eight
+//     MFMAs), K-step 32, double-buffered LDS-DMA stages (64 KiB) and <= 128 VGPRs, so TWO workgroups share a CU and one's
+//     prologue / epilogue / stage wait overlaps the other's MFMAs (in-kernel stamps on the register-staged 32x32x2 kernel:
+//     K-loop 200-250 us with three workgroups per CU taking turns, then 80-130 us of epilogue per tile). Operands swapped
+//     (W block as A): a lane owns four consecutive output columns of one row and stores 16 bytes. Same K order, same bits.
+//     122 TFLOP/s at B = 1024 against 111 for the register-staged kernel (K-step 16 with four workgroups per CU: the same).
+#define FT_BM 128
+#define FT_BK 32
+#define FT_TILE_BYTES (FT_BM * FT_BK * 4)            // 16 KiB per operand
+#define FT_STAGE_BYTES (2 * FT_TILE_BYTES)
+#define FT_LDS_BYTES (2 * FT_STAGE_BYTES)            // 64 KiB
+template <int ACT>
+__device__ __forceinline__ void f32t_epilogue(f32x4v (&acc)[2][4], const TdnnParams& p, int b, int t0, int n0, int out_len,
+                                              int wm, int wn, int lane) {
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+    const bool vec_ok = (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 15) == 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + kq * 4;
+        float bias[4], sc[4], sh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool nv = n + e < p.units;
+            bias[e] = (nv && p.bias) ? p.bias[n + e] : 0.0f;
+            sc[e] = (nv && p.scale) ? p.scale[n + e] : 1.0f;
+            sh[e] = (nv && p.shift) ? p.shift[n + e] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = wm * 32 + i * 16 + r16;
+            if (m >= rows_valid) continue;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] = apply_act(acc[i][j][e] + bias[e], ACT);
+                if (p.scale) v[e] = v[e] * sc[e] + sh[e];
+            }
+            const int64_t off = (out_row0 + m) * p.ldy + n;
+            if (p.y_dtype == KTF_F32) {
+                float* yp = reinterpret_cast<float*>(p.y) + off;
+                if (vec_ok && n + 4 <= p.units) {
+                    *reinterpret_cast<fv4*>(yp) = fv4{v[0], v[1], v[2], v[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.units) yp[e] = v[e];
+                }
+            } else {
+                unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + off;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (n + e < p.units) yp[e] = f2bf(v[e]);
+            }
+        }
+    }
+}
+
+template <int BK>
+__global__ __launch_bounds__(512, 2) void tdnn_f32t_kernel(TdnnParams p) {
+    constexpr int CH = BK / 4;                               // 16-byte chunks per row
+    constexpr int ROWB = BK * 4;
+    constexpr int TILE_BYTES = FT_BM * ROWB;
+    constexpr int STAGE_BYTES = 2 * TILE_BYTES;
+    constexpr int NDMA = (FT_BM * CH) / 512;                 // DMAs per thread, stage and operand: 2 (BK 32) / 1 (BK 16)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ftm[];
+    const int b = blockIdx.z;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = blockIdx.y * FT_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = blockIdx.x * FT_BM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    // staging: chunk q = i*512 + tid of a tile -> row q/CH, LDS position q%CH holds global chunk (q%CH) ^ (row&(CH-1))
+    int a_t[NDMA];
+    unsigned a_cb[NDMA], w_ob[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q / CH;
+        const unsigned chunk = (unsigned)(((q % CH) ^ (row & (CH - 1))) * 16);
+        a_cb[i] = chunk;
+        a_t[i] = start + (t0 + row) * p.sub;
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 4u + chunk;
+    }
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 4;
+    const char* wb = reinterpret_cast<const char*>(p.w);
+    const unsigned ldxb = (unsigned)p.ldx * 4u;
+    const int nk = p.ktot / BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 4;
+#define FT_STAGE()                                                                                                     \
+    {                                                                                                                  \
+        unsigned char* st_ = ftm + (is_ks & 1) * STAGE_BYTES + wave * 1024;                                            \
+        _Pragma("unroll") for (int i = 0; i < NDMA; ++i) {                                                             \
+            int r_ = a_t[i] + is_off;                                                                                  \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + ((unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db)),    \
+                                             (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);                                  \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + (w_ob[i] + (unsigned)(is_ks * ROWB))),                  \
+                                             (lds_ptr_t*)(st_ + TILE_BYTES + i * 8192), 16, 0, 0);                     \
+        }                                                                                                              \
+        ++is_ks;                                                                                                       \
+        is_db += ROWB;                                                                                                 \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
+    }
+    FT_STAGE()
+
+    f32x4v acc[2][4];                                        // [row block i][column block j] of the wave's 32 x 64 outputs
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int sw = r16 & (CH - 1);
+    const int a_row_off = (wm * 32 + r16) * ROWB + kq * 4;
+    const int b_row_off = TILE_BYTES + (wn * 64 + r16) * ROWB + kq * 4;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage ks landed (nothing else is in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (is_ks < nk) FT_STAGE()                           // stage ks+1 -> the buffer every wave finished reading
+        const unsigned char* st = ftm + (ks & 1) * STAGE_BYTES;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int co = (c ^ sw) << 4;                    // rows r, r+16, r+32, r+48 share r & (CH-1): same position
+            float av[2], bv[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const float*>(st + a_row_off + i * 16 * ROWB + co);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = *reinterpret_cast<const float*>(st + b_row_off + j * 16 * ROWB + co);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j], av[i], acc[i][j], 0, 0, 0);
+        }
+    }
+#undef FT_STAGE
+    if (p.act == KTF_ACT_NONE) f32t_epilogue<KTF_ACT_NONE>(acc, p, b, t0, n0, out_len, wm, wn, lane);
+    else if (p.act == KTF_ACT_RELU) f32t_epilogue<KTF_ACT_RELU>(acc, p, b, t0, n0, out_len, wm, wn, lane);
+    else if (p.act == KTF_ACT_SIGMOID) f32t_epilogue<KTF_ACT_SIGMOID>(acc, p, b, t0, n0, out_len, wm, wn, lane);
+    else f32t_epilogue<KTF_ACT_TANH>(acc, p, b, t0, n0, out_len, wm, wn, lane);
+}
+
 // (2) <= 8 output rows in all (tdnn6 of a single utterance: one 3000-long row against 512 units; the 64-tiles would run 8
 //     workgroups through a 94-step serial loop). One single-wave workgroup owns 16 units of ONE output row: all lanes
 //     issue the DMAs of a 16 x 32 weight slice and the row's 32 inputs into a 16-deep ring (loads 14 steps ahead, no
@@ -2277,7 +2481,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         KTF_REQUIRE(d->x_dtype == KTF_F32 && d->w_dtype == KTF_F32, "ktf_tdnn: F32 gemm needs fp32 x and w");
         // W must cover round_up(units, 128) rows (the host pads to 256)
         const int64_t wg128 = (int64_t)ktf_cdiv(d->units, 128) * ktf_cdiv(Tout, 128) * B;
-        const char* lat_env = getenv("KTF_F32_LATENCY");                    // "0": 128x128 / register-staged tiles only (A/B, parity test)
+        const char* lat_env = getenv("KTF_F32_LATENCY");                    // "0": the register-staged 32x32x2 tile kernels only (A/B, parity test)
         const bool lat = !(lat_env && lat_env[0] == '0');
         if (lat && B * Tout <= 8) {
             dim3 grid((unsigned)ktf_cdiv(d->units, RV_UNITS), (unsigned)Tout, (unsigned)B);
@@ -2297,6 +2501,10 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                 FS_LAUNCH(32, 64);
             }
 #undef FS_LAUNCH
+        } else if (lat) {
+            dim3 grid((unsigned)ktf_cdiv(d->units, FT_BM), (unsigned)ktf_cdiv(Tout, FT_BM), (unsigned)B);
+            (void)hipFuncSetAttribute((const void*)tdnn_f32t_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, FT_LDS_BYTES);
+            hipLaunchKernelGGL(tdnn_f32t_kernel<32>, grid, dim3(512), FT_LDS_BYTES, st, p);
         } else if (wg128 >= 256) {
             dim3 grid((unsigned)ktf_cdiv(d->units, 128), (unsigned)ktf_cdiv(Tout, 128), (unsigned)B);
             hipLaunchKernelGGL((tdnn_f32_kernel<2, 16>), grid, dim3(256), 0, st, p);

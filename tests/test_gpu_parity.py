@@ -300,10 +300,10 @@ def test_tdnn_options_vs_oracle(gemm, tol):
 
 
 def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
-    """Few workgroups (a single utterance) take the LDS-DMA-staged fp32 kernels: 64x64 tiles of 16x16x4 MFMAs, and a
-    row-vector fmaf chain for <= 8 output rows (tdnn6). Both sum in K order like the 32x32x2 tile kernels
-    (KTF_F32_LATENCY=0 forces those), so the outputs are bit-identical and a batch still equals its single-utterance
-    calls; the two large shapes at the end check that the throughput kernel agrees with itself under the switch."""
+    """The fp32 path runs on LDS-DMA-staged kernels: 128x128 tiles (two workgroups per CU), 64-row tiles when there are
+    few workgroups (a single utterance), and a row-vector fmaf chain for <= 8 output rows (tdnn6). All sum in K order
+    like the register-staged 32x32x2 tile kernels they replace (KTF_F32_LATENCY=0 brings those back), so the outputs are
+    bit-identical and a batch still equals its single-utterance calls."""
     rng = np.random.default_rng(5)
     for (B, T, D, U, ctx, sub, pad, act) in [
         (1, 1, 3000, 512, [0], 1, "SAME", None),            # row-vector kernel
@@ -316,7 +316,7 @@ def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
         (3, 131, 40, 33, [-1, 0, 2], 3, "SAME", "sigmoid"),
         (2, 140, 96, 130, [-2, 0, 2], 1, "VALID", "tanh"),
         (1, 65, 30, 64, [-2, -1, 0, 1, 2], 1, "SAME", None),
-        (8, 1000, 64, 500, [-1, 0, 1], 1, "SAME", "relu"),  # >= 256 128-tiles: throughput kernel either way
+        (8, 1000, 64, 500, [-1, 0, 1], 1, "SAME", "relu"),  # >= 256 128-tiles: throughput kernel
         (20, 300, 40, 701, [-2, 2], 2, "VALID", None),
     ]:
         x = rng.standard_normal((B, T, D)).astype(np.float32)
