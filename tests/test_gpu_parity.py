@@ -17,7 +17,15 @@ import synth
 import kaldi_tflite_amd as ktf
 from oracle import ktf_oracle as O
 
-ktf.models.Sequential.min_tiles = {}        # the reduced-precision tests below must reach their kernels even at toy sizes
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _reduced_modes_reach_their_kernels():
+    # the reduced-precision tests below must reach their kernels even at toy sizes (tiny batches are otherwise routed to fp32)
+    old = ktf.models.Sequential.min_tiles
+    ktf.models.Sequential.min_tiles = {}
+    yield
+    ktf.models.Sequential.min_tiles = old
 
 pytestmark = pytest.mark.gpu
 Ls = ktf.layers

@@ -110,6 +110,15 @@ def test_gemm_mode_selection_host_logic():
     assert (d.x_dtype, d.w_dtype, d.y_dtype, d.gemm) == (L.KTF_F16, L.KTF_F16, L.KTF_F16, L.GEMM_F16)
     with pytest.raises(ValueError):
         ktf.layers.TDNN(8, context=[0], gemm="fp8")
+    # batches of only a few 256-row tiles run on the exact fp32 kernels in every reduced mode (Sequential.batch_gemm)
+    S = ktf.models.Sequential
+    assert S([], gemm="bf16").batch_gemm(1, 998) == L.GEMM_F32 and S([], gemm="bf16").batch_gemm(2, 998) == L.GEMM_BF16
+    assert S([], gemm="f16").batch_gemm(5, 200) == L.GEMM_F32 and S([], gemm="f16").batch_gemm(6, 200) == L.GEMM_F16
+    assert S([], gemm="bf16x3").batch_gemm(7, 998) == L.GEMM_F32 and S([], gemm="bf16x3").batch_gemm(8, 998) == L.GEMM_BF16X3
+    assert S([], gemm="f32").batch_gemm(1024, 998) == L.GEMM_F32
+    m = S([], gemm="bf16")
+    m.min_tiles = {}
+    assert m.batch_gemm(1, 10) == L.GEMM_BF16
 
 
 def test_no_cpu_fallback():
