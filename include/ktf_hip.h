@@ -170,8 +170,9 @@ int ktf_vad_index(const float* feats, int64_t B, int64_t T, int32_t D, const Ktf
 int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int64_t ldx, const int32_t* lens,
                  const KtfCmvnCfg* cfg, float* out, int64_t ldo, int32_t* out_lens, float* work, void* stream);
 /* Fused hot path: VAD -> per-utterance compaction -> CMVN (xvector_extractor.py:162-166).
- * out_dtype KTF_F32 or KTF_BF16. idx_work = B*T int32, work = B*T*2*D floats. T <= 38,400 frames per utterance
- * (the frame -> row map of an utterance lives in LDS); longer recordings: ktf_vad_index + ktf_cmvn_f32, or split. */
+ * out_dtype KTF_F32, KTF_BF16 or KTF_F16. idx_work = B*T int32 (on return: the kept frame numbers of each utterance;
+ * for recordings of more than 38,400 frames, whose frame -> row map no longer fits in LDS beside the kernel's scratch, the
+ * map itself: row of frame t, or -1), work = B*T*2*D floats. Any T < 2^31 / ldo. */
 int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* vad, const KtfCmvnCfg* cmvn,
                  void* out, int32_t out_dtype, int64_t ldo, int32_t* lens, int32_t* idx_work, float* work,
                  void* stream);
@@ -199,8 +200,16 @@ typedef struct KtfTdnnDesc {
     int32_t act;            /* KTF_ACT_* */
     int32_t gemm;           /* KTF_GEMM_* */
     int32_t x_dtype, w_dtype, y_dtype;
-    int32_t reserved;
+    int32_t flags;          /* KTF_TDNN_* bits, 0 = default */
 } KtfTdnnDesc;
+
+/* KtfTdnnDesc.flags */
+#define KTF_TDNN_REF_TILES 1      /* KTF_GEMM_F32 only: run the register-staged 32x32x2 tile kernels, the bitwise reference the
+                                   * LDS-DMA-staged fp32 kernels are tested against (slower; same bits) */
+#define KTF_TDNN_DET_STATS 2      /* ktf_tdnn_stats / ktf_tdnn_split_stats only: run-to-run reproducible pooling. Every
+                                   * 128-row block of an utterance stores its fp64 column sums in a slot of its own instead
+                                   * of adding them with atomics; `sums` is then (B, ktf_stats_slots(T), 2, units), need not
+                                   * be zeroed, and is reduced in slot order by ktf_stats_finalize_slots */
 
 /* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
 int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);
@@ -211,7 +220,9 @@ int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* le
 
 /* ktf_tdnn fused with the reducing StatsPooling that follows it (sequential.py:68-79 order "tdnn5 -> stats"): the layer
  * output is never written; instead sums[b, 0, u] += sum_t y[b,t,u] and sums[b, 1, u] += sum_t y[b,t,u]^2 (fp64, over
- * the valid rows). `sums` (B, 2, units) must be zeroed by the caller before the call. Implemented by the bf16 ring
+ * the valid rows). `sums` (B, 2, units) must be zeroed by the caller before the call (the order of the fp64 atomic adds
+ * of an utterance's row blocks is not fixed: results can differ in the last fp64 bits from run to run; see
+ * KTF_TDNN_DET_STATS for the reproducible form). Implemented by the bf16 ring
  * kernels only: KTF_GEMM_BF16 (bf16 x) or KTF_GEMM_BF16X3 (fp32 x, w_lo given), units > 128, SAME padding,
  * subsampling 1. */
 int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
@@ -234,6 +245,12 @@ int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, vo
  * with n_b = lens[b] (or T when lens is NULL); stats_pooling.py:231-240. */
 int ktf_stats_finalize(const double* sums, const int32_t* lens, int64_t T, int64_t B, int32_t D, int32_t include_std,
                        float eps, float* out, int64_t ld_out, void* stream);
+/* KTF_TDNN_DET_STATS layout: number of 128-row slots of an utterance of T rows (2 * ceil(T / 256): whole 256-row tiles),
+ * and the finalize that adds the slots
+ * 0 .. ceil(n_b / 128) - 1 of sums (B, slots, 2, D) in that order before forming mean / std as above. */
+int64_t ktf_stats_slots(int64_t T);
+int ktf_stats_finalize_slots(const double* sums, int64_t slots, const int32_t* lens, int64_t T, int64_t B, int32_t D,
+                             int32_t include_std, float eps, float* out, int64_t ld_out, void* stream);
 
 /* elementwise y = act(x) * scale + shift per column (stand-alone ReLU / BatchNorm layers); scale/shift may be NULL */
 int ktf_affine_act_f32(const float* x, int64_t rows, int32_t D, int32_t act, const float* scale, const float* shift,

@@ -29,6 +29,19 @@ void ktf_set_error(const char* fmt, ...);
         }                                                                         \
     } while (0)
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS: once per call site (= kernel instantiation) and device, not per
+// launch (a per-launch hipFuncSetAttribute was ~10 host calls per batch-1 extraction).
+#define KTF_LDS_ONCE(bytes, ...)                                                                       \
+    do {                                                                                               \
+        static unsigned long long done_ = 0;                                                           \
+        int dev_ = 0;                                                                                  \
+        (void)hipGetDevice(&dev_);                                                                     \
+        if (!((__atomic_load_n(&done_, __ATOMIC_RELAXED) >> (dev_ & 63)) & 1ull)) {                    \
+            (void)hipFuncSetAttribute((const void*)(__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+            (void)__atomic_fetch_or(&done_, 1ull << (dev_ & 63), __ATOMIC_RELAXED);                    \
+        }                                                                                              \
+    } while (0)
+
 static inline int ktf_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 #ifdef __HIPCC__

@@ -22,6 +22,18 @@
 
 #include "common.h"
 
+// Kernel-selection knobs and the per-tile stamp buffer exist in probe builds only (-DKTF_TILE_PROBE, tools/tile_probe.py):
+// the product library reads no environment variable and keeps no state.
+#ifdef KTF_TILE_PROBE
+#define KTF_KNOB(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+static long long* g_probe_buf = nullptr;
+extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
+#define KTF_PROBE_BUF g_probe_buf
+#else
+#define KTF_KNOB(name, dflt) (dflt)
+#define KTF_PROBE_BUF ((long long*)nullptr)
+#endif
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) float fv4;
@@ -41,7 +53,21 @@ struct TdnnParams {
     int64_t T, ldx, ldy, Tout;
     int32_t units, din_pad, nctx, sub, valid, act, y_dtype, ktot;
     int32_t ctx[16];
+    int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
 };
+
+// Adds (slots == 0) or stores (slots > 0: block `slot` of utterance b is written by exactly one wave) a column's partial sums.
+__device__ __forceinline__ void stats_out(double* __restrict__ stats, const TdnnParams& p, int b, int slot, int n, double s, double q) {
+    if (p.stat_slots > 0) {
+        double* dst = stats + (((int64_t)b * p.stat_slots + slot) * 2) * p.units + n;
+        dst[0] = s;
+        dst[p.units] = q;
+    } else {
+        double* dst = stats + ((int64_t)b * 2) * p.units + n;
+        atomicAdd(dst, s);
+        atomicAdd(dst + p.units, q);
+    }
+}
 
 __device__ __forceinline__ int tdnn_out_len(int len, const TdnnParams& p, int& start) {
     start = 0;
@@ -634,11 +660,7 @@ __device__ __forceinline__ void ring_epilogue(f32x16 (&acc)[4][2], const TdnnPar
             s += __shfl_xor(s, 32, 64);      // the two half-waves hold the same column
             q += __shfl_xor(q, 32, 64);
             const int n = n0 + wn * 64 + j * 32 + (lane & 31);
-            if (lane < 32 && n < p.units) {
-                double* dst = stats + ((int64_t)b * 2) * p.units + n;
-                atomicAdd(dst, s);
-                atomicAdd(dst + p.units, q);
-            }
+            if (lane < 32 && n < p.units) stats_out(stats, p, b, (t0 >> 7) + wm, n, s, q);
         }
         return;
     }
@@ -706,7 +728,7 @@ __device__ __forceinline__ void ring_epilogue(f32x16 (&acc)[4][2], const TdnnPar
 
 // STATS: instead of storing y, the epilogue adds every column's sum and sum of squares over the tile's valid rows (fp64)
 // into stats[b][0|1][unit] — statistics pooling fused into the producing GEMM, the (B,T,units) activation never exists.
-template <int ACT, bool STATS, int DBG = 0>
+template <int ACT, bool STATS>
 __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                          double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -804,11 +826,11 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
     for (int ks = 0; ks < nk; ++ks) {
         if (ks + 2 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (DBG < 3) __builtin_amdgcn_s_barrier();      // DBG 3,4: no barrier (timing only)
+        __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // every wave is past the barrier, i.e. has finished reading stage ks-1: that buffer is refilled with stage ks+3
         // (the iterator's stage); its four DMA instructions are spread between the MFMA groups
-        const bool refill = (DBG == 0 || DBG == 2) && is_ks < nk;   // DBG 1,3,4: timing-only builds without the steady-state DMA
+        const bool refill = is_ks < nk;
         const unsigned char* sa = rsm + (ks & (R_NSTAGE - 1)) * R_STAGE_BYTES;
         const unsigned char* sb = sa + R_TILE_BYTES;
         if (ks == 0) {
@@ -825,10 +847,9 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
             for (int i = half * 2; i < half * 2 + 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (DBG != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
-                    else asm volatile("" :: "v"(a0[i]), "v"(b0[j]));
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);   // keep the MFMA group ahead of the LDS reads / DMA that follow it
-            if (half == 0 && (DBG != 4 || ks == 0)) {
+            if (half == 0) {
                 // second-half fragments of this stage: issued behind the first MFMA group so their latency is covered
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a1[i] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + i * 32 * 64 + coff1);
@@ -846,10 +867,9 @@ __global__ __launch_bounds__(512) void tdnn_bf16r_kernel(TdnnParams p, int mtile
             for (int i = half * 2; i < half * 2 + 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    if (DBG != 2) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-                    else asm volatile("" :: "v"(a1[i]), "v"(b1[j]));
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if (half == 0 && ks + 1 < nk && DBG != 4) {
+            if (half == 0 && ks + 1 < nk) {
                 // pre-read the first-half fragments of stage ks+1 (landed and visible since this K-step's barrier); all
                 // MFMAs that consume the old a0/b0 have been issued
                 const unsigned char* san = rsm + ((ks + 1) & (R_NSTAGE - 1)) * R_STAGE_BYTES;
@@ -929,11 +949,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
             s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);      // the four 16-lane groups hold the same column
             s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
             const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-            if (lane < 16 && n < p.units) {
-                double* dst = stats + ((int64_t)b * 2) * p.units + n;
-                atomicAdd(dst, s);
-                atomicAdd(dst + p.units, q);
-            }
+            if (lane < 16 && n < p.units) stats_out(stats, p, b, (t0 >> 7) + wm, n, s, q);
         }
         return;
     }
@@ -1592,11 +1608,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
             sm += __shfl_xor(sm, 16, 64); sq += __shfl_xor(sq, 16, 64);
             sm += __shfl_xor(sm, 32, 64); sq += __shfl_xor(sq, 32, 64);
             const int n = n0 + nl;
-            if (lane < 16 && n < p.units) {
-                double* dst = stats + ((int64_t)b * 2) * p.units + n;
-                atomicAdd(dst, sm);
-                atomicAdd(dst + p.units, sq);
-            }
+            if (lane < 16 && n < p.units) stats_out(stats, p, b, t0 >> 7, n, sm, sq);
         }
         H_PROBE(4)
         H_PROBE_HW()
@@ -2474,6 +2486,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.out_lens = out_lens; p.T = T; p.ldx = ldx; p.ldy = ldy; p.Tout = Tout;
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
     p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
+    p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
     for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
     hipStream_t st = (hipStream_t)stream;
     const unsigned ntiles = (unsigned)ktf_cdiv(d->units, 128);
@@ -2481,8 +2494,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         KTF_REQUIRE(d->x_dtype == KTF_F32 && d->w_dtype == KTF_F32, "ktf_tdnn: F32 gemm needs fp32 x and w");
         // W must cover round_up(units, 128) rows (the host pads to 256)
         const int64_t wg128 = (int64_t)ktf_cdiv(d->units, 128) * ktf_cdiv(Tout, 128) * B;
-        const char* lat_env = getenv("KTF_F32_LATENCY");                    // "0": the register-staged 32x32x2 tile kernels only (A/B, parity test)
-        const bool lat = !(lat_env && lat_env[0] == '0');
+        const bool lat = !(d->flags & KTF_TDNN_REF_TILES);   // flag: the register-staged 32x32x2 tile kernels (bitwise reference of the DMA-staged ones)
         if (lat && B * Tout <= 8) {
             dim3 grid((unsigned)ktf_cdiv(d->units, RV_UNITS), (unsigned)Tout, (unsigned)B);
             hipLaunchKernelGGL(tdnn_f32_rowvec_kernel, grid, dim3(64), 0, st, p);
@@ -2492,7 +2504,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     do {                                                                                                               \
         const int lds = FS_NSTAGE * (FS_BM + BN_) * BK_ * 4;                                                           \
         dim3 grid_((unsigned)ktf_cdiv(d->units, BN_), (unsigned)ktf_cdiv(Tout, FS_BM), (unsigned)B);                   \
-        (void)hipFuncSetAttribute((const void*)tdnn_f32s_kernel<BK_, BN_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        KTF_LDS_ONCE(lds, tdnn_f32s_kernel<BK_, BN_>); \
         hipLaunchKernelGGL((tdnn_f32s_kernel<BK_, BN_>), grid_, dim3(64 * 4 * (BN_ / 16)), lds, st, p);                 \
     } while (0)
             if (d->din_pad % 64 == 0) {
@@ -2503,7 +2515,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
 #undef FS_LAUNCH
         } else if (lat) {
             dim3 grid((unsigned)ktf_cdiv(d->units, FT_BM), (unsigned)ktf_cdiv(Tout, FT_BM), (unsigned)B);
-            (void)hipFuncSetAttribute((const void*)tdnn_f32t_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, FT_LDS_BYTES);
+            KTF_LDS_ONCE(FT_LDS_BYTES, tdnn_f32t_kernel<32>);
             hipLaunchKernelGGL(tdnn_f32t_kernel<32>, grid, dim3(512), FT_LDS_BYTES, st, p);
         } else if (wg128 >= 256) {
             dim3 grid((unsigned)ktf_cdiv(d->units, 128), (unsigned)ktf_cdiv(Tout, 128), (unsigned)B);
@@ -2533,7 +2545,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     do {                                                                                                    \
         const size_t lds = (size_t)2 * 128 * BfCfg<BK>::PITCH * 2 * (X3 ? 2 : 1) * sizeof(unsigned short);  \
         if (lds > 64 * 1024)                                                                                \
-            (void)hipFuncSetAttribute((const void*)tdnn_bf16_kernel<BK, XF, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            KTF_LDS_ONCE((int)lds, tdnn_bf16_kernel<BK, XF, X3>); \
         hipLaunchKernelGGL((tdnn_bf16_kernel<BK, XF, X3>), grid, dim3(256), lds, st, p);                     \
     } while (0)
         if (x3 && d->units > 128 && ldy % 4 == 0) {
@@ -2543,7 +2555,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
 #define X_LAUNCH1(A, ST, SP)                                                                                           \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)tdnn_x3r_kernel<A, ST, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, X_LDS_BYTES); \
+        KTF_LDS_ONCE(X_LDS_BYTES, tdnn_x3r_kernel<A, ST, SP>); \
         hipLaunchKernelGGL((tdnn_x3r_kernel<A, ST, SP>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
 #define X_LAUNCH(A)                                                                                                    \
@@ -2553,10 +2565,10 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     } while (0)
 #define XS_LAUNCH(A)                                                                                                   \
     do {                                                                                                               \
-        (void)hipFuncSetAttribute((const void*)tdnn_x3s_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, XS_LDS_BYTES); \
+        KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A>); \
         hipLaunchKernelGGL((tdnn_x3s_kernel<A>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
-            static const int x3s_env = getenv("KTF_X3S") ? atoi(getenv("KTF_X3S")) : 1;      // 0: 32x32x16 kernel (A/B)
+            const int x3s_env = KTF_KNOB("KTF_X3S", 1);      // probe builds: 0 = 32x32x16 kernel (A/B)
             if (split_in && stats_sums && x3s_env) {
                 if (d->act == KTF_ACT_NONE) XS_LAUNCH(KTF_ACT_NONE);
                 else if (d->act == KTF_ACT_RELU) XS_LAUNCH(KTF_ACT_RELU);
@@ -2585,30 +2597,30 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
 #define R_LAUNCH(A)                                                                                                    \
     do {                                                                                                               \
         if (stats_sums) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
+            KTF_LDS_ONCE(R_LDS_BYTES, tdnn_bf16r_kernel<A, true>); \
             hipLaunchKernelGGL((tdnn_bf16r_kernel<A, true>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
         } else {                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
+            KTF_LDS_ONCE(R_LDS_BYTES, tdnn_bf16r_kernel<A, false>); \
             hipLaunchKernelGGL((tdnn_bf16r_kernel<A, false>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr); \
         }                                                                                                              \
     } while (0)
                 // 128x256 tiles with two workgroups per CU win while the fixed per-tile phases are comparable to the K-loop
-                // (K <= 768); deeper K amortises them and the 256x256 tile moves fewer bytes per flop. KTF_HTILE=0/1 forces.
-                static const int htile_env = getenv("KTF_HTILE") ? atoi(getenv("KTF_HTILE")) : -1;
+                // (K <= 768); deeper K amortises them and the 256x256 tile moves fewer bytes per flop (probe builds: KTF_HTILE=0/1 forces).
+                const int htile_env = KTF_KNOB("KTF_HTILE", -1);
                 const bool htile = htile_env >= 0 ? (htile_env != 0) : (p.ktot <= 768);
                 if (htile && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE)) {
                     const int mt_h = ktf_cdiv(Tout, H_BM);
                     const int64_t gt_h = B * (int64_t)mt_h;
                     const int64_t nb_h = ((gt_h + 7) / 8) * 8 * ntiles_r;
                     KTF_REQUIRE(nb_h < (1ll << 31), "ktf_tdnn: grid too large");
-                    static long long* dbgptr = getenv("KTF_DBG_PTR") ? (long long*)strtoull(getenv("KTF_DBG_PTR"), nullptr, 10) : nullptr;
+                    long long* const dbgptr = KTF_PROBE_BUF;
 #define H_LAUNCH(A, ST)                                                                                                \
     do {                                                                                                               \
         if (f16) {                                                                                                     \
-            (void)hipFuncSetAttribute((const void*)tdnn_bf16h_kernel<A, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); \
+            KTF_LDS_ONCE(H_LDS_BYTES, tdnn_bf16h_kernel<A, ST, true>); \
             hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST, true>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums, dbgptr); \
         } else {                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)tdnn_bf16h_kernel<A, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES); \
+            KTF_LDS_ONCE(H_LDS_BYTES, tdnn_bf16h_kernel<A, ST, false>); \
             hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST, false>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums, dbgptr); \
         }                                                                                                              \
     } while (0)
@@ -2618,15 +2630,15 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                     KTF_CHECK_LAUNCH("ktf_tdnn");
                     return KTF_OK;
                 }
-                static const int mfma16 = getenv("KTF_MFMA16") ? atoi(getenv("KTF_MFMA16")) : 1;     // default: 16x16x32 variant (0 = 32x32x16, A/B)
+                const int mfma16 = KTF_KNOB("KTF_MFMA16", 1);     // 16x16x32 variant (probe builds: 0 = 32x32x16, A/B)
                 if ((mfma16 || f16) && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE)) {
 #define S_LAUNCH(A, ST)                                                                                                \
     do {                                                                                                               \
         if (f16) {                                                                                                     \
-            (void)hipFuncSetAttribute((const void*)tdnn_bf16r16_kernel<A, ST, true>, hipFuncAttributeMaxDynamicSharedMemorySize, R16_LDS_BYTES); \
+            KTF_LDS_ONCE(R16_LDS_BYTES, tdnn_bf16r16_kernel<A, ST, true>); \
             hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST, true>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
         } else {                                                                                                       \
-            (void)hipFuncSetAttribute((const void*)tdnn_bf16r16_kernel<A, ST, false>, hipFuncAttributeMaxDynamicSharedMemorySize, R16_LDS_BYTES); \
+            KTF_LDS_ONCE(R16_LDS_BYTES, tdnn_bf16r16_kernel<A, ST, false>); \
             hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST, false>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
         }                                                                                                              \
     } while (0)
@@ -2636,21 +2648,6 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                     KTF_CHECK_LAUNCH("ktf_tdnn");
                     return KTF_OK;
                 }
-                static const int dbg = getenv("KTF_GEMM_DBG") ? atoi(getenv("KTF_GEMM_DBG")) : 0;   // timing experiments only
-                if (dbg && d->act == KTF_ACT_RELU && !stats_sums) {
-#define R_DBG(N)                                                                                                      \
-    else if (dbg == N) {                                                                                              \
-        (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<KTF_ACT_RELU, false, N>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES); \
-        hipLaunchKernelGGL((tdnn_bf16r_kernel<KTF_ACT_RELU, false, N>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr); \
-    }
-                    if (false) {}
-                    R_DBG(1) R_DBG(3) R_DBG(4)
-#undef R_DBG
-                    else {
-                        (void)hipFuncSetAttribute((const void*)tdnn_bf16r_kernel<KTF_ACT_RELU, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, R_LDS_BYTES);
-                        hipLaunchKernelGGL((tdnn_bf16r_kernel<KTF_ACT_RELU, false, 2>), dim3((unsigned)nblocks), dim3(512), R_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, (double*)nullptr);
-                    }
-                } else
                 if (d->act == KTF_ACT_NONE) R_LAUNCH(KTF_ACT_NONE);
                 else if (d->act == KTF_ACT_RELU) R_LAUNCH(KTF_ACT_RELU);
                 else if (d->act == KTF_ACT_SIGMOID) R_LAUNCH(KTF_ACT_SIGMOID);
@@ -2661,7 +2658,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                 const int64_t gtiles = B * (int64_t)mtiles;
                 const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_g;
                 KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
-                (void)hipFuncSetAttribute((const void*)tdnn_bf16g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G_LDS_BYTES);
+                KTF_LDS_ONCE(G_LDS_BYTES, tdnn_bf16g_kernel);
                 hipLaunchKernelGGL(tdnn_bf16g_kernel, dim3((unsigned)nblocks), dim3(256), G_LDS_BYTES, st, p, mtiles, ntiles_g, (int)gtiles);
             } else if (k64) BF_LAUNCH(64, false, false); else BF_LAUNCH(32, false, false);
         }
@@ -2731,18 +2728,33 @@ extern "C" int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t
     return KTF_OK;
 }
 
+// 128-row blocks, rounded up to whole 256-row tiles (a 256-row tile always writes both of its blocks)
+extern "C" int64_t ktf_stats_slots(int64_t T) { return T <= 0 ? 2 : 2 * ((T + 255) / 256); }
+
 // mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)
-__global__ void stats_finalize_kernel(const double* __restrict__ sums, const int32_t* __restrict__ lens, int64_t T,
+__global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t slots, const int32_t* __restrict__ lens, int64_t T,
                                       int64_t B, int D, int include_std, float eps, float* __restrict__ out, int64_t ldo) {
     const int64_t total = B * D;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = e / D;
         const int c = (int)(e - b * D);
-        const double n = (double)(lens ? lens[b] : (int)T);
-        const double mean = sums[(b * 2) * D + c] / n;
+        const int len = lens ? lens[b] : (int)T;
+        const double n = (double)len;
+        double s = 0.0, q = 0.0;
+        if (slots == 0) {
+            s = sums[(b * 2) * D + c];
+            q = sums[(b * 2 + 1) * D + c];
+        } else {
+            const int used = (len + 127) >> 7;                 // blocks holding valid rows, added in block order
+            for (int k = 0; k < used; ++k) {
+                s += sums[((b * slots + k) * 2) * D + c];
+                q += sums[((b * slots + k) * 2 + 1) * D + c];
+            }
+        }
+        const double mean = s / n;
         out[b * ldo + c] = (float)mean;
         if (include_std) {
-            const double var = sums[(b * 2 + 1) * D + c] / n - mean * mean;
+            const double var = q / n - mean * mean;
             out[b * ldo + D + c] = (float)sqrt(fmax(var, 0.0) + (double)eps);
         }
     }
@@ -2755,8 +2767,21 @@ extern "C" int ktf_stats_finalize(const double* sums, const int32_t* lens, int64
     if (B == 0) return KTF_OK;
     int blocks = ktf_cdiv(B * D, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, lens, T, B, D, include_std, eps, out, ld_out);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, (int64_t)0, lens, T, B, D, include_std, eps, out, ld_out);
     KTF_CHECK_LAUNCH("ktf_stats_finalize");
+    return KTF_OK;
+}
+
+extern "C" int ktf_stats_finalize_slots(const double* sums, int64_t slots, const int32_t* lens, int64_t T, int64_t B, int32_t D,
+                                        int32_t include_std, float eps, float* out, int64_t ld_out, void* stream) {
+    KTF_REQUIRE(sums && out, "ktf_stats_finalize_slots: null argument");
+    KTF_REQUIRE(B >= 0 && D > 0 && ld_out >= (include_std ? 2 : 1) * (int64_t)D, "ktf_stats_finalize_slots: bad sizes");
+    KTF_REQUIRE(slots >= ktf_stats_slots(T), "ktf_stats_finalize_slots: %lld slots < ktf_stats_slots(%lld)", (long long)slots, (long long)T);
+    if (B == 0) return KTF_OK;
+    int blocks = ktf_cdiv(B * D, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, slots, lens, T, B, D, include_std, eps, out, ld_out);
+    KTF_CHECK_LAUNCH("ktf_stats_finalize_slots");
     return KTF_OK;
 }
 

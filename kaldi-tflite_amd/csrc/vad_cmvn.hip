@@ -43,8 +43,21 @@ __device__ __forceinline__ bool vad_keep(const float* __restrict__ f, int64_t T,
     }
     // vad.py:124-135,187-193: denominators at the edges = number of taps inside the sequence
     int den = 2 * ctx + 1;
-    if (t < ctx) den = ctx + 1 + (int)t;
-    else if (t >= T - ctx) den = ctx + (int)(T - t);
+    if (T >= 2 * (int64_t)ctx) {
+        if (t < ctx) den = ctx + 1 + (int)t;
+        else if (t >= T - ctx) den = ctx + (int)(T - t);
+    } else {
+        // fewer than 2*ctx frames: the reference scatters the edge sizes ctx+1 .. 2ctx (left) then 2ctx .. ctx+1 (right) at
+        // indexes floormod(i + T, T), i = 0 .. ctx-1, -ctx .. -1, in that order, and the LAST write to a frame stands
+        bool hit = false;
+        for (int j = ctx - 1; j >= 0 && !hit; --j) {
+            int64_t i = (T - ctx + j) % T;
+            if (i < 0) i += T;
+            if (i == t) { den = 2 * ctx - j; hit = true; }
+        }
+        for (int j = ctx - 1; j >= 0 && !hit; --j)
+            if ((int64_t)j % T == t) { den = ctx + 1 + j; hit = true; }
+    }
     return ((float)cnt / (float)den) >= c.proportion_threshold;
 }
 
@@ -319,19 +332,21 @@ __global__ __launch_bounds__(VC_THREADS) void vad_cmvn_kernel(const float* __res
                                                               int64_t ldo, int32_t* __restrict__ lens,
                                                               int32_t* __restrict__ idx_work,
                                                               float* __restrict__ work, int64_t stage_floats,
-                                                              int64_t bs_floats) {
+                                                              int64_t bs_floats, int64_t pos_ints) {
     extern __shared__ __attribute__((aligned(16))) float vc_lds[];
     float* gm = vc_lds;                      // VC_GM floats (also the reduction scratch of the VAD phase)
-    int* pos = reinterpret_cast<int*>(vc_lds + VC_GM);        // T ints: frame -> compacted row (-1 = dropped)
-    float* bsp = bs_floats ? vc_lds + VC_GM + ((T + 3) & ~3ll) : nullptr;
-    float* stage = vc_lds + VC_GM + ((T + 3) & ~3ll) + bs_floats;
+    const int b = blockIdx.x;
+    int32_t* idx = idx_work + (int64_t)b * T;
+    // frame -> compacted row (-1 = dropped): T ints of LDS; a recording too long for that (pos_ints == 0, > 38,400 frames)
+    // keeps the map in the caller's idx_work instead (written and read by this workgroup only: same CU, same L1)
+    int* pos = pos_ints ? reinterpret_cast<int*>(vc_lds + VC_GM) : reinterpret_cast<int*>(idx);
+    float* bsp = bs_floats ? vc_lds + VC_GM + pos_ints : nullptr;
+    float* stage = vc_lds + VC_GM + pos_ints + bs_floats;
     float* red = gm;
     int* scan = reinterpret_cast<int*>(gm + 64);
-    const int b = blockIdx.x;
     const float* f = feats + (int64_t)b * T * D;
-    int32_t* idx = idx_work + (int64_t)b * T;
     const float thr = vad_threshold(f, T, D, vc, red);
-    const int n = vad_compact(f, T, D, vc, thr, idx, pos, scan);
+    const int n = vad_compact(f, T, D, vc, thr, pos_ints ? idx : nullptr, pos, scan);
     __syncthreads();  // pos[] written by this workgroup is read below by other threads of it
     int* ol = lens + b;
     float* xs = ((int64_t)n * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
@@ -344,7 +359,6 @@ static int check_vad(const char* who, const float* feats, int64_t B, int64_t T, 
     KTF_REQUIRE(c->energy_coeff >= 0 && c->energy_coeff < D, "%s: energy_coeff %d outside [0,%d)", who, c->energy_coeff, D);
     KTF_REQUIRE(c->frames_context >= 0, "%s: frames_context must be >= 0", who);
     KTF_REQUIRE(c->energy_mean_scale >= 0.0f, "%s: energy_mean_scale must be >= 0", who);
-    KTF_REQUIRE(T == 0 || T >= 2 * (int64_t)c->frames_context, "%s: T=%lld shorter than 2*frames_context", who, (long long)T);
     KTF_REQUIRE(T < (1ll << 31), "%s: T too large", who);
     return KTF_OK;
 }
@@ -397,7 +411,7 @@ extern "C" int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int
     int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo;
     if ((VC_GM + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;     // block sums only when they fit beside the staged utterance
     const size_t lds = (VC_GM + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)cmvn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    KTF_LDS_ONCE(160 * 1024, cmvn_kernel);
     hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)B), dim3(VC_THREADS), lds, (hipStream_t)stream, x, T, D, ldx, lens, *cfg,
                        out, ldo, out_lens, work, stage_floats, bs_floats);
     KTF_CHECK_LAUNCH("ktf_cmvn_f32");
@@ -421,25 +435,27 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
         return KTF_OK;
     }
     hipStream_t st = (hipStream_t)stream;
-    // the frame -> compacted-row map lives in LDS: (T + VC_GM) * 4 B <= 158 KiB, i.e. utterances up to ~6.5 min at 10 ms
-    KTF_REQUIRE((VC_GM + ((T + 3) & ~3ll)) * 4 <= 158 * 1024, "ktf_vad_cmvn: %lld frames per utterance exceed the fused kernel's limit (38,400): split the recording", (long long)T);
+    // the frame -> compacted-row map lives in LDS while (T + VC_GM) * 4 B <= 158 KiB (utterances up to ~6.5 min at 10 ms);
+    // beyond that it lives in idx_work (which then holds the map, not the kept frame numbers)
+    int64_t pos_ints = (T + 3) & ~3ll;
+    if ((VC_GM + pos_ints) * 4 > 158 * 1024) pos_ints = 0;
     int64_t stage_floats = vc_stage_floats(T, D);
-    if ((VC_GM + ((T + 3) & ~3ll) + stage_floats) * 4 > 158 * 1024) stage_floats = 0;
+    if ((VC_GM + pos_ints + stage_floats) * 4 > 158 * 1024) stage_floats = 0;
     int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo;
-    if ((VC_GM + ((T + 3) & ~3ll) + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;
-    const size_t lds = (VC_GM + (size_t)((T + 3) & ~3ll) + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
+    if ((VC_GM + pos_ints + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;
+    const size_t lds = (VC_GM + (size_t)pos_ints + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
     if (out_dtype == KTF_F32) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        KTF_LDS_ONCE(160 * 1024, vad_cmvn_kernel<float>);
         hipLaunchKernelGGL(vad_cmvn_kernel<float>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad, *cmvn,
-                           (float*)out, ldo, lens, idx_work, work, stage_floats, bs_floats);
+                           (float*)out, ldo, lens, idx_work, work, stage_floats, bs_floats, pos_ints);
     } else if (out_dtype == KTF_F16) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        KTF_LDS_ONCE(160 * 1024, vad_cmvn_kernel<_Float16>);
         hipLaunchKernelGGL(vad_cmvn_kernel<_Float16>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
-                           *cmvn, (_Float16*)out, ldo, lens, idx_work, work, stage_floats, bs_floats);
+                           *cmvn, (_Float16*)out, ldo, lens, idx_work, work, stage_floats, bs_floats, pos_ints);
     } else {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)vad_cmvn_kernel<unsigned short>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        KTF_LDS_ONCE(160 * 1024, vad_cmvn_kernel<unsigned short>);
         hipLaunchKernelGGL(vad_cmvn_kernel<unsigned short>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
-                           *cmvn, (unsigned short*)out, ldo, lens, idx_work, work, stage_floats, bs_floats);
+                           *cmvn, (unsigned short*)out, ldo, lens, idx_work, work, stage_floats, bs_floats, pos_ints);
     }
     KTF_CHECK_LAUNCH("ktf_vad_cmvn");
     return KTF_OK;

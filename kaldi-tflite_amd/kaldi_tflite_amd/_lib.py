@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libktf_hip.so")
 KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
 GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16 = 0, 1, 2, 3
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+TDNN_REF_TILES, TDNN_DET_STATS = 1, 2          # KtfTdnnDesc.flags
 IN_WAV, IN_FRAMES, IN_WINDOWED, IN_WAV_I16 = 0, 1, 2, 3
 OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
 
@@ -66,7 +67,7 @@ class TdnnDesc(C.Structure):
     _fields_ = [("units", C.c_int32), ("din", C.c_int32), ("din_pad", C.c_int32), ("nctx", C.c_int32),
                 ("ctx", C.c_int32 * 16), ("subsampling", C.c_int32), ("valid", C.c_int32), ("act", C.c_int32),
                 ("gemm", C.c_int32), ("x_dtype", C.c_int32), ("w_dtype", C.c_int32), ("y_dtype", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("flags", C.c_int32)]
 
 
 _P = C.c_void_p
@@ -91,6 +92,8 @@ PROTOTYPES = {
     "ktf_tdnn_split_stats": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ktf_split_bf16": (C.c_int, [_P, _i64, _i32, _i64, _P, _P, _i64, _P]),
     "ktf_stats_finalize": (C.c_int, [_P, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
+    "ktf_stats_slots": (_i64, [_i64]),
+    "ktf_stats_finalize_slots": (C.c_int, [_P, _i64, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_affine_act_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P]),
     "ktf_convert_pad": (C.c_int, [_P, _i32, _i64, _i32, _i64, _P, _i32, _i64, _P]),
     "ktf_stats_pool": (C.c_int, [_P, _i32, _i64, _i64, _i32, _i64, _P, _i32, _i32, _f32, _P, _i64, _P]),

@@ -8,6 +8,7 @@ API difference is the tensor type (torch.Tensor on an MI355X instead of tf.Tenso
 """
 
 import collections
+import zlib
 
 import numpy as np
 import torch
@@ -39,6 +40,16 @@ def _to_device(x):
     a = np.asarray(x)
     dt = np.float64 if a.dtype == np.float64 else np.float32
     return torch.as_tensor(np.ascontiguousarray(a, dtype=dt), device=dev)
+
+
+def _per_device(layer, device, make):
+    """One device-resident constant set per (layer, device): a layer called on a second GPU must not hand kernels
+    pointers into the first one's memory."""
+    cache = layer.__dict__.setdefault("_dev_cache", {})
+    key = str(device)
+    if key not in cache:
+        cache[key] = make()
+    return cache[key]
 
 
 class Layer:
@@ -199,13 +210,12 @@ class Framing(Layer):
         B = int(np.prod(lead)) if len(lead) else 1
         T = self.numFrames(n)
         cfg = self._cfg()
-        if not hasattr(self, "_tables"):
-            self._tables = ops.FrontendTables(self.frameWidth, device=x.device)
+        tables = _per_device(self, x.device, lambda: ops.FrontendTables(self.frameWidth, device=x.device))
         if x.dim() == 2 and not x.is_contiguous():
             cfg.row_stride = x.stride(0)
         else:
             x = x.reshape(B, n)
-        out = ops.frontend(x, kind, cfg, self._tables, L.OUT_FRAMES, n, B, T)
+        out = ops.frontend(x, kind, cfg, tables, L.OUT_FRAMES, n, B, T)
         if self.dynamicInputShape:
             return out.reshape(lead[0] if len(lead) else 1, -1, self.frameWidth)
         return out.reshape(*lead, T, self.frameWidth)
@@ -241,7 +251,7 @@ class Windowing(Layer):
             raise ValueError(f"window size (input shape axis = {self.sampleAxis}) needs to be > 0")
         self.windowFunc = ops.window_function(self.windowType, M, self.blackmanCoeff)
         self._M = M
-        self._tables = None
+        self._dev_cache = {}
         self.built = True
 
     def get_config(self):
@@ -265,10 +275,9 @@ class Windowing(Layer):
             raise ValueError(f"layer was built for frames of {self._M} samples, got {M}")
         lead = x.shape[:-1]
         rows = int(np.prod(lead))
-        if self._tables is None:
-            self._tables = ops.FrontendTables(M, window=self.windowFunc, device=x.device)
+        tables = _per_device(self, x.device, lambda: ops.FrontendTables(M, window=self.windowFunc, device=x.device))
         self._seed += 1
-        r = ops.frontend(x.reshape(1, rows, M), L.IN_FRAMES, self._cfg(M), self._tables, L.OUT_WINDOWED, rows, 1, rows,
+        r = ops.frontend(x.reshape(1, rows, M), L.IN_FRAMES, self._cfg(M), tables, L.OUT_WINDOWED, rows, 1, rows,
                          seed=self._seed, want_energy=self.returnEnergy)
         if self.returnEnergy:
             out, en = r
@@ -308,7 +317,7 @@ class FilterBank(Layer):
         M = input_shape[self.sampleAxis]
         self.fftLength, self.melBank = ops.mel_bank_dense(M, self.numBins, self.sampleFreq, self.lowerCutoff, self.upperCutoff)
         self._M = M
-        self._tables = None
+        self._dev_cache = {}
         self.built = True
 
     def nextPowerOf2(self, n):
@@ -333,11 +342,10 @@ class FilterBank(Layer):
             raise ValueError(f"layer was built for frames of {self._M} samples, got {M}")
         lead = x.shape[:-1]
         rows = int(np.prod(lead))
-        if self._tables is None:
-            self._tables = ops.FrontendTables(M, mel_bank=self.melBank, device=x.device)
+        tables = _per_device(self, x.device, lambda: ops.FrontendTables(M, mel_bank=self.melBank, device=x.device))
         cfg = L.FrontendCfg(frame_size=M, frame_shift=M, nfft=max(64, self.fftLength), num_mels=self.numBins, num_ceps=1,
                             use_power=int(self.usePower), use_log=int(self.useLogFBank), eps=self.eps)
-        out = ops.frontend(x.reshape(1, rows, M), L.IN_WINDOWED, cfg, self._tables, L.OUT_FBANK, rows, 1, rows)
+        out = ops.frontend(x.reshape(1, rows, M), L.IN_WINDOWED, cfg, tables, L.OUT_FBANK, rows, 1, rows)
         return out.reshape(*lead, self.numBins)
 
 
@@ -363,7 +371,7 @@ class DCT(Layer):
         if featDim < self.length:
             raise ValueError("input feature length must be >= DCT length")
         self.dct = ops.dct_matrix(featDim, self.length)
-        self._dct_dev = None
+        self._dev_cache = {}
         self.built = True
 
     def compute_output_shape(self, input_shape):
@@ -377,10 +385,9 @@ class DCT(Layer):
 
     def call(self, inputs):
         x = inputs.to(torch.float32).contiguous()
-        if self._dct_dev is None:
-            self._dct_dev = ops.to_device_f32(self.dct, x.device)
+        dct_dev = _per_device(self, x.device, lambda: ops.to_device_f32(self.dct, x.device))
         lead = x.shape[:-1]
-        out = ops.dct(x.reshape(-1, x.shape[-1]), self._dct_dev, None, self.length)
+        out = ops.dct(x.reshape(-1, x.shape[-1]), dct_dev, None, self.length)
         return out.reshape(*lead, self.length)
 
 
@@ -693,6 +700,7 @@ class TDNN(Layer):
         self.batchAxis, self.timeAxis, self.featAxis = 0, 1, -1
         self.kernel = None     # keras layout (1, K, D, units), numpy fp32
         self.bias = None
+        self.kernelFlags = 0   # KtfTdnnDesc.flags of this layer's launches (L.TDNN_REF_TILES: bitwise-reference fp32 tiles)
         self._dev = {}
 
     # ---- weights
@@ -701,7 +709,9 @@ class TDNN(Layer):
         self.inputDim = D
         if self.kernel is None or self.kernel.shape != (1, self.kernelWidth, D, self.units):
             # Glorot-uniform like the reference's default initialisers (tdnn.py:40-41)
-            rng = np.random.default_rng(abs(hash(self.name)) % (2**32))
+            # seeded from the layer NAME with a process-independent hash: every rank of a multi-GPU job draws the same
+            # initial weights for a layer that is not found in the nnet3 file
+            rng = np.random.default_rng(zlib.crc32(self.name.encode()))
             fan_in, fan_out = self.kernelWidth * D, self.kernelWidth * self.units
             lim = np.sqrt(6.0 / (fan_in + fan_out))
             self.kernel = rng.uniform(-lim, lim, (1, self.kernelWidth, D, self.units)).astype(np.float32)
@@ -766,8 +776,9 @@ class TDNN(Layer):
         self._dev[key] = (w, w_lo, bias)
         return self._dev[key]
 
-    def desc(self, gemm, x_dtype, y_dtype, act=None):
+    def desc(self, gemm, x_dtype, y_dtype, act=None, flags=0):
         d = L.TdnnDesc()
+        d.flags = flags
         d.units, d.din, d.din_pad, d.nctx = self.units, self.inputDim, ops.round_up(self.inputDim, 32), self.kernelWidth
         for i, c in enumerate(self.context):
             d.ctx[i] = int(c)
@@ -805,7 +816,7 @@ class TDNN(Layer):
         return c
 
     def forward(self, x, lens=None, relu=False, bn=None, gemm=None, out_dtype=torch.float32, ldy=None, out=None,
-                out_lens=None):
+                out_lens=None, flags=0):
         """Low-level launch used by call() and by the fused Sequential runner.
         x: (B, T, ldx) fp32/bf16 with ldx >= round_up(D,32) (pad columns finite). Returns y (B, Tout, ldy)."""
         gemm = _GEMM[self.gemm] if gemm is None else gemm
@@ -813,7 +824,7 @@ class TDNN(Layer):
         act = "relu" if relu else None
         if relu and self.activation not in (None, "linear"):
             raise ValueError("cannot fuse a ReLU after a TDNN that already has an activation")
-        d = self.desc(gemm, x.dtype, out_dtype, act=act if relu else None)
+        d = self.desc(gemm, x.dtype, out_dtype, act=act if relu else None, flags=flags | self.kernelFlags)
         B, T = x.shape[0], x.shape[1]
         Tout = self.outputTimesteps(T)
         ldy = self.units if ldy is None else ldy

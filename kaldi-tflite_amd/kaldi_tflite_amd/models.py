@@ -2,13 +2,14 @@
 ktf.models — SequentialFromConfig / XvectorExtractor / XvectorExtractorFromConfig with the
 reference's signatures (kaldi_tflite/lib/models/kaldi/{sequential,xvector_extractor}.py).
 
-The builders parse the same two-level YAML as the reference. At call time the model does not
+The builders read the same two-level YAML as the reference. At call time the model does not
 run layer by layer: the canonical chains are recognised and dispatched to fused kernels
 (Framing+MFCC in one launch, VAD+compaction+CMVN in one launch, every [affine, relu, batchnorm]
 triple as one MFMA GEMM with a fused epilogue), on ragged utterance-strided activations so a
 batch of B utterances equals B independent batch-1 calls of the reference.
 """
 
+import math
 import os
 
 import numpy as np
@@ -17,7 +18,7 @@ import torch
 from . import _lib as L
 from . import ops
 from .io import KaldiNnet3Reader, ReadKaldiArray
-from .layers import TDNN, BatchNorm, CMVN, Framing, Layer, MFCC, ReLU, StatsPooling, VAD, _GEMM
+from .layers import TDNN, BatchNorm, CMVN, Framing, MFCC, ReLU, StatsPooling, VAD, _GEMM
 
 
 class Input:
@@ -28,38 +29,88 @@ class Input:
         self.name = name
 
 
+# ------------------------------------------------------------------------------------------------ config -> layers
+# One row per layer kind of the model YAML (models/kaldi/sequential.py:29-83): the spellings the reference accepts, the
+# layer class, how the layer is named from the entry's `name`, and whether the entry's `cfg` dict is its kwargs.
+_LAYER_KINDS = (
+    (("affine", "tdnn"), TDNN, "{}.affine", True),
+    (("relu",), ReLU, "{}.relu", False),
+    (("batchnorm", "bn"), BatchNorm, "{}.batchnorm", False),
+    (("stats", "stats_extraction", "stats_pooling"), StatsPooling, "{}", True),
+)
+_KIND_OF = {alias: row for row in _LAYER_KINDS for alias in row[0]}
+
+
 def cfg2layers(layerCfg):
-    """models/kaldi/sequential.py:29-83: one config entry -> list of layers."""
-    layerTypes = layerCfg.get("type", [])
-    if isinstance(layerTypes, str):
-        layerTypes = [layerTypes]
-    if len(layerTypes) == 0:
+    """One entry of `model_config.layers` -> the layers it stands for, in order. `type` is a kind or a list of kinds
+    ("affine" | "tdnn", "relu", "batchnorm" | "bn", "stats" | "stats_extraction" | "stats_pooling"); the entry's `cfg`
+    holds the keyword arguments of its parametrised layer. KeyError without a `type`, ValueError for an unknown one."""
+    kinds = layerCfg.get("type") or []
+    if isinstance(kinds, str):
+        kinds = [kinds]
+    if not kinds:
         raise KeyError("layer config does not define layer 'type'")
-    name = layerCfg.get("name", None)
-    layers = []
-    for layerType in layerTypes:
-        t = layerType.lower()
-        cfg = layerCfg.get("cfg", {})
-        if t in ["affine", "tdnn"]:
-            cfg["name"] = f"{name}.affine"
-            layer = TDNN(**cfg)
-        elif t in ["relu"]:
-            layer = ReLU(name=f"{name}.relu")
-        elif t in ["batchnorm", "bn"]:
-            layer = BatchNorm(name=f"{name}.batchnorm")
-        elif t in ["stats", "stats_extraction", "stats_pooling"]:
-            cfg["name"] = name
-            layer = StatsPooling(**cfg)
-        else:
-            raise ValueError(f"unsupported layer type '{t}'")
-        layers.append(layer)
-    return layers
+    built = []
+    for kind in kinds:
+        row = _KIND_OF.get(kind.lower())
+        if row is None:
+            raise ValueError(f"unsupported layer type '{kind.lower()}'")
+        _, cls, name_fmt, takes_cfg = row
+        kwargs = dict(layerCfg.get("cfg") or {}) if takes_cfg else {}
+        kwargs["name"] = name_fmt.format(layerCfg.get("name"))
+        built.append(cls(**kwargs))
+    return built
+
+
+class _Workspace:
+    """Device scratch of one model. One byte arena per (role, device, stream), grown to the largest request seen and
+    re-viewed for every call: memory is bounded by the largest batch processed, not by the number of distinct
+    (batch, length) shapes (variable-length audio used to allocate a full activation set per shape). Arenas are keyed
+    by the CURRENT stream as well, so two streams / threads driving one model never share scratch; calls on one stream
+    are ordered by the stream."""
+
+    def __init__(self):
+        self._arenas = {}
+        self._where = None
+
+    def enter(self, device):
+        """Bind the following get() calls to `device` and its current stream (looked up once per model call)."""
+        self._where = (str(device), torch.cuda.current_stream(device).cuda_stream)
+
+    def get(self, role, shape, dtype, device):
+        if self._where is None or self._where[0] != str(device):
+            self.enter(device)
+        key = (role,) + self._where
+        sig = (tuple(shape), dtype)
+        slot = self._arenas.get(key)             # [arena bytes, signature of the current view, the view]
+        if slot is not None and slot[1] == sig:
+            return slot[2]
+        count = int(math.prod(shape))
+        nbytes = max(count * dtype.itemsize, 16)
+        if slot is None or slot[0].numel() < nbytes:
+            slot = [torch.zeros((nbytes,), dtype=torch.uint8, device=device), None, None]
+            self._arenas[key] = slot
+        view = slot[0][:nbytes].view(dtype)[:count].view(shape)
+        if slot[1] is not None:
+            view.zero_()              # a different shape re-slices old bytes: pad columns must read as finite zeros
+        slot[1], slot[2] = sig, view
+        return view
+
+    def bytes(self):
+        return sum(s[0].numel() for s in self._arenas.values())
+
+    def clear(self):
+        self._arenas.clear()
 
 
 class Sequential:
     """Keras-Sequential stand-in: `.layers`, `.name`, `mdl(x, training=False)`, `get_layer`, `summary`.
     `gemm` selects the TDNN arithmetic of the fused runner: "f32" (exact fp32 MFMA, default = the reference's
-    precision), "bf16" or "bf16x3"."""
+    precision), "bf16x3" (split-bf16, fp32-grade), "bf16" or "f16"."""
+
+    split_planes = True         # bf16x3: hi/lo bf16 activation planes between the wide layers (no in-loop conversion)
+    # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
+    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32}
 
     def __init__(self, layers=None, name=None, gemm="f32"):
         self.input = None
@@ -73,9 +124,10 @@ class Sequential:
         if gemm not in _GEMM:
             raise ValueError(f"gemm must be one of {sorted(_GEMM)}")
         self.gemm = gemm
-        self.fuse_stats = True      # bf16 mode: pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
+        self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
+        self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"
-        self._ws = {}
+        self._ws = _Workspace()
         self._build()
 
     def _build(self):
@@ -126,10 +178,6 @@ class Sequential:
                 return None
         return steps
 
-    split_planes = os.environ.get("KTF_X3_SPLIT", "1") != "0"     # bf16x3: hi/lo activation planes between wide layers
-    # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
-    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32}
-
     def batch_gemm(self, B, T):
         """GEMM arithmetic for a batch of B utterances of up to T frames: the model's mode, except that a handful of
         256-row tiles (single utterances) cannot fill the chip on the 256-wide ring kernels -- the exact fp32 kernels have
@@ -139,13 +187,36 @@ class Sequential:
             gemm = L.GEMM_F32
         return gemm
 
+    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T):
+        """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
+        Returns the pooled (1, B, od) view."""
+        sp = nxt[1]
+        D = l.units
+        od = 2 * D if sp.includeStd else D
+        ld = ops.round_up(od, 32)
+        B = x_or_planes.shape[1] if split else x_or_planes.shape[0]
+        slots = ops.stats_slots(T) if self.deterministic else 0
+        sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev)
+        sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev)
+        w, w_lo, bias = l.device_weights(dev, gemm)
+        scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
+        xdt = torch.bfloat16 if split else x_or_planes.dtype
+        d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
+                   flags=L.TDNN_DET_STATS if slots else 0)
+        (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
+        ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf, slots=slots)
+        return sbuf[:, :od].unsqueeze(0)
+
     def run_ragged(self, x, lens=None):
         """x: (B, T, D) view of an utterance-strided buffer whose row stride is a multiple of 8 and >= round_up(D, 32)
         (pad columns finite); lens: int32 (B,) valid rows per utterance or None. Returns (B, T', units) for frame-level
-        outputs or (B, 1, units) after a reducing StatsPooling."""
+        outputs or (B, 1, units) after a reducing StatsPooling. The result is a view of this model's workspace: it is
+        overwritten by the model's next call on the same stream (`__call__` hands out an owned copy)."""
         steps = self._plan()
         if steps is None:
             raise NotImplementedError("this layer stack is not supported by the fused ragged runner")
+        dev = x.device
+        self._ws.enter(dev)
         gemm = self.batch_gemm(x.shape[0], x.shape[1])
         act_dtype = L.act_torch_dtype(gemm)
         pooled = False
@@ -159,33 +230,26 @@ class Sequential:
                 skip = False
                 continue
             nxt = steps[si + 1] if si + 1 < len(steps) else None
-            if use_planes and st[0] == "tdnn" and not pooled and st[1].units > 128:
+            out_role = f"act{si & 1}"            # layer si reads what layer si-1 wrote: two arenas alternate
+            if st[0] == "tdnn":
                 _, l, relu, bn = st
                 if relu and l.activation not in (None, "linear"):
                     raise ValueError("cannot fuse a ReLU after a TDNN that already has an activation")
+                can_pool = (self.fuse_stats and not pooled and nxt is not None and nxt[0] == "stats" and
+                            nxt[1].inputPeriod == 1 and l.units > 128 and l.padding == "SAME" and l.subsamplingFactor == 1)
+            if use_planes and st[0] == "tdnn" and not pooled and l.units > 128:
                 if planes is None:                                   # first wide layer: split its fp32 input once
                     B, T, D = x.shape
-                    planes = self._buffer(("xp", id(l), B, T, str(x.device)), (2, B, T, ops.round_up(D, 32)), torch.bfloat16, x.device)
+                    planes = self._ws.get("split_in", (2, B, T, ops.round_up(D, 32)), torch.bfloat16, dev)
                     src = x if (x.dtype == torch.float32 and x.stride(2) == 1 and x.stride(0) == T * x.stride(1)) else x.to(torch.float32).contiguous()
                     ops.split_bf16(src, D, planes)
                 B, T = planes.shape[1], planes.shape[2]
-                w, w_lo, bias = l.device_weights(x.device, gemm)
-                scale, shift = bn.affine_device(x.device) if bn is not None else (None, None)
-                fuse = (self.fuse_stats and nxt is not None and nxt[0] == "stats" and nxt[1].inputPeriod == 1 and
-                        l.padding == "SAME" and l.subsamplingFactor == 1)
-                if fuse:
-                    sp = nxt[1]
-                    D = l.units
-                    od = 2 * D if sp.includeStd else D
-                    ld = ops.round_up(od, 32)
-                    sums = self._buffer(("sum", id(l), B, D, str(x.device)), (B, 2, D), torch.float64, x.device)
-                    sbuf = self._buffer(("s", id(sp), B, ld, str(x.device)), (B, ld), torch.float32, x.device)
-                    d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None)
-                    ops.tdnn_split_stats(planes, lens, d, w, w_lo, bias, scale, shift, sums)
-                    ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf)
-                    x = sbuf[:, :od].unsqueeze(0)
+                if can_pool:
+                    x = self._pooled_by_gemm(l, relu, bn, nxt, planes, lens, gemm, True, dev, T)
                     lens, pooled, skip, planes = None, True, True, None
                     continue
+                w, w_lo, bias = l.device_weights(dev, gemm)
+                scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
                 out_lens = None
@@ -193,13 +257,13 @@ class Sequential:
                     out_lens = torch.empty_like(lens)
                 keep = nxt is not None and nxt[0] == "tdnn" and nxt[1].units > 128        # the consumer reads planes too
                 if keep:
-                    ybuf = self._buffer(("yp", id(l), B, Tout, ldy, str(x.device)), (2, B, Tout, ldy), torch.bfloat16, x.device)
+                    ybuf = self._ws.get(out_role, (2, B, Tout, ldy), torch.bfloat16, dev)
                     d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None)
                     ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf[0], ybuf[1], out_lens)
                     planes = ybuf
                     x = ybuf[0][:, :, : l.units]                     # shape carrier only (the values live in `planes`)
                 else:
-                    ybuf = self._buffer(("y", id(l), B, Tout, ldy, torch.float32, str(x.device)), (B, Tout, ldy), torch.float32, x.device)
+                    ybuf = self._ws.get(out_role, (B, Tout, ldy), torch.float32, dev)
                     d = l.desc(gemm, torch.bfloat16, torch.float32, act="relu" if relu else None)
                     ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
                     planes = None
@@ -209,34 +273,14 @@ class Sequential:
                 continue
             if planes is not None:
                 raise RuntimeError("internal: split planes reached a layer that cannot read them")
-            if (self.fuse_stats and st[0] == "tdnn" and not pooled and gemm in (L.GEMM_BF16, L.GEMM_BF16X3, L.GEMM_F16) and nxt is not None
-                    and st[1].effective_gemm(gemm, st[2]) == gemm
-                    and nxt[0] == "stats" and nxt[1].inputPeriod == 1 and st[1].units > 128 and st[1].padding == "SAME"
-                    and st[1].subsamplingFactor == 1):
-                # [affine, relu, batchnorm] -> reducing StatsPooling: pooled inside the GEMM epilogue, y is never written
-                _, l, relu, bn = st
-                sp = nxt[1]
-                xdt = L.act_torch_dtype(gemm)
-                if x.dtype != xdt or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
-                    x = _padded_copy(x, xdt)
-                B, T, _ = x.shape
-                D = l.units
-                od = 2 * D if sp.includeStd else D
-                ld = ops.round_up(od, 32)
-                sums = self._buffer(("sum", id(l), B, D, str(x.device)), (B, 2, D), torch.float64, x.device)
-                sbuf = self._buffer(("s", id(sp), B, ld, str(x.device)), (B, ld), torch.float32, x.device)
-                w, w_lo, bias = l.device_weights(x.device, gemm)
-                d = l.desc(gemm, x.dtype, xdt, act="relu" if relu else None)
-                scale, shift = bn.affine_device(x.device) if bn is not None else (None, None)
-                ops.tdnn_stats(x, lens, d, w, w_lo, bias, scale, shift, sums)
-                ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf)
-                x = sbuf[:, :od].unsqueeze(0)
-                lens = None
-                pooled = True
-                skip = True
-                continue
             if st[0] == "tdnn":
-                _, l, relu, bn = st
+                if (can_pool and gemm in (L.GEMM_BF16, L.GEMM_BF16X3, L.GEMM_F16) and l.effective_gemm(gemm, relu) == gemm):
+                    xdt = L.act_torch_dtype(gemm)
+                    if x.dtype != xdt or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
+                        x = _padded_copy(x, xdt)
+                    x = self._pooled_by_gemm(l, relu, bn, nxt, x, lens, gemm, False, dev, x.shape[1])
+                    lens, pooled, skip = None, True, True
+                    continue
                 g = L.GEMM_F32 if pooled else l.effective_gemm(gemm, relu)
                 ydt = torch.float32 if (pooled or g != gemm) else act_dtype
                 if x.dtype != L.act_torch_dtype(g) or x.stride(2) != 1 or \
@@ -245,11 +289,11 @@ class Sequential:
                 B, T, _ = x.shape
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
-                ybuf = self._buffer(("y", id(l), B, Tout, ldy, ydt, str(x.device)), (B, Tout, ldy), ydt, x.device)
+                ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev)
                 out_lens = None
                 if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
                     out_lens = torch.empty_like(lens)
-                sc_sh = bn.affine_device(x.device) if bn is not None else None
+                sc_sh = bn.affine_device(dev) if bn is not None else None
                 l.forward(x, lens=lens, relu=relu, bn=sc_sh, gemm=g, out_dtype=ydt, ldy=ldy, out=ybuf, out_lens=out_lens)
                 if out_lens is not None:
                     lens = out_lens
@@ -258,26 +302,16 @@ class Sequential:
                 l = st[1]
                 B, T, D = x.shape
                 od = 2 * D if l.includeStd else D
-                ld = ops.round_up(od, 32)
-                sbuf = self._buffer(("s", id(l), B, ld, str(x.device)), (B, ld), torch.float32, x.device)
+                sbuf = self._ws.get("pooled", (B, ops.round_up(od, 32)), torch.float32, dev)
                 l.reduce_all(x, D, lens=lens, out=sbuf)
                 x = sbuf[:, :od].unsqueeze(0)       # (1, B, od): the pooled vectors form ONE B-row matrix
                 lens = None
                 pooled = True
             else:
-                l = st[1]
-                xc = x.to(torch.float32).contiguous()
-                x = l(xc)
+                x = st[1](x.to(torch.float32).contiguous())
         if pooled:
             return x.reshape(x.shape[1], 1, x.shape[2])
         return x
-
-    def _buffer(self, key, shape, dtype, device):
-        b = self._ws.get(key)
-        if b is None:
-            b = torch.zeros(shape, dtype=dtype, device=device)   # zeros: pad columns must stay finite
-            self._ws[key] = b
-        return b
 
     def __call__(self, inputs, training=False):
         x = inputs
@@ -285,11 +319,9 @@ class Sequential:
             x = ops.to_device_f32(x)
         if training:
             raise NotImplementedError("inference only")
-        for l in self.layers:
-            if not l.built:
-                self.input = Input(shape=(None, x.shape[-1]))
-                self._build()
-                break
+        if any(not l.built for l in self.layers):
+            self.input = Input(shape=(None, x.shape[-1]))
+            self._build()
         if self._plan() is not None and x.dim() == 3:
             y = self.run_ragged(_padded_copy(x, torch.float32), None)
             return y.contiguous().clone()
@@ -313,25 +345,30 @@ def _padded_copy(x, dtype):
 
 
 def SequentialFromConfig(cfg, nnet3Path=None, name=None, gemm="f32"):
-    """models/kaldi/sequential.py:86-143."""
-    layersConfig = cfg.get("layers", [])
-    if len(layersConfig) == 0:
+    """models/kaldi/sequential.py:86-143 — `cfg["layers"]`: an "input" entry with `shape` [batch, time, feat], then
+    entries for `cfg2layers`. With `nnet3Path`, every layer takes the weights of the nnet3 components matching its name
+    (a layer without a match keeps its initialisation and is reported, as in the reference)."""
+    entries = cfg.get("layers") or []
+    if not entries:
         raise ValueError("no layers defined in config")
-    inputCfg = layersConfig[0]
-    if inputCfg.get("type", "") != "input":
+    head, body = entries[0], entries[1:]
+    if head.get("type", "") != "input":
         raise ValueError("first layer in sequential model needs to be of type 'input'")
-    batchSize, timesteps, featDim = inputCfg["shape"]
-    layers = [Input(shape=(timesteps, featDim), batch_size=batchSize)]
-    for lCfg in cfg["layers"][1:]:
-        layers.extend(cfg2layers(lCfg))
-    mdl = Sequential(layers, name=name, gemm=gemm)
-    if nnet3Path is not None:
-        nnet3Mdl = KaldiNnet3Reader(nnet3Path, True)
-        for layer in mdl.layers:
-            try:
-                layer.set_weights(nnet3Mdl.getWeights(layer.name))
-            except KeyError:
-                print(f"component with name '{layer.name}' not found in nnet3 model, skipping initialization")
+    batch, time, feat = head["shape"]
+    stack = [Input(shape=(time, feat), batch_size=batch)]
+    for entry in body:
+        stack += cfg2layers(entry)
+    mdl = Sequential(stack, name=name, gemm=gemm)
+    if nnet3Path is None:
+        return mdl
+    source = KaldiNnet3Reader(nnet3Path, True)
+    for layer in mdl.layers:
+        try:
+            weights = source.getWeights(layer.name)
+        except KeyError:
+            print(f"component with name '{layer.name}' not found in nnet3 model, skipping initialization")
+            continue
+        layer.set_weights(weights)
     return mdl
 
 
@@ -343,18 +380,22 @@ def downloadModel(link, outPath, sha256=None):
         f"sha256 {sha256}); place the extracted tarball there")
 
 
-def XvectorExtractorFromConfig(cfgPath, name=None, gemm="f32"):
-    """models/kaldi/xvector_extractor.py:25-71."""
+def _load_yaml(path):
     import yaml
-    with open(cfgPath) as f:
-        cfg = yaml.safe_load(f)
-    with open(cfg["extractor"]["xvec"]["model_config_path"], "r") as f:
-        kaldiCfg = yaml.safe_load(f)
-    kaldiMdlPath = cfg["extractor"]["xvec"]["model_path"]
-    if not os.path.exists(kaldiMdlPath):
-        downloadDir = os.path.join(os.path.dirname(cfg["extractor"]["xvec"]["model_config_path"]), kaldiCfg["name"])
-        downloadModel(kaldiCfg["download"]["link"], downloadDir, kaldiCfg["download"]["hash"])
-    return XvectorExtractor(cfg["extractor"], name=name, gemm=gemm)
+    with open(path, "r") as f:
+        return yaml.safe_load(f)
+
+
+def XvectorExtractorFromConfig(cfgPath, name=None, gemm="f32"):
+    """models/kaldi/xvector_extractor.py:25-71 — `cfgPath`: YAML with an `extractor` section (framing / mfcc / vad / cmvn
+    kwargs + `xvec` paths). The nnet3 model must already be on disk (see downloadModel)."""
+    ext = _load_yaml(cfgPath)["extractor"]
+    paths = ext["xvec"]
+    if not os.path.exists(paths["model_path"]):
+        kaldi = _load_yaml(paths["model_config_path"])
+        target = os.path.join(os.path.dirname(paths["model_config_path"]), kaldi["name"])
+        downloadModel(kaldi["download"]["link"], target, kaldi["download"]["hash"])
+    return XvectorExtractor(ext, name=name, gemm=gemm)
 
 
 class XvectorExtractor:
@@ -362,68 +403,46 @@ class XvectorExtractor:
 
     The reference flattens the voiced frames of the whole batch into one sequence (:164-165) and is therefore only
     defined for batch = 1; here every batch row is an independent utterance and the result is (B, lda_dim)
-    (squeezed to (lda_dim,) for B = 1 exactly like the reference's tf.squeeze)."""
+    (squeezed to (lda_dim,) for B = 1 exactly like the reference's tf.squeeze).
+
+    Scratch lives in per-stream workspaces (`_Workspace`); results handed to the caller are owned tensors."""
 
     def __init__(self, cfg, name=None, chunk_size=300, gemm="f32", **kwargs):
-        import yaml
-        self.name = name if name is not None else "xvector_extractor"
-        fcfg = dict(cfg["framing"])
-        self.framing = Framing(**fcfg)
-        self.mfcc = MFCC(**cfg["mfcc"])
-        self.vad = VAD(**cfg["vad"])
-        self.cmvn = CMVN(**cfg["cmvn"])
-        with open(cfg["xvec"]["model_config_path"], "r") as f:
-            nnet3Cfg = yaml.safe_load(f)
-        self.xvec = SequentialFromConfig(nnet3Cfg["model_config"], cfg["xvec"]["model_path"], "cmvn2xvec", gemm=gemm)
-        globalMean = ReadKaldiArray(cfg["xvec"]["global_mean_path"], binary=False)
-        ldaMat = ReadKaldiArray(cfg["xvec"]["lda_matrix_path"], binary=True)
-        self._init_post(globalMean, ldaMat)
-        self.gemm = gemm
-        self._ws = {}
+        nnet3 = _load_yaml(cfg["xvec"]["model_config_path"])
+        seq = SequentialFromConfig(nnet3["model_config"], cfg["xvec"]["model_path"], "cmvn2xvec", gemm=gemm)
+        self._setup(cfg, seq, ReadKaldiArray(cfg["xvec"]["global_mean_path"], binary=False),
+                    ReadKaldiArray(cfg["xvec"]["lda_matrix_path"], binary=True), name)
 
     @classmethod
     def from_parts(cls, cfg, sequential, global_mean, lda_mat, name=None):
         """Build from an already-constructed Sequential and in-memory LDA parameters (used with synthetic weights)."""
         self = cls.__new__(cls)
+        self._setup(cfg, sequential, global_mean, lda_mat, name)
+        return self
+
+    def _setup(self, cfg, sequential, global_mean, lda_mat, name):
         self.name = name if name is not None else "xvector_extractor"
-        self.framing = Framing(**cfg["framing"])
+        self.framing = Framing(**dict(cfg["framing"]))
         self.mfcc = MFCC(**cfg["mfcc"])
         self.vad = VAD(**cfg["vad"])
         self.cmvn = CMVN(**cfg["cmvn"])
         self.xvec = sequential
-        self._init_post(global_mean, lda_mat)
         self.gemm = sequential.gemm
-        self._ws = {}
-        return self
-
-    def _init_post(self, globalMean, ldaMat):
-        ldaMat = np.asarray(ldaMat, np.float32)
-        self.xvecGlobalMean = np.asarray(globalMean, np.float32)
-        self.ldaOffset = np.ascontiguousarray(ldaMat[..., -1:].T)      # (1, out)
-        self.ldaMat = np.ascontiguousarray(ldaMat[..., :-1].T)         # (in, out)
-        self._post_dev = None
+        lda = np.asarray(lda_mat, np.float32)                          # transform.mat: (out, in + 1), last column = offset
+        self.xvecGlobalMean = np.asarray(global_mean, np.float32)
+        self.ldaOffset = np.ascontiguousarray(lda[..., -1:].T)          # (1, out)
+        self.ldaMat = np.ascontiguousarray(lda[..., :-1].T)             # (in, out)
+        self._post_dev = {}
+        self._ws = _Workspace()
+        self._graphs = {}
+        self.last_lens = None
 
     @property
     def layers(self):
         return [self.framing, self.mfcc, self.vad, self.cmvn, self.xvec]
 
-    def _workspace(self, B, T, D, device, feat_dtype):
-        key = (B, T, D, str(device), feat_dtype)
-        ws = self._ws.get(key)
-        if ws is None:
-            ld = ops.round_up(D, 32)
-            ws = {
-                "mfcc": torch.empty((B, T, D), dtype=torch.float32, device=device),
-                "feats": torch.zeros((B, T, ld), dtype=feat_dtype, device=device),
-                "lens": torch.zeros((B,), dtype=torch.int32, device=device),
-                "idx": torch.empty((B, T), dtype=torch.int32, device=device),
-                "work": torch.empty((B * T * 2 * D + 2 * D,), dtype=torch.float32, device=device),
-            }
-            self._ws[key] = ws
-        return ws
-
-    def features(self, inputs):
-        """wav -> (mfcc (B,T,C), cmvn'd voiced features view (B,T,C), lens (B,)) — the front half of call()."""
+    def _features(self, inputs):
+        """wav -> (mfcc (B,T,C), CMVN'd voiced features (B,T,C) view, lens (B,)): workspace views."""
         fr, mf = self.framing, self.mfcc
         x, kind = fr.device_samples(inputs)          # fp32, or int16 PCM as it is
         if x.dim() == 1:
@@ -435,16 +454,28 @@ class XvectorExtractor:
             mf.build((None, None, fr.frameWidth))
         T = fr.numFrames(N)
         D = mf.numMfccs
-        gemm = self.xvec.batch_gemm(B, T)
-        feat_dtype = L.act_torch_dtype(gemm)
-        ws = self._workspace(B, T, D, x.device, feat_dtype)
+        dev = x.device
+        feat_dtype = L.act_torch_dtype(self.xvec.batch_gemm(B, T))
+        ws = self._ws
+        ws.enter(dev)
+        mfcc = ws.get("mfcc", (B, T, D), torch.float32, dev)
+        feats = ws.get("feats", (B, T, ops.round_up(D, 32)), feat_dtype, dev)
+        lens = ws.get("lens", (B,), torch.int32, dev)
+        idx = ws.get("idx", (B, T), torch.int32, dev)
+        work = ws.get("cmvn_work", (B * T * 2 * D + 2 * D,), torch.float32, dev)
         cfg = L.FrontendCfg.from_buffer_copy(mf._cfg)
         cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift
         cfg.pad_mode = 0 if fr.snipEdges else 1
         cfg.row_stride = 0 if x.is_contiguous() else x.stride(0)
-        ops.frontend(x, kind, cfg, mf.tables(x.device), L.OUT_MFCC, N, B, T, seed=mf.next_seed(), out=ws["mfcc"])
-        ops.vad_cmvn(ws["mfcc"], self.vad.cfg(), self.cmvn.cfg(), ws["feats"], ws["lens"], ws["idx"], ws["work"])
-        return ws["mfcc"], ws["feats"][:, :, :D], ws["lens"]
+        ops.frontend(x, kind, cfg, mf.tables(dev), L.OUT_MFCC, N, B, T, seed=mf.next_seed(), out=mfcc)
+        ops.vad_cmvn(mfcc, self.vad.cfg(), self.cmvn.cfg(), feats, lens, idx, work)
+        return mfcc, feats[:, :, :D], lens
+
+    def features(self, inputs):
+        """wav -> (mfcc (B,T,C), CMVN'd voiced features (B,T,C) with rows >= lens[b] unspecified, lens (B,) int32) — the
+        front half of call(), as OWNED tensors."""
+        mfcc, feats, lens = self._features(inputs)
+        return mfcc.clone(), feats.clone(), lens.clone()
 
     def extract_stream(self, host_batches, depth=3):
         """Extension: x-vectors of a sequence of HOST batches (pinned (B,N) int16 / fp32 tensors) with the upload of batch
@@ -472,21 +503,63 @@ class XvectorExtractor:
             free[k].record(compute)
             yield y
 
+    def _extract(self, inputs, out=None):
+        _, feats, lens = self._features(inputs)
+        self.last_lens = lens                                          # voiced-frame counts of the last call (workspace view)
+        h = self.xvec.run_ragged(feats, lens)                      # (B, 1, 512)
+        B = h.shape[0]
+        h2 = h.reshape(B, h.shape[-1])
+        key = str(h2.device)
+        if key not in self._post_dev:
+            self._post_dev[key] = (ops.to_device_f32(self.xvecGlobalMean, h2.device), ops.to_device_f32(self.ldaMat, h2.device),
+                                   ops.to_device_f32(self.ldaOffset.reshape(-1), h2.device))
+        mean, A, off = self._post_dev[key]
+        if not h2.is_contiguous():
+            h2 = h2.contiguous()
+        return ops.xvec_post(h2, mean, A, off, out=out)
+
     def __call__(self, inputs, training=False):
         if hasattr(inputs, "shape") and len(inputs.shape) == 2 and inputs.shape[0] == 0:
             L.require_gpu()
             return torch.empty((0, self.ldaMat.shape[1]), dtype=torch.float32, device=ops.default_device())
-        _, feats, lens = self.features(inputs)
-        h = self.xvec.run_ragged(feats, lens)                      # (B, 1, 512)
-        B = h.shape[0]
-        h2 = h.reshape(B, h.shape[-1])
-        if self._post_dev is None or self._post_dev[0].device != h2.device:
-            self._post_dev = (ops.to_device_f32(self.xvecGlobalMean, h2.device), ops.to_device_f32(self.ldaMat, h2.device),
-                              ops.to_device_f32(self.ldaOffset.reshape(-1), h2.device))
-        mean, A, off = self._post_dev
-        if not h2.is_contiguous():
-            h2 = h2.contiguous()
-        y = ops.xvec_post(h2, mean, A, off)
-        return y.squeeze(0) if B == 1 else y
+        y = self._extract(inputs)
+        return y.squeeze(0) if y.shape[0] == 1 else y
 
     call = __call__
+
+    def compile(self, example):
+        """Extension: capture the whole wav -> x-vector step for inputs of `example`'s shape / dtype into ONE HIP graph and
+        return `run(wav) -> x-vector(s)`. A replay issues the same kernels on the same buffers as `__call__` (bit-identical
+        results) with a single host call, which is what a latency-bound caller (batch 1: ~10 launches of 5-30 us each)
+        wants. `run` copies `wav` into the captured input buffer, replays, and returns an owned tensor. Dither (a fresh
+        seed per call) is frozen into the graph: compile a model whose MFCC has dither = 0."""
+        L.require_gpu()
+        ex, _ = self.framing.device_samples(example)
+        if ex.dim() == 1:
+            ex = ex.unsqueeze(0)
+        static_in = ex.contiguous().clone()
+        dev = static_in.device
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):                # warm-up on the capture stream: workspaces, tables, LDS opt-ins
+            for _ in range(2):
+                self._extract(static_in)
+            static_out = torch.empty((static_in.shape[0], self.ldaMat.shape[1]), dtype=torch.float32, device=dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                self._extract(static_in, out=static_out)
+        torch.cuda.current_stream(dev).wait_stream(side)
+
+        def run(wav):
+            w, _ = self.framing.device_samples(wav)
+            if w.dim() == 1:
+                w = w.unsqueeze(0)
+            if w.shape != static_in.shape or w.dtype != static_in.dtype:
+                raise ValueError(f"compiled for {tuple(static_in.shape)} {static_in.dtype}, got {tuple(w.shape)} {w.dtype}")
+            static_in.copy_(w)
+            graph.replay()
+            y = static_out.clone()
+            return y.squeeze(0) if y.shape[0] == 1 else y
+
+        run.graph = graph
+        return run

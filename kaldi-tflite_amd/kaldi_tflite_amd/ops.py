@@ -308,12 +308,19 @@ def tdnn(x, lens, desc, w, w_lo, bias, scale, shift, y, out_lens=None):
     return y
 
 
-def tdnn_stats(x, lens, desc, w, w_lo, bias, scale, shift, sums):
-    """Fused TDNN + reducing stats pooling: accumulates fp64 column sums / sums of squares into `sums` (B,2,units)."""
+def stats_slots(T):
+    """128-row slots of the reproducible pooling layout (KTF_TDNN_DET_STATS) for utterances of up to T rows."""
+    return int(L.load().ktf_stats_slots(int(T)))
+
+
+def tdnn_stats(x, lens, desc, w, w_lo, bias, scale, shift, sums, zero=True):
+    """Fused TDNN + reducing stats pooling: accumulates fp64 column sums / sums of squares into `sums` (B,2,units), or
+    stores them per 128-row block into (B,slots,2,units) when desc.flags has TDNN_DET_STATS (zero=False then)."""
     lib = L.load()
     B, T = x.shape[0], x.shape[1]
     with torch.cuda.device(x.device):
-        sums.zero_()
+        if zero:
+            sums.zero_()
         rc = lib.ktf_tdnn_stats(L.ptr(x), B, T, x.stride(1), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo), L.ptr(bias),
                                 L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
     L.check(rc, "ktf_tdnn_stats")
@@ -356,23 +363,29 @@ def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_le
     return y
 
 
-def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums):
+def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums, zero=True):
     lib = L.load()
     B, T = xp.shape[1], xp.shape[2]
     with torch.cuda.device(xp.device):
-        sums.zero_()
+        if zero:
+            sums.zero_()
         rc = lib.ktf_tdnn_split_stats(L.ptr(xp[0]), L.ptr(xp[1]), B, T, xp.stride(2), L.ptr(lens), C.byref(desc), L.ptr(w),
                                       L.ptr(w_lo), L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
     L.check(rc, "ktf_tdnn_split_stats")
     return sums
 
 
-def stats_finalize(sums, lens, T, D, include_std, eps, out):
+def stats_finalize(sums, lens, T, D, include_std, eps, out, slots=0):
+    """sums (B,2,D) [slots == 0] or (B,slots,2,D) fp64 -> out (B, ld) mean | std."""
     lib = L.load()
     B = sums.shape[0]
     with torch.cuda.device(sums.device):
-        rc = lib.ktf_stats_finalize(L.ptr(sums), L.ptr(lens), T, B, D, int(include_std), eps, L.ptr(out), out.stride(0),
-                                    L.stream_ptr())
+        if slots:
+            rc = lib.ktf_stats_finalize_slots(L.ptr(sums), slots, L.ptr(lens), T, B, D, int(include_std), eps, L.ptr(out),
+                                              out.stride(0), L.stream_ptr())
+        else:
+            rc = lib.ktf_stats_finalize(L.ptr(sums), L.ptr(lens), T, B, D, int(include_std), eps, L.ptr(out), out.stride(0),
+                                        L.stream_ptr())
     L.check(rc, "ktf_stats_finalize")
     return out
 

@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -80,3 +81,52 @@ def test_shard_range_partitions():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ----------------------------------------------------------------------------- bench.py's own launcher (python bench.py --gpus N)
+_RANK_SCRIPT = """
+import os, sys, json
+sys.path.insert(0, {pkg!r})
+import torch
+from kaldi_tflite_amd import parallel as P
+rank, local_rank, world = P.init_from_env(backend="gloo")
+t = torch.tensor([float(rank + 1)])
+torch.distributed.all_reduce(t)
+P.barrier(world)
+secs = P.max_over_ranks(0.5 * (rank + 1), world, torch.device("cpu"))
+if rank == 0:
+    print(json.dumps({{"ranks_seen": torch.distributed.get_world_size(), "sum": float(t.item()), "max_s": secs,
+                      "argv": sys.argv[1:], "master": os.environ["MASTER_ADDR"]}}))
+torch.distributed.destroy_process_group()
+"""
+
+
+def test_bench_self_launcher_starts_the_ranks(tmp_path, monkeypatch):
+    """`python bench.py --gpus N` with no launcher around it: bench.py starts N ranks itself through
+    torch.distributed.run on 127.0.0.1 before it touches the GPU. The same command line is run here on a 2-rank gloo
+    stand-in script, and main() is checked to take that route exactly when WORLD_SIZE is unset."""
+    import json
+    import subprocess
+    sys.path.insert(0, ROOT)
+    import bench
+    script = tmp_path / "ranks.py"
+    script.write_text(_RANK_SCRIPT.format(pkg=os.path.join(ROOT, "kaldi-tflite_amd")))
+    cmd = bench.launch_command(2, ["--gpus", "2", "--steps", "3"], script=str(script))
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in cmd and "127.0.0.1" in cmd
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    got = json.loads(line)
+    assert got == {"ranks_seen": 2, "sum": 3.0, "max_s": 1.0, "argv": ["--gpus", "2", "--steps", "3"], "master": "127.0.0.1"}
+    # main(): --gpus 2 without WORLD_SIZE -> self_launch (no GPU call before it); with WORLD_SIZE set -> the rank path
+    calls = []
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(bench.subprocess, "call", lambda c, env=None: calls.append((c, env)) or 0)
+    with pytest.raises(SystemExit) as ex:
+        bench.main(["--gpus", "2", "--steps", "1"])
+    assert ex.value.code == 0 and len(calls) == 1
+    c, e = calls[0]
+    assert c[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"] and "--nproc-per-node=2" in c
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

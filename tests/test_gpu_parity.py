@@ -310,7 +310,7 @@ def test_tdnn_options_vs_oracle(gemm, tol):
 def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
     """The fp32 path runs on LDS-DMA-staged kernels: 128x128 tiles (two workgroups per CU), 64-row tiles when there are
     few workgroups (a single utterance), and a row-vector fmaf chain for <= 8 output rows (tdnn6). All sum in K order
-    like the register-staged 32x32x2 tile kernels they replace (KTF_F32_LATENCY=0 brings those back), so the outputs are
+    like the register-staged 32x32x2 tile kernels they replace (KtfTdnnDesc.flags = KTF_TDNN_REF_TILES), so the outputs are
     bit-identical and a batch still equals its single-utterance calls."""
     rng = np.random.default_rng(5)
     for (B, T, D, U, ctx, sub, pad, act) in [
@@ -340,11 +340,9 @@ def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
             xin = t.prepare_input(dev(x), ktf._lib.GEMM_F32)
             return host(t.forward(xin, lens=lens))[:, :, :U]
         got = run()
-        os.environ["KTF_F32_LATENCY"] = "0"
-        try:
-            tile = run()
-        finally:
-            del os.environ["KTF_F32_LATENCY"]
+        t.kernelFlags = ktf._lib.TDNN_REF_TILES          # KtfTdnnDesc.flags: the register-staged reference tiles
+        tile = run()
+        t.kernelFlags = 0
         if lens is None:
             assert np.array_equal(got, tile), (B, T, D, U, np.abs(got - tile).max())
             want = O.tdnn(x, W, b, ctx, sub, pad, act, dtype=np.float64)

@@ -202,3 +202,38 @@ def test_xvector_post_consistency():
     ref = (z["xvectors"].astype(np.float64) - mean) @ lda[:, :-1].T.astype(np.float64) + lda[:, -1]
     ref = ref * np.sqrt(128.0) / np.linalg.norm(ref, axis=-1, keepdims=True)
     assert np.abs(ref - y).max() < 1e-5
+
+
+def test_xvector_post_kaldi_golden():
+    # a12 pinned: the reference ships the Kaldi-computed 512-d embedding of librispeech_2.wav before and after
+    # `ivector-subtract-global-mean | transform-vec | ivector-normalize-length` (testdata/models/src/0008_sitw_v2_1a/
+    # xvector.unnorm.ark.txt -> xvector.ark.txt, produced by testdata/models/src/compute_xvectors.sh with the shipped
+    # mean.vec / transform.mat): exactly the chain of xvector_extractor.py:174-184.
+    z = G.load("e2e_0008.npz")
+    from kaldi_tflite_amd.io import ReadKaldiArray
+    mean = ReadKaldiArray(G.GOLDEN + "/xvectors_train_combined_200k.mean.vec.txt", binary=False)
+    lda = ReadKaldiArray(G.GOLDEN + "/xvectors_train_combined_200k.transform.mat", binary=True)
+    for dt, tol in ((np.float32, 1e-5), (np.float64, 1e-5)):
+        got = O.xvector_post(z["xvector_unnorm"], mean, lda, dtype=dt)
+        assert got.shape == (1, 128)
+        err = np.abs(got - z["xvector"].reshape(1, 128)).max()
+        assert err <= tol, (dt, err)          # measured 2.7e-6: the text ark keeps 7 significant digits
+
+
+def test_torch_cpu_restatement_equals_the_numpy_oracle():
+    # oracle/ktf_torch_cpu.py (the timed CPU baseline of bench.py) against the fp64 NumPy oracle: dense and ragged
+    # batches, the features-only configuration, full 0008 topology
+    import synth
+    from oracle.ktf_torch_cpu import KtfRef
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321, narrow=False)
+    ref = KtfRef(cfg, synth.oracle_layers(w), w["mean"], w["lda"])
+    for ragged in (False, True):
+        wav = synth.make_wav(2, 16000 * 3 + 51, seed=7, ragged=ragged)
+        want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+        got = ref(wav).numpy()
+        assert got.shape == want.shape and np.abs(got - want).max() < 1e-4, (ragged, np.abs(got - want).max())
+    wav = synth.make_wav(1, 16000 * 5, seed=9)
+    fcfg = {k: v for k, v in cfg["framing"].items() if k != "dynamic_input_shape"}
+    want = O.cmvn(O.mfcc(O.framing(wav, **fcfg), **cfg["mfcc"], dtype=np.float64), **cfg["cmvn"], dtype=np.float64)
+    assert np.abs(ref.features(wav).numpy() - want).max() < 2e-3       # log-domain features of sigma = 1000 noise

@@ -42,7 +42,12 @@ def main():
     wav = torch.clamp(torch.round(1000.0 * torch.randn((B, N), generator=g, device=dev)), -32767, 32767)
     T = mdl.framing.numFrames(N)
     mdl(wav)      # builds workspaces
-    ws = mdl._ws[next(iter(mdl._ws))]
+    D = mdl.mfcc.numMfccs
+    fdt = L.act_torch_dtype(mdl.xvec.batch_gemm(B, T))
+    W = mdl._ws
+    ws = {"mfcc": W.get("mfcc", (B, T, D), torch.float32, dev), "feats": W.get("feats", (B, T, 32), fdt, dev),
+          "lens": W.get("lens", (B,), torch.int32, dev), "idx": W.get("idx", (B, T), torch.int32, dev),
+          "work": W.get("cmvn_work", (B * T * 2 * D + 2 * D,), torch.float32, dev)}
     if a.what in ("frontend", "all"):
         fr, mf = mdl.framing, mdl.mfcc
         c = L.FrontendCfg.from_buffer_copy(mf._cfg)

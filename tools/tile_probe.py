@@ -2,7 +2,7 @@
 """Per-tile phase timestamps of the 128x256 bf16 TDNN kernel (needs a build with -DKTF_TILE_PROBE: make CXXFLAGS+=...).
 
 The kernel then stores s_memrealtime stamps (setup, first stage landed, K-loop end, epilogue phases) per tile into the
-buffer whose address is passed in KTF_DBG_PTR; this script prints the mean phase times and the per-CU overlap.
+buffer handed to the probe build's ktf_probe_set_buffer(); this script prints the mean phase times and the per-CU overlap.
 """
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -11,10 +11,11 @@ for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "test
 import torch, numpy as np
 dev = torch.device("cuda", 0)
 dbg = torch.zeros((65536, 16), dtype=torch.int64, device=dev)
-os.environ["KTF_DBG_PTR"] = str(dbg.data_ptr())
 os.environ.setdefault("KTF_HTILE", "1")
+import ctypes
 import kaldi_tflite_amd as ktf
 from kaldi_tflite_amd import _lib as L
+L.load().ktf_probe_set_buffer(ctypes.c_void_p(dbg.data_ptr()))      # exists in -DKTF_TILE_PROBE builds only
 B, T = 1024, 998
 from kaldi_tflite_amd import ops
 for name, din, units, ctx in [("tdnn2", 512, 512, [-2, 0, 2]), ("tdnn4", 512, 512, [0]), ("tdnn5", 512, 1500, [0]),
