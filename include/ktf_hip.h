@@ -210,6 +210,12 @@ typedef struct KtfTdnnDesc {
                                    * 128-row block of an utterance stores its fp64 column sums in a slot of its own instead
                                    * of adding them with atomics; `sums` is then (B, ktf_stats_slots(T), 2, units), need not
                                    * be zeroed, and is reduced in slot order by ktf_stats_finalize_slots */
+#define KTF_TDNN_K_INTERLEAVED 4  /* ktf_tdnn_split / ktf_tdnn_split_stats only: the K axis of W (both planes) is ordered
+                                   * (32-feature chunk, context, feature in chunk) instead of (context, feature), i.e. column
+                                   * ((d / 32) * nctx + k) * 32 + d % 32 holds W[u, k * Din_pad + d]. The kernel then walks
+                                   * the contexts of one feature chunk in consecutive K-steps, so the three (five) reads of an
+                                   * activation row piece by a multi-context layer are adjacent in time and hit in L2 instead of
+                                   * returning to HBM / MALL 16 K-steps apart */
 
 /* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
 int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);

@@ -6,16 +6,37 @@
 //     (v_permlane32_swap / v_permlane16_swap for lane bits 5 and 4, DPP row_ror:8 / row_shl|shr:4 with bank masks for
 //     bits 3 and 2, DPP quad_perm for bits 1 and 0) — no LDS, no address arithmetic; twiddles are per-lane constants;
 //   * one LDS round trip puts the spectrum in natural order for the real-FFT split (X[k], X[256-k]);
-//   * the sparse mel bank is spread over all 64 lanes as (filter, <=16-bin slice) work items with the weights in
-//     registers and a 2-step segmented reduction; the DCT column of each lane lives in registers.
+//   * the sparse mel bank is spread over all 64 lanes as (filter, <=16-bin slice) work items and a 2-step segmented
+//     reduction; each lane computes one cepstral coefficient (its DCT column);
+//   * the per-lane mel weights (16) and DCT column (32) are kept in LDS as lane-linear 16-byte records, not in registers:
+//     12 more conflict-free ds_read_b128 per frame buy 48 VGPRs, i.e. 5 waves per SIMD instead of 3 — the kernel is bound
+//     by the latency of its dependent DPP / permlane / LDS chains, not by VALU throughput, so resident waves are what it needs.
 // Used by ktf_frontend_f32 when the caller provides the KtfFrontendTables.fast_* tables; any other configuration runs
 // the generic kernel of frontend.hip.
 #include "common.h"
 
-#define F5_WAVES 4
+// Measured on MI355X (1024 x 998 frames, tools/ab_f5.sh; VGPRs / waves per SIMD of the hot <no dither, fp32 input, 400> instance):
+//   constants in registers, 4 waves per workgroup                 136 VGPR, 3 waves/SIMD   0.945 ms   (round 1)
+//   mel weights + DCT column in LDS                                122 VGPR, 4 waves/SIMD   0.876 ms
+//   + twiddles in LDS, 4 waves per workgroup                        82 VGPR, 5 waves/SIMD   0.90  ms   (LDS-limited: 5 workgroups)
+//   + 8 waves per workgroup (tables shared by twice the waves)      80 VGPR, 6 waves/SIMD   0.854 ms   <- this build
+// 0.854 ms = 2040 cycles per frame and SIMD for ~490 vector instructions: 4.2 cycles per instruction, i.e. the VALU issue
+// rate of this DPP / permlane / transcendental mix; more resident waves no longer help.
+#ifndef F5_WAVES
+#define F5_WAVES 8
+#endif
+#define F5_WAVE_FLOATS (2 * 256 + 64)   // per-wave LDS: Z[256] float2 (reused for P[256] float once the spectrum is split) | feat[64]
 #define F5_THREADS (F5_WAVES * KTF_WAVE)
 #define F5_MAXW 16          // bins per mel work item (upper bound; the table says how many are used)
-#define F5_MAXMEL 32        // DCT rows kept in registers
+#define F5_MAXMEL 32        // DCT rows per lane
+#ifndef F5_MINWAVES
+#define F5_MINWAVES 6       // waves per SIMD the register allocation of the hot instance is held to (__launch_bounds__); the
+                            // dither / int16 / mirror-padding instances keep 4 (they would spill in the frame loop)
+#endif
+#ifndef F5_TW_LDS
+#define F5_TW_LDS 1         // 1: the per-lane FFT twiddles (26 floats) also live in LDS records instead of registers
+#endif
+#define F5_TWREC 28         // floats per lane in the twiddle record (7 x 16 B): tw1[3] tw2[3] tw3[3] rw[4] (+2 pad)
 
 // ---- cross-lane primitives (all VALU: no LDS pipe)
 #define DPP_QUAD_XOR1 0xB1      // quad_perm:[1,0,3,2]
@@ -134,7 +155,7 @@ __device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t
 // MFIX: frame size known at compile time (400 = 25 ms at 16 kHz, the shipped configuration) or 0 = cfg.frame_size: with
 // a constant M the `sample index < M` predicates of the loads, DC removal and pre-emphasis fold away.
 template <bool DITHER, bool PLAIN, int MFIX>
-__global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
+__global__ __launch_bounds__(F5_THREADS, (PLAIN && !DITHER) ? F5_MINWAVES : 4) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                                  int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                                  int out_stage, float* __restrict__ out,
                                                                  uint64_t seed, int64_t T) {
@@ -145,17 +166,31 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
     const int nm = cfg.num_mels, nc = cfg.num_ceps;
     const int maxw = tab.reserved;          // bins per mel work item actually used (<= F5_MAXW)
 
-    // LDS: window[512] | per wave: Z[256] float2, P[256] float, feat[64] float
+    // LDS: window[512] | dct4[8][64] f32x4 | melw4[4][64] f32x4 | (twiddle records) | per wave: Z[256] float2 = P[256] float, feat[64] float
     float* win = lds5;
-    float* wbase = lds5 + NF + wave * (2 * N2 + N2 + 64);
+    float* dct4 = lds5 + NF;                                   // record (m4, lane) = dct[4 m4 .. 4 m4 + 3][lane]
+    float* melw4 = dct4 + F5_MAXMEL * KTF_WAVE;                // record (j4, lane) = this lane's mel weights 4 j4 .. 4 j4 + 3
+    float* twl = melw4 + F5_MAXW * KTF_WAVE;                    // F5_TW_LDS: record (q, lane), q < 7
+    float* wbase = twl + (F5_TW_LDS ? F5_TWREC * KTF_WAVE : 0) + wave * F5_WAVE_FLOATS;
     float2* Zb = reinterpret_cast<float2*>(wbase);
-    float* Pb = wbase + 2 * N2;
-    float* feat = Pb + N2;
+    float* Pb = wbase;               // the power spectrum overwrites Z: a wave's LDS operations execute in program order, and
+                                     // every Z read of the split precedes the first P write
+    float* feat = wbase + 2 * N2;
     if (in_kind != KTF_IN_WINDOWED)
         for (int i = tid; i < NF; i += F5_THREADS) win[i] = (i < M) ? tab.window[i] : 0.0f;
     if (lane < 64) feat[lane] = 0.0f;
 
     // ---- per-lane constants (registers for the whole kernel)
+#if F5_TW_LDS
+    for (int i = tid; i < F5_TWREC * KTF_WAVE; i += F5_THREADS) {
+        const int e = i & 3, l = (i >> 2) & 63, f = 4 * (i >> 8) + e;       // float f of lane l's record
+        float val = 0.0f;
+        if (f < 18) val = tab.fast_tw[l * 18 + f];
+        else if (f < 26) val = tab.rtwiddle[2 * (l + 64 * ((f - 18) >> 1)) + ((f - 18) & 1)];
+        twl[i] = val;
+    }
+#define F5_TWQ(q) (*reinterpret_cast<const f32x4*>(twl + ((q) * KTF_WAVE + lane) * 4))
+#else
     float2 tw1[3], tw2[3], tw3[3], rw[4];
     {
         const float* t = tab.fast_tw + lane * 18;
@@ -171,17 +206,20 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
             rw[j] = make_float2(tab.rtwiddle[2 * k], tab.rtwiddle[2 * k + 1]);
         }
     }
+#endif
     const int mel_start = tab.fast_mel_meta[lane * 4 + 0];
     const int mel_filter = tab.fast_mel_meta[lane * 4 + 2];
     const int mel_flags = tab.fast_mel_meta[lane * 4 + 3];      // bit0: lane+1 same filter, bit1: lane+2 same, bit2: first
-    float melw[F5_MAXW];                                        // zero beyond the item's length
-#pragma unroll
-    for (int j = 0; j < F5_MAXW; ++j) melw[j] = tab.fast_mel_w[lane * F5_MAXW + j];
-    float dctc[F5_MAXMEL];
+    for (int i = tid; i < F5_MAXW * KTF_WAVE; i += F5_THREADS) {          // weights are zero beyond an item's length
+        const int e = i & 3, l = (i >> 2) & 63, j4 = i >> 8;
+        melw4[i] = tab.fast_mel_w[l * F5_MAXW + 4 * j4 + e];
+    }
     float lift = 1.0f;
     if (out_stage == KTF_OUT_MFCC) {
-#pragma unroll
-        for (int m = 0; m < F5_MAXMEL; ++m) dctc[m] = (m < nm && lane < nc) ? tab.dct[m * nc + lane] : 0.0f;
+        for (int i = tid; i < F5_MAXMEL * KTF_WAVE; i += F5_THREADS) {
+            const int e = i & 3, l = (i >> 2) & 63, m = 4 * (i >> 8) + e;
+            dct4[i] = (m < nm && l < nc) ? tab.dct[m * nc + l] : 0.0f;
+        }
         if (cfg.use_lifter && tab.lifter && lane < nc) lift = tab.lifter[lane];
     }
     // output index of this lane's FFT results: X[mo + 64*r4]
@@ -314,6 +352,13 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
             const float g = dpp_mov<DPP_QUAD_XOR1>(s);
             z[k] = even ? make_float2(v[2 * k], g) : make_float2(g, v[2 * k + 1]);
         }
+#if F5_TW_LDS
+        // record floats: tw1 = 0..5, tw2 = 6..11, tw3 = 12..17, rw = 18..25
+        const f32x4 q0 = F5_TWQ(0), q1 = F5_TWQ(1), q2 = F5_TWQ(2), q3 = F5_TWQ(3), q4 = F5_TWQ(4);
+        const float2 tw1[3] = {make_float2(q0.x, q0.y), make_float2(q0.z, q0.w), make_float2(q1.x, q1.y)};
+        const float2 tw2[3] = {make_float2(q1.z, q1.w), make_float2(q2.x, q2.y), make_float2(q2.z, q2.w)};
+        const float2 tw3[3] = {make_float2(q3.x, q3.y), make_float2(q3.z, q3.w), make_float2(q4.x, q4.y)};
+#endif
         bfly4(z);                                   // over k (stride 64)
 #pragma unroll
         for (int r = 1; r < 4; ++r) z[r] = cmulf(z[r], tw1[r - 1]);
@@ -333,6 +378,10 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
         F5_WAVE_SYNC();
         // ---- split the packed spectrum, |X[k]|(^2)  (filterbank.py:232-235; bin 256 carries no mel weight)
         float pw[4];
+#if F5_TW_LDS
+        const f32x4 q4b = F5_TWQ(4), q5 = F5_TWQ(5), q6 = F5_TWQ(6);
+        const float2 rw[4] = {make_float2(q4b.z, q4b.w), make_float2(q5.x, q5.y), make_float2(q5.z, q5.w), make_float2(q6.x, q6.y)};
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = lane + 64 * j;
@@ -356,8 +405,15 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
         //      the wave's own P/feat area), then a segmented reduction over <= 4 adjacent lanes
         float acc = 0.0f;
 #pragma unroll
-        for (int j = 0; j < F5_MAXW; ++j)
-            if (j < maxw) acc = fmaf(Pb[mel_start + j], melw[j], acc);
+        for (int j4 = 0; j4 < F5_MAXW / 4; ++j4) {
+            if (4 * j4 < maxw) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(melw4 + (j4 * KTF_WAVE + lane) * 4);
+                acc = fmaf(Pb[mel_start + 4 * j4 + 0], w.x, acc);
+                if (4 * j4 + 1 < maxw) acc = fmaf(Pb[mel_start + 4 * j4 + 1], w.y, acc);
+                if (4 * j4 + 2 < maxw) acc = fmaf(Pb[mel_start + 4 * j4 + 2], w.z, acc);
+                if (4 * j4 + 3 < maxw) acc = fmaf(Pb[mel_start + 4 * j4 + 3], w.w, acc);
+            }
+        }
         {
             const float t1 = __shfl_down(acc, 1, 64);
             if (mel_flags & 1) acc += t1;
@@ -379,10 +435,11 @@ __global__ __launch_bounds__(F5_THREADS) void frontend512_kernel(const void* __r
 #pragma unroll
         for (int m4 = 0; m4 < F5_MAXMEL / 4; ++m4) {
             const f32x4 f = *reinterpret_cast<const f32x4*>(feat + 4 * m4);   // rows >= num_mels are zero
-            c = fmaf(f.x, dctc[4 * m4 + 0], c);
-            c = fmaf(f.y, dctc[4 * m4 + 1], c);
-            c = fmaf(f.z, dctc[4 * m4 + 2], c);
-            c = fmaf(f.w, dctc[4 * m4 + 3], c);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(dct4 + (m4 * KTF_WAVE + lane) * 4);
+            c = fmaf(f.x, d.x, c);
+            c = fmaf(f.y, d.y, c);
+            c = fmaf(f.z, d.z, c);
+            c = fmaf(f.w, d.w, c);
         }
         c *= lift;
         if (lane == 0 && cfg.use_energy) c = logE;
@@ -402,7 +459,7 @@ int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind
     if (gx < 1) gx = 1;
     if (gx > gmax) gx = gmax;
     const dim3 grid((unsigned)gx, (unsigned)B);
-    const size_t lds = sizeof(float) * (512 + F5_WAVES * (512 + 256 + 64));
+    const size_t lds = sizeof(float) * (512 + (F5_MAXMEL + F5_MAXW + (F5_TW_LDS ? F5_TWREC : 0)) * KTF_WAVE + F5_WAVES * F5_WAVE_FLOATS);
     const bool dither = cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED;
     const bool plain = in_kind != KTF_IN_WAV_I16 && !(in_kind == KTF_IN_WAV && cfg->pad_mode);
 #define F5_LAUNCH(DI, PL, MF)                                                                                          \

@@ -33,6 +33,9 @@ extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
 #define KTF_KNOB(name, dflt) (dflt)
 #define KTF_PROBE_BUF ((long long*)nullptr)
 #endif
+#ifndef KTF_X3S_DEFAULT
+#define KTF_X3S_DEFAULT 2     // split-bf16 planes: 16x16x32 kernel for every layer (measured 62.3 k vs 58.6 k x-vectors/s with 1 = pooling layer only)
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -53,6 +56,7 @@ struct TdnnParams {
     int64_t T, ldx, ldy, Tout;
     int32_t units, din_pad, nctx, sub, valid, act, y_dtype, ktot;
     int32_t ctx[16];
+    int32_t kinter;         // KTF_TDNN_K_INTERLEAVED: K runs (32-wide feature chunk, context, feature) instead of (context, feature)
     int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
 };
 
@@ -988,18 +992,32 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + (lane & 31) * 8 + 4);
                     const int64_t off = (out_row0 + m) * p.ldy + n8;
                     unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + off;
+                    const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned short hh[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hh[e] = f2bf(vv[e]);
                     if (n8 + 8 <= p.units) {
                         u32x4 pk;
-                        pk.x = (unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16);
-                        pk.y = (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16);
-                        pk.z = (unsigned)f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16);
-                        pk.w = (unsigned)f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16);
+                        pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
+                        pk.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
+                        pk.z = (unsigned)hh[4] | ((unsigned)hh[5] << 16);
+                        pk.w = (unsigned)hh[6] | ((unsigned)hh[7] << 16);
                         *reinterpret_cast<u32x4*>(yp) = pk;
+                        if (p.y_lo) {            // split-bf16 output: the residual plane, the next layer's lo operand
+                            u32x4 pl;
+                            pl.x = (unsigned)f2bf(vv[0] - bf2f(hh[0])) | ((unsigned)f2bf(vv[1] - bf2f(hh[1])) << 16);
+                            pl.y = (unsigned)f2bf(vv[2] - bf2f(hh[2])) | ((unsigned)f2bf(vv[3] - bf2f(hh[3])) << 16);
+                            pl.z = (unsigned)f2bf(vv[4] - bf2f(hh[4])) | ((unsigned)f2bf(vv[5] - bf2f(hh[5])) << 16);
+                            pl.w = (unsigned)f2bf(vv[6] - bf2f(hh[6])) | ((unsigned)f2bf(vv[7] - bf2f(hh[7])) << 16);
+                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y_lo) + off) = pl;
+                        }
                     } else {
-                        const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
 #pragma unroll
                         for (int e = 0; e < 8; ++e)
-                            if (n8 + e < p.units) yp[e] = f2bf(vv[e]);
+                            if (n8 + e < p.units) {
+                                yp[e] = hh[e];
+                                if (p.y_lo) reinterpret_cast<unsigned short*>(p.y_lo)[off + e] = f2bf(vv[e] - bf2f(hh[e]));
+                            }
                     }
                 }
             }
@@ -1882,7 +1900,18 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // (two staged passes) measured 10 us per tile slower than the 32x32 kernel's, which cancels the K-loop gain at K <= 1536.
 #define XS_STAGE_BYTES (4 * R_TILE_BYTES)                // 64 KiB
 #define XS_LDS_BYTES (2 * XS_STAGE_BYTES)                // 128 KiB
-template <int ACT>
+// PIPE = 1: hand-scheduled K-step. The stage's operand DMAs are no longer issued in one burst behind the barrier (all eight
+// waves then sit in DMA issue and LDS latency together while the matrix pipes idle) but one at a time between groups of six
+// MFMAs, and the A fragments of row group g+1 are read while the MFMAs of group g run (two fragment register sets).
+// DOFF: waves 4-7 (the SIMD partners of waves 0-3) start their DMA slots DOFF chunks later, so that partners do not sit in
+// DMA issue at the same time.
+#ifndef KTF_X3_PIPE
+#define KTF_X3_PIPE 1
+#endif
+#ifndef KTF_X3_DOFF
+#define KTF_X3_DOFF 0
+#endif
+template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -1948,11 +1977,19 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + 3 * R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         ++is_ks;                                                                                                       \
-        is_db += R_BK * 2;                                                                                             \
-        if (is_db == dpad_b) {                                                                                         \
-            is_db = 0;                                                                                                 \
-            ++is_c;                                                                                                    \
-            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        if (p.kinter) {                                                                                                \
+            if (++is_c == p.nctx) {                                                                                    \
+                is_c = 0;                                                                                              \
+                is_db += R_BK * 2;                                                                                     \
+            }                                                                                                          \
+            is_off = p.ctx[is_c];                                                                                      \
+        } else {                                                                                                       \
+            is_db += R_BK * 2;                                                                                         \
+            if (is_db == dpad_b) {                                                                                     \
+                is_db = 0;                                                                                             \
+                ++is_c;                                                                                                \
+                is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                            \
+            }                                                                                                          \
         }                                                                                                              \
     }
     XS_STAGE()
@@ -1960,6 +1997,90 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int coff = (((lane >> 4) ^ fr) << 4);
     const int a_row_off = (wm * 128 + (lane & 15)) * 64 + coff;
     const int b_row_off = (wn * 64 + (lane & 15)) * 64 + coff;
+    if constexpr (PIPE == 1) {
+        const int doff = (wave >= 4) ? KTF_X3_DOFF : 0;        // wave-uniform
+        for (int ks = 0; ks < nk; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage ks landed (nothing else is in flight)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const unsigned char* sa = rsm + (ks & 1) * XS_STAGE_BYTES;
+            const unsigned char* sw = sa + 2 * R_TILE_BYTES;
+            const bool refill = is_ks < nk;                     // stage ks+1 -> the buffer every wave finished reading
+            unsigned char* st_ = rsm + (is_ks & 1) * XS_STAGE_BYTES + wave * 1024;
+            unsigned va[2], vw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r_ = a_t[i] + is_off;
+                r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);
+                va[i] = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;
+                vw[i] = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));
+            }
+            // DMA n of the stage: 0,1 = A hi / lo rows 0-127; 2,3 = rows 128-255; 4,5 = W hi / lo rows 0-127; 6,7 = rows 128-255
+#define XS_DMA(n)                                                                                                      \
+    {                                                                                                                  \
+        const char* src_ = ((n) < 4) ? ((((n) & 1) ? xl : xh) + va[(n) >> 1]) : ((((n) & 1) ? wl : wh) + vw[((n) - 4) >> 1]); \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)src_,                                                             \
+            (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) : 2 + ((n) & 1)) * R_TILE_BYTES + (((n) >> 1) & 1) * 8192), 16, 0, 0); \
+    }
+            bfrag8 bh[4], bl[4], af[2][4];                      // af[set][0,1] = hi fragments of the group's two rows, [2,3] = lo
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
+                bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                af[0][r] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + r * 16 * 64);
+                af[0][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + r * 16 * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cur = g & 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24
+#pragma unroll
+                    for (int m = 6 * c; m < 6 * c + 6; ++m) {
+                        const int r = m / 12, t = (m % 12) / 4, j = m & 3;     // row, term (hh, lh, hl), column block
+                        f32x4v& cc = acc[2 * g + r][j];
+                        cc = mfma16x16x32<false>(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c == 0 && g < 3) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            af[cur ^ 1][r] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + (2 * (g + 1) + r) * 16 * 64);
+                            af[cur ^ 1][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + (2 * (g + 1) + r) * 16 * 64);
+                        }
+                    }
+                    if (refill) {
+                        const int n = 4 * g + c - doff;         // slot -> DMA index (wave-uniform)
+                        if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
+                        else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#undef XS_DMA
+            if (refill) {
+                ++is_ks;
+                if (p.kinter) {                  // next context of the same 32 features; after the last one, the next features
+                    if (++is_c == p.nctx) {
+                        is_c = 0;
+                        is_db += R_BK * 2;
+                    }
+                    is_off = p.ctx[is_c];
+                } else {
+                    is_db += R_BK * 2;
+                    if (is_db == dpad_b) {
+                        is_db = 0;
+                        ++is_c;
+                        is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;
+                    }
+                }
+            }
+        }
+    } else
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage ks landed (nothing else is in flight)
         __builtin_amdgcn_s_barrier();
@@ -1994,7 +2115,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         }
     }
 #undef XS_STAGE
-    ring_epilogue16<ACT, true>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+    if (!STATS) __syncthreads();      // all fragment reads done before the LDS is reused as the store staging area
+    ring_epilogue16<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ F32, few workgroups (latency)
@@ -2487,6 +2609,8 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
     p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
+    p.kinter = (d->flags & KTF_TDNN_K_INTERLEAVED) ? 1 : 0;
+    if (p.kinter) KTF_REQUIRE(split_in && d->units > 128 && ldy % 4 == 0, "ktf_tdnn: KTF_TDNN_K_INTERLEAVED is implemented by the split-plane kernel only (ktf_tdnn_split*, units > 128)");
     for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
     hipStream_t st = (hipStream_t)stream;
     const unsigned ntiles = (unsigned)ktf_cdiv(d->units, 128);
@@ -2563,13 +2687,18 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         if (stats_sums) { if (split_in) X_LAUNCH1(A, true, true); else X_LAUNCH1(A, true, false); }                    \
         else { if (split_in) X_LAUNCH1(A, false, true); else X_LAUNCH1(A, false, false); }                            \
     } while (0)
+#define XS_LAUNCH1(A, ST)                                                                                              \
+    do {                                                                                                               \
+        KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST>); \
+        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+    } while (0)
 #define XS_LAUNCH(A)                                                                                                   \
     do {                                                                                                               \
-        KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A>); \
-        hipLaunchKernelGGL((tdnn_x3s_kernel<A>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        if (stats_sums) XS_LAUNCH1(A, true); else XS_LAUNCH1(A, false);                                                \
     } while (0)
-            const int x3s_env = KTF_KNOB("KTF_X3S", 1);      // probe builds: 0 = 32x32x16 kernel (A/B)
-            if (split_in && stats_sums && x3s_env) {
+            const int x3s_env = KTF_KNOB("KTF_X3S", KTF_X3S_DEFAULT);   // probe builds: 0 = 32x32x16 kernels everywhere (A/B)
+            // split planes in: the 16x16x32 kernel (x3s_env 2: also for the layers that write planes / fp32 out, else pooling only)
+            if (split_in && (p.kinter || (x3s_env && (stats_sums || x3s_env >= 2)))) {
                 if (d->act == KTF_ACT_NONE) XS_LAUNCH(KTF_ACT_NONE);
                 else if (d->act == KTF_ACT_RELU) XS_LAUNCH(KTF_ACT_RELU);
                 else if (d->act == KTF_ACT_SIGMOID) XS_LAUNCH(KTF_ACT_SIGMOID);
@@ -2580,6 +2709,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             else if (d->act == KTF_ACT_SIGMOID) X_LAUNCH(KTF_ACT_SIGMOID);
             else X_LAUNCH(KTF_ACT_TANH);
 #undef XS_LAUNCH
+#undef XS_LAUNCH1
 #undef X_LAUNCH
 #undef X_LAUNCH1
         } else if (x3) {

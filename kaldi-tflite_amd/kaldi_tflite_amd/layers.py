@@ -755,15 +755,18 @@ class TDNN(Layer):
         K, D = self.kernelWidth, self.inputDim
         return np.ascontiguousarray(self.kernel[0].reshape(K * D, self.units).T)
 
-    def device_weights(self, device, gemm):
-        """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for bf16x3), bias."""
-        key = (str(device), gemm)
+    def device_weights(self, device, gemm, k_interleaved=False):
+        """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for bf16x3), bias.
+        `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, split-plane kernel."""
+        key = (str(device), gemm, bool(k_interleaved))
         if key in self._dev:
             return self._dev[key]
         K, D = self.kernelWidth, self.inputDim
         Dp, Up = ops.round_up(D, 32), ops.round_up(self.units, 256)
         W = np.zeros((Up, K, Dp), np.float32)
         W[: self.units, :, :D] = np.transpose(self.kernel[0], (2, 0, 1))     # [u, k, d]
+        if k_interleaved:
+            W = np.ascontiguousarray(W.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3))
         W = torch.as_tensor(W.reshape(Up, K * Dp), device=device)
         w_lo = None
         if gemm == L.GEMM_F32:

@@ -109,6 +109,7 @@ class Sequential:
     precision), "bf16x3" (split-bf16, fp32-grade), "bf16" or "f16"."""
 
     split_planes = True         # bf16x3: hi/lo bf16 activation planes between the wide layers (no in-loop conversion)
+    k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
     # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
     min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32}
 
@@ -198,11 +199,12 @@ class Sequential:
         slots = ops.stats_slots(T) if self.deterministic else 0
         sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev)
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev)
-        w, w_lo, bias = l.device_weights(dev, gemm)
+        kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
+        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint)
         scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
         xdt = torch.bfloat16 if split else x_or_planes.dtype
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
-                   flags=L.TDNN_DET_STATS if slots else 0)
+                   flags=(L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0))
         (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
         ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf, slots=slots)
         return sbuf[:, :od].unsqueeze(0)
@@ -248,7 +250,9 @@ class Sequential:
                     x = self._pooled_by_gemm(l, relu, bn, nxt, planes, lens, gemm, True, dev, T)
                     lens, pooled, skip, planes = None, True, True, None
                     continue
-                w, w_lo, bias = l.device_weights(dev, gemm)
+                kint = bool(self.k_interleaved and l.kernelWidth > 1)
+                kflag = L.TDNN_K_INTERLEAVED if kint else 0
+                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint)
                 scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
@@ -258,13 +262,13 @@ class Sequential:
                 keep = nxt is not None and nxt[0] == "tdnn" and nxt[1].units > 128        # the consumer reads planes too
                 if keep:
                     ybuf = self._ws.get(out_role, (2, B, Tout, ldy), torch.bfloat16, dev)
-                    d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None)
+                    d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None, flags=kflag)
                     ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf[0], ybuf[1], out_lens)
                     planes = ybuf
                     x = ybuf[0][:, :, : l.units]                     # shape carrier only (the values live in `planes`)
                 else:
                     ybuf = self._ws.get(out_role, (B, Tout, ldy), torch.float32, dev)
-                    d = l.desc(gemm, torch.bfloat16, torch.float32, act="relu" if relu else None)
+                    d = l.desc(gemm, torch.bfloat16, torch.float32, act="relu" if relu else None, flags=kflag)
                     ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
                     planes = None
                     x = ybuf[:, :, : l.units]
