@@ -426,3 +426,21 @@ def test_reference_yaml_topology_is_parseable():
         mdl = ktf.models.SequentialFromConfig(cfg, None, "cmvn2xvec")
         assert mdl.get_layer("tdnn1.affine").kernel.shape == (1, 5, feat, 512)
         assert mdl.get_layer("tdnn6.affine").kernel.shape == (1, 1, 3000, out)
+
+
+def test_shipped_yaml_configs_build_the_reference_topologies():
+    # kaldi_tflite_amd/data/**/*.yml (tools/write_model_configs.py): the YAML files a user of the reference passes to the builders
+    data = os.path.join(os.path.dirname(ktf.__file__), "data")
+    for name, feat, out, right in [("0008_sitw_v2_1a", 30, 512, 10000), ("0006_callhome_diarization_v2_1a", 23, 128, 400)]:
+        with open(os.path.join(data, "kaldi_models", "configs", f"{name}.yml")) as f:
+            cfg = yaml.safe_load(f)
+        assert cfg["name"] == name and cfg["download"]["link"].endswith(f"{name}.tar.gz") and len(cfg["download"]["hash"]) == 64
+        mdl = ktf.models.SequentialFromConfig(cfg["model_config"], None, "cmvn2xvec")
+        assert [l.name for l in mdl.layers][-2:] == ["stats", "tdnn6.affine"] and len(mdl.layers) == 17
+        assert mdl.get_layer("tdnn1.affine").kernel.shape == (1, 5, feat, 512)
+        assert mdl.get_layer("tdnn6.affine").kernel.shape == (1, 1, 3000, out)
+        assert mdl.get_layer("stats").rightContext == right and mdl.get_layer("tdnn3.affine").context == [-3, 0, 3]
+    with open(os.path.join(data, "tflite_models", "0008_sitw_v2_1a.yml")) as f:
+        ext = yaml.safe_load(f)["extractor"]
+    assert ext == dict(synth.extractor_cfg(dither=1.0), xvec=ext["xvec"])
+    assert ext["xvec"]["model_config_path"] == "data/kaldi_models/configs/0008_sitw_v2_1a.yml"
