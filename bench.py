@@ -7,9 +7,11 @@ tdnn6 -> LDA/length-norm) over one batch of synthetic 10 s / 16 kHz utterances t
 Workload (config.workload): the BASELINE "8 192 utterances over 8 GPUs" configuration = 1 024 utterances per GPU
 (weak scaling: per-GPU batch fixed), 0008_sitw_v2_1a topology with seeded random weights, dither 0.
 
-The timed arithmetic (`dtype`) defaults to "bf16x3": split-bf16 operands on the bf16 MFMA pipe with fp32 accumulation —
-the fastest mode that meets north_star's <= 1e-4 max-abs deviation (the line carries the measured deviation of the timed
-mode at the full 10 s size and `tolerance_ok`). `--gemm f32` times the exact fp32 path; bf16 / f16 are side legs.
+The timed arithmetic (`dtype`) defaults to "f16x2": two half-precision MFMA passes with fp32 accumulation (weights exact as
+hi + lo halves, activations stored as one half plane of ReLU outputs with the BatchNorm folded into the next layer) — the
+fastest mode that meets north_star's <= 1e-4 max-abs deviation (the line carries the measured deviation of the timed mode at
+the full 10 s size and `tolerance_ok`). `--gemm bf16x3` (split-bf16, 4e-6) and `--gemm f32` (exact) are the tighter modes;
+one-pass bf16 / f16 are side legs outside the tolerance.
 
     python bench.py                      # 1 GPU
     python bench.py --gpus 8             # starts 8 ranks itself (torch.distributed.run) when WORLD_SIZE is unset
@@ -37,11 +39,12 @@ for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "test
 
 FLOP_PER_FRAME_TDNN = 2 * 2_679_808          # 5 frame-level layers
 MFCC_FLOP_PER_FRAME = 25_000                 # FFT-512 + window + sparse mel + DCT
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
-MFMA_PASSES = {"bf16": 1, "f16": 1, "bf16x3": 3, "f32": 1}                        # MFMA passes per algorithmic FLOP
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x2": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+MFMA_PASSES = {"bf16": 1, "f16": 1, "bf16x3": 3, "f16x2": 2, "f32": 1}                            # MFMA passes per algorithmic FLOP
 TOLERANCE = 1e-4                             # north_star: max-abs x-vector deviation vs the fp32 reference path
 KERNELS = {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=768 layers)",
            "bf16x3": "tdnn_x3r_kernel<.., SPLIT> (tdnn2-4) + tdnn_x3s_kernel (tdnn5 + pooling) + tdnn_x3r_kernel (tdnn1)",
+           "f16x2": "tdnn_x3s_kernel<.., F16, TERMS = 2> (all five frame-level layers; tdnn5 with fused pooling)",
            "f32": "tdnn_f32t_kernel", "f16": "tdnn_bf16r16_kernel<.., F16> + tdnn_bf16h_kernel<.., F16>"}
 
 
@@ -52,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--gemm", default="bf16x3", choices=["bf16", "f16", "bf16x3", "f32"])
+    ap.add_argument("--gemm", default="f16x2", choices=["bf16", "f16", "bf16x3", "f16x2", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other modes, latency, PLDA)")
@@ -181,9 +184,9 @@ def main(argv=None):
         "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],
         "algorithmic_flop_per_step": flops_per_step,
         "per_layer_tflops": {k: _layer_flops(k, B, T) / (v * 1e-3) / 1e12 for k, v in gemm_stats["per_layer_ms"].items()},
-        "note": ("achieved / frac count ALGORITHMIC flops (SURVEY 8d: 5 359 616 per voiced frame); the split-bf16 mode issues "
-                 "3 bf16 MFMA passes per algorithmic flop, so the matrix pipe is busy at frac_mfma_issue_equivalent")
-                if args.gemm == "bf16x3" else "",
+        "note": ("achieved / frac count ALGORITHMIC flops (SURVEY 8d: 5 359 616 per voiced frame); this mode issues "
+                 f"{MFMA_PASSES[args.gemm]} 16-bit MFMA passes per algorithmic flop, so the matrix pipe is busy at frac_mfma_issue_equivalent")
+                if MFMA_PASSES[args.gemm] > 1 else "",
     }
     # HBM traffic of those launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE),
     # committed under profiles/: it cannot be collected from inside this process
@@ -201,7 +204,7 @@ def main(argv=None):
     # side measurements and the CPU baseline belong to the single-GPU run only (rank 0 at N = 1)
     if world == 1:
         # the deviation of the TIMED mode from the fp64 CPU oracle at the full utterance length: part of the headline
-        dev_info = _parity_sample(torch, ktf, synth, cfg, w, [args.gemm] if args.no_extra else ["f32", "bf16x3", "f16", "bf16"], dev, N)
+        dev_info = _parity_sample(torch, ktf, synth, cfg, w, [args.gemm] if args.no_extra else ["f32", "bf16x3", "f16x2", "f16", "bf16"], dev, N)
         out["max_abs_dev_vs_fp64_oracle"] = dev_info[args.gemm]
         out["tolerance"] = TOLERANCE
         out["tolerance_ok"] = bool(dev_info[args.gemm] <= TOLERANCE)
@@ -232,7 +235,7 @@ class _GemmProfiler:
         split, stats = "split" in name, "stats" in name
 
         def wrapped(x, lens, desc, *a, **k):
-            rows = (x.shape[1] * x.shape[2]) if split else (x.shape[0] * x.shape[1])
+            rows = (x.shape[1] * x.shape[2]) if x.dim() == 4 else (x.shape[0] * x.shape[1])
             if rows < 4096:          # tdnn6 (one row per utterance) is not the dominant kernel
                 return orig(x, lens, desc, *a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -289,9 +292,9 @@ def _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N):
     the bench workload and one with quiet blocks (ragged), per GEMM mode."""
     import numpy as np
     from oracle import ktf_oracle as O
-    wav = np.concatenate([synth.make_wav(1, N, seed=1234), synth.make_wav(1, N, seed=4242, ragged=True)], 0)
+    wav = np.concatenate([synth.make_wav(2, N, seed=1234), synth.make_wav(2, N, seed=4242, ragged=True)], 0)
     want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
-    res = {"sample": f"2 utterances x {N} samples (one all-voiced as timed, one with 30 % quiet 0.5 s blocks), 0008 topology, fp64 NumPy oracle"}
+    res = {"sample": f"4 utterances x {N} samples (two all-voiced as timed, two with 30 % quiet 0.5 s blocks), 0008 topology, fp64 NumPy oracle"}
     for g in modes:
         m = synth.build_extractor(ktf, cfg, w, gemm=g)
         m.xvec.min_tiles = {}          # two utterances would be routed to the fp32 kernels: measure the mode's own
@@ -327,7 +330,7 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     import numpy as np
     res = {}
     B = wav.shape[0]
-    for g in ("f32", "bf16x3", "f16", "bf16"):
+    for g in ("f32", "bf16x3", "f16x2", "f16", "bf16"):
         if g == gemm:
             continue
         m = synth.build_extractor(ktf, cfg, w, gemm=g)

@@ -49,6 +49,12 @@ extern "C" {
 #define KTF_GEMM_BF16X3 2   /* split-bf16: x=hi+lo, w=hi+lo, 3 bf16 MFMA passes, fp32 accumulate */
 #define KTF_GEMM_F16 3      /* v_mfma_f32_16x16x32_f16: half operands (x, w of KTF_F16), fp32 accumulate; ring kernels only
                              * (units > 128, ReLU or no activation) */
+#define KTF_GEMM_F16X2 4    /* two half-precision MFMA passes, fp32 accumulate: acc += x * w_hi + x * w_lo with w = w_hi + w_lo
+                             * (both KTF_F16: the weights are exact to ~22 bits) and the activations as ONE half plane. Meets
+                             * the 1e-4 x-vector tolerance when the stored activations are the ReLU outputs with the following
+                             * BatchNorm folded into the NEXT layer's weights (dead units are then exact zeros instead of a
+                             * rounded constant; the host side does this): 2.8e-5 .. 4.8e-5 measured. Through
+                             * ktf_tdnn_split / ktf_tdnn_split_stats with x_lo = y_lo = NULL; units > 128 */
 
 /* activations fused into the ktf_tdnn epilogue */
 #define KTF_ACT_NONE 0

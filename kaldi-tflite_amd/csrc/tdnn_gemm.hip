@@ -916,7 +916,7 @@ __device__ __forceinline__ f32x4v mfma16x16x32(const bfrag8& a, const bfrag8& b,
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int ACT, bool STATS>
+template <int ACT, bool STATS, bool F16 = false>
 __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats,
                                                 unsigned char* rsm, int b, int t0, int n0, int out_len, int wm, int wn,
                                                 int wave, int lane) {
@@ -995,7 +995,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                     const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     unsigned short hh[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hh[e] = f2bf(vv[e]);
+                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(vv[e]);
                     if (n8 + 8 <= p.units) {
                         u32x4 pk;
                         pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
@@ -1911,9 +1911,13 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 #ifndef KTF_X3_DOFF
 #define KTF_X3_DOFF 0
 #endif
-template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE>
+// F16 / TERMS: the same kernel as the 2-pass half-precision mode (KTF_GEMM_F16X2): IEEE-half operands, activations as ONE
+// half plane (no residual plane: the A lo DMAs, fragments and the lo*hi pass drop out; the stage keeps its layout), weights
+// as hi + lo half planes: acc += x*w_hi + x*w_lo, i.e. exact weights and half-rounded activations.
+template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE, bool F16 = false, int TERMS = 3>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
+    static_assert(TERMS == 3 || (TERMS == 2 && PIPE == 1), "the 2-pass form exists for the scheduled K-step only");
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
@@ -1969,7 +1973,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
             const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                      \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+            if (TERMS == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                             \
@@ -2031,32 +2035,46 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 af[0][r] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + r * 16 * 64);
-                af[0][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + r * 16 * 64);
+                if (TERMS == 3) af[0][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + r * 16 * 64);
             }
             __builtin_amdgcn_sched_barrier(0);
+            constexpr int PER_ROW = 4 * TERMS, PER_CHUNK = PER_ROW / 2;      // MFMAs per tile row / per chunk (4 chunks per 2-row group)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cur = g & 1;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24
+                for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24 (4c .. 4c+3 of 16)
 #pragma unroll
-                    for (int m = 6 * c; m < 6 * c + 6; ++m) {
-                        const int r = m / 12, t = (m % 12) / 4, j = m & 3;     // row, term (hh, lh, hl), column block
+                    for (int m = PER_CHUNK * c; m < PER_CHUNK * c + PER_CHUNK; ++m) {
+                        const int r = m / PER_ROW, j = m & 3;                  // row, column block
+                        const int t = (TERMS == 3) ? (m % PER_ROW) / 4 : 2 * ((m % PER_ROW) / 4);   // term: 0 hh, 1 lh, 2 hl
+#if defined(KTF_X3_ABL) && (KTF_X3_ABL & 1)   // timing-only ablations (wrong results). 1: drop one of the three MFMA passes
+                        if (t == 2) continue;
+#endif
                         f32x4v& cc = acc[2 * g + r][j];
-                        cc = mfma16x16x32<false>(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc);
+                        cc = mfma16x16x32<F16>(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (c == 0 && g < 3) {
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
                             af[cur ^ 1][r] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + (2 * (g + 1) + r) * 16 * 64);
-                            af[cur ^ 1][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + (2 * (g + 1) + r) * 16 * 64);
+                            if (TERMS == 3) af[cur ^ 1][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + (2 * (g + 1) + r) * 16 * 64);
                         }
                     }
+#if defined(KTF_X3_ABL) && (KTF_X3_ABL & 2)   // 2: no steady-state operand DMA (the MFMAs chew on stale stages)
+                    if (false) {
+#else
                     if (refill) {
+#endif
                         const int n = 4 * g + c - doff;         // slot -> DMA index (wave-uniform)
-                        if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
-                        else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
+                        if (TERMS == 3) {
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
+                            else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
+                        } else {                                   // no residual plane of the activations: six DMAs
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(5)
+                            else if (n == 4) XS_DMA(6) else if (n == 5) XS_DMA(7)
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -2116,7 +2134,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     }
 #undef XS_STAGE
     if (!STATS) __syncthreads();      // all fragment reads done before the LDS is reused as the store staging area
-    ring_epilogue16<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+    ring_epilogue16<ACT, STATS, F16>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
 }
 
 // ------------------------------------------------------------------------------------ F32, few workgroups (latency)
@@ -2573,10 +2591,17 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                        const void* x_lo = nullptr, void* y_lo = nullptr) {
     KTF_REQUIRE(x && d && w && (y || stats_sums), "ktf_tdnn: null argument");
     const bool split_in = d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16;     // activations as hi/lo bf16 planes
+    const bool half2 = d->gemm == KTF_GEMM_F16X2;                                    // one half plane in, hi + lo half weights
     if (split_in) KTF_REQUIRE(x_lo, "ktf_tdnn_split: null lo plane");
+    if (half2) {
+        KTF_REQUIRE(d->x_dtype == KTF_F16 && d->w_dtype == KTF_F16 && w_lo && !x_lo && !y_lo,
+                    "ktf_tdnn: F16X2 takes ONE half activation plane (x_lo, y_lo NULL) and half weights as w (hi) + w_lo");
+        KTF_REQUIRE(d->units > 128 && (stats_sums || (ldy % 8 == 0 && (d->y_dtype == KTF_F16 || d->y_dtype == KTF_F32))),
+                    "ktf_tdnn: F16X2 runs on the 256x256 kernel only (units > 128, ldy %% 8 == 0, half or fp32 output)");
+    }
     if (y_lo) KTF_REQUIRE(split_in && d->y_dtype == KTF_BF16, "ktf_tdnn_split: a split output needs split input and y_dtype bf16");
     if (stats_sums) {
-        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) || split_in ||
+        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) || split_in || half2 ||
                      (d->gemm == KTF_GEMM_F16 && d->x_dtype == KTF_F16)) &&
                         d->units > 128 && !d->valid && d->subsampling == 1,
                     "ktf_tdnn_stats: needs a ring kernel (bf16, f16 or bf16x3 gemm, units > 128, SAME padding, no subsampling)");
@@ -2592,7 +2617,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     KTF_REQUIRE(ldy >= d->units, "ktf_tdnn: ldy < units");
     KTF_REQUIRE(d->act >= KTF_ACT_NONE && d->act <= KTF_ACT_TANH, "ktf_tdnn: bad activation %d", d->act);
     KTF_REQUIRE(d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F16, "ktf_tdnn: bad y_dtype");
-    KTF_REQUIRE(d->y_dtype != KTF_F16 || d->gemm == KTF_GEMM_F16, "ktf_tdnn: half output needs KTF_GEMM_F16");
+    KTF_REQUIRE(d->y_dtype != KTF_F16 || d->gemm == KTF_GEMM_F16 || half2, "ktf_tdnn: half output needs KTF_GEMM_F16 or KTF_GEMM_F16X2");
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_tdnn: scale and shift go together");
     KTF_REQUIRE(T < (1ll << 30) && B < 65536, "ktf_tdnn: T or B too large");
     const int64_t Tout = ktf_tdnn_out_len(T, d);
@@ -2610,7 +2635,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
     p.kinter = (d->flags & KTF_TDNN_K_INTERLEAVED) ? 1 : 0;
-    if (p.kinter) KTF_REQUIRE(split_in && d->units > 128 && ldy % 4 == 0, "ktf_tdnn: KTF_TDNN_K_INTERLEAVED is implemented by the split-plane kernel only (ktf_tdnn_split*, units > 128)");
+    if (p.kinter) KTF_REQUIRE(half2 || (split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_K_INTERLEAVED is implemented by the split-plane kernel only (ktf_tdnn_split*, units > 128)");
     for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
     hipStream_t st = (hipStream_t)stream;
     const unsigned ntiles = (unsigned)ktf_cdiv(d->units, 128);
@@ -2648,6 +2673,20 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             dim3 grid((unsigned)ktf_cdiv(d->units, 64), (unsigned)ktf_cdiv(Tout, 64), (unsigned)B);
             hipLaunchKernelGGL((tdnn_f32_kernel<1, 32>), grid, dim3(256), 0, st, p);
         }
+    } else if (half2) {
+        const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
+        const int64_t gtiles = B * (int64_t)mtiles;
+        const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
+        KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
+        KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn: F16X2 fuses ReLU or no activation");
+#define H2_LAUNCH(A, ST)                                                                                               \
+    do {                                                                                                               \
+        KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST, 1, true, 2>);                                                \
+        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 2>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+    } while (0)
+        if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true); else H2_LAUNCH(KTF_ACT_RELU, false); }
+        else { if (stats_sums) H2_LAUNCH(KTF_ACT_NONE, true); else H2_LAUNCH(KTF_ACT_NONE, false); }
+#undef H2_LAUNCH
     } else if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3 || d->gemm == KTF_GEMM_F16) {
         const bool f16 = d->gemm == KTF_GEMM_F16;
         if (f16) {
@@ -2818,7 +2857,8 @@ extern "C" int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int
                               const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                               const float* shift, void* y, void* y_lo, int64_t ldy, int32_t* out_lens, void* stream) {
     KTF_REQUIRE(y && d, "ktf_tdnn_split: null argument");
-    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes)");
+    KTF_REQUIRE((d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16) || d->gemm == KTF_GEMM_F16X2,
+                "ktf_tdnn_split: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes) or KTF_GEMM_F16X2 (one half plane)");
     return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, y, ldy, out_lens, nullptr, stream, x_lo, y_lo);
 }
 
@@ -2826,7 +2866,8 @@ extern "C" int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t 
                                     const int32_t* lens, const KtfTdnnDesc* d, const void* w, const void* w_lo,
                                     const float* bias, const float* scale, const float* shift, double* sums, void* stream) {
     KTF_REQUIRE(sums && d, "ktf_tdnn_split_stats: null argument");
-    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_stats: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes)");
+    KTF_REQUIRE((d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16) || d->gemm == KTF_GEMM_F16X2,
+                "ktf_tdnn_split_stats: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes) or KTF_GEMM_F16X2 (one half plane)");
     return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream, x_lo, nullptr);
 }
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KTF_LIBRARY") or os.path.join(_HERE, "libktf_hip.so")
 
 KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
-GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16 = 0, 1, 2, 3
+GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED = 1, 2, 4          # KtfTdnnDesc.flags
 IN_WAV, IN_FRAMES, IN_WINDOWED, IN_WAV_I16 = 0, 1, 2, 3
@@ -34,7 +34,7 @@ def ktf_dtype(t):
 def act_torch_dtype(gemm):
     """Storage dtype of the frame-level activations for a GEMM mode."""
     import torch
-    return {GEMM_BF16: torch.bfloat16, GEMM_F16: torch.float16}.get(gemm, torch.float32)
+    return {GEMM_BF16: torch.bfloat16, GEMM_F16: torch.float16, GEMM_F16X2: torch.float16}.get(gemm, torch.float32)
 
 
 class FrontendCfg(C.Structure):

@@ -599,6 +599,7 @@ class BatchNorm(Layer):
         self.epsilon = epsilon
         self.gamma = self.moving_mean = self.moving_variance = None
         self._dev = None
+        self._version = 0          # bumped by set_weights: consumers that folded this layer's affine into their weights re-fold
 
     def build(self, input_shape):
         D = input_shape[-1]
@@ -632,12 +633,17 @@ class BatchNorm(Layer):
             raise ValueError("gamma / mean / variance shapes differ")
         self.gamma, self.moving_mean, self.moving_variance = gamma, mean, var
         self._dev = None
+        self._version += 1
+
+    def affine64(self):
+        """(scale, shift) of the inference transform y = scale * x + shift, float64."""
+        g = self.gamma.astype(np.float64)
+        scale = g / np.sqrt(self.moving_variance.astype(np.float64) + self.epsilon)
+        return scale, -self.moving_mean.astype(np.float64) * scale
 
     def affine(self):
         """(scale, shift) of the inference transform, computed in float64 on the host."""
-        g = self.gamma.astype(np.float64)
-        scale = g / np.sqrt(self.moving_variance.astype(np.float64) + self.epsilon)
-        shift = -self.moving_mean.astype(np.float64) * scale
+        scale, shift = self.affine64()
         return scale.astype(np.float32), shift.astype(np.float32)
 
     def affine_device(self, device):
@@ -662,7 +668,7 @@ def reshapeKaldiTdnnWeights(weights, units, kernel_width):
 
 _ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
 _GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat16": L.GEMM_BF16, "bf16x3": L.GEMM_BF16X3,
-         "f16": L.GEMM_F16, "float16": L.GEMM_F16}
+         "f16": L.GEMM_F16, "float16": L.GEMM_F16, "f16x2": L.GEMM_F16X2}
 
 
 class TDNN(Layer):
@@ -755,27 +761,43 @@ class TDNN(Layer):
         K, D = self.kernelWidth, self.inputDim
         return np.ascontiguousarray(self.kernel[0].reshape(K * D, self.units).T)
 
-    def device_weights(self, device, gemm, k_interleaved=False):
-        """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for bf16x3), bias.
-        `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, split-plane kernel."""
-        key = (str(device), gemm, bool(k_interleaved))
+    def device_weights(self, device, gemm, k_interleaved=False, fold=None):
+        """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for the two-part modes),
+        bias. `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, split-plane
+        kernel. `fold`: the BatchNorm whose affine y = s*x + h precedes this layer and is folded INTO it, so that the stored
+        activations are the ReLU outputs themselves: W'[u,k,d] = W[u,k,d] * s[d], b'[u] = b[u] + sum_kd W[u,k,d] * h[d]
+        (float64 on the host; exact for replicate padding, every context row carries the same per-feature affine)."""
+        key = (str(device), gemm, bool(k_interleaved), None if fold is None else (id(fold), fold._version))
         if key in self._dev:
             return self._dev[key]
         K, D = self.kernelWidth, self.inputDim
         Dp, Up = ops.round_up(D, 32), ops.round_up(self.units, 256)
-        W = np.zeros((Up, K, Dp), np.float32)
-        W[: self.units, :, :D] = np.transpose(self.kernel[0], (2, 0, 1))     # [u, k, d]
+        Wk = np.transpose(self.kernel[0], (2, 0, 1)).astype(np.float64)       # [u, k, d]
+        bias64 = self.bias.astype(np.float64) if self.useBias else None
+        if fold is not None:
+            s64, h64 = fold.affine64()
+            if s64.shape != (D,):
+                raise ValueError(f"cannot fold a {s64.shape[0]}-wide BatchNorm into a layer with input dim {D}")
+            extra = np.einsum("ukd,d->u", Wk, h64)
+            bias64 = extra if bias64 is None else bias64 + extra
+            Wk = Wk * s64[None, None, :]
+        W = np.zeros((Up, K, Dp), np.float64)
+        W[: self.units, :, :D] = Wk
         if k_interleaved:
             W = np.ascontiguousarray(W.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3))
         W = torch.as_tensor(W.reshape(Up, K * Dp), device=device)
         w_lo = None
         if gemm == L.GEMM_F32:
-            w = W
+            w = W.to(torch.float32)
+        elif gemm == L.GEMM_F16X2:
+            w = W.to(torch.float16)
+            w_lo = (W - w.to(torch.float64)).to(torch.float16)
         else:
+            W = W.to(torch.float32)
             w = W.to(torch.float16 if gemm == L.GEMM_F16 else torch.bfloat16)
             if gemm == L.GEMM_BF16X3:
                 w_lo = (W - w.to(torch.float32)).to(torch.bfloat16)
-        bias = ops.to_device_f32(self.bias, device) if self.useBias else None
+        bias = ops.to_device_f32(bias64, device) if bias64 is not None else None
         self._dev[key] = (w, w_lo, bias)
         return self._dev[key]
 
@@ -790,7 +812,7 @@ class TDNN(Layer):
         d.act = _ACTS[a.lower() if isinstance(a, str) else a]
         d.gemm = gemm
         d.x_dtype = L.ktf_dtype(x_dtype)
-        d.w_dtype = {L.GEMM_F32: L.KTF_F32, L.GEMM_F16: L.KTF_F16}.get(gemm, L.KTF_BF16)
+        d.w_dtype = {L.GEMM_F32: L.KTF_F32, L.GEMM_F16: L.KTF_F16, L.GEMM_F16X2: L.KTF_F16}.get(gemm, L.KTF_BF16)
         d.y_dtype = L.ktf_dtype(y_dtype)
         return d
 
@@ -842,7 +864,7 @@ class TDNN(Layer):
     def effective_gemm(self, gemm, relu=False):
         """The half-precision mode runs on the ring kernels only (units > 128, ReLU or no activation); any other layer
         of an "f16" model is evaluated by the exact fp32 kernel instead."""
-        if gemm != L.GEMM_F16:
+        if gemm not in (L.GEMM_F16, L.GEMM_F16X2):
             return gemm
         a = self.activation.lower() if isinstance(self.activation, str) else self.activation
         ok = self.units > 128 and (a in (None, "linear") or (a == "relu" and not relu))

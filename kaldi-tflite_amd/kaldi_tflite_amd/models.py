@@ -106,12 +106,14 @@ class _Workspace:
 class Sequential:
     """Keras-Sequential stand-in: `.layers`, `.name`, `mdl(x, training=False)`, `get_layer`, `summary`.
     `gemm` selects the TDNN arithmetic of the fused runner: "f32" (exact fp32 MFMA, default = the reference's
-    precision), "bf16x3" (split-bf16, fp32-grade), "bf16" or "f16"."""
+    precision), "bf16x3" (split-bf16, fp32-grade), "f16x2" (two half-precision passes: exact weights, half activations with
+    BatchNorm folded forward — inside the 1e-4 x-vector tolerance at two thirds of the split-bf16 matrix work), "bf16" or
+    "f16" (one pass, outside that tolerance)."""
 
     split_planes = True         # bf16x3: hi/lo bf16 activation planes between the wide layers (no in-loop conversion)
     k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
     # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
-    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32}
+    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32}
 
     def __init__(self, layers=None, name=None, gemm="f32"):
         self.input = None
@@ -188,21 +190,22 @@ class Sequential:
             gemm = L.GEMM_F32
         return gemm
 
-    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T):
+    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
-        Returns the pooled (1, B, od) view."""
+        `split`: the input is a (2,B,T,ld) pair of bf16 planes or ONE (B,T,ld) half plane (F16X2) read by the split-plane
+        kernel; `fold`: the preceding BatchNorm folded into this layer's weights. Returns the pooled (1, B, od) view."""
         sp = nxt[1]
         D = l.units
         od = 2 * D if sp.includeStd else D
         ld = ops.round_up(od, 32)
-        B = x_or_planes.shape[1] if split else x_or_planes.shape[0]
+        B = x_or_planes.shape[1] if x_or_planes.dim() == 4 else x_or_planes.shape[0]
         slots = ops.stats_slots(T) if self.deterministic else 0
         sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev)
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev)
         kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
-        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint)
+        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold)
         scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
-        xdt = torch.bfloat16 if split else x_or_planes.dtype
+        xdt = x_or_planes.dtype
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
                    flags=(L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0))
         (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
@@ -227,6 +230,7 @@ class Sequential:
         # of fp32, so the GEMM K-loop carries no conversion (ktf_tdnn_split); `planes` holds them while they exist
         use_planes = gemm == L.GEMM_BF16X3 and self.split_planes
         planes = None
+        pending_bn = None            # F16X2: the BatchNorm of the previous layer, to be folded into the next layer's weights
         for si, st in enumerate(steps):
             if skip:
                 skip = False
@@ -239,6 +243,42 @@ class Sequential:
                     raise ValueError("cannot fuse a ReLU after a TDNN that already has an activation")
                 can_pool = (self.fuse_stats and not pooled and nxt is not None and nxt[0] == "stats" and
                             nxt[1].inputPeriod == 1 and l.units > 128 and l.padding == "SAME" and l.subsamplingFactor == 1)
+            if (gemm == L.GEMM_F16X2 and st[0] == "tdnn" and not pooled and l.effective_gemm(gemm, relu) == gemm):
+                # two half passes: activations travel as ONE half plane holding the ReLU outputs; this layer's BatchNorm is
+                # not applied in its epilogue but folded into the weights of the next layer when that one runs here too
+                if x.dtype != torch.float16 or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32) \
+                        or x.stride(0) != x.shape[1] * x.stride(1):
+                    x = _padded_copy(x, torch.float16)
+                B, T, _ = x.shape
+                xin = x                                  # the kernel takes the row stride from the view
+                fold, pending_bn = pending_bn, None
+                kint = bool(self.k_interleaved and l.kernelWidth > 1)
+                kflag = L.TDNN_K_INTERLEAVED if kint else 0
+                if can_pool:
+                    x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold)
+                    lens, pooled, skip = None, True, True
+                    continue
+                nl = nxt[1] if nxt is not None and nxt[0] == "tdnn" else None
+                defer_bn = (bn is not None and nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm)
+                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold)
+                scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
+                Tout = l.outputTimesteps(T)
+                ldy = ops.round_up(l.units, 32)
+                out_lens = None
+                if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
+                    out_lens = torch.empty_like(lens)
+                ydt = torch.float16 if nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm else torch.float32
+                ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev)
+                d = l.desc(gemm, torch.float16, ydt, act="relu" if relu else None, flags=kflag)
+                ops.tdnn_split(xin, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
+                if defer_bn:
+                    pending_bn = bn
+                x = ybuf[:, :, : l.units]
+                if out_lens is not None:
+                    lens = out_lens
+                continue
+            if pending_bn is not None:
+                raise RuntimeError("internal: a deferred BatchNorm reached a layer that cannot fold it")
             if use_planes and st[0] == "tdnn" and not pooled and l.units > 128:
                 if planes is None:                                   # first wide layer: split its fp32 input once
                     B, T, D = x.shape

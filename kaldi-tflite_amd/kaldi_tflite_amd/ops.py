@@ -351,12 +351,19 @@ def split_bf16(src, D, planes):
     return planes
 
 
+def _planes(xp):
+    """(hi, lo, B, T, ldx) of a (2,B,T,ldx) pair of planes, or of ONE (B,T,ldx) plane (KTF_GEMM_F16X2: lo = None)."""
+    if xp.dim() == 4:
+        return xp[0], xp[1], xp.shape[1], xp.shape[2], xp.stride(2)
+    return xp, None, xp.shape[0], xp.shape[1], xp.stride(1)
+
+
 def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_lens=None):
-    """xp: (2,B,T,ldx) bf16 planes. y: (B,Tout,ldy) bf16 hi plane (+ y_lo) or fp32."""
+    """xp: (2,B,T,ldx) bf16 hi/lo planes, or one (B,T,ldx) half plane (F16X2). y: (B,Tout,ldy) 16-bit plane (+ y_lo) or fp32."""
     lib = L.load()
-    B, T = xp.shape[1], xp.shape[2]
+    hi, lo, B, T, ldx = _planes(xp)
     with torch.cuda.device(xp.device):
-        rc = lib.ktf_tdnn_split(L.ptr(xp[0]), L.ptr(xp[1]), B, T, xp.stride(2), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo),
+        rc = lib.ktf_tdnn_split(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo),
                                 L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(y_lo), y.stride(1), L.ptr(out_lens),
                                 L.stream_ptr())
     L.check(rc, "ktf_tdnn_split")
@@ -365,11 +372,11 @@ def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_le
 
 def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums, zero=True):
     lib = L.load()
-    B, T = xp.shape[1], xp.shape[2]
+    hi, lo, B, T, ldx = _planes(xp)
     with torch.cuda.device(xp.device):
         if zero:
             sums.zero_()
-        rc = lib.ktf_tdnn_split_stats(L.ptr(xp[0]), L.ptr(xp[1]), B, T, xp.stride(2), L.ptr(lens), C.byref(desc), L.ptr(w),
+        rc = lib.ktf_tdnn_split_stats(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(lens), C.byref(desc), L.ptr(w),
                                       L.ptr(w_lo), L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
     L.check(rc, "ktf_tdnn_split_stats")
     return sums

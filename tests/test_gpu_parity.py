@@ -579,13 +579,14 @@ def test_half_mode_fused_stats_and_batch_independence():
     assert np.array_equal(host(fused(dev(wav[1:2]))), a[1])
 
 
-@pytest.mark.parametrize("gemm,tol", [("bf16", 2e-4), ("f16", 2e-4), ("bf16x3", 2e-5)])
+@pytest.mark.parametrize("gemm,tol", [("bf16", 2e-4), ("f16", 2e-4), ("bf16x3", 2e-5), ("f16x2", 2e-5)])
 def test_fused_tdnn_stats_random_shapes(gemm, tol):
     """[affine, relu, batchnorm] -> reducing StatsPooling, pooled inside the GEMM epilogue (ktf_tdnn_stats), over shapes
     with awkward widths and ragged utterance lengths; operands pre-rounded so only accumulation order differs."""
     rng = np.random.default_rng(77)
     rnd = {"bf16": lambda a: torch.as_tensor(a).to(torch.bfloat16).float().numpy(),
-           "f16": lambda a: a.astype(np.float16).astype(np.float32), "bf16x3": lambda a: a}[gemm]
+           "f16": lambda a: a.astype(np.float16).astype(np.float32), "bf16x3": lambda a: a,
+           "f16x2": lambda a: a}[gemm]                  # f16x2: exact weights (hi + lo); the INPUT is pre-rounded below
     for U, D, ctx in [(129, 64, [0]), (300, 96, [-1, 0, 1]), (1500, 512, [0]), (257, 40, [-2, 0, 2])]:
         cfg = {"type": "sequential", "layers": [
             {"name": "input", "type": "input", "shape": [None, None, D]},
@@ -604,6 +605,8 @@ def test_fused_tdnn_stats_random_shapes(gemm, tol):
         mdl.get_layer("t.batchnorm").set_weights(list(bn))
         B, T = 3, 397
         x = rnd(rng.standard_normal((B, T, D)).astype(np.float32))
+        if gemm == "f16x2":
+            x = x.astype(np.float16).astype(np.float32)
         lens = np.array([T, 131, 260], np.int32)
         layers = [{"kind": "tdnn", "W": W, "b": b, "context": ctx}, {"kind": "relu"},
                   {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]},
@@ -753,7 +756,7 @@ def test_extractor_edge_cases():
     assert np.array_equal(a, b[::-1])
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("bf16", 5e-2), ("f16", 1e-3)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16x2", 2e-4), ("bf16", 5e-2), ("f16", 1e-3)])
 def test_extractor_8khz_callhome_topology(gemm, tol):
     """The reference's second model family (0006_callhome_diarization_v2_1a.yml: 8 kHz, 23-dim MFCC, 128-dim embedding):
     200-sample frames -> nfft 256 takes the generic front-end kernel, tdnn6 has 128 units."""

@@ -54,11 +54,11 @@ def test_xvec_post_kaldi_golden():
 
 
 # ----------------------------------------------------------------------------- whole pipeline at the BASELINE size
-@pytest.mark.parametrize("gemm", ["f32", "bf16x3"])
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16x2"])
 def test_extractor_full_topology_10s_vs_oracle(gemm):
     """0008 topology, full widths, 160 000-sample utterances (998 frames): max-abs deviation from the fp64 oracle within
-    the north_star bound (1e-4), for the exact path and for the split-bf16 path bench.py times by default. One utterance
-    is all-voiced stationary noise (the bench workload), two have quiet blocks (ragged)."""
+    the north_star bound (1e-4), for the exact path, the split-bf16 path and the two-pass half path bench.py times by default.
+    One utterance is all-voiced stationary noise (the bench workload), two have quiet blocks (ragged)."""
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
     wav = np.concatenate([synth.make_wav(1, 160000, seed=1234), synth.make_wav(2, 160000, seed=4242, ragged=True)], 0)
@@ -152,7 +152,7 @@ def test_long_recording_beyond_38400_frames():
 
 
 # ----------------------------------------------------------------------------- reproducible fused pooling
-@pytest.mark.parametrize("gemm", ["bf16x3", "bf16", "f16"])
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16x2", "bf16", "f16"])
 def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
     """KTF_TDNN_DET_STATS (the models' default): per-128-row partial sums added in block order -> bitwise identical
     x-vectors run after run and batch == single; the fp64-atomic form agrees to the last fp32 bits."""
@@ -173,7 +173,7 @@ def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
 
 
 # ----------------------------------------------------------------------------- hipGraph product path
-@pytest.mark.parametrize("gemm,B", [("f32", 1), ("bf16x3", 16)])
+@pytest.mark.parametrize("gemm,B", [("f32", 1), ("bf16x3", 16), ("f16x2", 16)])
 def test_compiled_extractor_replays_bitwise(gemm, B):
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
@@ -238,3 +238,113 @@ def test_windowing_1000_frames_11_overrides():
         assert tuple(w.shape) == frames.shape and tuple(e.shape) == (1, 1000, 1)
         tol = 2 * cfg["dither"] if cfg["dither"] else 2e-7
         assert G.rmse(want_w, host(w)) < tol and G.rmse(want_e, host(e)) < tol, o
+
+
+# ----------------------------------------------------------------------------- two-pass half mode (KTF_GEMM_F16X2)
+def _emulate_f16x2(layers, x):
+    """fp64 evaluation of exactly what the f16x2 route computes up to accumulation order: activations rounded to IEEE half
+    where the route stores them (the network input, and every ReLU output that feeds another wide layer, BEFORE its
+    BatchNorm, which is folded into the consumer's weights), weights = half hi + half lo of the (folded) weights."""
+    h16 = lambda a: a.astype(np.float16).astype(np.float64)          # noqa: E731
+    tl = [i for i, l in enumerate(layers) if l["kind"] == "tdnn"]
+    a = np.asarray(x, np.float64)
+    pend = None
+    i = 0
+    while i < len(layers):
+        l = layers[i]
+        if l["kind"] != "tdnn":
+            a = O.sequential_forward([l], a[None], dtype=np.float64)[0]
+            i += 1
+            continue
+        W = np.asarray(l["W"], np.float64)
+        b = np.asarray(l["b"], np.float64)
+        K = len(l["context"])
+        if pend is not None:
+            s_, h_ = pend
+            b = b + W @ np.tile(h_, K)
+            W = W * np.tile(s_, K)
+            pend = None
+        Wq = h16(W) + h16(W - h16(W))
+        z = O.tdnn(h16(a)[None], Wq, b, l["context"], l.get("subsampling_factor", 1), l.get("padding", "SAME"), None, dtype=np.float64)[0]
+        nxt = layers[i + 1:i + 3]
+        if len(nxt) == 2 and nxt[0]["kind"] == "relu" and nxt[1]["kind"] == "bn":
+            r = np.maximum(z, 0.0)
+            bn = nxt[1]
+            s_ = np.float64(bn["rms"]) / np.sqrt(np.asarray(bn["var"], np.float64) + 1e-3)
+            h_ = -np.asarray(bn["mean"], np.float64) * s_
+            more = i + 3 < len(layers) and layers[i + 3]["kind"] == "tdnn" and np.asarray(layers[i + 3]["W"]).shape[0] > 128
+            if more:
+                a, pend = r.astype(np.float32).astype(np.float64), (s_, h_)
+            else:
+                a = r * s_ + h_
+            i += 3
+        else:
+            a = z
+            i += 1
+    return a
+
+
+def test_f16x2_route_equals_its_fp64_emulation_and_options():
+    """KTF_GEMM_F16X2 through the Sequential runner: BatchNorm folded forward, one half plane between wide layers, VALID
+    padding, subsampling, multi-context layers (chunk-interleaved K), ragged lengths, a frame-level fp32 output. A single
+    layer equals the fp64 emulation of the same roundings to fp32 accumulation noise (1e-6). Behind a STORED half plane the
+    two can only agree statistically: the fp32 accumulator and the fp64 emulation round a handful of ReLU outputs that sit on
+    a half rounding boundary to different neighbours (2e-4 of the elements; each such flip moves a consumer's output by
+    |w| * half-ulp = 3e-5), so: the typical output agrees to accumulation noise, the disagreements stay below the mode's
+    own deviation from the exact network, and both deviate from the exact network by the same amount."""
+    rng = np.random.default_rng(31)
+    D = 40
+    spec = [(300, [-2, 0, 2], "VALID", 1), (260, [-1, 0, 1], "SAME", 2), (520, [-3, 0, 3], "VALID", 1), (200, [0], "SAME", 1)]
+    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
+    for i, (U, ctx, pad, sub) in enumerate(spec):
+        lcfg.append({"name": f"t{i}", "type": ["affine", "relu", "batchnorm"],
+                     "cfg": {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}})
+    mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm="f16x2")
+    layers, din = [], D
+    for i, (U, ctx, pad, sub) in enumerate(spec):
+        W = (rng.standard_normal((U, len(ctx) * din)) / np.sqrt(len(ctx) * din)).astype(np.float32)
+        b = (rng.standard_normal(U) * 0.1).astype(np.float32)
+        bn = (np.float32(1.0), rng.uniform(-0.2, 0.4, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
+        mdl.get_layer(f"t{i}.affine").set_weights([W, b])
+        mdl.get_layer(f"t{i}.batchnorm").set_weights(list(bn))
+        layers += [{"kind": "tdnn", "W": W, "b": b, "context": ctx, "padding": pad, "subsampling_factor": sub}, {"kind": "relu"},
+                   {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]}]
+        din = U
+    B, T = 3, 301
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    lens = np.array([T, 97, 222], np.int32)
+    got = host(mdl.run_ragged(dev(x), torch.as_tensor(lens, device="cuda")))
+    for i in range(B):
+        emu = _emulate_f16x2(layers, x[i, : lens[i]])
+        want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)[0]
+        n = want.shape[0]
+        assert n > 0 and emu.shape == want.shape
+        diff, err_emu, err_got = np.abs(got[i, :n] - emu), np.abs(emu - want).max(), np.abs(got[i, :n] - want).max()
+        assert np.median(diff) < 5e-6 and np.mean(diff > 3e-5) < 0.15 and diff.max() < err_emu, (np.median(diff), diff.max(), err_emu)
+        assert abs(err_got - err_emu) < 0.1 * err_emu and err_got < 5e-3     # half-rounded activations, frame level (no pooling)
+    # re-importing BatchNorm weights re-folds (the folded operands are keyed by the BatchNorm's version)
+    bn0 = mdl.get_layer("t0.batchnorm")
+    bn0.set_weights([np.float32(1.0), bn0.moving_mean * 0.5, bn0.moving_variance * 1.5])
+    layers[2] = {"kind": "bn", "rms": np.float32(1.0), "mean": bn0.moving_mean, "var": bn0.moving_variance}
+    got2 = host(mdl.run_ragged(dev(x), torch.as_tensor(lens, device="cuda")))
+    emu2 = _emulate_f16x2(layers, x[0, : lens[0]])
+    assert np.median(np.abs(got2[0, : emu2.shape[0]] - emu2)) < 5e-6 and np.abs(got2[0] - got[0]).max() > 1e-3
+    # one layer alone: no stored half plane between the roundings and the output -> equal to accumulation noise
+    one = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg[:2]}, None, "m1", gemm="f16x2")
+    one.get_layer("t0.affine").set_weights(mdl.get_layer("t0.affine").get_weights(), fmt="tensorflow")
+    one.get_layer("t0.batchnorm").set_weights(mdl.get_layer("t0.batchnorm").get_weights(), fmt="tensorflow")
+    g1 = host(one.run_ragged(dev(x), None))[0]
+    assert np.abs(g1 - _emulate_f16x2(layers[:3], x[0])).max() < 5e-6
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_f16x2_tolerance_over_weight_seeds(seed):
+    # the 1e-4 bound of the two-pass half mode is a property of rounding, not of one weight draw: other seeds, other audio
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=seed, narrow=False)
+    wav = synth.make_wav(3, 160000, seed=100 + seed, ragged=True)
+    want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+    got = host(synth.build_extractor(ktf, cfg, w, gemm="f16x2")(dev(wav)))
+    err = np.abs(got - want).max()
+    print(f"f16x2 seed {seed}: {err:.3e}")
+    assert err <= 1e-4, err
