@@ -1898,8 +1898,13 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // (4 x 16 KiB, the chunk permutation of the 16x16x32 bf16 kernel), double buffered -- 96 MFMAs per wave per K-step cover one
 // stage of DMA latency. Only the reducing (fused StatsPooling) form exists: a 16x16-layout epilogue that writes hi/lo planes
 // (two staged passes) measured 10 us per tile slower than the 32x32 kernel's, which cancels the K-loop gain at K <= 1536.
+#ifndef KTF_X2_RING3
+#define KTF_X2_RING3 0        // 1: three 48 KiB stages for the 2-pass form (two stages of DMA in flight). Measured: no gain over
+                              // two (92.7 k vs 93.4 k x-vectors/s) -- the operand stream costs issue slots and clock, not latency
+#endif
 #define XS_STAGE_BYTES (4 * R_TILE_BYTES)                // 64 KiB
 #define XS_LDS_BYTES (2 * XS_STAGE_BYTES)                // 128 KiB
+#define X2_LDS_BYTES (KTF_X2_RING3 ? 9 * R_TILE_BYTES : XS_LDS_BYTES)     // 2-pass form: three 48 KiB stages = 144 KiB
 // PIPE = 1: hand-scheduled K-step. The stage's operand DMAs are no longer issued in one burst behind the barrier (all eight
 // waves then sit in DMA issue and LDS latency together while the matrix pipes idle) but one at a time between groups of six
 // MFMAs, and the A fragments of row group g+1 are read while the MFMAs of group g run (two fragment register sets).
@@ -1911,6 +1916,7 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 #ifndef KTF_X3_DOFF
 #define KTF_X3_DOFF 0
 #endif
+
 // F16 / TERMS: the same kernel as the 2-pass half-precision mode (KTF_GEMM_F16X2): IEEE-half operands, activations as ONE
 // half plane (no residual plane: the A lo DMAs, fragments and the lo*hi pass drop out; the stage keeps its layout), weights
 // as hi + lo half planes: acc += x*w_hi + x*w_lo, i.e. exact weights and half-rounded activations.
@@ -1918,6 +1924,13 @@ template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE, bool F16 = false, int TER
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
     static_assert(TERMS == 3 || (TERMS == 2 && PIPE == 1), "the 2-pass form exists for the scheduled K-step only");
+    // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused. Its
+    // 48 KiB of live data per stage would also fit THREE deep (KTF_X2_RING3: DMAs of stage k+2 issued during step k, counted
+    // vmcnt at the barrier), which measured no faster.
+    constexpr int NST = (TERMS == 2 && KTF_X2_RING3) ? 3 : 2;
+    constexpr int STG = (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;
+    constexpr int WOFF = (NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
+    int fill_slot = 0, cur_slot = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     const int id = blockIdx.x;
     const int xcd = id & 7, slot = id >> 3;
@@ -1967,7 +1980,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int dpad_b = p.din_pad * 2;
 #define XS_STAGE()                                                                                                     \
     {                                                                                                                  \
-        unsigned char* st_ = rsm + (is_ks & 1) * XS_STAGE_BYTES + wave * 1024;                                         \
+        unsigned char* st_ = rsm + fill_slot * STG + wave * 1024;                                                      \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             int r_ = a_t[i] + is_off;                                                                                  \
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
@@ -1977,9 +1990,10 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                             \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + 2 * R_TILE_BYTES + i * 8192), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + 3 * R_TILE_BYTES + i * 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);   \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
+        fill_slot = (fill_slot + 1 == NST) ? 0 : fill_slot + 1;                                                        \
         ++is_ks;                                                                                                       \
         if (p.kinter) {                                                                                                \
             if (++is_c == p.nctx) {                                                                                    \
@@ -1997,6 +2011,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         }                                                                                                              \
     }
     XS_STAGE()
+    if (NST == 3 && nk > 1) XS_STAGE()
     const int fr = (4 - (((lane & 15) >> 2) & 3)) & 3;
     const int coff = (((lane >> 4) ^ fr) << 4);
     const int a_row_off = (wm * 128 + (lane & 15)) * 64 + coff;
@@ -2004,13 +2019,16 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     if constexpr (PIPE == 1) {
         const int doff = (wave >= 4) ? KTF_X3_DOFF : 0;        // wave-uniform
         for (int ks = 0; ks < nk; ++ks) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage ks landed (nothing else is in flight)
+            // stage ks landed: nothing else is in flight (two stages), or only the six DMAs of stage ks+1 are (three stages)
+            if (NST == 3 && ks + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const unsigned char* sa = rsm + (ks & 1) * XS_STAGE_BYTES;
-            const unsigned char* sw = sa + 2 * R_TILE_BYTES;
-            const bool refill = is_ks < nk;                     // stage ks+1 -> the buffer every wave finished reading
-            unsigned char* st_ = rsm + (is_ks & 1) * XS_STAGE_BYTES + wave * 1024;
+            const unsigned char* sa = rsm + cur_slot * STG;
+            const unsigned char* sw = sa + WOFF;
+            cur_slot = (cur_slot + 1 == NST) ? 0 : cur_slot + 1;
+            const bool refill = is_ks < nk;                     // next stage -> the buffer every wave finished reading
+            unsigned char* st_ = rsm + fill_slot * STG + wave * 1024;
             unsigned va[2], vw[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -2024,7 +2042,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     {                                                                                                                  \
         const char* src_ = ((n) < 4) ? ((((n) & 1) ? xl : xh) + va[(n) >> 1]) : ((((n) & 1) ? wl : wh) + vw[((n) - 4) >> 1]); \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)src_,                                                             \
-            (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) : 2 + ((n) & 1)) * R_TILE_BYTES + (((n) >> 1) & 1) * 8192), 16, 0, 0); \
+            (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, 0); \
     }
             bfrag8 bh[4], bl[4], af[2][4];                      // af[set][0,1] = hi fragments of the group's two rows, [2,3] = lo
 #pragma unroll
@@ -2081,6 +2099,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             }
 #undef XS_DMA
             if (refill) {
+                fill_slot = (fill_slot + 1 == NST) ? 0 : fill_slot + 1;
                 ++is_ks;
                 if (p.kinter) {                  // next context of the same 32 features; after the last one, the next features
                     if (++is_c == p.nctx) {
@@ -2681,8 +2700,8 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn: F16X2 fuses ReLU or no activation");
 #define H2_LAUNCH(A, ST)                                                                                               \
     do {                                                                                                               \
-        KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST, 1, true, 2>);                                                \
-        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 2>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        KTF_LDS_ONCE(X2_LDS_BYTES, tdnn_x3s_kernel<A, ST, 1, true, 2>);                                                \
+        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 2>), dim3((unsigned)nblocks), dim3(512), X2_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
         if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true); else H2_LAUNCH(KTF_ACT_RELU, false); }
         else { if (stats_sums) H2_LAUNCH(KTF_ACT_NONE, true); else H2_LAUNCH(KTF_ACT_NONE, false); }
