@@ -57,6 +57,9 @@ struct TdnnParams {
     int32_t units, din_pad, nctx, sub, valid, act, y_dtype, ktot;
     int32_t ctx[16];
     int32_t kinter;         // KTF_TDNN_K_INTERLEAVED: K runs (32-wide feature chunk, context, feature) instead of (context, feature)
+#ifdef KTF_TILE_PROBE
+    long long* probe;       // per-tile s_memrealtime stamps (probe builds)
+#endif
     int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
 };
 
@@ -916,40 +919,65 @@ __device__ __forceinline__ f32x4v mfma16x16x32(const bfrag8& a, const bfrag8& b,
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int ACT, bool STATS, bool F16 = false>
-__device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats,
-                                                unsigned char* rsm, int b, int t0, int n0, int out_len, int wm, int wn,
-                                                int wave, int lane) {
-    float* et = reinterpret_cast<float*>(rsm);
-    float bias[4], sc[4], sh[4];
+// per-lane epilogue constants of the 16x16 accumulator layout: bias / BatchNorm scale / shift of the lane's four columns
+struct Epi16Prm { float bias[4], sc[4], sh[4]; };
+__device__ __forceinline__ Epi16Prm epi16_load(const TdnnParams& p, int n0, int wn, int lane) {
+    Epi16Prm e;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = n0 + wn * 64 + j * 16 + (lane & 15);
         const bool nv = n < p.units;
-        bias[j] = (nv && p.bias) ? p.bias[n] : 0.0f;
-        sc[j] = (nv && p.scale) ? p.scale[n] : 1.0f;
-        sh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
+        e.bias[j] = (nv && p.bias) ? p.bias[n] : 0.0f;
+        e.sc[j] = (nv && p.scale) ? p.scale[n] : 1.0f;
+        e.sh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
     }
+    return e;
+}
+
+template <int ACT, bool STATS, bool F16 = false>
+__device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats,
+                                                unsigned char* rsm, int b, int t0, int n0, int out_len, int wm, int wn,
+                                                int wave, int lane, const Epi16Prm& prm) {
+    float* et = reinterpret_cast<float*>(rsm);
+    const float (&bias)[4] = prm.bias;
+    const float (&sc)[4] = prm.sc;
+    const float (&sh)[4] = prm.sh;
     const int rows_valid = out_len - t0;
     if (STATS) {
+        // A lane holds 32 rows of each of its 4 columns. Their sum and sum of squares are taken in fp32 RELATIVE TO A PIVOT
+        // (row 0 of the wave's 128-row block: a constant column -- a dead ReLU unit -- gives exactly 0 and 0, not fp32
+        // cancellation noise) and only the per-lane results go to fp64: 32 x 3 fp32 operations per column instead of 32 x 3
+        // fp64 ones (the fp64 form was 4.3 us per tile, a fifth of a K = 512 tile's K-loop).
+        const int rv = rows_valid - wm * 128;                  // valid rows of this wave's block (may be <= 0)
+        const int g4 = lane >> 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            double s = 0.0, q = 0.0;
+            float v0 = acc[0][j][0] + bias[j];
+            if (ACT == KTF_ACT_RELU) v0 = fmaxf(v0, 0.0f);
+            else if (ACT != KTF_ACT_NONE) v0 = apply_act(v0, ACT);
+            v0 = v0 * sc[j] + sh[j];
+            const float pv = __shfl(v0, lane & 15, 64);          // row 0 of the block lives in the g4 == 0 lane of this column
+            float s32 = 0.0f, q32 = 0.0f;
+            int cnt = 0;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = wm * 128 + i * 16 + (lane >> 4) * 4 + r;
                     float v = acc[i][j][r] + bias[j];
                     if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
                     else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
                     v = v * sc[j] + sh[j];
-                    if (m < rows_valid) {
-                        s += (double)v;
-                        q += (double)v * (double)v;
+                    if (rv >= 128 || i * 16 + g4 * 4 + r < rv) {       // first term wave-uniform: full blocks carry no row predicate
+                        const float u = v - pv;
+                        s32 += u;
+                        q32 = fmaf(u, u, q32);
+                        ++cnt;
                     }
                 }
             }
+            const double pd = (double)pv, sd = (double)s32, nd = (double)cnt;
+            double s = sd + nd * pd;
+            double q = (double)q32 + 2.0 * pd * sd + nd * pd * pd;
             s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);      // the four 16-lane groups hold the same column
             s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
             const int n = n0 + wn * 64 + j * 16 + (lane & 15);
@@ -1338,7 +1366,7 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
 #undef S_DMA_B
 #undef S_ADVANCE
     if (STATS) {
-        ring_epilogue16<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+        ring_epilogue16<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, epi16_load(p, n0, wn, lane));
     } else if (p.y_dtype == KTF_F32) {
         ring_epilogue16_direct<ACT>(acc, p, b, t0, n0, out_len, wm, wn, lane);
     } else {
@@ -1898,6 +1926,11 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // (4 x 16 KiB, the chunk permutation of the 16x16x32 bf16 kernel), double buffered -- 96 MFMAs per wave per K-step cover one
 // stage of DMA latency. Only the reducing (fused StatsPooling) form exists: a 16x16-layout epilogue that writes hi/lo planes
 // (two staged passes) measured 10 us per tile slower than the 32x32 kernel's, which cancels the K-loop gain at K <= 1536.
+#ifndef KTF_X2_PK
+#define KTF_X2_PK 0           // 1: packed single-barrier epilogue (PK) for the 2-pass form's half plane. Measured equal to the
+                              // fp32-staged four-pass one (92.5 k vs 92.1 k x-vectors/s): both are bound by the CU's store issue
+                              // rate (128 KB per tile at ~14 B/clk = the 5.2 us the epilogue takes), not by LDS or barriers
+#endif
 #ifndef KTF_X2_RING3
 #define KTF_X2_RING3 0        // 1: three 48 KiB stages for the 2-pass form (two stages of DMA in flight). Measured: no gain over
                               // two (92.7 k vs 93.4 k x-vectors/s) -- the operand stream costs issue slots and clock, not latency
@@ -1920,16 +1953,30 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // F16 / TERMS: the same kernel as the 2-pass half-precision mode (KTF_GEMM_F16X2): IEEE-half operands, activations as ONE
 // half plane (no residual plane: the A lo DMAs, fragments and the lo*hi pass drop out; the stage keeps its layout), weights
 // as hi + lo half planes: acc += x*w_hi + x*w_lo, i.e. exact weights and half-rounded activations.
-template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE, bool F16 = false, int TERMS = 3>
+// PK (2-pass form with one 16-bit output plane): the MFMA operands are swapped (W fragment as A), so a lane's four accumulator
+// values are four CONSECUTIVE output columns; bias / ReLU / affine and the half pack happen in registers, the whole 256 x 256
+// tile is staged as 16-bit pairs (one ds_write_b64 per accumulator quad, 520-byte pitch) behind ONE barrier and streamed out
+// as 16-byte row pieces (ring_epilogue16_pk of the bf16 kernel) -- instead of four fp32-staged 64-row passes with two
+// barriers each. Products commute and the K order is unchanged: the values are bit-identical to the unswapped form.
+template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE, bool F16 = false, int TERMS = 3, bool PK = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
     static_assert(TERMS == 3 || (TERMS == 2 && PIPE == 1), "the 2-pass form exists for the scheduled K-step only");
+    static_assert(!PK || (TERMS == 2 && !STATS), "the packed epilogue writes one 16-bit plane");
+#ifdef KTF_TILE_PROBE
+    long long* xprobe = p.probe ? p.probe + (int64_t)blockIdx.x * 8 : nullptr;
+#define XS_PROBE(k) if (xprobe && threadIdx.x == 0) xprobe[k] = wall_clock64();
+#else
+#define XS_PROBE(k)
+#endif
+    XS_PROBE(0)
     // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused. Its
     // 48 KiB of live data per stage would also fit THREE deep (KTF_X2_RING3: DMAs of stage k+2 issued during step k, counted
     // vmcnt at the barrier), which measured no faster.
     constexpr int NST = (TERMS == 2 && KTF_X2_RING3) ? 3 : 2;
     constexpr int STG = (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;
     constexpr int WOFF = (NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
+    static_assert(!(PK && NST == 3), "the packed epilogue parks its column constants right behind a two-stage ring");
     int fill_slot = 0, cur_slot = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     const int id = blockIdx.x;
@@ -2012,6 +2059,20 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     }
     XS_STAGE()
     if (NST == 3 && nk > 1) XS_STAGE()
+    Epi16Prm eprm;
+    if constexpr (PK) {
+        if (tid < R_BN) {                                    // column constants parked behind the staging image (read in the epilogue)
+            float* prm = reinterpret_cast<float*>(rsm + R16_PRM_OFF);
+            const int n = n0 + tid;
+            const bool nv = n < p.units;
+            prm[tid] = (nv && p.bias) ? p.bias[n] : 0.0f;
+            prm[R_BN + tid] = (nv && p.scale) ? p.scale[n] : 1.0f;
+            prm[2 * R_BN + tid] = (nv && p.shift) ? p.shift[n] : 0.0f;
+        }
+    } else {
+        eprm = epi16_load(p, n0, wn, lane);                  // issued here: the ~1 us of global-load latency hides under the K-loop
+    }
+    XS_PROBE(1)
     const int fr = (4 - (((lane & 15) >> 2) & 3)) & 3;
     const int coff = (((lane >> 4) ^ fr) << 4);
     const int a_row_off = (wm * 128 + (lane & 15)) * 64 + coff;
@@ -2024,6 +2085,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (ks == 0) { XS_PROBE(2) }
             const unsigned char* sa = rsm + cur_slot * STG;
             const unsigned char* sw = sa + WOFF;
             cur_slot = (cur_slot + 1 == NST) ? 0 : cur_slot + 1;
@@ -2070,7 +2132,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                         if (t == 2) continue;
 #endif
                         f32x4v& cc = acc[2 * g + r][j];
-                        cc = mfma16x16x32<F16>(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc);
+                        if constexpr (PK) cc = mfma16x16x32<F16>(t == 2 ? bl[j] : bh[j], af[cur][r], cc);
+                        else cc = mfma16x16x32<F16>(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (c == 0 && g < 3) {
@@ -2152,8 +2215,12 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         }
     }
 #undef XS_STAGE
+    XS_PROBE(3)
     if (!STATS) __syncthreads();      // all fragment reads done before the LDS is reused as the store staging area
-    ring_epilogue16<ACT, STATS, F16>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+    if constexpr (PK) ring_epilogue16_pk<ACT, F16>(acc, p, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+    else ring_epilogue16<ACT, STATS, F16>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm);
+    XS_PROBE(4)
+#undef XS_PROBE
 }
 
 // ------------------------------------------------------------------------------------ F32, few workgroups (latency)
@@ -2654,6 +2721,9 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
     p.kinter = (d->flags & KTF_TDNN_K_INTERLEAVED) ? 1 : 0;
+#ifdef KTF_TILE_PROBE
+    p.probe = KTF_PROBE_BUF;
+#endif
     if (p.kinter) KTF_REQUIRE(half2 || (split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_K_INTERLEAVED is implemented by the split-plane kernel only (ktf_tdnn_split*, units > 128)");
     for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
     hipStream_t st = (hipStream_t)stream;
@@ -2698,13 +2768,15 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
         KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
         KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn: F16X2 fuses ReLU or no activation");
-#define H2_LAUNCH(A, ST)                                                                                               \
+#define H2_LAUNCH(A, ST, PKD)                                                                                          \
     do {                                                                                                               \
-        KTF_LDS_ONCE(X2_LDS_BYTES, tdnn_x3s_kernel<A, ST, 1, true, 2>);                                                \
-        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 2>), dim3((unsigned)nblocks), dim3(512), X2_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        constexpr int lds_ = (PKD) ? (R16_LDS_BYTES > X2_LDS_BYTES ? R16_LDS_BYTES : X2_LDS_BYTES) : X2_LDS_BYTES;      \
+        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<A, ST, 1, true, 2, PKD>);                                                   \
+        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 2, PKD>), dim3((unsigned)nblocks), dim3(512), lds_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
-        if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true); else H2_LAUNCH(KTF_ACT_RELU, false); }
-        else { if (stats_sums) H2_LAUNCH(KTF_ACT_NONE, true); else H2_LAUNCH(KTF_ACT_NONE, false); }
+        const bool pk = !stats_sums && d->y_dtype == KTF_F16 && KTF_X2_PK;      // one half plane out: packed single-barrier epilogue
+        if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true, false); else if (pk) H2_LAUNCH(KTF_ACT_RELU, false, true); else H2_LAUNCH(KTF_ACT_RELU, false, false); }
+        else { if (stats_sums) H2_LAUNCH(KTF_ACT_NONE, true, false); else if (pk) H2_LAUNCH(KTF_ACT_NONE, false, true); else H2_LAUNCH(KTF_ACT_NONE, false, false); }
 #undef H2_LAUNCH
     } else if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3 || d->gemm == KTF_GEMM_F16) {
         const bool f16 = d->gemm == KTF_GEMM_F16;
