@@ -1933,7 +1933,12 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 #endif
 #ifndef KTF_X2_RING3
 #define KTF_X2_RING3 0        // 1: three 48 KiB stages for the 2-pass form (two stages of DMA in flight). Measured: no gain over
-                              // two (92.7 k vs 93.4 k x-vectors/s) -- the operand stream costs issue slots and clock, not latency
+                              // two (92.7 k vs 93.4 k x-vectors/s), and 90.5 k vs 92.4 k when the third stage is used to read the
+                              // next stage's first fragments under the last MFMA group (so that a step opens with MFMAs instead of
+                              // an LDS read burst): neither DMA latency nor LDS latency is what the K-step waits for. PMC
+                              // (profiles/r2_pmc_f16x2.txt): the matrix pipes are busy 54 % of the kernel at ~2.1 GHz, the waves sit
+                              // in s_waitcnt / s_barrier a third of their life; without the operand DMAs the same MFMAs run 27 %
+                              // faster (timing-only ablation) -- the DMA instructions' issue time in the MFMA waves is the cost.
 #endif
 #define XS_STAGE_BYTES (4 * R_TILE_BYTES)                // 64 KiB
 #define XS_LDS_BYTES (2 * XS_STAGE_BYTES)                // 128 KiB
@@ -1973,10 +1978,9 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused. Its
     // 48 KiB of live data per stage would also fit THREE deep (KTF_X2_RING3: DMAs of stage k+2 issued during step k, counted
     // vmcnt at the barrier), which measured no faster.
-    constexpr int NST = (TERMS == 2 && KTF_X2_RING3) ? 3 : 2;
+    constexpr int NST = (TERMS == 2 && KTF_X2_RING3 && !PK) ? 3 : 2;
     constexpr int STG = (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;
     constexpr int WOFF = (NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
-    static_assert(!(PK && NST == 3), "the packed epilogue parks its column constants right behind a two-stage ring");
     int fill_slot = 0, cur_slot = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     const int id = blockIdx.x;
@@ -2770,7 +2774,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn: F16X2 fuses ReLU or no activation");
 #define H2_LAUNCH(A, ST, PKD)                                                                                          \
     do {                                                                                                               \
-        constexpr int lds_ = (PKD) ? (R16_LDS_BYTES > X2_LDS_BYTES ? R16_LDS_BYTES : X2_LDS_BYTES) : X2_LDS_BYTES;      \
+        constexpr int lds_ = (PKD) ? (R16_LDS_BYTES > XS_LDS_BYTES ? R16_LDS_BYTES : XS_LDS_BYTES) : X2_LDS_BYTES;      \
         KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<A, ST, 1, true, 2, PKD>);                                                   \
         hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 2, PKD>), dim3((unsigned)nblocks), dim3(512), lds_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
