@@ -61,6 +61,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other modes, latency, PLDA)")
     ap.add_argument("--atomic-pooling", action="store_true", help="fp64-atomic fused pooling instead of the reproducible form")
     ap.add_argument("--ctx-major-k", action="store_true", help="A/B: weights in (context, feature) K order instead of the chunk-interleaved one")
+    ap.add_argument("--row-major-w", action="store_true", help="A/B: row-major weights instead of the LDS-image tiles")
+    ap.add_argument("--row-major-x", action="store_true", help="A/B: row-major half planes between the f16x2 layers instead of chunk-major")
     return ap.parse_args(argv)
 
 
@@ -115,6 +117,8 @@ def main(argv=None):
     mdl = synth.build_extractor(ktf, cfg, w, gemm=args.gemm)
     mdl.xvec.deterministic = not args.atomic_pooling
     mdl.xvec.k_interleaved = not args.ctx_major_k
+    mdl.xvec.w_tiled = not args.row_major_w
+    mdl.xvec.chunked = not args.row_major_x
 
     B, N = args.batch, int(args.seconds * 16000)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -222,6 +222,19 @@ typedef struct KtfTdnnDesc {
                                    * the contexts of one feature chunk in consecutive K-steps, so the three (five) reads of an
                                    * activation row piece by a multi-context layer are adjacent in time and hit in L2 instead of
                                    * returning to HBM / MALL 16 K-steps apart */
+#define KTF_TDNN_W_TILED 8        /* ktf_tdnn_split / ktf_tdnn_split_stats only: W (both planes) is stored as the kernel's LDS
+                                   * stage images instead of row-major: for N-tile nt (256 units) and K-step ks (32 columns of
+                                   * the K order in force) one contiguous 16 KiB block at ((nt * ktot / 32 + ks) * 16 KiB),
+                                   * holding for row r and 16-byte position q the columns 32 ks + 8 (q ^ ((4 - (r >> 2)) & 3))
+                                   * .. + 7 of unit 256 nt + r at byte 64 r + 16 q. A weight DMA instruction then copies 1 KiB of
+                                   * consecutive bytes (8 whole cache lines) instead of gathering 16 rows x 64 B */
+#define KTF_TDNN_X_CHUNKED 16     /* ktf_tdnn_split* only: the 16-bit input plane(s) are stored chunk-major: element (b, t, d) at
+                                   * ((b * ldx / 32 + d / 32) * T + t) * 32 + d % 32 (ldx = din_pad). The row gather of a K-step
+                                   * (256 rows x one 32-feature chunk) then reads consecutive 64-byte row pieces: 1 KiB of
+                                   * consecutive bytes per DMA instruction, and the context-shifted re-reads of the same chunk in
+                                   * the next K-steps (KTF_TDNN_K_INTERLEAVED) touch the same cache lines */
+#define KTF_TDNN_Y_CHUNKED 32     /* ... and the 16-bit output plane(s) are written in that layout (ldy a multiple of 32; pad columns
+                                   * of the last chunk are written as zeros): what the next layer reads with KTF_TDNN_X_CHUNKED */
 
 /* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
 int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);

@@ -56,6 +56,8 @@ struct TdnnParams {
     int64_t T, ldx, ldy, Tout;
     int32_t units, din_pad, nctx, sub, valid, act, y_dtype, ktot;
     int32_t ctx[16];
+    int32_t xchunk, ychunk; // KTF_TDNN_X_CHUNKED / KTF_TDNN_Y_CHUNKED: 16-bit activations stored (utterance, 32-feature chunk, row, 32)
+    int32_t wtiled;         // KTF_TDNN_W_TILED: W stored as the kernel's LDS images, one contiguous 16 KiB block per (N-tile, K-step)
     int32_t kinter;         // KTF_TDNN_K_INTERLEAVED: K runs (32-wide feature chunk, context, feature) instead of (context, feature)
 #ifdef KTF_TILE_PROBE
     long long* probe;       // per-tile s_memrealtime stamps (probe builds)
@@ -1008,7 +1010,43 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
             }
         }
         __syncthreads();
-        if (p.y_dtype != KTF_F32) {
+        if (p.y_dtype != KTF_F32 && p.ychunk) {
+            // chunk-major 16-bit output: an instruction stores 16 rows of ONE 32-column chunk = 1 KiB of consecutive bytes.
+            // Columns beyond `units` inside the last chunk are stored too: they are exact zeros (zero weight rows, no bias),
+            // which is what the consumer's pad columns must hold.
+            const int piece = lane & 3, rr = lane >> 2;
+            const int64_t nchy = p.ldy >> 5;
+#pragma unroll
+            for (int sp = 0; sp < 4; ++sp) {
+                const int item = sp * 8 + wave;                       // (chunk of the tile, group of 16 staged rows)
+                const int cidx = item & 7, srow = (item >> 3) * 16 + rr;
+                const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
+                const int n8 = n0 + cidx * 32 + piece * 8;
+                if (m < rows_valid && n8 < p.ldy) {
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + cidx * 32 + piece * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + cidx * 32 + piece * 8 + 4);
+                    const int64_t off = (((int64_t)b * nchy + (n8 >> 5)) * p.Tout + (t0 + m)) * 32 + (n8 & 31);
+                    const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    unsigned short hh[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(vv[e]);
+                    u32x4 pk;
+                    pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
+                    pk.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
+                    pk.z = (unsigned)hh[4] | ((unsigned)hh[5] << 16);
+                    pk.w = (unsigned)hh[6] | ((unsigned)hh[7] << 16);
+                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
+                    if (p.y_lo) {
+                        u32x4 pl;
+                        pl.x = (unsigned)f2bf(vv[0] - bf2f(hh[0])) | ((unsigned)f2bf(vv[1] - bf2f(hh[1])) << 16);
+                        pl.y = (unsigned)f2bf(vv[2] - bf2f(hh[2])) | ((unsigned)f2bf(vv[3] - bf2f(hh[3])) << 16);
+                        pl.z = (unsigned)f2bf(vv[4] - bf2f(hh[4])) | ((unsigned)f2bf(vv[5] - bf2f(hh[5])) << 16);
+                        pl.w = (unsigned)f2bf(vv[6] - bf2f(hh[6])) | ((unsigned)f2bf(vv[7] - bf2f(hh[7])) << 16);
+                        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y_lo) + off) = pl;
+                    }
+                }
+            }
+        } else if (p.y_dtype != KTF_F32) {
             // bf16 output: 16-byte stores (8 columns per lane, two staged rows per wave instruction)
             const int n8 = n0 + (lane & 31) * 8;
 #pragma unroll
@@ -2014,8 +2052,10 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         const unsigned chunk = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
         a_cb[i] = chunk;
         a_t[i] = start + (t0 + row) * p.sub;
-        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + chunk;
+        w_ob[i] = p.wtiled ? (unsigned)nt * (unsigned)(p.ktot / R_BK) * (unsigned)R_TILE_BYTES + (unsigned)q * 16u
+                           : (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + chunk;
     }
+    const unsigned w_step = p.wtiled ? (unsigned)R_TILE_BYTES : (unsigned)(R_BK * 2);      // bytes between consecutive K-steps of W
 
     f32x4v acc[8][4];
 #pragma unroll
@@ -2035,12 +2075,13 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             int r_ = a_t[i] + is_off;                                                                                  \
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                      \
+            const unsigned vo_ = p.xchunk ? (((unsigned)is_db >> 6) * (unsigned)p.T + (unsigned)r_) * 64u + a_cb[i]   \
+                                          : (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                           \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
             if (TERMS == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-            const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                             \
+            const unsigned vo_ = w_ob[i] + (unsigned)is_ks * w_step;                                                   \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);   \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
@@ -2100,8 +2141,9 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             for (int i = 0; i < 2; ++i) {
                 int r_ = a_t[i] + is_off;
                 r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);
-                va[i] = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;
-                vw[i] = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));
+                va[i] = p.xchunk ? (((unsigned)is_db >> 6) * (unsigned)p.T + (unsigned)r_) * 64u + a_cb[i]
+                                 : (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;
+                vw[i] = w_ob[i] + (unsigned)is_ks * w_step;
             }
             // DMA n of the stage: 0,1 = A hi / lo rows 0-127; 2,3 = rows 128-255; 4,5 = W hi / lo rows 0-127; 6,7 = rows 128-255
 #define XS_DMA(n)                                                                                                      \
@@ -2725,6 +2767,15 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
     p.kinter = (d->flags & KTF_TDNN_K_INTERLEAVED) ? 1 : 0;
+    p.wtiled = (d->flags & KTF_TDNN_W_TILED) ? 1 : 0;
+    p.xchunk = (d->flags & KTF_TDNN_X_CHUNKED) ? 1 : 0;
+    p.ychunk = (d->flags & KTF_TDNN_Y_CHUNKED) ? 1 : 0;
+    if (p.xchunk || p.ychunk) {
+        KTF_REQUIRE(half2 || (split_in && d->units > 128), "ktf_tdnn: chunk-major activations are implemented by the split-plane kernel only");
+        KTF_REQUIRE(!p.xchunk || ldx == d->din_pad, "ktf_tdnn: KTF_TDNN_X_CHUNKED needs ldx == din_pad (whole 32-feature chunks)");
+        KTF_REQUIRE(!p.ychunk || (!stats_sums && ldy % 32 == 0 && d->y_dtype != KTF_F32), "ktf_tdnn: KTF_TDNN_Y_CHUNKED needs a 16-bit output with ldy %% 32 == 0");
+    }
+    if (p.wtiled) KTF_REQUIRE(half2 || (split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_W_TILED is implemented by the split-plane kernel only");
 #ifdef KTF_TILE_PROBE
     p.probe = KTF_PROBE_BUF;
 #endif
@@ -2832,7 +2883,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     } while (0)
             const int x3s_env = KTF_KNOB("KTF_X3S", KTF_X3S_DEFAULT);   // probe builds: 0 = 32x32x16 kernels everywhere (A/B)
             // split planes in: the 16x16x32 kernel (x3s_env 2: also for the layers that write planes / fp32 out, else pooling only)
-            if (split_in && (p.kinter || (x3s_env && (stats_sums || x3s_env >= 2)))) {
+            if (split_in && (p.kinter || p.wtiled || p.xchunk || p.ychunk || (x3s_env && (stats_sums || x3s_env >= 2)))) {
                 if (d->act == KTF_ACT_NONE) XS_LAUNCH(KTF_ACT_NONE);
                 else if (d->act == KTF_ACT_RELU) XS_LAUNCH(KTF_ACT_RELU);
                 else if (d->act == KTF_ACT_SIGMOID) XS_LAUNCH(KTF_ACT_SIGMOID);

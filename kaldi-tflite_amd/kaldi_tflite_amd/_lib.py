@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("KTF_LIBRARY") or os.path.join(_HERE, "libktf_hip.so")
 KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
 GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
-TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED = 1, 2, 4          # KtfTdnnDesc.flags
+TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED, TDNN_X_CHUNKED, TDNN_Y_CHUNKED = 1, 2, 4, 8, 16, 32   # KtfTdnnDesc.flags
 IN_WAV, IN_FRAMES, IN_WINDOWED, IN_WAV_I16 = 0, 1, 2, 3
 OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
 

@@ -761,13 +761,13 @@ class TDNN(Layer):
         K, D = self.kernelWidth, self.inputDim
         return np.ascontiguousarray(self.kernel[0].reshape(K * D, self.units).T)
 
-    def device_weights(self, device, gemm, k_interleaved=False, fold=None):
+    def device_weights(self, device, gemm, k_interleaved=False, fold=None, w_tiled=False):
         """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for the two-part modes),
         bias. `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, split-plane
         kernel. `fold`: the BatchNorm whose affine y = s*x + h precedes this layer and is folded INTO it, so that the stored
         activations are the ReLU outputs themselves: W'[u,k,d] = W[u,k,d] * s[d], b'[u] = b[u] + sum_kd W[u,k,d] * h[d]
         (float64 on the host; exact for replicate padding, every context row carries the same per-feature affine)."""
-        key = (str(device), gemm, bool(k_interleaved), None if fold is None else (id(fold), fold._version))
+        key = (str(device), gemm, bool(k_interleaved), None if fold is None else (id(fold), fold._version), bool(w_tiled))
         if key in self._dev:
             return self._dev[key]
         K, D = self.kernelWidth, self.inputDim
@@ -785,7 +785,16 @@ class TDNN(Layer):
         W[: self.units, :, :D] = Wk
         if k_interleaved:
             W = np.ascontiguousarray(W.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3))
-        W = torch.as_tensor(W.reshape(Up, K * Dp), device=device)
+        W = W.reshape(Up, K * Dp)
+        if w_tiled:
+            # KTF_TDNN_W_TILED: (N-tile, K-step) blocks in the kernel's LDS image order: row r keeps its four 16-byte chunks
+            # at positions chunk ^ ((4 - (r >> 2)) & 3)
+            nt, nks = Up // 256, K * Dp // 32
+            r = np.arange(256)
+            src = np.arange(4)[None, :] ^ ((4 - ((r >> 2) & 3)) & 3)[:, None]              # [row, position] -> chunk
+            W5 = W.reshape(nt, 256, nks, 4, 8)
+            W = np.ascontiguousarray(W5[:, r[:, None], :, src, :].transpose(2, 3, 0, 1, 4)).reshape(Up, K * Dp)
+        W = torch.as_tensor(W, device=device)
         w_lo = None
         if gemm == L.GEMM_F32:
             w = W.to(torch.float32)

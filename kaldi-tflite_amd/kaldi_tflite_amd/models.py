@@ -112,6 +112,8 @@ class Sequential:
 
     split_planes = True         # bf16x3: hi/lo bf16 activation planes between the wide layers (no in-loop conversion)
     k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
+    w_tiled = True              # ... and the weights stored as the kernel's LDS stage images (contiguous 1 KiB per DMA instruction)
+    chunked = True              # f16x2: the half plane between two layers of the route is stored (chunk of 32 features, row, 32)
     # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
     min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32}
 
@@ -190,7 +192,7 @@ class Sequential:
             gemm = L.GEMM_F32
         return gemm
 
-    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None):
+    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
         `split`: the input is a (2,B,T,ld) pair of bf16 planes or ONE (B,T,ld) half plane (F16X2) read by the split-plane
         kernel; `fold`: the preceding BatchNorm folded into this layer's weights. Returns the pooled (1, B, od) view."""
@@ -203,11 +205,12 @@ class Sequential:
         sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev)
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev)
         kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
-        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold)
+        wt = bool(split and self.w_tiled)
+        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=wt)
         scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
         xdt = x_or_planes.dtype
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
-                   flags=(L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0))
+                   flags=flags | (L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if wt else 0))
         (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
         ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf, slots=slots)
         return sbuf[:, :od].unsqueeze(0)
@@ -231,6 +234,7 @@ class Sequential:
         use_planes = gemm == L.GEMM_BF16X3 and self.split_planes
         planes = None
         pending_bn = None            # F16X2: the BatchNorm of the previous layer, to be folded into the next layer's weights
+        x_chunked = False            # F16X2: the current activation buffer is chunk-major (KTF_TDNN_Y_CHUNKED of its producer)
         for si, st in enumerate(steps):
             if skip:
                 skip = False
@@ -253,14 +257,16 @@ class Sequential:
                 xin = x                                  # the kernel takes the row stride from the view
                 fold, pending_bn = pending_bn, None
                 kint = bool(self.k_interleaved and l.kernelWidth > 1)
-                kflag = L.TDNN_K_INTERLEAVED if kint else 0
+                kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if self.w_tiled else 0) | \
+                        (L.TDNN_X_CHUNKED if x_chunked else 0)
+                x_chunked = False
                 if can_pool:
-                    x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold)
+                    x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold, flags=kflag & L.TDNN_X_CHUNKED)
                     lens, pooled, skip = None, True, True
                     continue
                 nl = nxt[1] if nxt is not None and nxt[0] == "tdnn" else None
                 defer_bn = (bn is not None and nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm)
-                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold)
+                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=self.w_tiled)
                 scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
@@ -269,6 +275,9 @@ class Sequential:
                     out_lens = torch.empty_like(lens)
                 ydt = torch.float16 if nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm else torch.float32
                 ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev)
+                if ydt == torch.float16 and self.chunked:          # only a layer of this route reads it: chunk-major plane
+                    kflag |= L.TDNN_Y_CHUNKED
+                    x_chunked = True
                 d = l.desc(gemm, torch.float16, ydt, act="relu" if relu else None, flags=kflag)
                 ops.tdnn_split(xin, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
                 if defer_bn:
@@ -291,8 +300,8 @@ class Sequential:
                     lens, pooled, skip, planes = None, True, True, None
                     continue
                 kint = bool(self.k_interleaved and l.kernelWidth > 1)
-                kflag = L.TDNN_K_INTERLEAVED if kint else 0
-                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint)
+                kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if self.w_tiled else 0)
+                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, w_tiled=self.w_tiled)
                 scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
