@@ -2069,14 +2069,18 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int lenm1 = len - 1;
     int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
     const int dpad_b = p.din_pad * 2;
+    // A-piece address = row * x_rm + is_xb + chunk: row-major planes x_rm = row pitch, is_xb = byte offset of the 32-feature chunk in
+    // the row; chunk-major planes x_rm = 64, is_xb = chunk index * T * 64 (branch-free: both are wave-uniform scalars)
+    const unsigned x_rm = p.xchunk ? 64u : ldxb;
+    const unsigned x_cs = p.xchunk ? (unsigned)p.T * 64u : (unsigned)(R_BK * 2);
+    unsigned is_xb = 0;
 #define XS_STAGE()                                                                                                     \
     {                                                                                                                  \
         unsigned char* st_ = rsm + fill_slot * STG + wave * 1024;                                                      \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             int r_ = a_t[i] + is_off;                                                                                  \
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = p.xchunk ? (((unsigned)is_db >> 6) * (unsigned)p.T + (unsigned)r_) * 64u + a_cb[i]   \
-                                          : (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                           \
+            const unsigned vo_ = (unsigned)r_ * x_rm + a_cb[i] + is_xb;                                                \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
             if (TERMS == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
@@ -2091,12 +2095,15 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             if (++is_c == p.nctx) {                                                                                    \
                 is_c = 0;                                                                                              \
                 is_db += R_BK * 2;                                                                                     \
+                is_xb += x_cs;                                                                                         \
             }                                                                                                          \
             is_off = p.ctx[is_c];                                                                                      \
         } else {                                                                                                       \
             is_db += R_BK * 2;                                                                                         \
+            is_xb += x_cs;                                                                                             \
             if (is_db == dpad_b) {                                                                                     \
                 is_db = 0;                                                                                             \
+                is_xb = 0;                                                                                             \
                 ++is_c;                                                                                                \
                 is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                            \
             }                                                                                                          \
@@ -2136,15 +2143,6 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             cur_slot = (cur_slot + 1 == NST) ? 0 : cur_slot + 1;
             const bool refill = is_ks < nk;                     // next stage -> the buffer every wave finished reading
             unsigned char* st_ = rsm + fill_slot * STG + wave * 1024;
-            unsigned va[2], vw[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                int r_ = a_t[i] + is_off;
-                r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);
-                va[i] = p.xchunk ? (((unsigned)is_db >> 6) * (unsigned)p.T + (unsigned)r_) * 64u + a_cb[i]
-                                 : (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;
-                vw[i] = w_ob[i] + (unsigned)is_ks * w_step;
-            }
             // DMA n of the stage: 0,1 = A hi / lo rows 0-127; 2,3 = rows 128-255; 4,5 = W hi / lo rows 0-127; 6,7 = rows 128-255
 #define XS_DMA(n)                                                                                                      \
     {                                                                                                                  \
@@ -2153,15 +2151,25 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, 0); \
     }
             bfrag8 bh[4], bl[4], af[2][4];                      // af[set][0,1] = hi fragments of the group's two rows, [2,3] = lo
+            // fragment reads in the order the MFMAs consume them (LDS returns in order: the first MFMA waits for two reads, not twelve)
+            af[0][0] = *reinterpret_cast<const bfrag8*>(sa + a_row_off);
+            bh[0] = *reinterpret_cast<const bfrag8*>(sw + b_row_off);
+            __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise moves the A read behind the eight B reads)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
-                bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
-            }
+            for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            if (TERMS == 3) af[0][2] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off);
 #pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                af[0][r] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + r * 16 * 64);
-                if (TERMS == 3) af[0][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + r * 16 * 64);
+            for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
+            af[0][1] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + 16 * 64);
+            if (TERMS == 3) af[0][3] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + 16 * 64);
+            unsigned va[2], vw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r_ = a_t[i] + is_off;
+                r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);
+                va[i] = (unsigned)r_ * x_rm + a_cb[i] + is_xb;
+                vw[i] = w_ob[i] + (unsigned)is_ks * w_step;
             }
             __builtin_amdgcn_sched_barrier(0);
             constexpr int PER_ROW = 4 * TERMS, PER_CHUNK = PER_ROW / 2;      // MFMAs per tile row / per chunk (4 chunks per 2-row group)
@@ -2214,12 +2222,15 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                     if (++is_c == p.nctx) {
                         is_c = 0;
                         is_db += R_BK * 2;
+                        is_xb += x_cs;
                     }
                     is_off = p.ctx[is_c];
                 } else {
                     is_db += R_BK * 2;
+                    is_xb += x_cs;
                     if (is_db == dpad_b) {
                         is_db = 0;
+                        is_xb = 0;
                         ++is_c;
                         is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;
                     }
