@@ -40,6 +40,7 @@ extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
 typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(4))) float fv4;
+typedef __attribute__((ext_vector_type(2))) unsigned uv2;
 
 struct TdnnParams {
     const void* x;
@@ -1029,7 +1030,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                     const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     unsigned short hh[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(vv[e]);
+                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(F16 ? fminf(fmaxf(vv[e], -65504.0f), 65504.0f) : vv[e]);   // half planes saturate instead of overflowing to inf
                     u32x4 pk;
                     pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
                     pk.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
@@ -1061,7 +1062,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                     const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     unsigned short hh[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(vv[e]);
+                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(F16 ? fminf(fmaxf(vv[e], -65504.0f), 65504.0f) : vv[e]);   // half planes saturate instead of overflowing to inf
                     if (n8 + 8 <= p.units) {
                         u32x4 pk;
                         pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
@@ -2287,8 +2288,10 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 // fp32 FMAs -- the summation order of v_mfma_f32_32x32x2_f32 -- so they are bit-identical to the 128x128 tile kernel and a
 // batch still equals its single-utterance calls.
 //
-// (1) 64 x BN tile, one 16x16 block (v_mfma_f32_16x16x4_f32) per wave: sixteen waves at BN = 64. K-step 64 when the per-context width
-//     allows it, else 32; 4-stage LDS-DMA ring (128 / 64 KiB), loads 3 steps ahead, one or two 16-byte DMAs per thread and
+// (1) 64 x BN tile, NB 16x16 blocks (v_mfma_f32_16x16x4_f32) per wave that share the A fragment: <BN, NB> = <32, 1> eight waves,
+//     <64, 1> sixteen, <96, 3> eight (the 1500-unit layer of one utterance: 256 workgroups in ONE round instead of 384 in
+//     two, 36 -> 21 us). K-step 64 when the per-context width
+//     allows it, else 32; 4-stage LDS-DMA ring (up to 160 KiB), loads 4 steps ahead, one to five 16-byte DMAs per thread and
 //     stage. Rows are BK*4 bytes; chunk c of row r sits at position c ^ (r & (CH-1)) (2-way on the scalar fragment reads).
 //     Measured at K = 1536 on one utterance (998 x 512 outputs, 128 workgroups): 40 us; four waves of one 32x32x2 block
 //     53 us (a dependent fp32 MFMA costs ~120 cycles against 64 of issue); four waves of 2x2 16x16x4 blocks 43 us; K-step
@@ -2299,10 +2302,17 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 //     LDS time per CU for 1.5x the L2->LDS bytes (the same layer: 26 us).
 #define FS_BM 64
 #define FS_NSTAGE 4
-template <int BK, int BN>
-__global__ __launch_bounds__(64 * 4 * (BN / 16)) void tdnn_f32s_kernel(TdnnParams p) {
-    constexpr int WN = BN / 16;                              // waves across the tile's columns
-    constexpr int NT = 64 * 4 * WN;                          // 1024 / 512 threads
+#ifndef KTF_FS_NB32
+#define KTF_FS_NB32 1  // 16-column blocks per wave of the 64 x 32 tile (2: four waves, one A fragment feeds two MFMAs)
+#endif
+#ifndef KTF_FS_ABL
+#define KTF_FS_ABL 0   // timing-only ablations (tools/b1_tile_probe.py; results are garbage): 1 no refill DMAs, 2 no MFMAs,
+#endif                 // 4 no fragment reads, 8 no barrier
+template <int BK, int BN, int NB>
+__global__ __launch_bounds__(64 * 4 * (BN / 16 / NB)) void tdnn_f32s_kernel(TdnnParams p) {
+    static_assert(BN % (16 * NB) == 0, "a wave owns NB 16-column blocks");
+    constexpr int WN = BN / 16 / NB;                         // waves across the tile's columns, NB blocks each (one A fragment
+    constexpr int NT = 64 * 4 * WN;                          // feeds NB MFMAs); 1024 / 512 threads
     constexpr int CH = BK / 4;                               // 16-byte chunks per row
     constexpr int ROWB = BK * 4;                             // bytes per staged row
     constexpr int A_BYTES = FS_BM * ROWB, W_BYTES = BN * ROWB;
@@ -2314,6 +2324,13 @@ __global__ __launch_bounds__(64 * 4 * (BN / 16)) void tdnn_f32s_kernel(TdnnParam
     constexpr int NDMA = HALVES ? 1 : NA + NW;
     static_assert(HALVES || ((FS_BM * CH) % NT == 0 && (BN * CH) % NT == 0), "staging does not divide");
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+#ifdef KTF_TILE_PROBE
+    long long* fprobe = p.probe ? p.probe + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+#define FS_PROBE(k) if (fprobe && threadIdx.x == 0) { fprobe[k] = wall_clock64(); fprobe[4 + k] = clock64(); }
+#else
+#define FS_PROBE(k)
+#endif
+    FS_PROBE(0)
     const int b = blockIdx.z;
     const int len = p.lens ? p.lens[b] : (int)p.T;
     int start;
@@ -2352,26 +2369,39 @@ __global__ __launch_bounds__(64 * 4 * (BN / 16)) void tdnn_f32s_kernel(TdnnParam
     const int lenm1 = len - 1;
     int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
     const int dpad_b = p.din_pad * 4;
-#define FS_STAGE()                                                                                                     \
+    // A stage is fetched in three pieces so that its DMAs can be spread over a K-step: FS_SRC (source offsets of stage
+    // is_ks into soff[], LDS destination st_d), FS_ADV (scalar cursor to the next stage; holds the only scalar load, of a
+    // context offset), FS_DMA(i) (the i-th 16-byte-per-lane DMA of the stage).
+    unsigned soff[NDMA];
+    unsigned char* st_d;
+#define FS_SRC()                                                                                                       \
     {                                                                                                                  \
-        unsigned char* st_ = fsm + (is_ks & (FS_NSTAGE - 1)) * STAGE_BYTES + wave * 1024;                              \
+        st_d = fsm + (is_ks & (FS_NSTAGE - 1)) * STAGE_BYTES + wave * 1024;                                            \
         if (HALVES) {                                        /* waves 8-15 land in the W tile: wave * 1024 >= A_BYTES */ \
             int r_ = a_t[0] + is_off;                                                                                  \
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const char* src_ = isw ? wb + (w_ob[0] + (unsigned)(is_ks * ROWB))                                         \
-                                   : xb + ((unsigned)r_ * ldxb + a_cb[0] + (unsigned)is_db);                           \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)src_, (lds_ptr_t*)st_, 16, 0, 0);                             \
+            soff[0] = isw ? w_ob[0] + (unsigned)(is_ks * ROWB) : (unsigned)r_ * ldxb + a_cb[0] + (unsigned)is_db;      \
         } else {                                                                                                       \
             _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
                 int r_ = a_t[i] + is_off;                                                                              \
                 r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                           \
-                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + ((unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db)),\
-                                                 (lds_ptr_t*)(st_ + i * (NT * 16)), 16, 0, 0);                         \
+                soff[i] = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                             \
             }                                                                                                          \
-            _Pragma("unroll") for (int i = 0; i < NW; ++i)                                                             \
-                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + (w_ob[i] + (unsigned)(is_ks * ROWB))),              \
-                                                 (lds_ptr_t*)(st_ + TILE_BYTES + i * (NT * 16)), 16, 0, 0);            \
+            _Pragma("unroll") for (int i = 0; i < NW; ++i) soff[NA + i] = w_ob[i] + (unsigned)(is_ks * ROWB);          \
         }                                                                                                              \
+    }
+#define FS_DMA(i_)                                                                                                     \
+    {                                                                                                                  \
+        if (HALVES)                                                                                                    \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)((isw ? wb : xb) + soff[0]), (lds_ptr_t*)st_d, 16, 0, 0);     \
+        else if ((i_) < NA)                                                                                            \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + soff[i_]), (lds_ptr_t*)(st_d + (i_) * (NT * 16)), 16, 0, 0); \
+        else                                                                                                           \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + soff[i_]),                                              \
+                                             (lds_ptr_t*)(st_d + TILE_BYTES + ((i_) - NA) * (NT * 16)), 16, 0, 0);     \
+    }
+#define FS_ADV()                                                                                                       \
+    {                                                                                                                  \
         ++is_ks;                                                                                                       \
         is_db += ROWB;                                                                                                 \
         if (is_db == dpad_b) {                                                                                         \
@@ -2380,58 +2410,125 @@ __global__ __launch_bounds__(64 * 4 * (BN / 16)) void tdnn_f32s_kernel(TdnnParam
             is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
         }                                                                                                              \
     }
-    for (int s_ = 0; s_ < FS_NSTAGE - 1 && s_ < nk; ++s_) FS_STAGE()
+#define FS_STAGE()                                                                                                     \
+    {                                                                                                                  \
+        FS_SRC()                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < NDMA; ++i) FS_DMA(i)                                                     \
+        FS_ADV()                                                                                                       \
+    }
+    for (int s_ = 0; s_ < FS_NSTAGE && s_ < nk; ++s_) FS_STAGE()
 
-    f32x4v acc;
+    f32x4v acc[NB];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = 0.0f;
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = 0.0f;
     const int r16 = lane & 15, kq = lane >> 4;
+    // Fragments: lane (row r16, quarter kq) takes element 4c + kq of its row for position c -- one float of each 16-byte
+    // chunk, a ds_read_b32 per operand and MFMA. (Tried: the lane reads chunk 4g + kq whole and the four lanes of a row
+    // transpose their 4 x 4 floats with v_permlane32_swap / v_permlane16_swap -- a quarter of the LDS instructions, same
+    // bits, 13 % slower: the swaps are slower than the reads they replace.)
     const int a_row_off = (wm * 16 + r16) * ROWB + kq * 4;
-    const int b_row_off = TILE_BYTES + (wn * 16 + r16) * ROWB + kq * 4;
+    const int b_row_off = TILE_BYTES + (wn * NB * 16 + r16) * ROWB + kq * 4;        // block j: + j * 16 rows
     const int sw = r16 & (CH - 1);
-    for (int ks = 0; ks < nk; ++ks) {
-        const int ahead = nk - 1 - ks;                       // stages issued beyond this one: min(ahead, 2), NDMA DMAs each
-        if (NDMA == 1) {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else if (NDMA == 2) {
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            static_assert(NDMA <= 3, "vmcnt table");
-            if (ahead >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+    // wait until at most `n_` (0..3) of this wave's stages are still in flight (NDMA DMAs each); s_waitcnt with vmcnt = v,
+    // expcnt / lgkmcnt left at their maxima
+#define FS_VM(v_) (((v_) & 15) | (((v_) >> 4) << 14) | 0x0f70)
+#define FS_WAIT(n_)                                                                                                    \
+    {                                                                                                                  \
+        static_assert(3 * NDMA <= 63, "vmcnt range");                                                                  \
+        const int n__ = (n_);                                                                                          \
+        if (n__ >= 3) __builtin_amdgcn_s_waitcnt(FS_VM(3 * NDMA));                                                     \
+        else if (n__ == 2) __builtin_amdgcn_s_waitcnt(FS_VM(2 * NDMA));                                                \
+        else if (n__ == 1) __builtin_amdgcn_s_waitcnt(FS_VM(NDMA));                                                    \
+        else __builtin_amdgcn_s_waitcnt(FS_VM(0));                                                                     \
+    }
+    // The fragments of step ks + 1 are read under the MFMAs of step ks (one workgroup per CU, both waves of a SIMD in the
+    // same phase: read latency in front of the MFMAs was 40 % of the step). A stage is refilled four steps ahead, into
+    // the slot whose fragments every wave took during the previous step.
+    float av[CH], bv[NB][CH];
+    {
+        const int issued = nk < FS_NSTAGE ? nk : FS_NSTAGE;
+        FS_WAIT(issued - 1)
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (is_ks < nk) FS_STAGE()                           // into the slot every wave finished reading last step
-        const unsigned char* st = fsm + (ks & (FS_NSTAGE - 1)) * STAGE_BYTES;
-        float av[CH], bv[CH];
+        FS_PROBE(1)
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            av[c] = *reinterpret_cast<const float*>(st + a_row_off + ((c ^ sw) << 4));
-            bv[c] = *reinterpret_cast<const float*>(st + b_row_off + ((c ^ sw) << 4));
-        }
+            av[c] = *reinterpret_cast<const float*>(fsm + a_row_off + ((c ^ sw) << 4));
 #pragma unroll
-        for (int c = 0; c < CH; ++c) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[c], acc, 0, 0, 0);
+            for (int j = 0; j < NB; ++j)
+                bv[j][c] = *reinterpret_cast<const float*>(fsm + b_row_off + j * 16 * ROWB + ((c ^ sw) << 4));
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0), as an instruction the compiler's counter model sees
+    }                                                        // (an inline-asm wait is not: fragments "pending" at the loop head
+                                                             // put a wait for the reads just issued in front of every MFMA)
+    for (int ks = 0; ks + 1 < nk; ++ks) {
+        const int beyond = nk - 2 - ks;                      // stages issued beyond ks + 1: min(beyond, 2)
+        FS_WAIT(beyond < 2 ? beyond : 2)
+        if (!(KTF_FS_ABL & 8)) __builtin_amdgcn_s_barrier(); // every wave has taken stage ks (its reads were waited for at the
+        asm volatile("" ::: "memory");                       // end of the previous step): the slot can be refilled
+        const bool refill = !(KTF_FS_ABL & 1) && is_ks < nk;
+        if (refill) {
+            FS_SRC()
+            FS_ADV()
+        }
+        // One position of the K-step at a time: its MFMA(s), then the fragment reads of the same position of the next stage
+        // into the registers those MFMAs just consumed, and every CH / NDMA positions one DMA of the refill. Bursts keep all
+        // waves in LDS issue (at most 15 LDS operations of a wave are in flight) or in the texture addresser's queue while
+        // the matrix pipes idle. In-kernel stamps (K = 1536, 64 x 32 tiles, tools/b1_tile_probe.py with -DKTF_FS_ABL): K-loop
+        // 22.7 us; MFMAs + barrier alone 13.8, fragment reads + barrier alone 13.9 (256 ds_read_b32 per step and workgroup
+        // at ~4.8 cycles each), DMA stream alone 9.4: the LDS instruction rate and the MFMAs are both near their limits.
+        const unsigned char* nst = fsm + ((ks + 1) & (FS_NSTAGE - 1)) * STAGE_BYTES;
+        constexpr int DSTEP = CH / NDMA > 0 ? CH / NDMA : 1;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (KTF_FS_ABL & 2) acc[j][c & 3] += av[c] * bv[j][c];
+                else acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[j][c], acc[j], 0, 0, 0);
+            }
+            if (c % DSTEP == 0 && c / DSTEP < NDMA) {
+                if (refill) FS_DMA(c / DSTEP)
+            }
+            if (KTF_FS_ABL & 4) {
+                av[c] += 1.0f;
+            } else {
+                av[c] = *reinterpret_cast<const float*>(nst + a_row_off + ((c ^ sw) << 4));
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    bv[j][c] = *reinterpret_cast<const float*>(nst + b_row_off + j * 16 * ROWB + ((c ^ sw) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
     }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c], bv[j][c], acc[j], 0, 0, 0);
+#undef FS_WAIT
+#undef FS_VM
+    FS_PROBE(2)
 #undef FS_STAGE
+#undef FS_SRC
+#undef FS_DMA
+#undef FS_ADV
     // 16x16 accumulator layout: acc[r] = out[row 4*(lane>>4) + r][col lane&15]
-    const int n = n0 + wn * 16 + r16;
-    if (n < p.units) {
+    const int rows_valid = out_len - t0;
+    const int64_t out_row0 = (int64_t)b * p.Tout + t0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = n0 + (wn * NB + j) * 16 + r16;
+        if (n >= p.units) continue;
         const float bias = p.bias ? p.bias[n] : 0.0f;
         const float sc = p.scale ? p.scale[n] : 1.0f;
         const float sh = p.shift ? p.shift[n] : 0.0f;
-        const int rows_valid = out_len - t0;
-        const int64_t out_row0 = (int64_t)b * p.Tout + t0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int m = wm * 16 + kq * 4 + r;
             if (m < rows_valid) {
-                float v = apply_act(acc[r] + bias, p.act);
+                float v = apply_act(acc[j][r] + bias, p.act);
                 if (p.scale) v = v * sc + sh;
                 const int64_t off = (out_row0 + m) * p.ldy + n;
                 if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off] = v;
@@ -2439,6 +2536,8 @@ __global__ __launch_bounds__(64 * 4 * (BN / 16)) void tdnn_f32s_kernel(TdnnParam
             }
         }
     }
+    FS_PROBE(3)
+#undef FS_PROBE
 }
 
 // (3) throughput form: 128x128 tile, EIGHT waves of 2x4 blocks of v_mfma_f32_16x16x4_f32 (six scalar LDS reads feed eight
@@ -2804,17 +2903,30 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
             hipLaunchKernelGGL(tdnn_f32_rowvec_kernel, grid, dim3(64), 0, st, p);
         } else if (lat && wg128 < 256) {
             const int64_t wg64 = (int64_t)ktf_cdiv(d->units, FS_BM) * ktf_cdiv(Tout, FS_BM) * B;
-#define FS_LAUNCH(BK_, BN_)                                                                                            \
+#define FS_LAUNCH(BK_, BN_, NB_)                                                                                       \
     do {                                                                                                               \
         const int lds = FS_NSTAGE * (FS_BM + BN_) * BK_ * 4;                                                           \
         dim3 grid_((unsigned)ktf_cdiv(d->units, BN_), (unsigned)ktf_cdiv(Tout, FS_BM), (unsigned)B);                   \
-        KTF_LDS_ONCE(lds, tdnn_f32s_kernel<BK_, BN_>); \
-        hipLaunchKernelGGL((tdnn_f32s_kernel<BK_, BN_>), grid_, dim3(64 * 4 * (BN_ / 16)), lds, st, p);                 \
+        KTF_LDS_ONCE(lds, tdnn_f32s_kernel<BK_, BN_, NB_>);                                                            \
+        hipLaunchKernelGGL((tdnn_f32s_kernel<BK_, BN_, NB_>), grid_, dim3(64 * 4 * (BN_ / 16 / NB_)), lds, st, p);      \
     } while (0)
             if (d->din_pad % 64 == 0) {
-                if (wg64 < 256) FS_LAUNCH(64, 32); else FS_LAUNCH(64, 64);
+                // tile width: one workgroup per CU (the ring takes most of the LDS), so the cost is (rounds of 256 workgroups) x
+                // (time of one, ~ width + fixed part); 96 columns only where the padded W rows cover the last tile
+                const int64_t mt = (int64_t)ktf_cdiv(Tout, FS_BM) * B;
+                int best = 32;
+                int64_t best_cost = INT64_MAX;
+                for (int bn = 32; bn <= 96; bn += 32) {
+                    if (bn == 96 && (int64_t)ktf_cdiv(d->units, 96) * 96 > (int64_t)ktf_cdiv(d->units, 128) * 128) continue;
+                    const int64_t cost = ktf_cdiv(ktf_cdiv(d->units, bn) * mt, 256) * (bn + 16);
+                    if (cost < best_cost) best_cost = cost, best = bn;
+                }
+                (void)wg64;
+                if (best == 32) FS_LAUNCH(64, 32, KTF_FS_NB32);
+                else if (best == 64) FS_LAUNCH(64, 64, 1);
+                else FS_LAUNCH(64, 96, 3);
             } else {
-                FS_LAUNCH(32, 64);
+                FS_LAUNCH(32, 64, 1);
             }
 #undef FS_LAUNCH
         } else if (lat) {

@@ -19,6 +19,15 @@
 #define VC_WAVES (VC_THREADS / KTF_WAVE)
 #define CMVN_CHUNK 32
 
+// phase stamps of workgroup 0 (probe builds only: tools/vc_phase_probe.py)
+#ifdef KTF_TILE_PROBE
+__device__ long long* ktf_vc_probe_ptr = nullptr;
+extern "C" void ktf_probe_set_vc_buffer(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ktf_vc_probe_ptr), &p, sizeof(p)); }
+#define VC_PROBE(k) { if (ktf_vc_probe_ptr && blockIdx.x == 0 && threadIdx.x == 0) ktf_vc_probe_ptr[k] = wall_clock64(); }
+#else
+#define VC_PROBE(k)
+#endif
+
 __device__ __forceinline__ float block_sum(float v, float* red /* VC_WAVES floats in LDS */) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,6 +157,7 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         }
     }
     __syncthreads();
+    VC_PROBE(3)
     if (len <= N) {
         // cmvn.py:214-222: statistics over all frames. VC_RG row groups x 32 columns per pass.
         const int rg = tid >> 5, dl = tid & 31;
@@ -217,6 +227,7 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         }
         __syncthreads();
     }
+    VC_PROBE(4)
     for (int item = tid; item < nchunk * ldo_i; item += VC_THREADS) {
         const int ch = item / ldo_i, d = item - ch * ldo_i;
         const int s0 = ch * CMVN_CHUNK;
@@ -270,6 +281,7 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
             }
         }
     }
+    VC_PROBE(5)
     if (!c.valid) {
         __syncthreads();
         const int n_head = half;                              // frames [0, half) use the first window
@@ -287,6 +299,7 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
             store_out<OutT>(out + (int64_t)t * ldo + d, v);
         }
     }
+    VC_PROBE(6)
     if (out_len && tid == 0) *out_len = c.valid ? nstart : len;
 }
 
@@ -345,12 +358,16 @@ __global__ __launch_bounds__(VC_THREADS) void vad_cmvn_kernel(const float* __res
     float* red = gm;
     int* scan = reinterpret_cast<int*>(gm + 64);
     const float* f = feats + (int64_t)b * T * D;
+    VC_PROBE(0)
     const float thr = vad_threshold(f, T, D, vc, red);
+    VC_PROBE(1)
     const int n = vad_compact(f, T, D, vc, thr, pos_ints ? idx : nullptr, pos, scan);
     __syncthreads();  // pos[] written by this workgroup is read below by other threads of it
+    VC_PROBE(2)
     int* ol = lens + b;
     float* xs = ((int64_t)n * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
     cmvn_block<OutT>(f, D, pos, (int)T, n, D, cc, out + (int64_t)b * T * ldo, ldo, xs, gm, ol, bsp);
+    VC_PROBE(7)
 }
 
 static int check_vad(const char* who, const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* c) {

@@ -77,7 +77,9 @@ class _Workspace:
         """Bind the following get() calls to `device` and its current stream (looked up once per model call)."""
         self._where = (str(device), torch.cuda.current_stream(device).cuda_stream)
 
-    def get(self, role, shape, dtype, device):
+    def get(self, role, shape, dtype, device, padded=True):
+        """`padded`: the view has pad columns nobody writes (they must read as finite zeros); a view without them is
+        handed out as is when the role's shape changes."""
         if self._where is None or self._where[0] != str(device):
             self.enter(device)
         key = (role,) + self._where
@@ -91,7 +93,7 @@ class _Workspace:
             slot = [torch.zeros((nbytes,), dtype=torch.uint8, device=device), None, None]
             self._arenas[key] = slot
         view = slot[0][:nbytes].view(dtype)[:count].view(shape)
-        if slot[1] is not None:
+        if slot[1] is not None and padded:
             view.zero_()              # a different shape re-slices old bytes: pad columns must read as finite zeros
         slot[1], slot[2] = sig, view
         return view
@@ -240,7 +242,11 @@ class Sequential:
                 skip = False
                 continue
             nxt = steps[si + 1] if si + 1 < len(steps) else None
-            out_role = f"act{si & 1}"            # layer si reads what layer si-1 wrote: two arenas alternate
+            # layer si reads what layer si-1 wrote: two arenas alternate; outputs with pad columns and the single rows
+            # after the pooling get arenas of their own, so that in steady state no role changes shape (a change costs a fill)
+            out_role = f"act{si & 1}" + ("s" if pooled else "")
+            if st[0] == "tdnn" and st[1].units % 32:
+                out_role += "p"
             if st[0] == "tdnn":
                 _, l, relu, bn = st
                 if relu and l.activation not in (None, "linear"):
@@ -274,7 +280,7 @@ class Sequential:
                 if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
                     out_lens = torch.empty_like(lens)
                 ydt = torch.float16 if nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm else torch.float32
-                ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev)
+                ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev, padded=ldy != l.units)
                 if ydt == torch.float16 and self.chunked:          # only a layer of this route reads it: chunk-major plane
                     kflag |= L.TDNN_Y_CHUNKED
                     x_chunked = True
@@ -310,13 +316,13 @@ class Sequential:
                     out_lens = torch.empty_like(lens)
                 keep = nxt is not None and nxt[0] == "tdnn" and nxt[1].units > 128        # the consumer reads planes too
                 if keep:
-                    ybuf = self._ws.get(out_role, (2, B, Tout, ldy), torch.bfloat16, dev)
+                    ybuf = self._ws.get(out_role, (2, B, Tout, ldy), torch.bfloat16, dev, padded=ldy != l.units)
                     d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None, flags=kflag)
                     ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf[0], ybuf[1], out_lens)
                     planes = ybuf
                     x = ybuf[0][:, :, : l.units]                     # shape carrier only (the values live in `planes`)
                 else:
-                    ybuf = self._ws.get(out_role, (B, Tout, ldy), torch.float32, dev)
+                    ybuf = self._ws.get(out_role, (B, Tout, ldy), torch.float32, dev, padded=ldy != l.units)
                     d = l.desc(gemm, torch.bfloat16, torch.float32, act="relu" if relu else None, flags=kflag)
                     ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
                     planes = None
@@ -342,7 +348,7 @@ class Sequential:
                 B, T, _ = x.shape
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
-                ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev)
+                ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev, padded=ldy != l.units)
                 out_lens = None
                 if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
                     out_lens = torch.empty_like(lens)

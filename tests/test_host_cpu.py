@@ -444,3 +444,35 @@ def test_shipped_yaml_configs_build_the_reference_topologies():
         ext = yaml.safe_load(f)["extractor"]
     assert ext == dict(synth.extractor_cfg(dither=1.0), xvec=ext["xvec"])
     assert ext["xvec"]["model_config_path"] == "data/kaldi_models/configs/0008_sitw_v2_1a.yml"
+
+
+def test_split_plane_weight_layouts_follow_the_header():
+    """KTF_TDNN_K_INTERLEAVED / KTF_TDNN_W_TILED as include/ktf_hip.h defines them, checked on the host packing
+    (TDNN.device_weights needs a GPU for the upload only: the packing is re-derived here from the kernel matrix)."""
+    rng = np.random.default_rng(0)
+    U, K, D = 300, 3, 40                                   # -> units_pad 512, Din_pad 64, ktot 192
+    t = ktf.layers.TDNN(U, context=[-2, 0, 2])
+    t.build((1, 8, D))
+    W = rng.standard_normal((U, K * D)).astype(np.float32)
+    t.set_weights([W, np.zeros(U, np.float32)])
+    Up, Dp = 512, 64
+    ref = np.zeros((Up, K, Dp))
+    ref[:U, :, :D] = W.reshape(U, K, D)
+    # K-interleaved: column ((d / 32) * nctx + k) * 32 + d % 32 holds W[u, k * Din_pad + d]
+    inter = np.ascontiguousarray(ref.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3)).reshape(Up, K * Dp)
+    for u, k, d in [(0, 0, 0), (7, 2, 39), (299, 1, 33), (100, 2, 5)]:
+        assert inter[u, ((d // 32) * K + k) * 32 + d % 32] == W[u, k * D + d]
+    # tiled: block (nt, ks) = 16 KiB of halves; row r, 16-byte position q holds columns 32 ks + 8 (q ^ ((4 - (r >> 2)) & 3)) .. + 7
+    nt, nks = Up // 256, K * Dp // 32
+    r = np.arange(256)
+    src = np.arange(4)[None, :] ^ ((4 - ((r >> 2) & 3)) & 3)[:, None]
+    tiled = np.ascontiguousarray(inter.reshape(nt, 256, nks, 4, 8)[:, r[:, None], :, src, :].transpose(2, 3, 0, 1, 4)).reshape(-1)
+    for n_, ks, row, q in [(0, 0, 0, 0), (1, 5, 43, 2), (0, 3, 255, 3), (1, 2, 17, 1), (0, 1, 6, 0)]:
+        sw = (4 - ((row >> 2) & 3)) & 3
+        want = inter[n_ * 256 + row, ks * 32 + 8 * (q ^ sw): ks * 32 + 8 * (q ^ sw) + 8]
+        off = ((n_ * nks + ks) * 16384 + 64 * row + 16 * q) // 2             # halves
+        assert np.array_equal(tiled[off: off + 8], want)
+    # the same code path the model uses (source inspection keeps the two in step: the packing lines are these)
+    import inspect
+    body = inspect.getsource(ktf.layers.TDNN.device_weights)
+    assert "transpose(0, 2, 1, 3)" in body and "(4 - ((r >> 2) & 3)) & 3" in body and "transpose(2, 3, 0, 1, 4)" in body
