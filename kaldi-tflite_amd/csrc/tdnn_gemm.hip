@@ -33,6 +33,9 @@ extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
 #define KTF_KNOB(name, dflt) (dflt)
 #define KTF_PROBE_BUF ((long long*)nullptr)
 #endif
+#ifndef KTF_X3_WFIRST
+#define KTF_X3_WFIRST 1       // split-plane kernel: the W half of stage 0 is issued before the utterance length is loaded
+#endif
 #ifndef KTF_X3S_DEFAULT
 #define KTF_X3S_DEFAULT 2     // split-bf16 planes: 16x16x32 kernel for every layer (measured 62.3 k vs 58.6 k x-vectors/s with 1 = pooling layer only)
 #endif
@@ -2028,23 +2031,12 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int nt = slot - (slot / ntiles) * ntiles;
     if (g >= gtiles) return;
     const int b = g / mtiles, mt = g - b * mtiles;
-    const int len = p.lens ? p.lens[b] : (int)p.T;
-    int start;
-    const int out_len = tdnn_out_len(len, p, start);
-    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
-    const int t0 = mt * R_BM;
-    if (t0 >= out_len || len <= 0) return;
     const int n0 = nt * R_BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const char* xh = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;
-    const char* xl = reinterpret_cast<const char*>(p.x_lo) + ((int64_t)b * p.T * p.ldx) * 2;
     const char* wh = reinterpret_cast<const char*>(p.w);
     const char* wl = reinterpret_cast<const char*>(p.w_lo);
-    const unsigned ldxb = (unsigned)p.ldx * 2u;
-
-    int a_t[2];
     unsigned a_cb[2], w_ob[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -2052,11 +2044,39 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         const int row = q >> 2;
         const unsigned chunk = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
         a_cb[i] = chunk;
-        a_t[i] = start + (t0 + row) * p.sub;
         w_ob[i] = p.wtiled ? (unsigned)nt * (unsigned)(p.ktot / R_BK) * (unsigned)R_TILE_BYTES + (unsigned)q * 16u
                            : (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + chunk;
     }
     const unsigned w_step = p.wtiled ? (unsigned)R_TILE_BYTES : (unsigned)(R_BK * 2);      // bytes between consecutive K-steps of W
+    // The W half of stage 0 depends on the kernel arguments only: it is in flight while the utterance length (a dependent
+    // scalar load) and everything derived from it are still on their way (stamps: 1.6-2.0 us from entry to the last DMA of
+    // stage 0, then 0.9 us until it lands, on tiles whose K = 512 loop takes 21 us).
+    if (KTF_X3_WFIRST) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned char* st_ = rsm + wave * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0);
+        }
+    }
+    // (Tried on top: the A half too, clamped to the buffer instead of the utterance -- valid while ctx[0] <= 0 -- and the
+    // epilogue constants before everything: 0.7 % and 1.5 % slower.)
+    if (KTF_X3_WFIRST) asm volatile("" ::: "memory");
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * R_BM;
+    if (t0 >= out_len || len <= 0) {
+        if (KTF_X3_WFIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing lands in the LDS of a finished workgroup
+        return;
+    }
+    const char* xh = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;
+    const char* xl = reinterpret_cast<const char*>(p.x_lo) + ((int64_t)b * p.T * p.ldx) * 2;
+    const unsigned ldxb = (unsigned)p.ldx * 2u;
+    int a_t[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_t[i] = start + (t0 + ((i * 512 + tid) >> 2)) * p.sub;
 
     f32x4v acc[8][4];
 #pragma unroll
@@ -2085,6 +2105,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
             if (TERMS == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
+        if (!(KTF_X3_WFIRST && is_ks == 0))                  /* stage 0's W half went out at kernel entry */           \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             const unsigned vo_ = w_ob[i] + (unsigned)is_ks * w_step;                                                   \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);   \
