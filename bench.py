@@ -51,8 +51,8 @@ KERNELS = {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--gemm", default="f16x2", choices=["bf16", "f16", "bf16x3", "f16x2", "f32"])
@@ -131,14 +131,17 @@ def main(argv=None):
             y = parallel.gather_embeddings(y, world)
         return y
 
-    for _ in range(args.warmup):
-        step()
     # a full Python GC pass over torch's ~170k long-lived objects stalls the host for 30-40 ms (measured: it landed in
-    # one call of a side measurement and doubled its time): collect now and park the survivors in the permanent generation
+    # one call of a side measurement and doubled its time): collect now and park the survivors in the permanent generation.
+    # Before the warm-up, not after it: an idle gap in front of the timed region sends the GPU back down its clock ramp
+    # (tools/ramp_probe.py: the first five steps after idling run 11.4 / 10.4 / 10.2 / 10.1 / 10.0 ms against 9.9 sustained).
     gc.collect()
     gc.freeze()
+    ops_prof = _GemmProfiler(ops, torch)             # warm-up steps run through the same event-bracketed launches
+    for _ in range(args.warmup):
+        step()
+    ops_prof.reset()
     # ---- timed region: exactly K steps between barrier + synchronize
-    ops_prof = _GemmProfiler(ops, torch)
     parallel.barrier(world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -250,6 +253,10 @@ class _GemmProfiler:
             return r
 
         return wrapped
+
+    def reset(self):
+        """Drops the launches recorded so far (the warm-up)."""
+        self.events = []
 
     def finish(self):
         for n in self.NAMES:

@@ -321,6 +321,9 @@ def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
         (2, 7, 64, 130, [-1, 1], 2, "SAME", "sigmoid"),
         (1, 998, 512, 512, [-2, 0, 2], 1, "SAME", "relu"),  # 64x64 DMA kernel
         (1, 300, 512, 1500, [0], 1, "SAME", None),
+        (1, 998, 512, 1500, [0], 1, "SAME", "relu"),        # 64x96 DMA kernel (three blocks per wave): one round of 256 workgroups
+        (2, 998, 64, 512, [-1, 0, 1], 1, "SAME", "relu"),   # 64x64 DMA kernel
+        (3, 500, 128, 700, [0], 1, "SAME", None),           # 64x96 with a partial last column tile
         (3, 131, 40, 33, [-1, 0, 2], 3, "SAME", "sigmoid"),
         (2, 140, 96, 130, [-2, 0, 2], 1, "VALID", "tanh"),
         (1, 65, 30, 64, [-2, -1, 0, 1, 2], 1, "SAME", None),

@@ -33,4 +33,22 @@ if len(sys.argv) > 4:
             v = v[1:]
             if v and not k.startswith("void at::") and not k.startswith("__amd"):
                 f.write(f"| `{k[:90]}` | {len(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} |\n")
-    print(open(out).read()[-1500:])
+    # launches of one kernel with different grids are different populations (the 1024-utterance step, the four-utterance
+    # parity pass): the averages above mix them, this table does not -- it is the one bench.py's avg_launch_ms agrees with
+    g = collections.defaultdict(list)
+    for r in csv.DictReader(open(sys.argv[4])):
+        g[(r["Kernel_Name"], r["Grid_Size_X"])].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(out, "a") as f:
+        f.write("\n## Per (kernel, grid size) — the TDNN GEMM launches of the timed step vs the parity pass\n\n")
+        f.write("| kernel | grid (threads) | calls | average ns | min ns | max ns |\n|---|---:|---:|---:|---:|---:|\n")
+        tot_ns, tot_n = 0, 0
+        for (k, gs), v in sorted(g.items(), key=lambda kv: -sum(kv[1])):
+            if k.startswith("void tdnn_") or k.startswith("tdnn_"):
+                f.write(f"| `{k[:90]}` | {gs} | {len(v)} | {sum(v) / len(v):.0f} | {min(v)} | {max(v)} |\n")
+                if int(gs) >= (1 << 20):
+                    tot_ns += sum(v)
+                    tot_n += len(v)
+        if tot_n:
+            f.write(f"\nMean duration of the {tot_n} full-size TDNN GEMM launches (grid >= 2^20 threads): **{tot_ns / tot_n / 1e6:.3f} ms** "
+                    "(`roofline.avg_launch_ms` of the bench line is the same quantity measured with HIP events).\n")
+    print(open(out).read()[-2500:])
