@@ -150,16 +150,19 @@ __device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t
         asm volatile("" ::: "memory");           \
     } while (0)
 
-// PLAIN: fp32 input without mirror padding (the hot path keeps its scalar-register budget); !PLAIN adds int16 samples
+// KIND 1: fp32 input without mirror padding (the hot path keeps its scalar-register budget); KIND 2: the same for int16
+// PCM (what a deployment uploads: half the PCIe bytes) -- eight 16-bit loads per lane instead of eight dword loads, nothing
+// else differs, so it keeps the hot instance's registers and occupancy; KIND 0 (general) adds int16 samples behind a run-time switch
 // and KtfFrontendCfg.pad_mode.
 // MFIX: frame size known at compile time (400 = 25 ms at 16 kHz, the shipped configuration) or 0 = cfg.frame_size: with
 // a constant M the `sample index < M` predicates of the loads, DC removal and pre-emphasis fold away.
-template <bool DITHER, bool PLAIN, int MFIX>
-__global__ __launch_bounds__(F5_THREADS, (PLAIN && !DITHER) ? F5_MINWAVES : 4) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
+template <bool DITHER, int KIND, int MFIX>
+__global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 4) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                                  int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                                  int out_stage, float* __restrict__ out,
                                                                  uint64_t seed, int64_t T) {
     constexpr int NF = 512, N2 = 256, NV = 8;
+    constexpr bool PLAIN = KIND != 0;
     extern __shared__ __attribute__((aligned(16))) float lds5[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = MFIX ? MFIX : cfg.frame_size;
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(F5_THREADS, (PLAIN && !DITHER) ? F5_MINWAVES : 4) v
     // grid = (frame groups per utterance, B): no division in the frame loop, 32-bit offsets from per-utterance bases
     const int b = blockIdx.y;
     const int Ti = (int)T;
-    const int i16 = !PLAIN && in_kind == KTF_IN_WAV_I16;
+    const int i16 = (KIND == 2) || (!PLAIN && in_kind == KTF_IN_WAV_I16);
     if (in_kind == KTF_IN_WAV_I16) in_kind = KTF_IN_WAV;
     const int64_t rstride = cfg.row_stride > 0 ? (int64_t)cfg.row_stride : n;
     const float* in_b = reinterpret_cast<const float*>(in_v) + (int64_t)b * ((in_kind == KTF_IN_WAV) ? rstride : T * (int64_t)M);
@@ -280,6 +283,16 @@ __global__ __launch_bounds__(F5_THREADS, (PLAIN && !DITHER) ? F5_MINWAVES : 4) v
 #pragma unroll
                 for (int j = 0; j < NV; ++j) v[j] = (float)raw[j];
             }
+        } else if (KIND == 2 && valid) {
+            const short* src = in_b16 + g0;
+            int raw[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + KTF_WAVE * j;
+                raw[j] = (i < M) ? (int)src[i] : 0;
+            }
+#pragma unroll
+            for (int j = 0; j < NV; ++j) v[j] = (float)raw[j];
         } else if (valid) {
             const float* src = in_b + g0;
 #pragma unroll
@@ -461,13 +474,21 @@ int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind
     const dim3 grid((unsigned)gx, (unsigned)B);
     const size_t lds = sizeof(float) * (512 + (F5_MAXMEL + F5_MAXW + (F5_TW_LDS ? F5_TWREC : 0)) * KTF_WAVE + F5_WAVES * F5_WAVE_FLOATS);
     const bool dither = cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED;
-    const bool plain = in_kind != KTF_IN_WAV_I16 && !(in_kind == KTF_IN_WAV && cfg->pad_mode);
-#define F5_LAUNCH(DI, PL, MF)                                                                                          \
-    hipLaunchKernelGGL((frontend512_kernel<DI, PL, MF>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg,    \
+    const bool padded = (in_kind == KTF_IN_WAV || in_kind == KTF_IN_WAV_I16) && cfg->pad_mode;
+    const int kind = padded ? 0 : (in_kind == KTF_IN_WAV_I16 ? 2 : 1);
+#define F5_LAUNCH(DI, KI, MF)                                                                                          \
+    hipLaunchKernelGGL((frontend512_kernel<DI, KI, MF>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg,    \
                        *tab, out_stage, out, seed, T)
-    if (dither) { if (plain) F5_LAUNCH(true, true, 0); else F5_LAUNCH(true, false, 0); }
-    else if (cfg->frame_size == 400) { if (plain) F5_LAUNCH(false, true, 400); else F5_LAUNCH(false, false, 400); }
-    else { if (plain) F5_LAUNCH(false, true, 0); else F5_LAUNCH(false, false, 0); }
+#define F5_KINDS(DI, MF)                                                                                               \
+    do {                                                                                                               \
+        if (kind == 1) F5_LAUNCH(DI, 1, MF);                                                                           \
+        else if (kind == 2) F5_LAUNCH(DI, 2, MF);                                                                      \
+        else F5_LAUNCH(DI, 0, MF);                                                                                     \
+    } while (0)
+    if (dither) F5_KINDS(true, 0);
+    else if (cfg->frame_size == 400) F5_KINDS(false, 400);
+    else F5_KINDS(false, 0);
+#undef F5_KINDS
 #undef F5_LAUNCH
     KTF_CHECK_LAUNCH("ktf_frontend_f32(fast512)");
     return KTF_OK;
