@@ -33,6 +33,15 @@ extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
 #define KTF_KNOB(name, dflt) (dflt)
 #define KTF_PROBE_BUF ((long long*)nullptr)
 #endif
+#ifndef KTF_X3_A_AUX
+#define KTF_X3_A_AUX 0        // cache policy of the steady-state operand DMAs of the split-plane kernel (0 default, 2 = nt, 1 = sc0, 16 = sc1)
+#endif
+#ifndef KTF_X3_W_AUX
+#define KTF_X3_W_AUX 0
+#endif
+#ifndef KTF_X3_Y_NT
+#define KTF_X3_Y_NT 1         // 1: the 16-bit activation planes are written with non-temporal stores (0: A/B)
+#endif
 #ifndef KTF_X3_WFIRST
 #define KTF_X3_WFIRST 1       // split-plane kernel: the W half of stage 0 is issued before the utterance length is loaded
 #endif
@@ -940,6 +949,14 @@ __device__ __forceinline__ Epi16Prm epi16_load(const TdnnParams& p, int n0, int 
     return e;
 }
 
+// 16-byte store of a piece of a 16-bit activation plane. The plane (1 GB per layer at 1024 utterances) is read by the NEXT
+// launch only: written non-temporally it does not push the weights and the activation tiles two workgroups share out of the
+// XCD's L2 (+1.2 % on the whole step; non-temporal operand LOADS cost 3-6 %).
+__device__ __forceinline__ void st16(u32x4* dst, const u32x4& v) {
+    if (KTF_X3_Y_NT) __builtin_nontemporal_store(v, dst);
+    else *dst = v;
+}
+
 template <int ACT, bool STATS, bool F16 = false>
 __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats,
                                                 unsigned char* rsm, int b, int t0, int n0, int out_len, int wm, int wn,
@@ -1039,14 +1056,14 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                     pk.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
                     pk.z = (unsigned)hh[4] | ((unsigned)hh[5] << 16);
                     pk.w = (unsigned)hh[6] | ((unsigned)hh[7] << 16);
-                    *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y) + off) = pk;
+                    st16(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y) + off), pk);
                     if (p.y_lo) {
                         u32x4 pl;
                         pl.x = (unsigned)f2bf(vv[0] - bf2f(hh[0])) | ((unsigned)f2bf(vv[1] - bf2f(hh[1])) << 16);
                         pl.y = (unsigned)f2bf(vv[2] - bf2f(hh[2])) | ((unsigned)f2bf(vv[3] - bf2f(hh[3])) << 16);
                         pl.z = (unsigned)f2bf(vv[4] - bf2f(hh[4])) | ((unsigned)f2bf(vv[5] - bf2f(hh[5])) << 16);
                         pl.w = (unsigned)f2bf(vv[6] - bf2f(hh[6])) | ((unsigned)f2bf(vv[7] - bf2f(hh[7])) << 16);
-                        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y_lo) + off) = pl;
+                        st16(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y_lo) + off), pl);
                     }
                 }
             }
@@ -1072,14 +1089,14 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                         pk.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
                         pk.z = (unsigned)hh[4] | ((unsigned)hh[5] << 16);
                         pk.w = (unsigned)hh[6] | ((unsigned)hh[7] << 16);
-                        *reinterpret_cast<u32x4*>(yp) = pk;
+                        st16(reinterpret_cast<u32x4*>(yp), pk);
                         if (p.y_lo) {            // split-bf16 output: the residual plane, the next layer's lo operand
                             u32x4 pl;
                             pl.x = (unsigned)f2bf(vv[0] - bf2f(hh[0])) | ((unsigned)f2bf(vv[1] - bf2f(hh[1])) << 16);
                             pl.y = (unsigned)f2bf(vv[2] - bf2f(hh[2])) | ((unsigned)f2bf(vv[3] - bf2f(hh[3])) << 16);
                             pl.z = (unsigned)f2bf(vv[4] - bf2f(hh[4])) | ((unsigned)f2bf(vv[5] - bf2f(hh[5])) << 16);
                             pl.w = (unsigned)f2bf(vv[6] - bf2f(hh[6])) | ((unsigned)f2bf(vv[7] - bf2f(hh[7])) << 16);
-                            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y_lo) + off) = pl;
+                            st16(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y_lo) + off), pl);
                         }
                     } else {
 #pragma unroll
@@ -2170,7 +2187,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     {                                                                                                                  \
         const char* src_ = ((n) < 4) ? ((((n) & 1) ? xl : xh) + va[(n) >> 1]) : ((((n) & 1) ? wl : wh) + vw[((n) - 4) >> 1]); \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)src_,                                                             \
-            (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, 0); \
+            (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, \
+            ((n) < 4) ? KTF_X3_A_AUX : KTF_X3_W_AUX);                                                                  \
     }
             bfrag8 bh[4], bl[4], af[2][4];                      // af[set][0,1] = hi fragments of the group's two rows, [2,3] = lo
             // fragment reads in the order the MFMAs consume them (LDS returns in order: the first MFMA waits for two reads, not twelve)
