@@ -42,6 +42,22 @@ extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
 #ifndef KTF_X3_Y_NT
 #define KTF_X3_Y_NT 1         // 1: the 16-bit activation planes are written with non-temporal stores (0: A/B)
 #endif
+#ifndef KTF_X2_PIPE
+#define KTF_X2_PIPE 1         // K-loop of the two-pass half form: 1 = in-phase hand-scheduled step (default), 2 = ping-pong wave halves.
+                              // Measured equal (97.6-98.3 k vs 96.3-97.7 k x-vectors/s on one box), and the ping-pong stamps
+                              // (tools/pp_seg_probe.py, K-step 10 of tdnn2) say why: MFMA segment 1028 cycles as paced, DMA issue
+                              // 470-560, fragment reads 250-340 -- and then 920-980 cycles at the counted vmcnt wait in front of the
+                              // barrier, in BOTH groups: the operand DMAs issued one K-step (2900 cycles) earlier have not landed.
+                              // With s_sleep in place of the MFMAs (same segment length) that wait is 250-300 cycles; every tile
+                              // reading the same (L2-hot) activations changes it by 4 %. Timing-only ablations of the whole step
+                              // (tdnn2 + tdnn3, ms): all 4.98, no DMA 3.76, no fragment reads 4.56, no MFMA 2.29, MFMA alone 3.62,
+                              // DMA alone 2.29 (64 GB/s per CU). An LDS-DMA stream that runs at 64 GB/s per CU beside idle matrix
+                              // pipes delivers ~34 GB/s beside busy ones: the K-step is bound by that, not by how the waves
+                              // interleave their instructions.
+#endif
+#ifndef KTF_X3_PRIO
+#define KTF_X3_PRIO 0
+#endif
 #ifndef KTF_X3_WFIRST
 #define KTF_X3_WFIRST 1       // split-plane kernel: the W half of stage 0 is issued before the utterance length is loaded
 #endif
@@ -2025,7 +2041,7 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE, bool F16 = false, int TERMS = 3, bool PK = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
-    static_assert(TERMS == 3 || (TERMS == 2 && PIPE == 1), "the 2-pass form exists for the scheduled K-step only");
+    static_assert(TERMS == 3 || (TERMS == 2 && PIPE >= 1), "the 2-pass form exists for the scheduled K-steps only");
     static_assert(!PK || (TERMS == 2 && !STATS), "the packed epilogue writes one 16-bit plane");
 #ifdef KTF_TILE_PROBE
     long long* xprobe = p.probe ? p.probe + (int64_t)blockIdx.x * 8 : nullptr;
@@ -2037,7 +2053,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused. Its
     // 48 KiB of live data per stage would also fit THREE deep (KTF_X2_RING3: DMAs of stage k+2 issued during step k, counted
     // vmcnt at the barrier), which measured no faster.
-    constexpr int NST = (TERMS == 2 && KTF_X2_RING3 && !PK) ? 3 : 2;
+    static_assert(PIPE != 2 || (TERMS == 2 && !PK), "the ping-pong K-loop exists for the 2-pass form");
+    constexpr int NST = (TERMS == 2 && (KTF_X2_RING3 || PIPE == 2) && !PK) ? 3 : 2;
     constexpr int STG = (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;
     constexpr int WOFF = (NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
     int fill_slot = 0, cur_slot = 0;
@@ -2088,12 +2105,17 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         if (KTF_X3_WFIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing lands in the LDS of a finished workgroup
         return;
     }
-    const char* xh = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;
+    const char* xh = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;      // (re-pointed by a timing ablation)
     const char* xl = reinterpret_cast<const char*>(p.x_lo) + ((int64_t)b * p.T * p.ldx) * 2;
     const unsigned ldxb = (unsigned)p.ldx * 2u;
     int a_t[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) a_t[i] = start + (t0 + ((i * 512 + tid) >> 2)) * p.sub;
+#if defined(KTF_X3_ABL) && (KTF_X3_ABL & 16)      // timing-only ablation: every tile reads the activations of tile 0 (hot in L2)
+    xh = reinterpret_cast<const char*>(p.x);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_t[i] = start + ((i * 512 + tid) >> 2) * p.sub;
+#endif
 
     f32x4v acc[8][4];
 #pragma unroll
@@ -2149,7 +2171,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         }                                                                                                              \
     }
     XS_STAGE()
-    if (NST == 3 && nk > 1) XS_STAGE()
+    if (NST == 3 && PIPE == 1 && nk > 1) XS_STAGE()
     Epi16Prm eprm;
     if constexpr (PK) {
         if (tid < R_BN) {                                    // column constants parked behind the staging image (read in the epilogue)
@@ -2168,7 +2190,128 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int coff = (((lane >> 4) ^ fr) << 4);
     const int a_row_off = (wm * 128 + (lane & 15)) * 64 + coff;
     const int b_row_off = (wn * 64 + (lane & 15)) * 64 + coff;
-    if constexpr (PIPE == 1) {
+    if constexpr (PIPE == 2) {
+        // Ping-pong K-loop. The two waves of a SIMD (wave w and w + 4: row halves 0 and 1 of the tile) alternate roles between
+        // barriers: while one issues its 64 MFMAs of a K-step from registers, the other issues its share of the operand
+        // DMAs (three stages ahead of the reads, 48 KiB stages, three-deep ring) and reads its fragments of the next stage
+        // into the registers its own MFMAs just released. The matrix pipe of a SIMD is fully paced by one wave's MFMA stream
+        // (64 x 16 cycles); everything that stalled a wave in the in-phase loop -- DMA issue into a busy texture addresser,
+        // LDS read latency, the barrier -- now stalls the wave that is NOT feeding the pipe.
+        //   group 0 (waves 0-3), step k:  MFMA(k)               | wait, barrier k |  issue(k + 3), read(k + 1)
+        //   group 1 (waves 4-7), step k:  issue(k + 2), read(k) | wait, barrier k |  MFMA(k)
+        // Stage k + 1 is complete at barrier k (every wave waits for its own share: all but its youngest six DMAs); the slot
+        // a group refills was last read before the previous barrier (group 1) or before this one (group 0).
+        const int grp = wave >> 2;                            // wave-uniform
+        if (nk > 1) XS_STAGE()                                // stage 1 (group 0 issues its share of stage 2 in its first slot)
+        bfrag8 af[8], bh[4], bl[4];
+#if defined(KTF_X3_ABL) && (KTF_X3_ABL & 4)       // timing-only ablation: fragments are read in the first step only
+#define PP_ABL4 1
+#else
+#define PP_ABL4 0
+#endif
+#if defined(KTF_X3_ABL)
+#define PP_DMA_ON (!(KTF_X3_ABL & 2))
+#define PP_MFMA_ON (!(KTF_X3_ABL & 8))
+#define PP_SLEEP() { if (KTF_X3_ABL & 32) { _Pragma("unroll") for (int z = 0; z < 16; ++z) __builtin_amdgcn_s_sleep(1); } }   /* 32: the MFMA segment idles for about as long instead */
+#else
+#define PP_SLEEP() {}
+#define PP_DMA_ON 1
+#define PP_MFMA_ON 1
+#endif
+#define PP_VM(v_) (((v_) & 15) | (((v_) >> 4) << 14) | 0x0f70)
+        // own DMAs of stage `need_` have landed: all but the 6 (is_ks - 1 - need_) youngest are complete
+#define PP_WAIT(need_)                                                                                                 \
+    {                                                                                                                  \
+        const int n__ = is_ks - 1 - (need_);                                                                           \
+        if (n__ >= 2) __builtin_amdgcn_s_waitcnt(PP_VM(12));                                                           \
+        else if (n__ == 1) __builtin_amdgcn_s_waitcnt(PP_VM(6));                                                       \
+        else __builtin_amdgcn_s_waitcnt(PP_VM(0));                                                                     \
+    }
+        PP_WAIT(0)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        XS_PROBE(2)
+        // reads are unconditional (a clamped stage index in the last step) and each group has a straight-line loop of its own:
+        // a fragment register defined on one side of a branch only is a phi, and the compiler then keeps TWO fragment sets
+        // (read into one, copy to the other: 64 more VGPRs, spills inside the MFMA stream)
+#define PP_READ(j_)                                                                                                    \
+    {                                                                                                                  \
+        const unsigned char* sa_ = rsm + (PP_ABL4 ? 0 : ((j_) % 3) * STG);                                             \
+        const unsigned char* sw_ = sa_ + WOFF;                                                                         \
+        if (!PP_ABL4 || (j_) == 0)                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bh[j] = *reinterpret_cast<const bfrag8*>(sw_ + b_row_off + j * 16 * 64); \
+        if (!PP_ABL4 || (j_) == 0)                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const bfrag8*>(sa_ + a_row_off + i * 16 * 64); \
+        if (!PP_ABL4 || (j_) == 0)                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw_ + R_TILE_BYTES + b_row_off + j * 16 * 64); \
+        __builtin_amdgcn_s_waitcnt(0xc07f);     /* lgkmcnt(0), visible to the compiler's counter model: complete before the barrier that releases the slot's refill */ \
+    }
+#define PP_MFMA()                                                                                                      \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x32<F16>(af[i], bh[j], acc[i][j]);      \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) acc[i][j] = mfma16x16x32<F16>(af[i], bl[j], acc[i][j]);      \
+        }                                                                                                              \
+    }
+#define PP_BARRIER(k_)                                                                                                 \
+    {                                                                                                                  \
+        if ((k_) + 1 < nk) PP_WAIT((k_) + 1)                                                                           \
+        __builtin_amdgcn_s_barrier();                                                                                  \
+        asm volatile("" ::: "memory");                                                                                 \
+    }
+        const int last = nk - 1;
+#ifdef KTF_TILE_PROBE
+        long long pt[6] = {0, 0, 0, 0, 0, 0};
+#define PP_T(i_) if (ks == 10) pt[i_] = clock64();
+#else
+#define PP_T(i_)
+#endif
+        if (grp == 0) {
+            if (PP_DMA_ON && is_ks < nk) XS_STAGE()                        // own share of stage 2
+            PP_READ(0)
+            for (int ks = 0; ks < nk; ++ks) {
+                PP_T(0)
+                if (PP_MFMA_ON) PP_MFMA() else PP_SLEEP()
+                PP_T(1)
+                PP_BARRIER(ks)
+                PP_T(2)
+                if (PP_DMA_ON && is_ks < nk) XS_STAGE()                    // own share of stage ks + 3
+                PP_T(3)
+                PP_READ(ks < last ? ks + 1 : last)
+                PP_T(4)
+            }
+        } else {
+            for (int ks = 0; ks < nk; ++ks) {
+                PP_T(0)
+                if (PP_DMA_ON && is_ks < nk) XS_STAGE()                    // own share of stage ks + 2
+                PP_T(1)
+                PP_READ(ks)
+                PP_T(2)
+                PP_BARRIER(ks)
+                PP_T(3)
+                if (PP_MFMA_ON) PP_MFMA() else PP_SLEEP()
+                PP_T(4)
+            }
+        }
+#ifdef KTF_TILE_PROBE
+        if (p.probe && (tid == 0 || tid == 256) && blockIdx.x < 4096) {
+            long long* q = p.probe + (int64_t)(65536 + blockIdx.x * 2 + grp) * 8;       // behind the per-tile stamps
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = pt[i];
+        }
+#endif
+#undef PP_T
+#undef PP_READ
+#undef PP_MFMA
+#undef PP_BARRIER
+#undef PP_ABL4
+#undef PP_DMA_ON
+#undef PP_MFMA_ON
+#undef PP_SLEEP
+#undef PP_VM
+#undef PP_WAIT
+    } else if constexpr (PIPE == 1) {
+        if (KTF_X3_PRIO && wave >= 4) __builtin_amdgcn_s_setprio(1);     // static priority for the later-dispatched half (A/B)
         const int doff = (wave >= 4) ? KTF_X3_DOFF : 0;        // wave-uniform
         for (int ks = 0; ks < nk; ++ks) {
             // stage ks landed: nothing else is in flight (two stages), or only the six DMAs of stage ks+1 are (three stages)
@@ -2247,7 +2390,14 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                             if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
                             else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
                         } else {                                   // no residual plane of the activations: six DMAs
+#if defined(KTF_X3_ABL) && (KTF_X3_ABL & 64)    // 64: no steady-state DMA of the activations (what a shared A window would save, x 2/3)
+                            if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(5)
+#elif defined(KTF_X3_ABL) && (KTF_X3_ABL & 128)  // 128: no steady-state DMA of the weight residual plane
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4)
+                            else if (n == 4) XS_DMA(6)
+#else
                             if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(5)
+#endif
                             else if (n == 4) XS_DMA(6) else if (n == 5) XS_DMA(7)
                         }
                     }
@@ -2987,9 +3137,11 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn: F16X2 fuses ReLU or no activation");
 #define H2_LAUNCH(A, ST, PKD)                                                                                          \
     do {                                                                                                               \
-        constexpr int lds_ = (PKD) ? (R16_LDS_BYTES > XS_LDS_BYTES ? R16_LDS_BYTES : XS_LDS_BYTES) : X2_LDS_BYTES;      \
-        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<A, ST, 1, true, 2, PKD>);                                                   \
-        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 2, PKD>), dim3((unsigned)nblocks), dim3(512), lds_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        constexpr int pipe_ = (PKD) ? 1 : KTF_X2_PIPE;                                                                 \
+        constexpr int lds_ = (PKD) ? (R16_LDS_BYTES > XS_LDS_BYTES ? R16_LDS_BYTES : XS_LDS_BYTES)                     \
+                                   : (pipe_ == 2 ? 9 * R_TILE_BYTES : X2_LDS_BYTES);                                   \
+        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<A, ST, pipe_, true, 2, PKD>);                                               \
+        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, pipe_, true, 2, PKD>), dim3((unsigned)nblocks), dim3(512), lds_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
         const bool pk = !stats_sums && d->y_dtype == KTF_F16 && KTF_X2_PK;      // one half plane out: packed single-barrier epilogue
         if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true, false); else if (pk) H2_LAUNCH(KTF_ACT_RELU, false, true); else H2_LAUNCH(KTF_ACT_RELU, false, false); }
