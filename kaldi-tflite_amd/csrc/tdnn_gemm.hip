@@ -54,6 +54,14 @@ extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
                               // DMA alone 2.29 (64 GB/s per CU). An LDS-DMA stream that runs at 64 GB/s per CU beside idle matrix
                               // pipes delivers ~34 GB/s beside busy ones: the K-step is bound by that, not by how the waves
                               // interleave their instructions.
+                              // Followed up and not kept: (a) without the steady-state activation DMAs (timing-only) the step is
+                              // 9 % shorter, without the weight-residual DMAs 7 %; (b) a shared activation window for the
+                              // multi-context layers (ONE 272-row window per 32-feature chunk read at row offset 8 + ctx by its
+                              // contexts' K-steps: operand DMA bytes per step 48 -> 37.7 KiB, bit-identical results) gave 1.5 % on
+                              // those layers, 0.4 % on the step, the same with the window fetched one or two chunks ahead: it
+                              // removes re-reads that hit in L2, not the first touch that comes from HBM, and it is the latter's
+                              // traffic the remaining operand stream competes with; (c) non-temporal operand loads cost 3-6 %;
+                              // non-temporal STORES of the activation plane are kept (+1.2 %).
 #endif
 #ifndef KTF_X3_PRIO
 #define KTF_X3_PRIO 0
