@@ -2943,27 +2943,67 @@ __global__ __launch_bounds__(64) void tdnn_f32_rowvec_kernel(TdnnParams p) {
             is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
         }                                                                                                              \
     }
-    for (int s_ = 0; s_ < RV_NSTAGE - 1 && s_ < nk; ++s_) RV_STAGE()
+    for (int s_ = 0; s_ < RV_NSTAGE && s_ < nk; ++s_) RV_STAGE()       // all sixteen slots
     float acc = 0.0f;
     const int u = tid & 15;
     const int sw = (u >> 1) & 7;
-    for (int ks = 0; ks < nk; ++ks) {
-        const int ahead = nk - 1 - ks;                       // stages in flight beyond this one: min(ahead, 14), 3 DMAs each
-        if (ahead >= RV_NSTAGE - 2) asm volatile("s_waitcnt vmcnt(42)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned char* st = rvm + (ks & (RV_NSTAGE - 1)) * RV_STAGE_BYTES;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const fv4 wv = *reinterpret_cast<const fv4*>(st + u * 128 + ((c ^ sw) << 4));
-            const fv4 xv = *reinterpret_cast<const fv4*>(st + 2048 + c * 16);
-            acc = fmaf(xv.x, wv.x, acc);
-            acc = fmaf(xv.y, wv.y, acc);
-            acc = fmaf(xv.z, wv.z, acc);
-            acc = fmaf(xv.w, wv.w, acc);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this stage's reads are done before its slot is refilled
-        if (is_ks < nk) RV_STAGE()
+    // The chain of K dependent FMAs is the floor (its order is the batch kernels' order). The 16 fragment reads of step
+    // ks + 1 are issued BEFORE the 32 FMAs of step ks (two register sets, loop unrolled by two so that no set is copied):
+    // with read -> wait -> FMA per step a third of the step was exposed LDS latency. Waits are s_waitcnt instructions the
+    // compiler's counter model sees (behind an inline-asm wait it re-waits for the reads just issued in front of the FMAs).
+#define RV_VM(v_) (((v_) & 15) | (((v_) >> 4) << 14) | 0x0f70)
+    // stage j_ has landed: stages up to min(j_ + 14, nk - 1) have been issued, 3 DMAs each, completing in order
+#define RV_LANDED(j_)                                                                                                  \
+    {                                                                                                                  \
+        if ((j_) + RV_NSTAGE - 2 <= nk - 1) __builtin_amdgcn_s_waitcnt(RV_VM(3 * (RV_NSTAGE - 2)));                    \
+        else __builtin_amdgcn_s_waitcnt(RV_VM(0));                                                                     \
     }
+#define RV_READ(wv_, xv_, j_)                                                                                          \
+    {                                                                                                                  \
+        const unsigned char* st_ = rvm + ((j_) & (RV_NSTAGE - 1)) * RV_STAGE_BYTES;                                    \
+        _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                \
+            wv_[c] = *reinterpret_cast<const fv4*>(st_ + u * 128 + ((c ^ sw) << 4));                                   \
+            xv_[c] = *reinterpret_cast<const fv4*>(st_ + 2048 + c * 16);                                               \
+        }                                                                                                              \
+    }
+#define RV_FMA(wv_, xv_)                                                                                               \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                                                    \
+        acc = fmaf(xv_[c].x, wv_[c].x, acc);                                                                           \
+        acc = fmaf(xv_[c].y, wv_[c].y, acc);                                                                           \
+        acc = fmaf(xv_[c].z, wv_[c].z, acc);                                                                           \
+        acc = fmaf(xv_[c].w, wv_[c].w, acc);                                                                           \
+    }
+    // one step: reads of stage j_ + 1 into the OTHER set, FMAs of stage j_ from THIS set, then slot j_ (read one step ago) is refilled
+#define RV_STEP(w_, x_, wn_, xn_, j_)                                                                                  \
+    {                                                                                                                  \
+        /* unconditional (the last step re-reads its own stage): a register set defined on one side of a branch only   \
+           is a phi, and the compiler then parks a wait for the reads in front of the FMAs */                           \
+        const int jn_ = (j_) + 1 < nk ? (j_) + 1 : nk - 1;                                                             \
+        RV_LANDED(jn_)                                                                                                 \
+        RV_READ(wn_, xn_, jn_)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        RV_FMA(w_, x_)                                                                                                 \
+        asm volatile("" : "+v"(acc));           /* the chain is complete HERE: without this the compiler sinks it below   \
+                                                   the refill block, i.e. behind a wait for the reads just issued */     \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        __builtin_amdgcn_s_waitcnt(0xc07f);                                                                            \
+        if (is_ks < nk) RV_STAGE()                                                                                     \
+    }
+    fv4 w0[8], x0[8], w1[8], x1[8];
+    RV_LANDED(0)
+    RV_READ(w0, x0, 0)
+    __builtin_amdgcn_s_waitcnt(0xc07f);                      // lgkmcnt(0)
+    int ks = 0;
+    for (; ks + 1 < nk; ks += 2) {
+        RV_STEP(w0, x0, w1, x1, ks)
+        RV_STEP(w1, x1, w0, x0, ks + 1)
+    }
+    if (ks < nk) RV_FMA(w0, x0)                              // odd step count: the last stage sits in set 0
+#undef RV_VM
+#undef RV_LANDED
+#undef RV_READ
+#undef RV_FMA
+#undef RV_STEP
 #undef RV_STAGE
     const int n = n0 + tid;
     if (tid < RV_UNITS && n < p.units) {
