@@ -2049,7 +2049,7 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 template <int ACT, bool STATS, int PIPE = KTF_X3_PIPE, bool F16 = false, int TERMS = 3, bool PK = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
-    static_assert(TERMS == 3 || (TERMS == 2 && PIPE >= 1), "the 2-pass form exists for the scheduled K-steps only");
+    static_assert(TERMS == 3 || (TERMS == 2 && PIPE >= 1) || (TERMS == 1 && PIPE == 1 && !PK), "the 2-pass and 1-pass forms exist for the scheduled K-steps only");
     static_assert(!PK || (TERMS == 2 && !STATS), "the packed epilogue writes one 16-bit plane");
 #ifdef KTF_TILE_PROBE
     long long* xprobe = p.probe ? p.probe + (int64_t)blockIdx.x * 8 : nullptr;
@@ -2098,7 +2098,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         for (int i = 0; i < 2; ++i) {
             unsigned char* st_ = rsm + wave * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0);
+            if (TERMS > 1) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0);
         }
     }
     // (Tried on top: the A half too, clamped to the buffer instead of the utterance -- valid while ctx[0] <= 0 -- and the
@@ -2156,7 +2156,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             const unsigned vo_ = w_ob[i] + (unsigned)is_ks * w_step;                                                   \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);   \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+            if (TERMS > 1) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         fill_slot = (fill_slot + 1 == NST) ? 0 : fill_slot + 1;                                                        \
         ++is_ks;                                                                                                       \
@@ -2350,8 +2350,10 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
             __builtin_amdgcn_sched_barrier(0);
             if (TERMS == 3) af[0][2] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off);
+            if (TERMS > 1) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
+                for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
+            }
             af[0][1] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + 16 * 64);
             if (TERMS == 3) af[0][3] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + 16 * 64);
             unsigned va[2], vw[2];
@@ -2397,6 +2399,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                         if (TERMS == 3) {
                             if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
                             else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
+                        } else if (TERMS == 1) {                   // one pass: no residual plane at all, four DMAs
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(6)
                         } else {                                   // no residual plane of the activations: six DMAs
 #if defined(KTF_X3_ABL) && (KTF_X3_ABL & 64)    // 64: no steady-state DMA of the activations (what a shared A window would save, x 2/3)
                             if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(5)
@@ -3073,8 +3077,8 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     const bool half2 = d->gemm == KTF_GEMM_F16X2;                                    // one half plane in, hi + lo half weights
     if (split_in) KTF_REQUIRE(x_lo, "ktf_tdnn_split: null lo plane");
     if (half2) {
-        KTF_REQUIRE(d->x_dtype == KTF_F16 && d->w_dtype == KTF_F16 && w_lo && !x_lo && !y_lo,
-                    "ktf_tdnn: F16X2 takes ONE half activation plane (x_lo, y_lo NULL) and half weights as w (hi) + w_lo");
+        KTF_REQUIRE(d->x_dtype == KTF_F16 && d->w_dtype == KTF_F16 && !x_lo && !y_lo,
+                    "ktf_tdnn: F16X2 takes ONE half activation plane (x_lo, y_lo NULL) and half weights as w (hi) + w_lo (w_lo NULL: one pass)");
         KTF_REQUIRE(d->units > 128 && (stats_sums || (ldy % 8 == 0 && (d->y_dtype == KTF_F16 || d->y_dtype == KTF_F32))),
                     "ktf_tdnn: F16X2 runs on the 256x256 kernel only (units > 128, ldy %% 8 == 0, half or fp32 output)");
     }
@@ -3188,8 +3192,13 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         constexpr int pipe_ = (PKD) ? 1 : KTF_X2_PIPE;                                                                 \
         constexpr int lds_ = (PKD) ? (R16_LDS_BYTES > XS_LDS_BYTES ? R16_LDS_BYTES : XS_LDS_BYTES)                     \
                                    : (pipe_ == 2 ? 9 * R_TILE_BYTES : X2_LDS_BYTES);                                   \
-        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<A, ST, pipe_, true, 2, PKD>);                                               \
-        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, pipe_, true, 2, PKD>), dim3((unsigned)nblocks), dim3(512), lds_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        if (!w_lo && !(PKD)) {                               /* no residual plane: ONE pass */                          \
+            KTF_LDS_ONCE(X2_LDS_BYTES, tdnn_x3s_kernel<A, ST, 1, true, 1, false>);                                     \
+            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 1, false>), dim3((unsigned)nblocks), dim3(512), X2_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        } else {                                                                                                       \
+            KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<A, ST, pipe_, true, 2, PKD>);                                           \
+            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, pipe_, true, 2, PKD>), dim3((unsigned)nblocks), dim3(512), lds_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        }                                                                                                              \
     } while (0)
         const bool pk = !stats_sums && d->y_dtype == KTF_F16 && KTF_X2_PK;      // one half plane out: packed single-barrier epilogue
         if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true, false); else if (pk) H2_LAUNCH(KTF_ACT_RELU, false, true); else H2_LAUNCH(KTF_ACT_RELU, false, false); }

@@ -761,13 +761,19 @@ class TDNN(Layer):
         K, D = self.kernelWidth, self.inputDim
         return np.ascontiguousarray(self.kernel[0].reshape(K * D, self.units).T)
 
-    def device_weights(self, device, gemm, k_interleaved=False, fold=None, w_tiled=False):
+    def device_weights(self, device, gemm, k_interleaved=False, fold=None, w_tiled=False, one_pass_mean=None):
         """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for the two-part modes),
         bias. `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, split-plane
         kernel. `fold`: the BatchNorm whose affine y = s*x + h precedes this layer and is folded INTO it, so that the stored
         activations are the ReLU outputs themselves: W'[u,k,d] = W[u,k,d] * s[d], b'[u] = b[u] + sum_kd W[u,k,d] * h[d]
-        (float64 on the host; exact for replicate padding, every context row carries the same per-feature affine)."""
-        key = (str(device), gemm, bool(k_interleaved), None if fold is None else (id(fold), fold._version), bool(w_tiled))
+        (float64 on the host; exact for replicate padding, every context row carries the same per-feature affine).
+        `one_pass_mean` (F16X2 only): (D,) mean of the stored input activations -> the weights as ONE half plane (w_lo is
+        None: the kernel runs one pass): rounded to nearest, and the constant part of the rounding error,
+        sum_kd (w_half - w)[u,k,d] * mean[d], subtracted from the fp32 bias. What is left of the weight rounding is
+        zero-mean over the frames, which is why this is offered for layers whose output is pooled right away."""
+        opm = None if one_pass_mean is None else np.asarray(one_pass_mean, np.float64)
+        key = (str(device), gemm, bool(k_interleaved), None if fold is None else (id(fold), fold._version), bool(w_tiled),
+               None if opm is None else zlib.crc32(opm.tobytes()))
         if key in self._dev:
             return self._dev[key]
         K, D = self.kernelWidth, self.inputDim
@@ -781,6 +787,15 @@ class TDNN(Layer):
             extra = np.einsum("ukd,d->u", Wk, h64)
             bias64 = extra if bias64 is None else bias64 + extra
             Wk = Wk * s64[None, None, :]
+        if opm is not None:
+            if gemm != L.GEMM_F16X2:
+                raise ValueError("one_pass_mean applies to the F16X2 mode")
+            if opm.shape != (D,):
+                raise ValueError(f"one_pass_mean has shape {opm.shape}, the layer's input dim is {D}")
+            Wh = Wk.astype(np.float16).astype(np.float64)
+            corr = np.einsum("ukd,d->u", Wh - Wk, opm)
+            bias64 = -corr if bias64 is None else bias64 - corr
+            Wk = Wh
         W = np.zeros((Up, K, Dp), np.float64)
         W[: self.units, :, :D] = Wk
         if k_interleaved:
@@ -800,7 +815,8 @@ class TDNN(Layer):
             w = W.to(torch.float32)
         elif gemm == L.GEMM_F16X2:
             w = W.to(torch.float16)
-            w_lo = (W - w.to(torch.float64)).to(torch.float16)
+            if opm is None:
+                w_lo = (W - w.to(torch.float64)).to(torch.float16)
         else:
             W = W.to(torch.float32)
             w = W.to(torch.float16 if gemm == L.GEMM_F16 else torch.bfloat16)

@@ -116,6 +116,9 @@ class Sequential:
     k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
     w_tiled = True              # ... and the weights stored as the kernel's LDS stage images (contiguous 1 KiB per DMA instruction)
     chunked = True              # f16x2: the half plane between two layers of the route is stored (chunk of 32 features, row, 32)
+    one_pass_tail = 2           # f16x2: the last N frame-level layers in front of the pooling run ONE half pass (weights rounded to
+                                # nearest half, the constant part of the rounding error moved into the fp32 bias) once calibrate()
+                                # has measured the mean of their input planes; 0 = every layer two passes
     # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
     min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32}
 
@@ -135,6 +138,8 @@ class Sequential:
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"
         self._ws = _Workspace()
+        self._xbar = {}              # calibrate(): id(layer) -> (D,) float64 mean of the layer's stored input plane
+        self._calibrating = None
         self._build()
 
     def _build(self):
@@ -194,7 +199,7 @@ class Sequential:
             gemm = L.GEMM_F32
         return gemm
 
-    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0):
+    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0, one_pass_mean=None):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
         `split`: the input is a (2,B,T,ld) pair of bf16 planes or ONE (B,T,ld) half plane (F16X2) read by the split-plane
         kernel; `fold`: the preceding BatchNorm folded into this layer's weights. Returns the pooled (1, B, od) view."""
@@ -208,7 +213,7 @@ class Sequential:
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev)
         kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
         wt = bool(split and self.w_tiled)
-        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=wt)
+        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=wt, one_pass_mean=one_pass_mean)
         scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
         xdt = x_or_planes.dtype
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
@@ -235,6 +240,7 @@ class Sequential:
         # of fp32, so the GEMM K-loop carries no conversion (ktf_tdnn_split); `planes` holds them while they exist
         use_planes = gemm == L.GEMM_BF16X3 and self.split_planes
         planes = None
+        stats_at = next((i for i, q in enumerate(steps) if q[0] == "stats"), -1)      # F16X2 one-pass policy counts layers back from here
         pending_bn = None            # F16X2: the BatchNorm of the previous layer, to be folded into the next layer's weights
         x_chunked = False            # F16X2: the current activation buffer is chunk-major (KTF_TDNN_Y_CHUNKED of its producer)
         for si, st in enumerate(steps):
@@ -262,17 +268,22 @@ class Sequential:
                 B, T, _ = x.shape
                 xin = x                                  # the kernel takes the row stride from the view
                 fold, pending_bn = pending_bn, None
+                if self._calibrating is not None:        # calibrate(): mean of this layer's stored input plane over the valid frames
+                    self._calibrating[id(l)] = _plane_mean(xin, lens, l.inputDim, x_chunked)
+                left = sum(1 for q in steps[si:stats_at] if q[0] == "tdnn") if stats_at > si else 0      # 1 = the pooled layer
+                opm = self._xbar.get(id(l)) if (self.one_pass_tail and 0 < left <= self.one_pass_tail and self._calibrating is None) else None
                 kint = bool(self.k_interleaved and l.kernelWidth > 1)
                 kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if self.w_tiled else 0) | \
                         (L.TDNN_X_CHUNKED if x_chunked else 0)
                 x_chunked = False
                 if can_pool:
-                    x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold, flags=kflag & L.TDNN_X_CHUNKED)
+                    x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold, flags=kflag & L.TDNN_X_CHUNKED,
+                                             one_pass_mean=opm)
                     lens, pooled, skip = None, True, True
                     continue
                 nl = nxt[1] if nxt is not None and nxt[0] == "tdnn" else None
                 defer_bn = (bn is not None and nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm)
-                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=self.w_tiled)
+                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=self.w_tiled, one_pass_mean=opm)
                 scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
@@ -372,6 +383,24 @@ class Sequential:
             return x.reshape(x.shape[1], 1, x.shape[2])
         return x
 
+    def calibrate(self, x, lens=None):
+        """Extension (F16X2): measures, on the utterances given, the mean of the activations every frame-level layer of the
+        two-pass route reads -- for a trained model the moving mean of the preceding BatchNorm; synthetic weights carry
+        statistics that are not their own, hence the measurement. With the means known, the last `one_pass_tail` layers in
+        front of the pooling run ONE half pass with bias-corrected weights (TDNN.device_weights). x as for run_ragged."""
+        if self.gemm != "f16x2":
+            return {}
+        self._calibrating = {}
+        mt = self.min_tiles
+        self.min_tiles = {}          # a handful of utterances would otherwise be routed to the exact fp32 kernels
+        try:
+            self.run_ragged(x, lens)
+            self._xbar = {k: v.double().cpu().numpy() for k, v in self._calibrating.items()}
+        finally:
+            self._calibrating = None
+            self.min_tiles = mt
+        return self._xbar
+
     def __call__(self, inputs, training=False):
         x = inputs
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
@@ -389,6 +418,22 @@ class Sequential:
         return x
 
     call = __call__
+
+
+def _plane_mean(x, lens, D, chunked):
+    """Mean over the valid frames of a stored (B, T, ld) activation plane (row-major, or chunk-major: the same bytes as
+    (B, ld / 32, T, 32)), first D features, fp64 on the device."""
+    B, T, ld = x.shape[0], x.shape[1], x.stride(1) if not chunked else x.shape[2]
+    if chunked:
+        ld = ops.round_up(x.shape[2], 32)
+        v = torch.as_strided(x, (B, ld // 32, T, 32), (x.stride(0), T * 32, 32, 1)).permute(0, 2, 1, 3).reshape(B, T, ld)
+    else:
+        v = x
+    v = v[:, :, :D].double()
+    if lens is None:
+        return v.mean((0, 1))
+    m = (torch.arange(T, device=x.device)[None, :] < lens[:, None]).double()
+    return (v * m[:, :, None]).sum((0, 1)) / m.sum().clamp_min(1.0)
 
 
 def _padded_copy(x, dtype):
@@ -576,6 +621,13 @@ class XvectorExtractor:
         if not h2.is_contiguous():
             h2 = h2.contiguous()
         return ops.xvec_post(h2, mean, A, off, out=out)
+
+    def calibrate(self, inputs):
+        """Extension: `Sequential.calibrate` on the features of these utterances (a handful is enough: the statistic is a
+        per-feature mean over all their voiced frames). Returns the number of layers that will run one pass."""
+        _, feats, lens = self._features(inputs)
+        self.xvec.calibrate(feats, lens)
+        return min(self.xvec.one_pass_tail, len(self.xvec._xbar))
 
     def __call__(self, inputs, training=False):
         if hasattr(inputs, "shape") and len(inputs.shape) == 2 and inputs.shape[0] == 0:

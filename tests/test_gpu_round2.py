@@ -339,15 +339,66 @@ def test_f16x2_route_equals_its_fp64_emulation_and_options():
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_f16x2_tolerance_over_weight_seeds(seed):
-    # the 1e-4 bound of the two-pass half mode is a property of rounding, not of one weight draw: other seeds, other audio
+    # the 1e-4 bound of the half mode is a property of rounding, not of one weight draw: other seeds, other audio -- for the
+    # form with two passes everywhere and for the calibrated form bench.py times (one pass in the two layers before the pooling)
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=seed, narrow=False)
     wav = synth.make_wav(3, 160000, seed=100 + seed, ragged=True)
     want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
-    got = host(synth.build_extractor(ktf, cfg, w, gemm="f16x2")(dev(wav)))
-    err = np.abs(got - want).max()
-    print(f"f16x2 seed {seed}: {err:.3e}")
-    assert err <= 1e-4, err
+    for cal in (False, True):
+        m = synth.build_extractor(ktf, cfg, w, gemm="f16x2", calibrate=cal)
+        m.xvec.min_tiles = {}
+        assert len(m.xvec._xbar) == (5 if cal else 0)
+        got = host(m(dev(wav)))
+        err = np.abs(got - want).max()
+        print(f"f16x2 seed {seed} calibrated {cal}: {err:.3e}")
+        assert err <= 1e-4, (cal, err)
+
+
+def test_f16x2_one_pass_layer_and_its_bias_correction():
+    """KtfTdnnDesc gemm F16X2 with w_lo = NULL runs ONE pass. TDNN.device_weights(one_pass_mean=) rounds the (folded) weights to
+    nearest half and moves the constant part of the rounding error, (w_half - w) . mean, into the fp32 bias: the kernel then
+    computes exactly x_half . w_half + bias' (fp32 accumulation), and the error against the exact layer, averaged over the
+    frames, is what the activations' deviation from the calibration mean leaves -- far below the uncorrected one."""
+    rng = np.random.default_rng(11)
+    B, T, D, U, ctx = 3, 700, 256, 600, [-1, 0, 2]
+    x = np.abs(rng.standard_normal((B, T, D))).astype(np.float32) * rng.uniform(0.2, 3.0, D).astype(np.float32)     # ReLU-like, per-feature means
+    W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+    b = rng.standard_normal(U).astype(np.float32)
+    t = Ls.TDNN(U, context=ctx)
+    t.build(x.shape)
+    t.set_weights([W, b])
+    xh = torch.as_tensor(x, device="cuda").to(torch.float16).contiguous()
+    xq = xh.float().cpu().numpy().astype(np.float64)
+    xbar = xq.mean((0, 1))
+
+    def layer(Wm, bias):                                     # fp64: y[t] = sum_k x[clip(t + ctx_k)] . Wm[:, k] + bias
+        y = np.zeros((B, T, U))
+        for k, o in enumerate(ctx):
+            idx = np.clip(np.arange(T) + o, 0, T - 1)
+            y += xq[:, idx, :] @ Wm[:, k * D:(k + 1) * D].T
+        return y + bias
+
+    exact = layer(W.astype(np.float64), b.astype(np.float64))
+    Wh = W.astype(np.float16).astype(np.float64)
+    corr = np.einsum("ukd,d->u", (Wh - W.astype(np.float64)).reshape(U, len(ctx), D), xbar)
+    for kint, tiled in ((False, False), (True, True)):
+        w, w_lo, bias = t.device_weights("cuda", ktf._lib.GEMM_F16X2, k_interleaved=kint, w_tiled=tiled, one_pass_mean=xbar)
+        assert w_lo is None and w.dtype == torch.float16
+        assert np.allclose(bias.cpu().numpy()[:U], b - corr, rtol=0, atol=1e-6)
+        y = torch.zeros((B, T, 608), dtype=torch.float32, device="cuda")
+        d = t.desc(ktf._lib.GEMM_F16X2, torch.float16, torch.float32,
+                   flags=(ktf._lib.TDNN_K_INTERLEAVED if kint else 0) | (ktf._lib.TDNN_W_TILED if tiled else 0))
+        ktf.ops.tdnn_split(xh, None, d, w, None, bias, None, None, y, None, None)
+        got = y[:, :, :U].cpu().numpy().astype(np.float64)
+        assert np.abs(got - layer(Wh, (b - corr).astype(np.float32).astype(np.float64))).max() < 2e-5      # the kernel: one pass, fp32 accumulation
+        err_mean = np.abs((got - exact).mean((0, 1)))                                                      # per unit, averaged over the frames
+        raw_mean = np.abs((layer(Wh, b.astype(np.float64)) - exact).mean((0, 1)))
+        assert err_mean.max() < 0.05 * raw_mean.max() and err_mean.max() < 2e-6, (err_mean.max(), raw_mean.max())
+    with pytest.raises(ValueError):
+        t.device_weights("cuda", ktf._lib.GEMM_F32, one_pass_mean=xbar)
+    with pytest.raises(ValueError):
+        t.device_weights("cuda", ktf._lib.GEMM_F16X2, one_pass_mean=xbar[:-1])
 
 
 @pytest.mark.gpu
