@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--row-major-w", action="store_true", help="A/B: row-major weights instead of the LDS-image tiles")
     ap.add_argument("--row-major-x", action="store_true", help="A/B: row-major half planes between the f16x2 layers instead of chunk-major")
     ap.add_argument("--two-pass-everywhere", action="store_true", help="A/B: f16x2 without the one-pass layers in front of the pooling")
+    ap.add_argument("--full-residual", action="store_true", help="A/B: f16x2 two-pass layers keep the weight residual of every input feature")
     return ap.parse_args(argv)
 
 
@@ -119,6 +120,8 @@ def main(argv=None):
     cfg = synth.extractor_cfg(dither=0.0)
     w = synth.make_weights(seed=4321, narrow=False)
     mdl = synth.build_extractor(ktf, cfg, w, gemm=args.gemm, calibrate=not args.two_pass_everywhere)
+    if args.full_residual:
+        mdl.xvec.lo_fraction = 0.0
     mdl.xvec.deterministic = not args.atomic_pooling
     mdl.xvec.k_interleaved = not args.ctx_major_k
     mdl.xvec.w_tiled = not args.row_major_w
@@ -177,6 +180,7 @@ def main(argv=None):
                                f"(BASELINE config: 8192 utterances batch-sharded over 8 GPUs = 1024 per GPU), dither 0, all {T} frames voiced",
                    "utterances_per_gpu": B, "samples_per_utterance": N, "frames_per_utterance": T,
                    "tdnn_gemm": args.gemm, "one_pass_layers": (mdl.xvec.one_pass_tail if (args.gemm == "f16x2" and mdl.xvec._xbar) else 0),
+                   "residual_free_input_fraction_of_the_other_layers": (mdl.xvec.lo_fraction if (args.gemm == "f16x2" and mdl.xvec._xbar) else 0.0),
                    "weights": "synthetic seed 4321 (pretrained final.raw not shipped)",
                    "gather": bool(world > 1 and not args.no_gather), "ranks_seen_by_collective_backend": ranks_seen,
                    "collective_backend": backend, "fused_pooling": "atomic" if args.atomic_pooling else "reproducible"},
@@ -190,8 +194,13 @@ def main(argv=None):
     if args.gemm == "f16x2" and not args.two_pass_everywhere and mdl.xvec._xbar:
         # MAC per frame: tdnn1 76 800, tdnn2 / tdnn3 786 432 each, tdnn4 262 144, tdnn5 768 000; the last one_pass_tail of them run one pass
         mac = [76800, 786432, 786432, 262144, 768000]
-        one = sum(mac[len(mac) - mdl.xvec.one_pass_tail:]) if mdl.xvec.one_pass_tail else 0
-        passes = 2.0 - one / float(sum(mac))
+        per = [2.0] * 5
+        for i in range(5):
+            if mdl.xvec.one_pass_tail and i >= 5 - mdl.xvec.one_pass_tail:
+                per[i] = 1.0
+            elif i >= 1 and mdl.xvec.lo_fraction > 0 and mdl.xvec.k_interleaved:      # tdnn2 / tdnn3: residual for the high-variance half only
+                per[i] = 2.0 - mdl.xvec.lo_fraction
+        passes = sum(m * q for m, q in zip(mac, per)) / float(sum(mac))
     out["roofline"] = {
         "bound": "mfma", "kernel": KERNELS[args.gemm],
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,

@@ -239,6 +239,11 @@ typedef struct KtfTdnnDesc {
                                    * the next K-steps (KTF_TDNN_K_INTERLEAVED) touch the same cache lines */
 #define KTF_TDNN_Y_CHUNKED 32     /* ... and the 16-bit output plane(s) are written in that layout (ldy a multiple of 32; pad columns
                                    * of the last chunk are written as zeros): what the next layer reads with KTF_TDNN_X_CHUNKED */
+#define KTF_TDNN_LO_PREFIX(chunks) (((chunks) + 1) << 8)   /* KTF_GEMM_F16X2 with KTF_TDNN_K_INTERLEAVED: only the first `chunks`
+                                   * 32-feature chunks of the input have a weight residual -- their K-steps run two passes,
+                                   * the rest one (the blocks of w_lo behind them are not read). The host orders the input
+                                   * features by decreasing activation variance and folds the constant part of the dropped
+                                   * residual into the bias (TDNN.device_weights). Bits 8..23; 0 = every chunk two passes */
 
 /* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
 int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);

@@ -100,6 +100,7 @@ struct TdnnParams {
     long long* probe;       // per-tile s_memrealtime stamps (probe builds)
 #endif
     int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
+    int32_t lo_steps;       // F16X2: K-steps [0, lo_steps) run two passes, the rest one (KTF_TDNN_LO_PREFIX); >= ktot / 32: all of them
 };
 
 // Adds (slots == 0) or stores (slots > 0: block `slot` of utterance b is written by exactly one wave) a column's partial sums.
@@ -2341,6 +2342,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, \
             ((n) < 4) ? KTF_X3_A_AUX : KTF_X3_W_AUX);                                                                  \
     }
+            const bool two = TERMS != 2 || ks < p.lo_steps;              // this step has a weight residual (always, outside the 2-pass form)
+            const bool two_next = TERMS != 2 || is_ks < p.lo_steps;     // ... and so has the stage being fetched
             bfrag8 bh[4], bl[4], af[2][4];                      // af[set][0,1] = hi fragments of the group's two rows, [2,3] = lo
             // fragment reads in the order the MFMAs consume them (LDS returns in order: the first MFMA waits for two reads, not twelve)
             af[0][0] = *reinterpret_cast<const bfrag8*>(sa + a_row_off);
@@ -2350,7 +2353,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
             __builtin_amdgcn_sched_barrier(0);
             if (TERMS == 3) af[0][2] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off);
-            if (TERMS > 1) {
+            if (TERMS > 1 && two) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
             }
@@ -2371,6 +2374,9 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                 const int cur = g & 1;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24 (4c .. 4c+3 of 16)
+                    // 2-pass form: the odd chunks are the residual passes of the group's two rows; a step behind the residual
+                    // prefix skips them (wave-uniform)
+                    if (TERMS != 2 || !(c & 1) || two)
 #pragma unroll
                     for (int m = PER_CHUNK * c; m < PER_CHUNK * c + PER_CHUNK; ++m) {
                         const int r = m / PER_ROW, j = m & 3;                  // row, column block
@@ -2408,9 +2414,9 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                             if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4)
                             else if (n == 4) XS_DMA(6)
 #else
-                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(5)
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) { if (two_next) XS_DMA(5) }
 #endif
-                            else if (n == 4) XS_DMA(6) else if (n == 5) XS_DMA(7)
+                            else if (n == 4) XS_DMA(6) else if (n == 5) { if (two_next) XS_DMA(7) }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -3117,6 +3123,12 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
     p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
+    {
+        const int pre = (d->flags >> 8) & 0xffff;             // KTF_TDNN_LO_PREFIX(chunks) = (chunks + 1) << 8
+        p.lo_steps = pre ? (pre - 1) * d->nctx : INT32_MAX;
+        if (pre) KTF_REQUIRE(d->gemm == KTF_GEMM_F16X2 && (d->flags & KTF_TDNN_K_INTERLEAVED) && w_lo,
+                             "ktf_tdnn: KTF_TDNN_LO_PREFIX needs KTF_GEMM_F16X2 with K-interleaved weights and a residual plane");
+    }
     p.kinter = (d->flags & KTF_TDNN_K_INTERLEAVED) ? 1 : 0;
     p.wtiled = (d->flags & KTF_TDNN_W_TILED) ? 1 : 0;
     p.xchunk = (d->flags & KTF_TDNN_X_CHUNKED) ? 1 : 0;

@@ -17,6 +17,11 @@ KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
 GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2 = 0, 1, 2, 3, 4
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED, TDNN_X_CHUNKED, TDNN_Y_CHUNKED = 1, 2, 4, 8, 16, 32   # KtfTdnnDesc.flags
+
+
+def TDNN_LO_PREFIX(chunks):
+    """KtfTdnnDesc.flags bits 8..23: only the first `chunks` 32-feature chunks have a weight residual (include/ktf_hip.h)."""
+    return (int(chunks) + 1) << 8
 IN_WAV, IN_FRAMES, IN_WINDOWED, IN_WAV_I16 = 0, 1, 2, 3
 OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
 

@@ -761,7 +761,8 @@ class TDNN(Layer):
         K, D = self.kernelWidth, self.inputDim
         return np.ascontiguousarray(self.kernel[0].reshape(K * D, self.units).T)
 
-    def device_weights(self, device, gemm, k_interleaved=False, fold=None, w_tiled=False, one_pass_mean=None):
+    def device_weights(self, device, gemm, k_interleaved=False, fold=None, w_tiled=False, one_pass_mean=None,
+                       in_perm=None, out_perm=None, lo_keep=None):
         """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for the two-part modes),
         bias. `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, split-plane
         kernel. `fold`: the BatchNorm whose affine y = s*x + h precedes this layer and is folded INTO it, so that the stored
@@ -770,10 +771,18 @@ class TDNN(Layer):
         `one_pass_mean` (F16X2 only): (D,) mean of the stored input activations -> the weights as ONE half plane (w_lo is
         None: the kernel runs one pass): rounded to nearest, and the constant part of the rounding error,
         sum_kd (w_half - w)[u,k,d] * mean[d], subtracted from the fp32 bias. What is left of the weight rounding is
-        zero-mean over the frames, which is why this is offered for layers whose output is pooled right away."""
+        zero-mean over the frames, which is why this is offered for layers whose output is pooled right away.
+        `in_perm` / `out_perm`: the stored input plane holds feature in_perm[j] at position j / this layer writes unit
+        out_perm[j] at position j (the model orders a plane by decreasing activation variance). `lo_keep` (F16X2, with
+        one_pass_mean): only the first lo_keep positions of the (permuted) input keep their weight residual
+        (KTF_TDNN_LO_PREFIX); the columns behind them are rounded to nearest half and bias-corrected like a one-pass layer.
+        Means and the folded BatchNorm are given in the ORIGINAL feature order."""
         opm = None if one_pass_mean is None else np.asarray(one_pass_mean, np.float64)
+        ip = None if in_perm is None else np.asarray(in_perm, np.int64)
+        op = None if out_perm is None else np.asarray(out_perm, np.int64)
         key = (str(device), gemm, bool(k_interleaved), None if fold is None else (id(fold), fold._version), bool(w_tiled),
-               None if opm is None else zlib.crc32(opm.tobytes()))
+               None if opm is None else zlib.crc32(opm.tobytes()), None if ip is None else zlib.crc32(ip.tobytes()),
+               None if op is None else zlib.crc32(op.tobytes()), lo_keep)
         if key in self._dev:
             return self._dev[key]
         K, D = self.kernelWidth, self.inputDim
@@ -793,9 +802,25 @@ class TDNN(Layer):
             if opm.shape != (D,):
                 raise ValueError(f"one_pass_mean has shape {opm.shape}, the layer's input dim is {D}")
             Wh = Wk.astype(np.float16).astype(np.float64)
+            if lo_keep is not None:                      # only the features stored behind position lo_keep lose their residual
+                order = np.arange(D) if ip is None else ip
+                keep = np.zeros(D, bool)
+                keep[order[:lo_keep]] = True
+                Wh[:, :, keep] = Wk[:, :, keep]
             corr = np.einsum("ukd,d->u", Wh - Wk, opm)
             bias64 = -corr if bias64 is None else bias64 - corr
             Wk = Wh
+        elif lo_keep is not None:
+            raise ValueError("lo_keep needs one_pass_mean (the bias correction of the dropped residual columns)")
+        if ip is not None:
+            if sorted(ip.tolist()) != list(range(D)):
+                raise ValueError("in_perm is not a permutation of the input features")
+            Wk = Wk[:, :, ip]
+        if op is not None:
+            if sorted(op.tolist()) != list(range(self.units)):
+                raise ValueError("out_perm is not a permutation of the units")
+            Wk = Wk[op]
+            bias64 = None if bias64 is None else bias64[op]
         W = np.zeros((Up, K, Dp), np.float64)
         W[: self.units, :, :D] = Wk
         if k_interleaved:
@@ -815,7 +840,7 @@ class TDNN(Layer):
             w = W.to(torch.float32)
         elif gemm == L.GEMM_F16X2:
             w = W.to(torch.float16)
-            if opm is None:
+            if opm is None or lo_keep is not None:       # (one pass: no residual plane at all)
                 w_lo = (W - w.to(torch.float64)).to(torch.float16)
         else:
             W = W.to(torch.float32)

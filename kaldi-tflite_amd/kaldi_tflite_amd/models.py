@@ -116,6 +116,9 @@ class Sequential:
     k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
     w_tiled = True              # ... and the weights stored as the kernel's LDS stage images (contiguous 1 KiB per DMA instruction)
     chunked = True              # f16x2: the half plane between two layers of the route is stored (chunk of 32 features, row, 32)
+    lo_fraction = 0.5           # f16x2, calibrated: in the two-pass layers in front of the one-pass tail, this fraction of the input
+                                # features -- the ones with the lowest activation variance; the producing layer writes its plane
+                                # in that order -- carries no weight residual (KTF_TDNN_LO_PREFIX); 0 = every feature keeps it
     one_pass_tail = 2           # f16x2: the last N frame-level layers in front of the pooling run ONE half pass (weights rounded to
                                 # nearest half, the constant part of the rounding error moved into the fp32 bias) once calibrate()
                                 # has measured the mean of their input planes; 0 = every layer two passes
@@ -139,6 +142,7 @@ class Sequential:
         self.dtype = "float32"
         self._ws = _Workspace()
         self._xbar = {}              # calibrate(): id(layer) -> (D,) float64 mean of the layer's stored input plane
+        self._xvar = {}              # ... and its variance
         self._calibrating = None
         self._build()
 
@@ -199,7 +203,8 @@ class Sequential:
             gemm = L.GEMM_F32
         return gemm
 
-    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0, one_pass_mean=None):
+    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0, one_pass_mean=None,
+                        in_perm=None):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
         `split`: the input is a (2,B,T,ld) pair of bf16 planes or ONE (B,T,ld) half plane (F16X2) read by the split-plane
         kernel; `fold`: the preceding BatchNorm folded into this layer's weights. Returns the pooled (1, B, od) view."""
@@ -213,7 +218,8 @@ class Sequential:
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev)
         kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
         wt = bool(split and self.w_tiled)
-        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=wt, one_pass_mean=one_pass_mean)
+        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=wt, one_pass_mean=one_pass_mean,
+                                         in_perm=in_perm)
         scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
         xdt = x_or_planes.dtype
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
@@ -221,6 +227,12 @@ class Sequential:
         (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
         ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf, slots=slots)
         return sbuf[:, :od].unsqueeze(0)
+
+    def _partial_ok(self, l, left):
+        """May layer `l` (with `left` frame-level layers up to and including the pooled one) drop the weight residual of its
+        low-variance input features? Calibrated, K-interleaved, at least two 32-feature chunks, not in the one-pass tail."""
+        return bool(self.lo_fraction > 0 and self._calibrating is None and id(l) in self._xvar and self.k_interleaved and
+                    l.kernelWidth > 1 and l.inputDim >= 64 and left > self.one_pass_tail)
 
     def run_ragged(self, x, lens=None):
         """x: (B, T, D) view of an utterance-strided buffer whose row stride is a multiple of 8 and >= round_up(D, 32)
@@ -242,6 +254,7 @@ class Sequential:
         planes = None
         stats_at = next((i for i, q in enumerate(steps) if q[0] == "stats"), -1)      # F16X2 one-pass policy counts layers back from here
         pending_bn = None            # F16X2: the BatchNorm of the previous layer, to be folded into the next layer's weights
+        cur_perm = None              # F16X2: feature order of the current activation plane (None = natural)
         x_chunked = False            # F16X2: the current activation buffer is chunk-major (KTF_TDNN_Y_CHUNKED of its producer)
         for si, st in enumerate(steps):
             if skip:
@@ -276,14 +289,28 @@ class Sequential:
                 kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if self.w_tiled else 0) | \
                         (L.TDNN_X_CHUNKED if x_chunked else 0)
                 x_chunked = False
+                in_perm, cur_perm = cur_perm, None
                 if can_pool:
                     x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold, flags=kflag & L.TDNN_X_CHUNKED,
-                                             one_pass_mean=opm)
+                                             one_pass_mean=opm, in_perm=in_perm)
                     lens, pooled, skip = None, True, True
                     continue
                 nl = nxt[1] if nxt is not None and nxt[0] == "tdnn" else None
                 defer_bn = (bn is not None and nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm)
-                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=self.w_tiled, one_pass_mean=opm)
+                # residual prefix: this layer's input plane was written in order of decreasing variance by its producer
+                lo_keep = None
+                if in_perm is not None and opm is None and self._partial_ok(l, left):
+                    keep = ops.round_up(int(math.ceil((1.0 - self.lo_fraction) * l.inputDim)), 32)
+                    if 32 <= keep < l.inputDim:
+                        lo_keep, opm = keep, self._xbar[id(l)]
+                        kflag |= L.TDNN_LO_PREFIX(keep // 32)
+                # ... and this layer orders ITS plane for a consumer that will do the same
+                out_perm = None
+                if defer_bn and nl is not None and self.chunked and self._partial_ok(nl, left - 1) and nl.inputDim == l.units:
+                    out_perm = np.argsort(-self._xvar[id(nl)], kind="stable")
+                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=self.w_tiled, one_pass_mean=opm,
+                                                 in_perm=in_perm, out_perm=out_perm, lo_keep=lo_keep)
+                cur_perm = out_perm
                 scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)
@@ -394,8 +421,10 @@ class Sequential:
         mt = self.min_tiles
         self.min_tiles = {}          # a handful of utterances would otherwise be routed to the exact fp32 kernels
         try:
+            self._xbar, self._xvar = {}, {}        # (no one-pass layer, no permuted plane while measuring)
             self.run_ragged(x, lens)
-            self._xbar = {k: v.double().cpu().numpy() for k, v in self._calibrating.items()}
+            self._xbar = {k: v[0].cpu().numpy() for k, v in self._calibrating.items()}
+            self._xvar = {k: v[1].cpu().numpy() for k, v in self._calibrating.items()}
         finally:
             self._calibrating = None
             self.min_tiles = mt
@@ -421,7 +450,7 @@ class Sequential:
 
 
 def _plane_mean(x, lens, D, chunked):
-    """Mean over the valid frames of a stored (B, T, ld) activation plane (row-major, or chunk-major: the same bytes as
+    """(mean, variance) over the valid frames of a stored (B, T, ld) activation plane (row-major, or chunk-major: the same bytes as
     (B, ld / 32, T, 32)), first D features, fp64 on the device."""
     B, T, ld = x.shape[0], x.shape[1], x.stride(1) if not chunked else x.shape[2]
     if chunked:
@@ -431,9 +460,12 @@ def _plane_mean(x, lens, D, chunked):
         v = x
     v = v[:, :, :D].double()
     if lens is None:
-        return v.mean((0, 1))
+        mean = v.mean((0, 1))
+        return mean, (v * v).mean((0, 1)) - mean * mean
     m = (torch.arange(T, device=x.device)[None, :] < lens[:, None]).double()
-    return (v * m[:, :, None]).sum((0, 1)) / m.sum().clamp_min(1.0)
+    n = m.sum().clamp_min(1.0)
+    mean = (v * m[:, :, None]).sum((0, 1)) / n
+    return mean, (v * v * m[:, :, None]).sum((0, 1)) / n - mean * mean
 
 
 def _padded_copy(x, dtype):

@@ -401,6 +401,60 @@ def test_f16x2_one_pass_layer_and_its_bias_correction():
         t.device_weights("cuda", ktf._lib.GEMM_F16X2, one_pass_mean=xbar[:-1])
 
 
+def test_f16x2_permuted_planes_and_residual_prefix():
+    """TDNN.device_weights(in_perm=, out_perm=): a layer reading a plane stored in another feature order and writing its own
+    units in another order computes the same numbers (up to the fp32 summation order along K). lo_keep = n with the
+    KTF_TDNN_LO_PREFIX flag: the K-steps of the first n / 32 chunks run two passes, the rest one pass on nearest-rounded,
+    bias-corrected columns -- checked against fp64 with exactly those weights."""
+    rng = np.random.default_rng(12)
+    B, T, D, U, ctx = 2, 600, 128, 300, [-2, 0, 2]
+    x = np.abs(rng.standard_normal((B, T, D))).astype(np.float32) * rng.uniform(0.1, 2.0, D).astype(np.float32)
+    W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+    b = rng.standard_normal(U).astype(np.float32)
+    t = Ls.TDNN(U, context=ctx)
+    t.build(x.shape)
+    t.set_weights([W, b])
+    ip, op = rng.permutation(D), rng.permutation(U)
+    xh = torch.as_tensor(x, device="cuda").to(torch.float16).contiguous()
+    xq = xh.float().cpu().numpy().astype(np.float64)
+    xbar = xq.mean((0, 1))
+
+    def layer(Wm, bias):
+        y = np.zeros((B, T, U))
+        for k, o in enumerate(ctx):
+            idx = np.clip(np.arange(T) + o, 0, T - 1)
+            y += xq[:, idx, :] @ Wm[:, k * D:(k + 1) * D].T
+        return y + bias
+
+    def run(xin, flags, **kw):
+        w, w_lo, bias = t.device_weights("cuda", ktf._lib.GEMM_F16X2, k_interleaved=True, w_tiled=True, **kw)
+        y = torch.zeros((B, T, 320), dtype=torch.float32, device="cuda")
+        d = t.desc(ktf._lib.GEMM_F16X2, torch.float16, torch.float32, flags=ktf._lib.TDNN_K_INTERLEAVED | ktf._lib.TDNN_W_TILED | flags)
+        ktf.ops.tdnn_split(xin, None, d, w, w_lo, bias, None, None, y, None, None)
+        return y[:, :, :U].cpu().numpy().astype(np.float64), bias.cpu().numpy()[:U]
+
+    nat, _ = run(xh, 0)
+    assert np.abs(nat - layer(W.astype(np.float64), b.astype(np.float64))).max() < 2e-5
+    xp = xh[:, :, torch.as_tensor(ip, device="cuda")].contiguous()
+    per, _ = run(xp, 0, in_perm=ip, out_perm=op)
+    assert np.abs(per - nat[:, :, op]).max() < 2e-5
+    # residual only for the first 64 stored features (two chunks of four)
+    keep = 64
+    got, bias = run(xp, ktf._lib.TDNN_LO_PREFIX(keep // 32), in_perm=ip, out_perm=op, lo_keep=keep, one_pass_mean=xbar)
+    Wd = W.astype(np.float64).reshape(U, len(ctx), D).copy()
+    dropped = ip[keep:]
+    Wd[:, :, dropped] = Wd[:, :, dropped].astype(np.float16).astype(np.float64)
+    corr = np.einsum("ukd,d->u", Wd - W.astype(np.float64).reshape(U, len(ctx), D), xbar)
+    assert np.allclose(bias, (b - corr)[op], rtol=0, atol=1e-6)
+    want = layer(Wd.reshape(U, -1), (b - corr).astype(np.float32).astype(np.float64))[:, :, op]
+    assert np.abs(got - want).max() < 2e-5
+    assert np.abs(got - nat[:, :, op]).max() > 1e-6          # (it IS a different computation)
+    with pytest.raises(ValueError):
+        t.device_weights("cuda", ktf._lib.GEMM_F16X2, lo_keep=64)
+    with pytest.raises(ValueError):
+        t.device_weights("cuda", ktf._lib.GEMM_F16X2, in_perm=np.zeros(D, np.int64))
+
+
 @pytest.mark.gpu
 def test_workspace_refills_only_views_with_pad_columns():
     """A role whose shape changes is re-zeroed only when the new view has pad columns nobody writes; in steady state the
