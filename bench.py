@@ -7,12 +7,14 @@ tdnn6 -> LDA/length-norm) over one batch of synthetic 10 s / 16 kHz utterances t
 Workload (config.workload): the BASELINE "8 192 utterances over 8 GPUs" configuration = 1 024 utterances per GPU
 (weak scaling: per-GPU batch fixed), 0008_sitw_v2_1a topology with seeded random weights, dither 0.
 
-The timed arithmetic (`dtype`) defaults to "f16x2": half-precision MFMA passes with fp32 accumulation — two per product in
-tdnn1-3 (weights exact as hi + lo halves), ONE in the two layers in front of the pooling (weights rounded to nearest half,
-the constant part of the rounding error moved into the fp32 bias using input means measured by XvectorExtractor.calibrate on
-four utterances that are neither timed nor checked; `--two-pass-everywhere` is the A/B) — activations stored as one half
-plane of ReLU outputs with the BatchNorm folded into the next layer: the fastest form that meets north_star's <= 1e-4
-max-abs deviation (the line carries the measured deviation of the timed model at the full 10 s size and `tolerance_ok`). `--gemm bf16x3` (split-bf16, 4e-6) and `--gemm f32` (exact) are the tighter modes;
+The timed arithmetic (`dtype`) defaults to "f16x2": half-precision MFMA passes with fp32 accumulation — two per product
+where the weight residual matters (tdnn1; the high-variance half of tdnn2's / tdnn3's input features), ONE elsewhere (their
+other half; the two layers in front of the pooling: weights rounded to nearest half, the constant part of the rounding error
+moved into the fp32 bias) — activations stored as one half plane of ReLU outputs, in order of decreasing variance, with the
+BatchNorm folded into the next layer. The input means / variances this needs are measured by XvectorExtractor.calibrate on
+four utterances that are neither timed nor checked (`--full-residual`, `--two-pass-everywhere` are the A/Bs). The fastest
+form that meets north_star's <= 1e-4 max-abs deviation (the line carries the measured deviation of the timed model at the full
+10 s size and `tolerance_ok`). `--gemm bf16x3` (split-bf16, 4e-6) and `--gemm f32` (exact) are the tighter modes;
 one-pass bf16 / f16 are side legs outside the tolerance.
 
     python bench.py                      # 1 GPU
@@ -46,8 +48,8 @@ MFMA_PASSES = {"bf16": 1, "f16": 1, "bf16x3": 3, "f16x2": 2, "f32": 1}          
 TOLERANCE = 1e-4                             # north_star: max-abs x-vector deviation vs the fp32 reference path
 KERNELS = {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=768 layers)",
            "bf16x3": "tdnn_x3r_kernel<.., SPLIT> (tdnn2-4) + tdnn_x3s_kernel (tdnn5 + pooling) + tdnn_x3r_kernel (tdnn1)",
-           "f16x2": "tdnn_x3s_kernel<.., F16, TERMS = 2> (tdnn1-3) and <.., TERMS = 1> (tdnn4, tdnn5 with fused pooling; two passes "
-                    "there too with --two-pass-everywhere)",
+           "f16x2": "tdnn_x3s_kernel<.., F16, TERMS = 2> (tdnn1-3; tdnn2 / tdnn3 with a residual prefix of half their K-steps) and "
+                    "<.., TERMS = 1> (tdnn4, tdnn5 with fused pooling); --full-residual / --two-pass-everywhere are the A/Bs",
            "f32": "tdnn_f32t_kernel", "f16": "tdnn_bf16r16_kernel<.., F16> + tdnn_bf16h_kernel<.., F16>"}
 
 
