@@ -430,6 +430,22 @@ class Sequential:
             self.min_tiles = mt
         return self._xbar
 
+    def calibrate_from_batchnorm(self):
+        """Extension (F16X2): the statistics calibrate() measures, taken from the model instead -- the plane a frame-level
+        layer reads holds the ReLU outputs the preceding BatchNorm was trained on, so its moving mean / variance ARE the
+        plane's mean / variance for a trained model (Kaldi's <StatsMean> / <StatsVar>). Not for synthetic weights, whose
+        BatchNorm statistics are not their own. Layers without a BatchNorm in front (the first one) stay uncalibrated."""
+        self._xbar, self._xvar = {}, {}
+        if self.gemm != "f16x2":
+            return {}
+        steps = self._plan() or []
+        for prev, cur in zip(steps, steps[1:]):
+            if prev[0] == "tdnn" and cur[0] == "tdnn" and prev[3] is not None and (prev[2] or prev[1].activation == "relu"):
+                bn = prev[3]
+                self._xbar[id(cur[1])] = np.asarray(bn.moving_mean, np.float64).copy()
+                self._xvar[id(cur[1])] = np.asarray(bn.moving_variance, np.float64).copy()
+        return self._xbar
+
     def __call__(self, inputs, training=False):
         x = inputs
         if not (isinstance(x, torch.Tensor) and x.is_cuda):

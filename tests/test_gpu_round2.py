@@ -173,11 +173,11 @@ def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
 
 
 # ----------------------------------------------------------------------------- hipGraph product path
-@pytest.mark.parametrize("gemm,B", [("f32", 1), ("bf16x3", 16), ("f16x2", 16)])
-def test_compiled_extractor_replays_bitwise(gemm, B):
+@pytest.mark.parametrize("gemm,B,cal", [("f32", 1, False), ("bf16x3", 16, False), ("f16x2", 16, False), ("f16x2", 16, True)])
+def test_compiled_extractor_replays_bitwise(gemm, B, cal):
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
-    mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm, calibrate=cal)     # cal: one-pass tail + residual prefix + permuted planes
     x0 = dev(synth.make_wav(B, 160000, seed=3, ragged=True))
     run = mdl.compile(x0)
     for seed in (3, 4, 5):

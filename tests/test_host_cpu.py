@@ -476,3 +476,20 @@ def test_split_plane_weight_layouts_follow_the_header():
     import inspect
     body = inspect.getsource(ktf.layers.TDNN.device_weights)
     assert "transpose(0, 2, 1, 3)" in body and "(4 - ((r >> 2) & 3)) & 3" in body and "transpose(2, 3, 0, 1, 4)" in body
+
+
+def test_calibrate_from_batchnorm_maps_each_layer_to_the_statistics_in_front_of_it():
+    """Sequential.calibrate_from_batchnorm (host only): the input plane of frame-level layer i + 1 is what the BatchNorm after
+    layer i was trained on, so that BatchNorm's moving mean / variance are handed to layer i + 1; the first layer (features
+    in, no BatchNorm in front) gets none, and nothing happens outside the f16x2 mode."""
+    import synth
+    w = synth.make_weights(seed=7, narrow=True)
+    m = synth.build_sequential(ktf, w, "f16x2")
+    got = m.calibrate_from_batchnorm()
+    steps = [q for q in m._plan() if q[0] == "tdnn"]
+    frame_level = steps[:5]
+    assert id(frame_level[0][1]) not in got
+    for prev, cur in zip(frame_level, frame_level[1:]):
+        assert np.array_equal(m._xbar[id(cur[1])], prev[3].moving_mean.astype(np.float64))
+        assert np.array_equal(m._xvar[id(cur[1])], prev[3].moving_variance.astype(np.float64))
+    assert synth.build_sequential(ktf, w, "bf16x3").calibrate_from_batchnorm() == {}
