@@ -109,8 +109,9 @@ class Sequential:
     """Keras-Sequential stand-in: `.layers`, `.name`, `mdl(x, training=False)`, `get_layer`, `summary`.
     `gemm` selects the TDNN arithmetic of the fused runner: "f32" (exact fp32 MFMA, default = the reference's
     precision), "bf16x3" (split-bf16, fp32-grade), "f16x2" (two half-precision passes: exact weights, half activations with
-    BatchNorm folded forward — inside the 1e-4 x-vector tolerance at two thirds of the split-bf16 matrix work), "bf16" or
-    "f16" (one pass, outside that tolerance)."""
+    BatchNorm folded forward — inside the 1e-4 x-vector tolerance at two thirds of the split-bf16 matrix work; after
+    calibrate() / calibrate_from_batchnorm() the weight residual, i.e. the second pass, is kept only where it matters:
+    `one_pass_tail`, `lo_fraction`), "bf16" or "f16" (one pass, outside that tolerance)."""
 
     split_planes = True         # bf16x3: hi/lo bf16 activation planes between the wide layers (no in-loop conversion)
     k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
@@ -273,16 +274,18 @@ class Sequential:
                 can_pool = (self.fuse_stats and not pooled and nxt is not None and nxt[0] == "stats" and
                             nxt[1].inputPeriod == 1 and l.units > 128 and l.padding == "SAME" and l.subsamplingFactor == 1)
             if (gemm == L.GEMM_F16X2 and st[0] == "tdnn" and not pooled and l.effective_gemm(gemm, relu) == gemm):
-                # two half passes: activations travel as ONE half plane holding the ReLU outputs; this layer's BatchNorm is
-                # not applied in its epilogue but folded into the weights of the next layer when that one runs here too
+                # half passes (two per product; one where calibrate() lets the weight residual go: the layers in front of the
+                # pooling, the low-variance input features of the others): activations travel as ONE half plane holding the
+                # ReLU outputs; this layer's BatchNorm is not applied in its epilogue but folded into the weights of the next
+                # layer when that one runs here too
                 if x.dtype != torch.float16 or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32) \
                         or x.stride(0) != x.shape[1] * x.stride(1):
                     x = _padded_copy(x, torch.float16)
                 B, T, _ = x.shape
                 xin = x                                  # the kernel takes the row stride from the view
                 fold, pending_bn = pending_bn, None
-                if self._calibrating is not None:        # calibrate(): mean of this layer's stored input plane over the valid frames
-                    self._calibrating[id(l)] = _plane_mean(xin, lens, l.inputDim, x_chunked)
+                if self._calibrating is not None:        # calibrate(): mean / variance of this layer's stored input plane over the valid frames
+                    self._calibrating[id(l)] = _plane_stats(xin, lens, l.inputDim, x_chunked)
                 left = sum(1 for q in steps[si:stats_at] if q[0] == "tdnn") if stats_at > si else 0      # 1 = the pooled layer
                 opm = self._xbar.get(id(l)) if (self.one_pass_tail and 0 < left <= self.one_pass_tail and self._calibrating is None) else None
                 kint = bool(self.k_interleaved and l.kernelWidth > 1)
@@ -465,7 +468,7 @@ class Sequential:
     call = __call__
 
 
-def _plane_mean(x, lens, D, chunked):
+def _plane_stats(x, lens, D, chunked):
     """(mean, variance) over the valid frames of a stored (B, T, ld) activation plane (row-major, or chunk-major: the same bytes as
     (B, ld / 32, T, 32)), first D features, fp64 on the device."""
     B, T, ld = x.shape[0], x.shape[1], x.stride(1) if not chunked else x.shape[2]
