@@ -42,9 +42,10 @@ extern "C" void ktf_probe_set_buffer(void* p) { g_probe_buf = (long long*)p; }
 #ifndef KTF_X3_Y_NT
 #define KTF_X3_Y_NT 1         // 1: the 16-bit activation planes are written with non-temporal stores (0: A/B)
 #endif
-#ifndef KTF_X1_RING3
-#define KTF_X1_RING3 1        // one-pass form: three 32 KiB stages (two K-steps of operand DMAs in flight) instead of two: its K-steps are
-                              // bound by the operand stream; tdnn4 0.75 -> 0.69 ms, tdnn5 1.89 -> 1.87 ms (0: A/B)
+#ifndef KTF_X1_STAGES
+#define KTF_X1_STAGES 3       // one-pass form: 32 KiB stages in the LDS ring (2, 3 or 4). Its K-steps are bound by the operand stream, so
+                              // a second K-step of DMAs in flight pays: tdnn4 0.73 -> 0.67 ms, tdnn5 1.80 -> 1.78 ms, +1.2 % on the step; a third
+                              // does not (4 stages: -0.5 %)
 #endif
 #ifndef KTF_X2_PIPE
 #define KTF_X2_PIPE 1         // K-loop of the two-pass half form: 1 = in-phase hand-scheduled step (default), 2 = ping-pong wave halves.
@@ -2067,9 +2068,9 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     // 48 KiB of live data per stage would also fit THREE deep (KTF_X2_RING3: DMAs of stage k+2 issued during step k, counted
     // vmcnt at the barrier), which measured no faster.
     static_assert(PIPE != 2 || (TERMS == 2 && !PK), "the ping-pong K-loop exists for the 2-pass form");
-    constexpr int NST = ((TERMS == 2 && (KTF_X2_RING3 || PIPE == 2) && !PK) || (TERMS == 1 && KTF_X1_RING3)) ? 3 : 2;
-    constexpr int STG = (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;
-    constexpr int WOFF = (NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
+    constexpr int NST = (TERMS == 1) ? KTF_X1_STAGES : (TERMS == 2 && (KTF_X2_RING3 || PIPE == 2) && !PK) ? 3 : 2;
+    constexpr int STG = (TERMS == 1) ? 2 * R_TILE_BYTES : (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;      // one pass: A | W
+    constexpr int WOFF = (TERMS == 1 || NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
     int fill_slot = 0, cur_slot = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     const int id = blockIdx.x;
@@ -2184,7 +2185,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         }                                                                                                              \
     }
     XS_STAGE()
-    if (NST == 3 && PIPE == 1 && nk > 1) XS_STAGE()
+    if (NST >= 3 && PIPE == 1 && nk > 1) XS_STAGE()
+    if (NST >= 4 && PIPE == 1 && nk > 2) XS_STAGE()
     Epi16Prm eprm;
     if constexpr (PK) {
         if (tid < R_BN) {                                    // column constants parked behind the staging image (read in the epilogue)
@@ -2328,7 +2330,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         const int doff = (wave >= 4) ? KTF_X3_DOFF : 0;        // wave-uniform
         for (int ks = 0; ks < nk; ++ks) {
             // stage ks landed: nothing else is in flight (two stages), or only the DMAs of stage ks+1 are (three stages)
-            if (NST == 3 && ks + 1 < nk) {                  // stage ks + 1 may stay in flight: four DMAs per thread, six with a residual plane
+            if (NST == 4 && ks + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // (one-pass form) stages ks + 1, ks + 2 in flight
+            else if (NST >= 3 && ks + 1 < nk) {             // stage ks + 1 may stay in flight: four DMAs per thread, six with a residual plane
                 if (TERMS == 1 || ks + 1 >= p.lo_steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             }
@@ -3212,7 +3215,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         constexpr int lds_ = (PKD) ? (R16_LDS_BYTES > XS_LDS_BYTES ? R16_LDS_BYTES : XS_LDS_BYTES)                     \
                                    : (pipe_ == 2 ? 9 * R_TILE_BYTES : X2_LDS_BYTES);                                   \
         if (!w_lo && !(PKD)) {                               /* no residual plane: ONE pass */                          \
-            constexpr int lds1_ = KTF_X1_RING3 ? 9 * R_TILE_BYTES : X2_LDS_BYTES;                                      \
+            constexpr int lds1_ = KTF_X1_STAGES * 2 * R_TILE_BYTES > 5 * R_TILE_BYTES ? KTF_X1_STAGES * 2 * R_TILE_BYTES : 5 * R_TILE_BYTES;   /* >= the epilogue's staging image */ \
             KTF_LDS_ONCE(lds1_, tdnn_x3s_kernel<A, ST, 1, true, 1, false>);                                            \
             hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, 1, true, 1, false>), dim3((unsigned)nblocks), dim3(512), lds1_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
         } else {                                                                                                       \
