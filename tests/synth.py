@@ -140,6 +140,29 @@ def make_wav(B, N, seed=1234, sigma=1000.0, ragged=False):
     return x
 
 
+def speech_wavs(n=160000):
+    """The reference's end-to-end test input (testdata/librispeech_2.wav, 22.5 s of read speech at 16 kHz; the input of
+    models/kaldi/xvector_extractor_test.py:70-96, committed as tests/golden/e2e_0008.npz:wav_int16) as fp32 in int16 scale:
+    (whole recording (1, 359665), its first two `n`-sample chunks (2, n)). Non-stationary audio: the VAD drops the pauses and
+    the activation statistics move along the utterance -- what the stationary noise of make_wav cannot exercise."""
+    z = np.load(os.path.join(GOLDEN, "e2e_0008.npz"))
+    sp = z["wav_int16"].astype(np.float32)
+    return sp[None, :], np.stack([sp[:n], sp[n:2 * n]], 0)
+
+
+def coloured_am_noise(B, N, seed=99):
+    """1/f-coloured noise with a 3 Hz / 0.31 Hz amplitude modulation (int16 scale): between stationary white noise and speech."""
+    rng = np.random.default_rng(seed)
+    f = np.fft.rfftfreq(N, 1 / 16000.0)
+    t = np.arange(N) / 16000.0
+    out = []
+    for _ in range(B):
+        pink = np.fft.irfft(np.fft.rfft(rng.standard_normal(N)) / np.sqrt(np.maximum(f, 20.0)), N)
+        pink *= 1000.0 / pink.std()
+        out.append(np.round(pink * (0.55 + 0.45 * np.sin(2 * np.pi * 3.0 * t)) * (1 + 0.5 * np.sin(2 * np.pi * 0.31 * t))))
+    return np.clip(np.stack(out, 0), -32767, 32767).astype(np.float32)
+
+
 # ----------------------------------------------------------------------------- nnet3 binary writer (test tool)
 def _tok(s):
     return s.encode() + b" "
