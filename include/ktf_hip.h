@@ -60,6 +60,16 @@ extern "C" {
                              * (w_half - w) . E[x], subtracted from the fp32 bias by the host, the x-vector deviation stays where
                              * two passes put it (4.6e-5 .. 7.0e-5 against 4.0e-5 .. 6.3e-5 over six weight seeds) */
 
+#define KTF_GEMM_F16MX 5    /* ONE half-precision MFMA pass plus two block-scaled (OCP MX) residual passes on
+                             * v_mfma_scale_f32_16x16x128_f8f6f4, which runs fp4 / fp6 operands at four times the half rate:
+                             *   y = x_h * w_h + x_l4 * w_4 + x_4 * w_l6
+                             * (x_h, w_h half; x_l4 = e2m1 image of x - x_h; w_4 = e2m1 image of w; x_4 = e2m1 image of x_h;
+                             * w_l6 = e2m3 image of w - w_h; one E8M0 scale per 32 K elements). 1.5 MFMA passes per algorithmic
+                             * flop with ~15 significant bits on BOTH operands: 1.5e-5 .. 3.7e-5 max-abs x-vector deviation on
+                             * speech, noise and modulated noise alike, with no calibration and no dependence on the input
+                             * distribution (KTF_GEMM_F16X2's two half passes are 7e-5 .. 1e-4 on 10 s of speech). Through
+                             * ktf_tdnn_mx / ktf_tdnn_mx_stats on the four-plane activation format ktf_mx_planes produces */
+
 /* activations fused into the ktf_tdnn epilogue */
 #define KTF_ACT_NONE 0
 #define KTF_ACT_RELU 1
@@ -275,6 +285,35 @@ int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t 
                          const float* shift, double* sums, void* stream);
 int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, void* hi, void* lo, int64_t ld_dst,
                    void* stream);
+/* KTF_GEMM_F16MX (tdnn.py:251-280 + ReLU + BatchNorm, as ktf_tdnn). Activations are FOUR chunk-major planes; with nch = ceil(D / 32)
+ * and record r = (b * nch + d / 32) * T + t of element (b, t, d):
+ *   xh  : r * 64 B  32 halves, x_h = half(x) (saturating at +-65504), element d % 32
+ *   xl4 : r * 16 B  32 e2m1 codes of x - x_h (element e in nibble e: byte e / 2, low nibble first)
+ *   x4  : r * 16 B  32 e2m1 codes of x_h
+ *   xs  : r * 4 B   uint32: byte 0 = E8M0 scale of the xl4 block, byte 1 = of the x4 block (value = code * 2^(scale - 127));
+ *                   scale = floor(log2(block max)) - 2, one more when the maximum would round past 6
+ * ktf_mx_planes makes them from fp32 rows (B, T, ld_src) (rows >= lens[b] are left unwritten); the layer itself writes them for
+ * the next layer (yh, yl4, y4, ys; D = units), or fp32 rows (yf, ldy), or -- ktf_tdnn_mx_stats -- the pooled sums of
+ * ktf_tdnn_stats (same `sums` layouts, KTF_TDNN_DET_STATS honoured). Exactly one output form per call; the others NULL.
+ * Weights, for N-tile nt (256 units, zero rows beyond `units`) and K-step ks of the KTF_TDNN_K_INTERLEAVED order, K-steps
+ * zero-padded to a multiple of 4 (nkp; a super-step ss = K-steps 4 ss .. 4 ss + 3):
+ *   wh : block (nt * nkp + ks) * 16 KiB: the KTF_TDNN_W_TILED image of w_h
+ *   wq : block (nt * nkp / 4 + ss) * 48 KiB, with kb = ks % 4, col = unit % 256, record q = kb * 256 + col:
+ *          [0, 16 Ki)       q * 16: 32 e2m1 codes of w (K-step ks, unit col)
+ *          [16 Ki, 32 Ki)   q * 16: bits 0..127 of the 32 e2m3 codes (6 bits each, element e at bit 6 e) of w - w_h
+ *          [32 Ki, 40 Ki)   q * 8 : bits 128..191 of the same
+ *          [40 Ki, 44 Ki)   q * 4 : uint32, byte 0 = E8M0 scale of the e2m1 block, byte 1 = of the e2m3 block
+ *          [44 Ki, 48 Ki)   unused
+ * SAME padding, subsampling 1, ReLU or no activation; scale / shift as in ktf_tdnn (NULL when the BatchNorm is folded into
+ * the next layer, TDNN.device_weights_mx). */
+int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, int64_t ld_src, const int32_t* lens, void* xh, void* xl4,
+                  void* x4, void* xs, void* stream);
+int ktf_tdnn_mx(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,
+                const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale, const float* shift,
+                void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, void* stream);
+int ktf_tdnn_mx_stats(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,
+                      const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
+                      const float* shift, double* sums, void* stream);
 /* finishes the fused pooling: out[b, c] = sums[b,0,c]/n_b, out[b, D+c] = sqrt(max(sums[b,1,c]/n_b - mean^2, 0) + eps)
  * with n_b = lens[b] (or T when lens is NULL); stats_pooling.py:231-240. */
 int ktf_stats_finalize(const double* sums, const int32_t* lens, int64_t T, int64_t B, int32_t D, int32_t include_std,

@@ -1,0 +1,530 @@
+// KTF_GEMM_F16MX: TDNN layer as ONE half-precision MFMA pass plus two block-scaled (MX) residual passes at four times the
+// half rate -- the gfx950-only v_mfma_scale_f32_16x16x128_f8f6f4:
+//
+//   y = x_h * w_h   (v_mfma_f32_16x16x32_f16;  x_h = half(x), w_h = half(w))
+//     + x_l4 * w_4  (fp4 x fp4:  x_l4 = e2m1 image of the activation residual x - x_h,  w_4 = e2m1 image of w)
+//     + x_4 * w_l6  (fp4 x fp6:  x_4  = e2m1 image of x_h,  w_l6 = e2m3 image of the weight residual w - w_h)
+//
+// every MX operand with one power-of-two scale per 32 consecutive K elements (one 32-feature chunk of one context offset).
+// 1.5 MFMA passes per algorithmic flop; the x-vector deviation stays at 1.5-3.7e-5 on speech, noise and modulated noise alike
+// (tools/emulate_schemes.py "mx4_46"; the half-only two-pass form is 7-10e-5 on 10 s of speech, the calibrated one-pass form
+// 4-7e-4): both operands keep ~15 significant bits, and nothing depends on the input distribution. The weight residual needs
+// the fp6 image (its error is the same in every frame and survives the statistics pooling); fp4 is enough for both
+// activation images.
+//
+// Activations travel between the layers of this route as four chunk-major planes (element (b, t, d), c = d / 32):
+//   xh  [b][c][t][32] half          x_h
+//   xl4 [b][c][t][16 B]             32 e2m1 codes of x - x_h      (element e in nibble e: byte e/2, low nibble first)
+//   x4  [b][c][t][16 B]             32 e2m1 codes of x_h
+//   xs  [b][c][t] uint32            byte 0 = E8M0 scale of the xl4 block, byte 1 = of the x4 block
+// written by the producing layer's epilogue (or ktf_mx_planes for the first layer), 3.125 B per activation.
+//
+// Kernel: 256 x 256 tile, 8 waves of 128 x 64 (8 x 4 MFMA tiles of 16 x 16), K in super-steps of four 32-deep K-steps:
+//   F0..F3  one half-precision K-step each from a two-stage LDS ring (A | W images of 16 KiB, LDS-DMA);
+//   M       the 64 scaled MFMAs of the super-step's 128 K elements (K-step j = K block j of the instruction) from a
+//           single-buffered side area that is refilled during F0 / F1 of the NEXT super-step.
+// The im2col matrix is implicit as in tdnn_gemm.hip: a K-step is one context offset of one 32-feature chunk, rows clamped
+// per utterance (SAME padding = edge replication, layers/tdnn/tdnn.py:246-247 of the reference).
+//
+// Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88, stats_pooling.py:211-240 when fused).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 hfrag8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef __attribute__((address_space(1))) const void glb_ptr_t;
+
+#define MX_TILE 16384                       // one half operand image of a K-step: 256 rows x 64 B
+#define MX_STAGE (2 * MX_TILE)              // A | W
+#define MX_SA_OFF (2 * MX_STAGE)            // side A: xl4 [4][256][16] | x4 [4][256][16] | scales [4][256] u32
+#define MX_SA_BYTES (2 * 16384 + 4096)
+#define MX_SW_OFF (MX_SA_OFF + MX_SA_BYTES)  // side W: w4 [4][256][16] | wl6a [4][256][16] | wl6b [4][256][8] | scales [4][256] u32 | pad
+#define MX_WQ_BLOCK 49152                   // bytes of one (N-tile, super-step) block of the MX weight planes (last 4 KiB unused)
+#define MX_LDS_BYTES (MX_SW_OFF + MX_WQ_BLOCK)      // 151,552 B
+#define MX_EPI_PITCH 260
+
+struct MxParams {
+    const char* xh;
+    const char* xl4;
+    const char* x4;
+    const char* xs;
+    const int32_t* lens;
+    const char* wh;          // [N-tile][K-step (padded to a multiple of 4)][16 KiB]: LDS images of w_h
+    const char* wq;          // [N-tile][super-step][MX_WQ_BLOCK]: LDS images of w_4 | w_l6 | scales
+    const float* bias;
+    const float* scale;
+    const float* shift;
+    char* yh;                // output planes (chunk-major), or
+    char* yl4;
+    char* y4;
+    char* ys;
+    float* yf;               // ... fp32 row-major (B, T, ldy)
+    int64_t ldy;
+    int64_t T;
+    int32_t units, nch_in, nctx, nk, nss, nch_out, stat_slots;
+    int32_t ctx[16];
+};
+
+// E8M0 scale byte of an e2m1 block whose largest magnitude is m: the maximum lands in the top binade [4, 8) x scale, one
+// binade lower when it would round past 6 (mantissa >= 1.75)
+__device__ __forceinline__ unsigned mx_fp4_scale_byte(float m) {
+    const unsigned bits = __float_as_uint(m);
+    int byte = (int)(bits >> 23) - 2 + ((bits & 0x7fffffu) >= 0x600000u ? 1 : 0);
+    return (unsigned)(byte < 1 ? 1 : byte);
+}
+
+// 32 values -> half plane piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word
+__device__ __forceinline__ void mx_encode32(const float (&v)[32], u32x4 (&hp)[4], u32x4& l4, u32x4& h4, unsigned& sw) {
+    float hf[32], lo[32];
+    float mh = 0.0f, ml = 0.0f;
+    unsigned short hb[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) {
+        const float c = fminf(fmaxf(v[e], -65504.0f), 65504.0f);      // half planes saturate instead of overflowing to inf
+        hb[e] = f2h(c);
+        hf[e] = h2f(hb[e]);
+        lo[e] = c - hf[e];
+        mh = fmaxf(mh, fabsf(hf[e]));
+        ml = fmaxf(ml, fabsf(lo[e]));
+    }
+    const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml);
+    const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u32x4 t;
+        t.x = (unsigned)hb[8 * k + 0] | ((unsigned)hb[8 * k + 1] << 16);
+        t.y = (unsigned)hb[8 * k + 2] | ((unsigned)hb[8 * k + 3] << 16);
+        t.z = (unsigned)hb[8 * k + 4] | ((unsigned)hb[8 * k + 5] << 16);
+        t.w = (unsigned)hb[8 * k + 6] | ((unsigned)hb[8 * k + 7] << 16);
+        hp[k] = t;
+    }
+    unsigned wl[4] = {0, 0, 0, 0}, wh_[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {            // dword k = elements 8k .. 8k+7, byte s = elements 8k+2s, 8k+2s+1
+        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 0], lo[8 * k + 1], sl, 0);
+        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 2], lo[8 * k + 3], sl, 1);
+        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 4], lo[8 * k + 5], sl, 2);
+        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 6], lo[8 * k + 7], sl, 3);
+        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 0], hf[8 * k + 1], sh, 0);
+        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 2], hf[8 * k + 3], sh, 1);
+        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 4], hf[8 * k + 5], sh, 2);
+        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 6], hf[8 * k + 7], sh, 3);
+    }
+    l4 = u32x4{wl[0], wl[1], wl[2], wl[3]};
+    h4 = u32x4{wh_[0], wh_[1], wh_[2], wh_[3]};
+    sw = bl | (bh << 8);
+}
+
+// ------------------------------------------------------------------------------------ fp32 features -> MX planes
+// One thread per (utterance, chunk, row). Rows at or beyond lens[b] are left unwritten (consumers clamp rows to len - 1).
+__global__ void mx_planes_kernel(const float* __restrict__ src, int64_t B, int64_t T, int64_t ld, int D, int nch,
+                                 const int32_t* __restrict__ lens, char* __restrict__ xh, char* __restrict__ xl4,
+                                 char* __restrict__ x4, char* __restrict__ xs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * nch * T) return;
+    const int64_t t = i % T, bc = i / T;
+    const int c = (int)(bc % nch);
+    const int64_t b = bc / nch;
+    if (lens && t >= lens[b]) return;
+    const float* row = src + (b * T + t) * ld + c * 32;
+    float v[32];
+#pragma unroll
+    for (int e = 0; e < 32; ++e) v[e] = (c * 32 + e < D) ? row[e] : 0.0f;
+    u32x4 hp[4], l4, h4;
+    unsigned sw;
+    mx_encode32(v, hp, l4, h4, sw);
+    u32x4* dh = reinterpret_cast<u32x4*>(xh + i * 64);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dh[k] = hp[k];
+    *reinterpret_cast<u32x4*>(xl4 + i * 16) = l4;
+    *reinterpret_cast<u32x4*>(x4 + i * 16) = h4;
+    *reinterpret_cast<unsigned*>(xs + i * 4) = sw;
+}
+
+extern "C" int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, int64_t ld_src, const int32_t* lens, void* xh,
+                             void* xl4, void* x4, void* xs, void* stream) {
+    KTF_REQUIRE(src && xh && xl4 && x4 && xs, "ktf_mx_planes: null argument");
+    KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ld_src >= D, "ktf_mx_planes: bad size");
+    if (B == 0 || T == 0) return KTF_OK;
+    const int nch = (D + 31) / 32;
+    const int64_t n = B * nch * T;
+    hipLaunchKernelGGL(mx_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, B, T, ld_src, (int)D, nch,
+                       lens, (char*)xh, (char*)xl4, (char*)x4, (char*)xs);
+    KTF_CHECK_LAUNCH("ktf_mx_planes");
+    return KTF_OK;
+}
+
+// ------------------------------------------------------------------------------------ the GEMM
+__device__ __forceinline__ float mx_act(float v, int act) { return act == KTF_ACT_RELU ? fmaxf(v, 0.0f) : v; }
+
+__device__ __forceinline__ void mx_stats_out(double* __restrict__ stats, const MxParams& p, int b, int slot, int n, double s, double q) {
+    if (p.stat_slots > 0) {
+        double* dst = stats + (((int64_t)b * p.stat_slots + slot) * 2) * p.units + n;
+        dst[0] = s;
+        dst[p.units] = q;
+    } else {
+        double* dst = stats + ((int64_t)b * 2) * p.units + n;
+        atomicAdd(dst, s);
+        atomicAdd(dst + p.units, q);
+    }
+}
+
+#define MX_OUT_PLANES 0
+#define MX_OUT_F32 1
+#define MX_OUT_STATS 2
+
+template <int ACT, int OUT>
+__global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, int ntiles, int gtiles, double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;             // an XCD runs all N-tiles of an M-tile back to back (its L2 keeps the A tile)
+    const int g = (slot / ntiles) * 8 + xcd;
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int n0 = nt * 256, t0 = mt * 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    if (t0 >= len || len <= 0) return;
+    const int lenm1 = len - 1;
+    const unsigned Tu = (unsigned)p.T;
+    const int64_t ub = (int64_t)b * p.nch_in * p.T;       // first (chunk, row) record of this utterance
+    const char* xh = p.xh + ub * 64;
+    const char* xl4 = p.xl4 + ub * 16;
+    const char* x4 = p.x4 + ub * 16;
+    const char* xs = p.xs + ub * 4;
+    const int nkp = p.nss * 4;
+    const char* wh = p.wh + (int64_t)nt * nkp * MX_TILE;
+    const char* wq = p.wq + (int64_t)nt * p.nss * MX_WQ_BLOCK;
+
+    // half stage: thread q = i * 512 + tid moves the 16-byte piece at LDS offset q * 16 (row q >> 2, position q & 3 holds chunk
+    // (q & 3) ^ ((4 - ((row >> 2) & 3)) & 3): conflict-free 16-byte fragment reads)
+    unsigned a_cb[2];
+    int a_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q >> 2;
+        a_cb[i] = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
+        a_row[i] = t0 + row;
+    }
+#define MX_KSTEP(ks_, c_, off_)                                                                                        \
+    const int kk_ = (ks_) < p.nk ? (ks_) : 0;             /* padded K-steps re-read step 0 (their weights are zero) */ \
+    const int c_ = kk_ / p.nctx;                                                                                       \
+    const int off_ = p.ctx[kk_ - c_ * p.nctx];
+#define MX_ISSUE_F16(ks_)                                                                                              \
+    {                                                                                                                  \
+        MX_KSTEP(ks_, c__, off__)                                                                                      \
+        unsigned char* st_ = rsm + ((ks_) & 1) * MX_STAGE + wave * 1024;                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            int r_ = a_row[i] + off__;                                                                                 \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 64u + a_cb[i];                                  \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            const unsigned vo_ = (unsigned)(ks_) * (unsigned)MX_TILE + (unsigned)(i * 512 + tid) * 16u;                \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + MX_TILE + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+    }
+    // side A of super-step ss: 32 KiB of e2m1 pieces (4 DMAs per wave) + 4 KiB of scale words (2 four-byte DMAs per wave)
+#define MX_ISSUE_SIDE_A(ss_)                                                                                           \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                                \
+            const int idx_ = n * 8 + wave;                                                                             \
+            const int plane_ = idx_ >> 4, kb_ = (idx_ >> 2) & 3, rg_ = idx_ & 3;                                       \
+            MX_KSTEP(4 * (ss_) + kb_, c__, off__)                                                                      \
+            int r_ = t0 + rg_ * 64 + lane + off__;                                                                     \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 16u;                                            \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)((plane_ ? x4 : xl4) + vo_),                                  \
+                                             (lds_ptr_t*)(rsm + MX_SA_OFF + plane_ * 16384 + (kb_ * 256 + rg_ * 64) * 16), 16, 0, 0); \
+        }                                                                                                              \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                                \
+            const int idx_ = n * 8 + wave;                                                                             \
+            const int kb_ = idx_ >> 2, rg_ = idx_ & 3;                                                                 \
+            MX_KSTEP(4 * (ss_) + kb_, c__, off__)                                                                      \
+            int r_ = t0 + rg_ * 64 + lane + off__;                                                                     \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 4u;                                             \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xs + vo_),                                                   \
+                                             (lds_ptr_t*)(rsm + MX_SA_OFF + 32768 + (kb_ * 256 + rg_ * 64) * 4), 4, 0, 0); \
+        }                                                                                                              \
+    }
+    // side W of super-step ss: one contiguous 48 KiB block (6 DMAs per wave)
+#define MX_ISSUE_SIDE_W(ss_)                                                                                           \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int n = 0; n < 6; ++n) {                                                                \
+            const int idx_ = n * 8 + wave;                                                                             \
+            const unsigned vo_ = (unsigned)(ss_) * (unsigned)MX_WQ_BLOCK + (unsigned)idx_ * 1024u + (unsigned)lane * 16u; \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wq + vo_), (lds_ptr_t*)(rsm + MX_SW_OFF + idx_ * 1024), 16, 0, 0); \
+        }                                                                                                              \
+    }
+    MX_ISSUE_F16(0)
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // epilogue constants of the lane's four columns (their global-load latency hides under the K-loop)
+    float ebias[4], esc[4], esh[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+        const bool nv = n < p.units;
+        ebias[j] = (nv && p.bias) ? p.bias[n] : 0.0f;
+        esc[j] = (nv && p.scale) ? p.scale[n] : 1.0f;
+        esh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
+    }
+
+    const int r16 = lane & 15, q4 = lane >> 4;
+    const int fr = (4 - ((r16 >> 2) & 3)) & 3;
+    const int coff = ((q4 ^ fr) << 4);
+    const int a_row_off = (wm * 128 + r16) * 64 + coff;
+    const int b_row_off = (wn * 64 + r16) * 64 + coff;
+    const int sa_row = q4 * 256 + wm * 128 + r16;          // side A record of row block 0 (+ 16 per block)
+    const int sw_col = q4 * 256 + wn * 64 + r16;           // side W record of column block 0
+
+    for (int ss = 0; ss < p.nss; ++ss) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ks = 4 * ss + j;
+            // stage ks has landed; behind it only this super-step's side DMAs may still be in flight (six per wave)
+            if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (ks + 1 < nkp) MX_ISSUE_F16(ks + 1)
+            if (j == 0) MX_ISSUE_SIDE_A(ss)                 // the side area was released by the barrier above (M of ss - 1 is done)
+            if (j == 1) MX_ISSUE_SIDE_W(ss)
+            const unsigned char* sa = rsm + (ks & 1) * MX_STAGE;
+            const unsigned char* sw = sa + MX_TILE;
+            hfrag8 bh[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) bh[jj] = *reinterpret_cast<const hfrag8*>(sw + b_row_off + jj * 1024);
+            hfrag8 a_cur = *reinterpret_cast<const hfrag8*>(sa + a_row_off);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                hfrag8 a_nxt = a_cur;
+                if (i < 7) a_nxt = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 1) * 1024);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
+                a_cur = a_nxt;
+            }
+        }
+        // M: the two block-scaled terms of this super-step (side data complete since the barrier of F3)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned char* sA = rsm + MX_SA_OFF;
+            const unsigned char* sW = rsm + MX_SW_OFF;
+            i32x8 w4[4], wl6[4];
+            unsigned wsc[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                const int rec = sw_col + jj * 16;
+                const u32x4 a = *reinterpret_cast<const u32x4*>(sW + rec * 16);
+                const u32x4 l0 = *reinterpret_cast<const u32x4*>(sW + 16384 + rec * 16);
+                const u32x2 l1 = *reinterpret_cast<const u32x2*>(sW + 32768 + rec * 8);
+                wsc[jj] = *reinterpret_cast<const unsigned*>(sW + 40960 + rec * 4);
+                w4[jj] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+                wl6[jj] = i32x8{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, 0, 0};
+            }
+            u32x4 l_n = *reinterpret_cast<const u32x4*>(sA + sa_row * 16);
+            u32x4 h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + sa_row * 16);
+            unsigned s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + sa_row * 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const u32x4 l = l_n, h = h_n;
+                const unsigned asc = s_n;
+                if (i < 7) {                             // the next row block's fragments are read under this one's MFMAs
+                    const int rec = sa_row + (i + 1) * 16;
+                    l_n = *reinterpret_cast<const u32x4*>(sA + rec * 16);
+                    h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + rec * 16);
+                    s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + rec * 4);
+                }
+                const i32x8 al = i32x8{(int)l.x, (int)l.y, (int)l.z, (int)l.w, 0, 0, 0, 0};
+                const i32x8 ah = i32x8{(int)h.x, (int)h.y, (int)h.z, (int)h.w, 0, 0, 0, 0};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)           // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
+                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, w4[jj], acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)           // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
+                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, wl6[jj], acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#undef MX_ISSUE_F16
+#undef MX_ISSUE_SIDE_A
+#undef MX_ISSUE_SIDE_W
+#undef MX_KSTEP
+
+    const int rows_valid = len - t0;
+    if constexpr (OUT == MX_OUT_STATS) {
+        // fused StatsPooling (stats_pooling.py:231-240): per column the sum and the sum of squares of the wave's 128 rows, taken in
+        // fp32 relative to a pivot (row 0 of the block: a constant column -- a dead ReLU unit -- gives exactly 0 and 0), then fp64
+        const int rv = rows_valid - wm * 128;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v0 = mx_act(acc[0][j][0] + ebias[j], ACT) * esc[j] + esh[j];
+            const float pv = __shfl(v0, lane & 15, 64);
+            float s32 = 0.0f, q32 = 0.0f;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = mx_act(acc[i][j][r] + ebias[j], ACT) * esc[j] + esh[j];
+                    if (rv >= 128 || i * 16 + q4 * 4 + r < rv) {
+                        const float u = v - pv;
+                        s32 += u;
+                        q32 = fmaf(u, u, q32);
+                        ++cnt;
+                    }
+                }
+            }
+            const double pd = (double)pv, sd = (double)s32, nd = (double)cnt;
+            double s = sd + nd * pd;
+            double q = (double)q32 + 2.0 * pd * sd + nd * pd * pd;
+            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+            if (lane < 16 && n < p.units) mx_stats_out(stats, p, b, (t0 >> 7) + wm, n, s, q);
+        }
+        return;
+    } else {
+        __syncthreads();                                 // every fragment read is done: the LDS becomes the store staging area
+        float* et = reinterpret_cast<float*>(rsm);
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {           // rows wm*128 + pass*32 .. +31 of both wave rows -> 64 staged rows
+#pragma unroll
+            for (int ih = 0; ih < 2; ++ih) {
+                const int i = pass * 2 + ih;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = wn * 64 + j * 16 + (lane & 15);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int srow = wm * 32 + ih * 16 + q4 * 4 + r;
+                        et[srow * MX_EPI_PITCH + col] = mx_act(acc[i][j][r] + ebias[j], ACT) * esc[j] + esh[j];
+                    }
+                }
+            }
+            __syncthreads();
+            if constexpr (OUT == MX_OUT_PLANES) {
+                // one thread per (staged row, 32-column chunk): the wave's 64 lanes are 64 rows of ONE chunk, so every store
+                // instruction writes consecutive records of a plane
+                const int cidx = wave, srow = lane;
+                const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
+                const int chunk = (n0 >> 5) + cidx;
+                if (m < rows_valid && chunk < p.nch_out) {
+                    float v[32];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const f32x4 t = *reinterpret_cast<const f32x4*>(et + srow * MX_EPI_PITCH + cidx * 32 + k * 4);
+                        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+                    }
+                    u32x4 hp[4], l4, h4;
+                    unsigned sw_;
+                    mx_encode32(v, hp, l4, h4, sw_);
+                    const int64_t rec = ((int64_t)b * p.nch_out + chunk) * p.T + (t0 + m);
+                    u32x4* dh = reinterpret_cast<u32x4*>(p.yh + rec * 64);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(hp[k], dh + k);
+                    __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));
+                    __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));
+                    __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));
+                }
+            } else {
+                const int nl = lane * 4;
+                const int n = n0 + nl;
+#pragma unroll
+                for (int sp = 0; sp < 8; ++sp) {
+                    const int srow = sp * 8 + wave;
+                    const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
+                    if (m < rows_valid) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(et + srow * MX_EPI_PITCH + nl);
+                        float* yp = p.yf + ((int64_t)b * p.T + t0 + m) * p.ldy + n;
+                        if (n + 4 <= p.units && (p.ldy & 3) == 0) {
+                            *reinterpret_cast<f32x4*>(yp) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (n + e < p.units) yp[e] = v[e];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// x planes (see the head of this file) -> one TDNN layer. Exactly one of {y planes, yf, stats} is written.
+static int mx_launch(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,
+                     const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale, const float* shift,
+                     void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, double* stats, void* stream, const char* who) {
+    KTF_REQUIRE(xh && xl4 && x4 && xs && d && wh && wq, "%s: null argument", who);
+    KTF_REQUIRE(d->gemm == KTF_GEMM_F16MX, "%s: needs KTF_GEMM_F16MX", who);
+    KTF_REQUIRE(B >= 0 && T >= 0 && B < 65536, "%s: bad size", who);
+    KTF_REQUIRE(d->units > 0 && d->din > 0 && d->din_pad % 32 == 0 && d->din_pad >= d->din, "%s: bad units / din / din_pad", who);
+    KTF_REQUIRE(d->nctx >= 1 && d->nctx <= 16, "%s: nctx %d outside [1,16]", who, d->nctx);
+    for (int i = 1; i < d->nctx; ++i) KTF_REQUIRE(d->ctx[i] > d->ctx[i - 1], "%s: context must be strictly ascending", who);
+    KTF_REQUIRE(!d->valid && d->subsampling == 1, "%s: SAME padding without subsampling only", who);
+    KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "%s: fuses ReLU or no activation", who);
+    KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift go together", who);
+    KTF_REQUIRE(T * (int64_t)d->din_pad * 2 < (1ll << 31), "%s: T * din_pad too large", who);
+    const int outs = (yh ? 1 : 0) + (yf ? 1 : 0) + (stats ? 1 : 0);
+    KTF_REQUIRE(outs == 1, "%s: exactly one of the plane / fp32 / pooled outputs", who);
+    if (yh) KTF_REQUIRE(yl4 && y4 && ys, "%s: a plane output needs all four planes", who);
+    if (yf) KTF_REQUIRE(ldy >= d->units, "%s: ldy < units", who);
+    if (B == 0 || T == 0) return KTF_OK;
+    MxParams p;
+    memset(&p, 0, sizeof(p));
+    p.xh = (const char*)xh; p.xl4 = (const char*)xl4; p.x4 = (const char*)x4; p.xs = (const char*)xs;
+    p.lens = lens; p.wh = (const char*)wh; p.wq = (const char*)wq; p.bias = bias; p.scale = scale; p.shift = shift;
+    p.yh = (char*)yh; p.yl4 = (char*)yl4; p.y4 = (char*)y4; p.ys = (char*)ys; p.yf = yf; p.ldy = ldy; p.T = T;
+    p.units = d->units; p.nch_in = d->din_pad / 32; p.nctx = d->nctx; p.nk = p.nch_in * d->nctx; p.nss = (p.nk + 3) / 4;
+    p.nch_out = (d->units + 31) / 32;
+    p.stat_slots = (stats && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(T) : 0;
+    for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
+    const int mtiles = ktf_cdiv(T, 256), ntiles = ktf_cdiv(d->units, 256);
+    const int64_t gtiles = B * mtiles;
+    const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles;
+    hipStream_t st = (hipStream_t)stream;
+    if (stats && !p.stat_slots) (void)0;      // (atomic form: the caller zeroes the sums)
+#define MX_LAUNCH(A, O)                                                                                                \
+    {                                                                                                                  \
+        KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O>);                                                              \
+        hipLaunchKernelGGL((tdnn_mx_kernel<A, O>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
+    }
+    const int o = stats ? MX_OUT_STATS : (yf ? MX_OUT_F32 : MX_OUT_PLANES);
+    if (d->act == KTF_ACT_RELU) {
+        if (o == MX_OUT_STATS) MX_LAUNCH(KTF_ACT_RELU, MX_OUT_STATS) else if (o == MX_OUT_F32) MX_LAUNCH(KTF_ACT_RELU, MX_OUT_F32) else MX_LAUNCH(KTF_ACT_RELU, MX_OUT_PLANES)
+    } else {
+        if (o == MX_OUT_STATS) MX_LAUNCH(KTF_ACT_NONE, MX_OUT_STATS) else if (o == MX_OUT_F32) MX_LAUNCH(KTF_ACT_NONE, MX_OUT_F32) else MX_LAUNCH(KTF_ACT_NONE, MX_OUT_PLANES)
+    }
+#undef MX_LAUNCH
+    KTF_CHECK_LAUNCH(who);
+    return KTF_OK;
+}
+
+extern "C" int ktf_tdnn_mx(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,
+                           const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
+                           const float* shift, void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, void* stream) {
+    return mx_launch(xh, xl4, x4, xs, B, T, lens, d, wh, wq, bias, scale, shift, yh, yl4, y4, ys, yf, ldy, nullptr, stream, "ktf_tdnn_mx");
+}
+
+extern "C" int ktf_tdnn_mx_stats(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T,
+                                 const int32_t* lens, const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias,
+                                 const float* scale, const float* shift, double* sums, void* stream) {
+    KTF_REQUIRE(sums, "ktf_tdnn_mx_stats: null sums");
+    return mx_launch(xh, xl4, x4, xs, B, T, lens, d, wh, wq, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, 0, sums, stream,
+                     "ktf_tdnn_mx_stats");
+}

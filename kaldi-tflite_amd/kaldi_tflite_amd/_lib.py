@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("KTF_LIBRARY") or os.path.join(_HERE, "libktf_hip.so")
 
 KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
-GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2 = 0, 1, 2, 3, 4
+GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2, GEMM_F16MX = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED, TDNN_X_CHUNKED, TDNN_Y_CHUNKED = 1, 2, 4, 8, 16, 32   # KtfTdnnDesc.flags
 
@@ -97,6 +97,9 @@ PROTOTYPES = {
     "ktf_tdnn_split": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
     "ktf_tdnn_split_stats": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ktf_split_bf16": (C.c_int, [_P, _i64, _i32, _i64, _P, _P, _i64, _P]),
+    "ktf_mx_planes": (C.c_int, [_P, _i64, _i64, _i32, _i64, _P, _P, _P, _P, _P, _P]),
+    "ktf_tdnn_mx": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
+    "ktf_tdnn_mx_stats": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ktf_stats_finalize": (C.c_int, [_P, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_stats_slots": (_i64, [_i64]),
     "ktf_stats_finalize_slots": (C.c_int, [_P, _i64, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),

@@ -668,7 +668,7 @@ def reshapeKaldiTdnnWeights(weights, units, kernel_width):
 
 _ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
 _GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat16": L.GEMM_BF16, "bf16x3": L.GEMM_BF16X3,
-         "f16": L.GEMM_F16, "float16": L.GEMM_F16, "f16x2": L.GEMM_F16X2}
+         "f16": L.GEMM_F16, "float16": L.GEMM_F16, "f16x2": L.GEMM_F16X2, "f16mx": L.GEMM_F16MX}
 
 
 class TDNN(Layer):
@@ -851,6 +851,36 @@ class TDNN(Layer):
         self._dev[key] = (w, w_lo, bias)
         return self._dev[key]
 
+    def device_weights_mx(self, device, fold=None):
+        """KTF_GEMM_F16MX operands on the device: (wh, wq, bias) -- the half plane and the block-scaled e2m1 / e2m3 planes of
+        the weights as the kernel's LDS images (include/ktf_hip.h, ktf_tdnn_mx; mx.weight_images), K ordered (32-feature chunk,
+        context, feature) and zero-padded to whole super-steps. `fold`: the BatchNorm in front of this layer folded INTO it (see
+        device_weights): the stored activations are then the ReLU outputs themselves."""
+        from . import mx
+        key = ("mx", str(device), None if fold is None else (id(fold), fold._version))
+        if key in self._dev:
+            return self._dev[key]
+        K, D = self.kernelWidth, self.inputDim
+        Dp, Up = ops.round_up(D, 32), ops.round_up(self.units, 256)
+        Wk = np.transpose(self.kernel[0], (2, 0, 1)).astype(np.float64)       # [u, k, d]
+        bias64 = self.bias.astype(np.float64) if self.useBias else None
+        if fold is not None:
+            s64, h64 = fold.affine64()
+            if s64.shape != (D,):
+                raise ValueError(f"cannot fold a {s64.shape[0]}-wide BatchNorm into a layer with input dim {D}")
+            extra = np.einsum("ukd,d->u", Wk, h64)
+            bias64 = extra if bias64 is None else bias64 + extra
+            Wk = Wk * s64[None, None, :]
+        W = np.zeros((Up, K, Dp), np.float64)
+        W[: self.units, :, :D] = Wk
+        W = np.ascontiguousarray(W.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3)).reshape(Up, (Dp // 32) * K, 32)
+        wh, wq, _ = mx.weight_images(W)
+        out = (torch.as_tensor(wh, device=device), torch.as_tensor(wq, device=device),
+               ops.to_device_f32(bias64, device) if bias64 is not None else None)
+        self._dev = {k: v for k, v in self._dev.items() if k[0] != "mx"}      # one MX image set per layer (a re-fold replaces it)
+        self._dev[key] = out
+        return out
+
     def desc(self, gemm, x_dtype, y_dtype, act=None, flags=0):
         d = L.TdnnDesc()
         d.flags = flags
@@ -914,10 +944,12 @@ class TDNN(Layer):
     def effective_gemm(self, gemm, relu=False):
         """The half-precision mode runs on the ring kernels only (units > 128, ReLU or no activation); any other layer
         of an "f16" model is evaluated by the exact fp32 kernel instead."""
-        if gemm not in (L.GEMM_F16, L.GEMM_F16X2):
+        if gemm not in (L.GEMM_F16, L.GEMM_F16X2, L.GEMM_F16MX):
             return gemm
         a = self.activation.lower() if isinstance(self.activation, str) else self.activation
         ok = self.units > 128 and (a in (None, "linear") or (a == "relu" and not relu))
+        if gemm == L.GEMM_F16MX:             # SAME padding without subsampling only
+            ok = ok and self.padding == "SAME" and self.subsamplingFactor == 1
         return gemm if ok else L.GEMM_F32
 
     def prepare_input(self, x, gemm):

@@ -19,6 +19,7 @@ from . import _lib as L
 from . import ops
 from .io import KaldiNnet3Reader, ReadKaldiArray
 from .layers import TDNN, BatchNorm, CMVN, Framing, MFCC, ReLU, StatsPooling, VAD, _GEMM
+from .mx import Planes
 
 
 class Input:
@@ -124,7 +125,7 @@ class Sequential:
                                 # nearest half, the constant part of the rounding error moved into the fp32 bias) once calibrate()
                                 # has measured the mean of their input planes; 0 = every layer two passes
     # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
-    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32}
+    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
 
     def __init__(self, layers=None, name=None, gemm="f32"):
         self.input = None
@@ -257,6 +258,7 @@ class Sequential:
         pending_bn = None            # F16X2: the BatchNorm of the previous layer, to be folded into the next layer's weights
         cur_perm = None              # F16X2: feature order of the current activation plane (None = natural)
         x_chunked = False            # F16X2: the current activation buffer is chunk-major (KTF_TDNN_Y_CHUNKED of its producer)
+        mxp = None                   # F16MX: the current activations as the four MX planes (mx.Planes)
         for si, st in enumerate(steps):
             if skip:
                 skip = False
@@ -273,6 +275,53 @@ class Sequential:
                     raise ValueError("cannot fuse a ReLU after a TDNN that already has an activation")
                 can_pool = (self.fuse_stats and not pooled and nxt is not None and nxt[0] == "stats" and
                             nxt[1].inputPeriod == 1 and l.units > 128 and l.padding == "SAME" and l.subsamplingFactor == 1)
+            if gemm == L.GEMM_F16MX and st[0] == "tdnn" and not pooled and l.effective_gemm(gemm, relu) == gemm:
+                # one half pass + two block-scaled residual passes (csrc/tdnn_mx.hip): activations travel as four chunk-major
+                # planes (half value, e2m1 images of the residual and of the value, block scales) holding the ReLU outputs; a
+                # layer's BatchNorm is folded into the weights of the next layer of the route
+                if mxp is None:                          # first layer of the route: fp32 rows -> planes
+                    B, T, D = x.shape
+                    src = x if (x.dtype == torch.float32 and x.stride(2) == 1 and x.stride(0) == T * x.stride(1)) \
+                        else x.to(torch.float32).contiguous()
+                    mxp = Planes.buffers(self._ws.get, "mx_in", B, T, D, dev)
+                    ops.mx_planes(src, D, lens, mxp)
+                B, T, _ = mxp.shape
+                fold, pending_bn = pending_bn, None
+                wh, wq, bias = l.device_weights_mx(dev, fold=fold)
+                d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None)
+                if can_pool:                             # ... -> reducing StatsPooling inside the epilogue (BatchNorm applied there)
+                    sp = nxt[1]
+                    od = 2 * l.units if sp.includeStd else l.units
+                    slots = ops.stats_slots(T) if self.deterministic else 0
+                    sums = self._ws.get("sums", (B, max(slots, 1), 2, l.units), torch.float64, dev, padded=False)
+                    sbuf = self._ws.get("pooled", (B, ops.round_up(od, 32)), torch.float32, dev)
+                    scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
+                    d.flags = L.TDNN_DET_STATS if slots else 0
+                    ops.tdnn_mx_stats(mxp, lens, d, wh, wq, bias, scale, shift, sums, zero=not slots)
+                    ops.stats_finalize(sums, lens, T, l.units, sp.includeStd, sp.epsilon, sbuf, slots=slots)
+                    x = sbuf[:, :od].unsqueeze(0)
+                    lens, pooled, skip, mxp = None, True, True, None
+                    continue
+                nl = nxt[1] if nxt is not None and nxt[0] == "tdnn" else None
+                in_route = nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm and nl.inputDim == l.units
+                defer_bn = bn is not None and in_route
+                scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
+                if in_route:
+                    out = Planes.buffers(self._ws.get, out_role + "mx", B, T, l.units, dev)
+                    ops.tdnn_mx(mxp, lens, d, wh, wq, bias, scale, shift, out)
+                    mxp = out
+                    x = out.xh                            # (shape carrier only)
+                else:
+                    ldy = ops.round_up(l.units, 32)
+                    ybuf = self._ws.get(out_role, (B, T, ldy), torch.float32, dev, padded=ldy != l.units)
+                    ops.tdnn_mx(mxp, lens, d, wh, wq, bias, scale, shift, ybuf)
+                    mxp = None
+                    x = ybuf[:, :, : l.units]
+                if defer_bn:
+                    pending_bn = bn
+                continue
+            if mxp is not None:
+                raise RuntimeError("internal: MX planes reached a layer that cannot read them")
             if (gemm == L.GEMM_F16X2 and st[0] == "tdnn" and not pooled and l.effective_gemm(gemm, relu) == gemm):
                 # half passes (two per product; one where calibrate() lets the weight residual go: the layers in front of the
                 # pooling, the low-variance input features of the others): activations travel as ONE half plane holding the

@@ -382,6 +382,43 @@ def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums, zero=Tru
     return sums
 
 
+def mx_planes(src, D, lens, planes):
+    """fp32 (B,T,ld) rows -> the four KTF_GEMM_F16MX planes (mx.Planes); rows >= lens[b] are left unwritten."""
+    lib = L.load()
+    B, T = src.shape[0], src.shape[1]
+    with torch.cuda.device(src.device):
+        rc = lib.ktf_mx_planes(L.ptr(src), B, T, D, src.stride(1), L.ptr(lens), L.ptr(planes.xh), L.ptr(planes.xl4), L.ptr(planes.x4),
+                               L.ptr(planes.xs), L.stream_ptr())
+    L.check(rc, "ktf_mx_planes")
+    return planes
+
+
+def tdnn_mx(xp, lens, desc, wh, wq, bias, scale, shift, y):
+    """xp: mx.Planes. y: mx.Planes (the next layer's input) or an fp32 (B,T,ldy) tensor."""
+    lib = L.load()
+    B, T, _ = xp.shape
+    planes = not isinstance(y, torch.Tensor)
+    with torch.cuda.device(xp.device):
+        rc = lib.ktf_tdnn_mx(L.ptr(xp.xh), L.ptr(xp.xl4), L.ptr(xp.x4), L.ptr(xp.xs), B, T, L.ptr(lens), C.byref(desc), L.ptr(wh),
+                             L.ptr(wq), L.ptr(bias), L.ptr(scale), L.ptr(shift),
+                             L.ptr(y.xh) if planes else None, L.ptr(y.xl4) if planes else None, L.ptr(y.x4) if planes else None,
+                             L.ptr(y.xs) if planes else None, None if planes else L.ptr(y), 0 if planes else y.stride(1), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_mx")
+    return y
+
+
+def tdnn_mx_stats(xp, lens, desc, wh, wq, bias, scale, shift, sums, zero=True):
+    lib = L.load()
+    B, T, _ = xp.shape
+    with torch.cuda.device(xp.device):
+        if zero:
+            sums.zero_()
+        rc = lib.ktf_tdnn_mx_stats(L.ptr(xp.xh), L.ptr(xp.xl4), L.ptr(xp.x4), L.ptr(xp.xs), B, T, L.ptr(lens), C.byref(desc),
+                                   L.ptr(wh), L.ptr(wq), L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_mx_stats")
+    return sums
+
+
 def stats_finalize(sums, lens, T, D, include_std, eps, out, slots=0):
     """sums (B,2,D) [slots == 0] or (B,slots,2,D) fp64 -> out (B, ld) mean | std."""
     lib = L.load()

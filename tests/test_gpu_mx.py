@@ -1,0 +1,213 @@
+"""GPU tests of KTF_GEMM_F16MX (csrc/tdnn_mx.hip; run with `-m gpu` on an MI355X): the device-side MX encoding against the
+NumPy codecs bit for bit, one TDNN layer against an fp64 emulation of exactly the three products the kernel forms
+(x_h w_h + x_l4 w_4 + x_4 w_l6 on the decoded operands) in all three output forms, and the layer against the EXACT fp64
+layer to show what the arithmetic costs (~2^-14 relative). The whole extractor in this mode is gated on speech in
+tests/test_gpu_speech.py and at the BASELINE size below."""
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import kaldi_tflite_amd as ktf
+from kaldi_tflite_amd import mx, ops
+from kaldi_tflite_amd import _lib as L
+from oracle import ktf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _reduced_modes_reach_their_kernels():
+    old = ktf.models.Sequential.min_tiles
+    ktf.models.Sequential.min_tiles = {}
+    yield
+    ktf.models.Sequential.min_tiles = old
+
+
+def dev(a, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda").to(dtype)
+
+
+def test_mx_planes_match_the_numpy_codecs_bit_for_bit():
+    """ktf_mx_planes: half plane, e2m1 codes of the residual and of the half value, E8M0 scales -- identical to mx.encode_activations
+    (round to nearest even, saturation, the scale rule) on values spanning 40 binades, exact zeros, a zero block and ties."""
+    rng = np.random.default_rng(5)
+    B, T, D = 3, 37, 70
+    x = (rng.standard_normal((B, T, D)) * np.exp2(rng.integers(-20, 20, (B, T, D)))).astype(np.float32)
+    x[0, 0, :32] = 0.0                                    # a zero block
+    x[0, 1, :8] = [0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 7.0]      # e2m1 ties (block max 7 -> scale 2, halves of these)
+    x[1, 2, 3] = 1e9                                      # saturates the half plane
+    x[rng.random((B, T, D)) < 0.3] = 0.0                  # ReLU-like zeros
+    lens = np.array([T, T - 5, 1], np.int32)
+    p = mx.Planes.empty(B, T, D, "cuda")
+    ops.mx_planes(dev(x), D, dev(lens, torch.int32), p)
+    Dp = 96
+    xp = np.zeros((B, T, Dp), np.float32)
+    xp[:, :, :D] = x
+    xh, cl, ch, sl, sh = mx.encode_activations(xp)
+    got_h = p.xh.cpu().numpy().transpose(0, 2, 1, 3).reshape(B, T, Dp)
+    got_l = mx.unpack4(p.xl4.cpu().numpy()).transpose(0, 2, 1, 3).reshape(B, T, Dp)
+    got_4 = mx.unpack4(p.x4.cpu().numpy()).transpose(0, 2, 1, 3).reshape(B, T, Dp)
+    got_s = p.xs.cpu().numpy().astype(np.uint32).transpose(0, 2, 1)
+    for b in range(B):
+        n = lens[b]
+        assert np.array_equal(got_h[b, :n].view(np.uint16), xh[b, :n].view(np.uint16))
+        assert np.array_equal(got_s[b, :n] & 255, sl[b, :n]), "residual scales"
+        assert np.array_equal((got_s[b, :n] >> 8) & 255, sh[b, :n]), "value scales"
+        # -0 and +0 codes are the same number
+        assert np.array_equal(got_l[b, :n] & np.where((got_l[b, :n] & 7) == 0, 7, 15), cl[b, :n] & np.where((cl[b, :n] & 7) == 0, 7, 15))
+        assert np.array_equal(got_4[b, :n] & np.where((got_4[b, :n] & 7) == 0, 7, 15), ch[b, :n] & np.where((ch[b, :n] & 7) == 0, 7, 15))
+        assert not p.xh[b, :, n:].any(), "rows beyond the utterance are left untouched"
+
+
+def _layer_case(rng, D, ctx, units, B, T, lens):
+    K = len(ctx)
+    W = (rng.standard_normal((units, K, D)) / np.sqrt(K * D)).astype(np.float32)
+    bias = (rng.standard_normal(units) * 0.1).astype(np.float32)
+    x = np.maximum(rng.standard_normal((B, T, D)) * np.exp2(rng.integers(-3, 3, (1, 1, D))), 0.0).astype(np.float32)     # ReLU-like
+    layer = ktf.layers.TDNN(units, context=list(ctx), name="t")
+    layer.build((None, None, D))
+    layer.set_weights([W.reshape(units, K * D), bias])
+    return layer, W, bias, x, np.asarray(lens, np.int32)
+
+
+def _emulate(layer, x, lens, relu):
+    """fp64 evaluation of the kernel's three products on the DECODED operands (what the MFMAs see), and of the exact layer."""
+    B, T, D = x.shape
+    K, ctx, units = layer.kernelWidth, layer.context, layer.units
+    Dp, Up = ops.round_up(D, 32), ops.round_up(units, 256)
+    xp = np.zeros((B, T, Dp), np.float32)
+    xp[:, :, :D] = x
+    xh, cl, ch, sl, sh = mx.encode_activations(xp)
+    blk = (B, T, Dp // 32, 32)
+    Xh = xh.astype(np.float64)
+    Xl = mx.decode_e2m1(cl.reshape(blk), sl).reshape(B, T, Dp)
+    X4 = mx.decode_e2m1(ch.reshape(blk), sh).reshape(B, T, Dp)
+    Wk = np.transpose(layer.kernel[0], (2, 0, 1)).astype(np.float64)          # [u, k, d]
+    Wp = np.zeros((Up, K, Dp))
+    Wp[:units, :, :D] = Wk
+    Wi = np.ascontiguousarray(Wp.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3)).reshape(Up, (Dp // 32) * K, 32)
+    _, _, (Wh, W4, W6) = mx.weight_images(Wi)
+    emu = np.zeros((B, T, units))
+    exact = np.zeros((B, T, units))
+    for b in range(B):
+        n = int(lens[b])
+        t = np.arange(n)
+        acc = np.zeros((n, Up))
+        ex = np.zeros((n, units))
+        for ks in range((Dp // 32) * K):
+            c, k = divmod(ks, K)
+            rows = np.clip(t + ctx[k], 0, n - 1)
+            sl_ = slice(c * 32, c * 32 + 32)
+            acc += Xh[b, rows, sl_] @ Wh[:, ks].T + Xl[b, rows, sl_] @ W4[:, ks].T + X4[b, rows, sl_] @ W6[:, ks].T
+            ex += xp[b, rows, sl_].astype(np.float64) @ Wi[:units, ks].T
+        emu[b, :n] = acc[:, :units] + layer.bias
+        exact[b, :n] = ex + layer.bias
+    if relu:
+        emu, exact = np.maximum(emu, 0), np.maximum(exact, 0)
+    return emu, exact
+
+
+CASES = [  # D, context, units, B, T, lens
+    (64, [-2, 0, 2], 512, 2, 300, [300, 77]),
+    (30, [-2, -1, 0, 1, 2], 512, 2, 270, [270, 3]),         # 5 K-steps padded to 8
+    (512, [0], 1500, 1, 256, [256]),
+    (96, [-3, 0, 3], 200, 3, 513, [513, 256, 1]),           # 9 K-steps padded to 12; three M-tiles; one N-tile with pad units
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_tdnn_mx_fp32_output_vs_emulation(case, relu):
+    rng = np.random.default_rng(11)
+    layer, W, bias, x, lens = _layer_case(rng, *case)
+    B, T, D = x.shape
+    p = mx.Planes.empty(B, T, D, "cuda")
+    dl = dev(lens, torch.int32)
+    ops.mx_planes(dev(x), D, dl, p)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"))
+    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None)
+    ldy = ops.round_up(layer.units, 4)
+    y = torch.full((B, T, ldy), 7.0, device="cuda")
+    ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, y)
+    got = y.cpu().numpy()
+    emu, exact = _emulate(layer, x, lens, relu)
+    for b in range(B):
+        n = lens[b]
+        scale = np.abs(exact[b, :n]).max()
+        assert np.abs(got[b, :n, : layer.units] - emu[b, :n]).max() <= 3e-6 * scale, "kernel != its own arithmetic"
+        assert np.abs(got[b, :n, : layer.units] - exact[b, :n]).max() <= 4e-4 * scale       # what three terms cost (max, not rms)
+        rms = np.sqrt(np.mean((got[b, :n, : layer.units] - exact[b, :n]) ** 2)) / np.sqrt(np.mean(exact[b, :n] ** 2) + 1e-30)
+        print(f"case {case[:3]} relu {relu} utt {b}: rel rms vs exact {rms:.2e}")
+        assert rms <= 6e-5
+        assert (got[b, n:] == 7.0).all(), "rows beyond the utterance are not written"
+
+
+@pytest.mark.parametrize("case", CASES[:2] + CASES[3:])
+def test_tdnn_mx_plane_output_feeds_the_next_layer(case):
+    """Plane output of one layer == ktf_mx_planes of its fp32 output (same encoder), up to the ties an fp32 summation-order
+    difference can flip: compared as decoded values."""
+    rng = np.random.default_rng(12)
+    layer, W, bias, x, lens = _layer_case(rng, *case)
+    B, T, D = x.shape
+    p = mx.Planes.empty(B, T, D, "cuda")
+    dl = dev(lens, torch.int32)
+    ops.mx_planes(dev(x), D, dl, p)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"))
+    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu")
+    out = mx.Planes.empty(B, T, layer.units, "cuda")
+    ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, out)
+    y = torch.zeros((B, T, ops.round_up(layer.units, 4)), device="cuda")
+    d32 = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu")
+    ops.tdnn_mx(p, dl, d32, wh, wq, bd, None, None, y)
+    ref = mx.Planes.empty(B, T, layer.units, "cuda")
+    ops.mx_planes(y, layer.units, dl, ref)
+    for b in range(B):
+        n = lens[b]
+        for a, r in zip(out.decode(), ref.decode()):
+            assert np.array_equal(a[b, :n], r[b, :n])
+        assert np.array_equal(out.xs[b, :, :n].cpu().numpy(), ref.xs[b, :, :n].cpu().numpy())
+
+
+def test_tdnn_mx_fused_pooling_vs_emulation():
+    rng = np.random.default_rng(13)
+    layer, W, bias, x, lens = _layer_case(rng, 512, [0], 1500, 3, 700, [700, 129, 256])
+    B, T, D = x.shape
+    U = layer.units
+    sc = rng.uniform(0.5, 2.0, U).astype(np.float32)
+    sh = rng.uniform(-1.0, 1.0, U).astype(np.float32)
+    p = mx.Planes.empty(B, T, D, "cuda")
+    dl = dev(lens, torch.int32)
+    ops.mx_planes(dev(x), D, dl, p)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"))
+    emu, _ = _emulate(layer, x, lens, True)
+    for det in (True, False):
+        d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=L.TDNN_DET_STATS if det else 0)
+        slots = ops.stats_slots(T) if det else 0
+        sums = torch.full((B, max(slots, 1), 2, U), 3.0, dtype=torch.float64, device="cuda")
+        ops.tdnn_mx_stats(p, dl, d, wh, wq, bd, dev(sc), dev(sh), sums, zero=not det)
+        out = torch.zeros((B, 2 * U), device="cuda")
+        ops.stats_finalize(sums, dl, T, U, True, 1e-10, out, slots=slots)
+        got = out.cpu().numpy()
+        for b in range(B):
+            v = emu[b, : lens[b]] * sc + sh
+            want = np.concatenate([v.mean(0), np.sqrt(np.maximum((v * v).mean(0) - v.mean(0) ** 2, 0) + 1e-10)])
+            assert np.abs(got[b] - want).max() <= 2e-5 * max(1.0, np.abs(want).max()), (det, b)
+
+
+@pytest.mark.parametrize("seed", [4321, 7])
+def test_extractor_f16mx_full_topology_10s_vs_oracle(seed):
+    """0008 topology, 160 000-sample utterances (bench workload + ragged): max-abs deviation from the fp64 oracle <= 1e-4
+    (measured 1-2e-5), with no calibration; batch == single-utterance calls bitwise."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=seed, narrow=False)
+    wav = np.concatenate([synth.make_wav(1, 160000, seed=1234), synth.make_wav(2, 160000, seed=4242, ragged=True)], 0)
+    want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+    got = mdl(dev(wav))
+    err = np.abs(got.cpu().numpy() - want).max()
+    print(f"extractor f16mx seed {seed}, 10 s, full topology: max-abs dev vs fp64 oracle {err:.3e}")
+    assert err <= 1e-4
+    for b in range(3):
+        assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), got[b]), "batch != single"
