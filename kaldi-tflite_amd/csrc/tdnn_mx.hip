@@ -42,7 +42,8 @@ typedef __attribute__((address_space(1))) const void glb_ptr_t;
 #define MX_SA_BYTES (2 * 16384 + 4096)
 #define MX_SW_OFF (MX_SA_OFF + MX_SA_BYTES)  // side W: w4 [4][256][16] | wl6a [4][256][16] | wl6b [4][256][8] | scales [4][256] u32 | pad
 #define MX_WQ_BLOCK 49152                   // bytes of one (N-tile, super-step) block of the MX weight planes (last 4 KiB unused)
-#define MX_LDS_BYTES (MX_SW_OFF + MX_WQ_BLOCK)      // 151,552 B
+#define MX_PRM_OFF (MX_SW_OFF + MX_WQ_BLOCK)        // bias | scale | shift of the tile's 256 columns (read by the epilogue)
+#define MX_LDS_BYTES (MX_PRM_OFF + 3 * 256 * 4)     // 154,624 B
 #define MX_EPI_PITCH 260
 
 struct MxParams {
@@ -75,42 +76,44 @@ __device__ __forceinline__ unsigned mx_fp4_scale_byte(float m) {
     return (unsigned)(byte < 1 ? 1 : byte);
 }
 
-// 32 values -> half plane piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word
+// 32 values -> half plane piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word.
+// (v_med3 clamp, v_cvt_pk_f16_f32, packed 16-bit maxima of the half magnitudes, v_cvt_scalef32_pk_fp4_f16 on the packed halves:
+// ~240 vector instructions per 32 values; the plain-C form was ~430.)
+typedef __attribute__((ext_vector_type(2))) float mx_f2;
+typedef __attribute__((ext_vector_type(2))) _Float16 mx_h2;
+typedef __attribute__((ext_vector_type(2))) unsigned short mx_us2;
 __device__ __forceinline__ void mx_encode32(const float (&v)[32], u32x4 (&hp)[4], u32x4& l4, u32x4& h4, unsigned& sw) {
-    float hf[32], lo[32];
-    float mh = 0.0f, ml = 0.0f;
-    unsigned short hb[32];
+    float lo[32];
+    unsigned hw[16];
+    mx_us2 hmax = {0, 0};
+    float ml = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 32; ++e) {
-        const float c = fminf(fmaxf(v[e], -65504.0f), 65504.0f);      // half planes saturate instead of overflowing to inf
-        hb[e] = f2h(c);
-        hf[e] = h2f(hb[e]);
-        lo[e] = c - hf[e];
-        mh = fmaxf(mh, fabsf(hf[e]));
-        ml = fmaxf(ml, fabsf(lo[e]));
+    for (int k = 0; k < 16; ++k) {
+        const float a = __builtin_amdgcn_fmed3f(v[2 * k], -65504.0f, 65504.0f);       // half planes saturate instead of overflowing to inf
+        const float b = __builtin_amdgcn_fmed3f(v[2 * k + 1], -65504.0f, 65504.0f);
+        const mx_h2 hh = __builtin_convertvector(mx_f2{a, b}, mx_h2);
+        hw[k] = __builtin_bit_cast(unsigned, hh);
+        lo[2 * k] = a - (float)hh[0];
+        lo[2 * k + 1] = b - (float)hh[1];
+        hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(mx_us2, hw[k] & 0x7fff7fffu));
+        ml = __builtin_fmaxf(ml, __builtin_fmaxf(__builtin_fabsf(lo[2 * k]), __builtin_fabsf(lo[2 * k + 1])));
     }
+    const unsigned short hm = hmax[0] > hmax[1] ? hmax[0] : hmax[1];
+    const float mh = (float)__builtin_bit_cast(_Float16, hm);
     const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml);
     const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        u32x4 t;
-        t.x = (unsigned)hb[8 * k + 0] | ((unsigned)hb[8 * k + 1] << 16);
-        t.y = (unsigned)hb[8 * k + 2] | ((unsigned)hb[8 * k + 3] << 16);
-        t.z = (unsigned)hb[8 * k + 4] | ((unsigned)hb[8 * k + 5] << 16);
-        t.w = (unsigned)hb[8 * k + 6] | ((unsigned)hb[8 * k + 7] << 16);
-        hp[k] = t;
-    }
-    unsigned wl[4] = {0, 0, 0, 0}, wh_[4] = {0, 0, 0, 0};
+    unsigned wl[4], wh_[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {            // dword k = elements 8k .. 8k+7, byte s = elements 8k+2s, 8k+2s+1
-        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 0], lo[8 * k + 1], sl, 0);
-        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 2], lo[8 * k + 3], sl, 1);
-        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 4], lo[8 * k + 5], sl, 2);
-        wl[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wl[k], lo[8 * k + 6], lo[8 * k + 7], sl, 3);
-        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 0], hf[8 * k + 1], sh, 0);
-        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 2], hf[8 * k + 3], sh, 1);
-        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 4], hf[8 * k + 5], sh, 2);
-        wh_[k] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(wh_[k], hf[8 * k + 6], hf[8 * k + 7], sh, 3);
+        unsigned x = 0, y = 0;
+#define MX_ENC_S(s_)                                                                                                   \
+        x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(x, lo[8 * k + 2 * s_], lo[8 * k + 2 * s_ + 1], sl, s_);           \
+        y = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(y, __builtin_bit_cast(mx_h2, hw[4 * k + s_]), sh, s_);
+        MX_ENC_S(0) MX_ENC_S(1) MX_ENC_S(2) MX_ENC_S(3)
+#undef MX_ENC_S
+        wl[k] = x;
+        wh_[k] = y;
+        hp[k] = u32x4{hw[4 * k], hw[4 * k + 1], hw[4 * k + 2], hw[4 * k + 3]};
     }
     l4 = u32x4{wl[0], wl[1], wl[2], wl[3]};
     h4 = u32x4{wh_[0], wh_[1], wh_[2], wh_[3]};
@@ -216,26 +219,26 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
     const int kk_ = (ks_) < p.nk ? (ks_) : 0;             /* padded K-steps re-read step 0 (their weights are zero) */ \
     const int c_ = kk_ / p.nctx;                                                                                       \
     const int off_ = p.ctx[kk_ - c_ * p.nctx];
-#define MX_ISSUE_F16(ks_)                                                                                              \
+    // one 16-byte-per-lane DMA of the half stage of K-step ks_: i = 0, 1 the A image (rows 0-127 / 128-255), 2, 3 the W image
+#define MX_DMA_F16(ks_, n_)                                                                                            \
     {                                                                                                                  \
-        MX_KSTEP(ks_, c__, off__)                                                                                      \
         unsigned char* st_ = rsm + ((ks_) & 1) * MX_STAGE + wave * 1024;                                               \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-            int r_ = a_row[i] + off__;                                                                                 \
+        if ((n_) < 2) {                                                                                                \
+            MX_KSTEP(ks_, c__, off__)                                                                                  \
+            int r_ = a_row[(n_) & 1] + off__;                                                                          \
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 64u + a_cb[i];                                  \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
-        }                                                                                                              \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
-            const unsigned vo_ = (unsigned)(ks_) * (unsigned)MX_TILE + (unsigned)(i * 512 + tid) * 16u;                \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + MX_TILE + i * 8192), 16, 0, 0); \
+            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 64u + a_cb[(n_) & 1];                           \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + ((n_) & 1) * 8192), 16, 0, 0); \
+        } else {                                                                                                       \
+            const unsigned vo_ = (unsigned)(ks_) * (unsigned)MX_TILE + (unsigned)(((n_) & 1) * 512 + tid) * 16u;       \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + MX_TILE + ((n_) & 1) * 8192), 16, 0, 0); \
         }                                                                                                              \
     }
-    // side A of super-step ss: 32 KiB of e2m1 pieces (4 DMAs per wave) + 4 KiB of scale words (2 four-byte DMAs per wave)
-#define MX_ISSUE_SIDE_A(ss_)                                                                                           \
+    // side A of super-step ss_: n_ = 0..3 the e2m1 pieces (32 KiB: plane, K block, 64-row group by wave), 4, 5 the scale words
+#define MX_DMA_SA(ss_, n_)                                                                                             \
     {                                                                                                                  \
-        _Pragma("unroll") for (int n = 0; n < 4; ++n) {                                                                \
-            const int idx_ = n * 8 + wave;                                                                             \
+        if ((n_) < 4) {                                                                                                \
+            const int idx_ = (n_) * 8 + wave;                                                                          \
             const int plane_ = idx_ >> 4, kb_ = (idx_ >> 2) & 3, rg_ = idx_ & 3;                                       \
             MX_KSTEP(4 * (ss_) + kb_, c__, off__)                                                                      \
             int r_ = t0 + rg_ * 64 + lane + off__;                                                                     \
@@ -243,9 +246,8 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
             const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 16u;                                            \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)((plane_ ? x4 : xl4) + vo_),                                  \
                                              (lds_ptr_t*)(rsm + MX_SA_OFF + plane_ * 16384 + (kb_ * 256 + rg_ * 64) * 16), 16, 0, 0); \
-        }                                                                                                              \
-        _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                                \
-            const int idx_ = n * 8 + wave;                                                                             \
+        } else {                                                                                                       \
+            const int idx_ = ((n_) - 4) * 8 + wave;                                                                    \
             const int kb_ = idx_ >> 2, rg_ = idx_ & 3;                                                                 \
             MX_KSTEP(4 * (ss_) + kb_, c__, off__)                                                                      \
             int r_ = t0 + rg_ * 64 + lane + off__;                                                                     \
@@ -255,16 +257,14 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
                                              (lds_ptr_t*)(rsm + MX_SA_OFF + 32768 + (kb_ * 256 + rg_ * 64) * 4), 4, 0, 0); \
         }                                                                                                              \
     }
-    // side W of super-step ss: one contiguous 48 KiB block (6 DMAs per wave)
-#define MX_ISSUE_SIDE_W(ss_)                                                                                           \
+    // side W of super-step ss_: piece n_ = 0..5 of one contiguous 48 KiB block
+#define MX_DMA_SW(ss_, n_)                                                                                             \
     {                                                                                                                  \
-        _Pragma("unroll") for (int n = 0; n < 6; ++n) {                                                                \
-            const int idx_ = n * 8 + wave;                                                                             \
-            const unsigned vo_ = (unsigned)(ss_) * (unsigned)MX_WQ_BLOCK + (unsigned)idx_ * 1024u + (unsigned)lane * 16u; \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wq + vo_), (lds_ptr_t*)(rsm + MX_SW_OFF + idx_ * 1024), 16, 0, 0); \
-        }                                                                                                              \
+        const int idx_ = (n_) * 8 + wave;                                                                              \
+        const unsigned vo_ = (unsigned)(ss_) * (unsigned)MX_WQ_BLOCK + (unsigned)idx_ * 1024u + (unsigned)lane * 16u;  \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wq + vo_), (lds_ptr_t*)(rsm + MX_SW_OFF + idx_ * 1024), 16, 0, 0); \
     }
-    MX_ISSUE_F16(0)
+    MX_DMA_F16(0, 2) MX_DMA_F16(0, 3) MX_DMA_F16(0, 0) MX_DMA_F16(0, 1)
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -272,15 +272,15 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // epilogue constants of the lane's four columns (their global-load latency hides under the K-loop)
-    float ebias[4], esc[4], esh[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+    // epilogue constants of the tile's columns: parked in LDS now (their global-load latency hides under the K-loop, and they
+    // hold no registers during it)
+    if (tid < 256) {
+        float* prm = reinterpret_cast<float*>(rsm + MX_PRM_OFF);
+        const int n = n0 + tid;
         const bool nv = n < p.units;
-        ebias[j] = (nv && p.bias) ? p.bias[n] : 0.0f;
-        esc[j] = (nv && p.scale) ? p.scale[n] : 1.0f;
-        esh[j] = (nv && p.shift) ? p.shift[n] : 0.0f;
+        prm[tid] = (nv && p.bias) ? p.bias[n] : 0.0f;
+        prm[256 + tid] = (nv && p.scale) ? p.scale[n] : 1.0f;
+        prm[512 + tid] = (nv && p.shift) ? p.shift[n] : 0.0f;
     }
 
     const int r16 = lane & 15, q4 = lane >> 4;
@@ -300,72 +300,115 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            if (ks + 1 < nkp) MX_ISSUE_F16(ks + 1)
-            if (j == 0) MX_ISSUE_SIDE_A(ss)                 // the side area was released by the barrier above (M of ss - 1 is done)
-            if (j == 1) MX_ISSUE_SIDE_W(ss)
+            constexpr bool live = true;
+            const bool next = ks + 1 < nkp;
             const unsigned char* sa = rsm + (ks & 1) * MX_STAGE;
             const unsigned char* sw = sa + MX_TILE;
             hfrag8 bh[4];
+            hfrag8 a_cur;
+            if (live) {
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) bh[jj] = *reinterpret_cast<const hfrag8*>(sw + b_row_off + jj * 1024);
-            hfrag8 a_cur = *reinterpret_cast<const hfrag8*>(sa + a_row_off);
+                for (int jj = 0; jj < 4; ++jj) bh[jj] = *reinterpret_cast<const hfrag8*>(sw + b_row_off + jj * 1024);
+                a_cur = *reinterpret_cast<const hfrag8*>(sa + a_row_off);
+            }
+            // the step's DMAs go out one or two at a time between the row blocks' MFMAs (issued in one burst behind the barrier,
+            // all eight waves sit in DMA issue while the matrix pipes idle): the next half stage first, then -- F0: side A,
+            // F1: side W of this super-step (the side area was released by the barrier of F0: M of ss - 1 is done)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                hfrag8 a_nxt = a_cur;
-                if (i < 7) a_nxt = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 1) * 1024);
+                if (live) {
+                    hfrag8 a_nxt = a_cur;
+                    if (i < 7) a_nxt = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 1) * 1024);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
-                a_cur = a_nxt;
+                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
+                    a_cur = a_nxt;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (next) {
+                    if (i == 0) MX_DMA_F16(ks + 1, 0)
+                    if (i == 1) MX_DMA_F16(ks + 1, 1)
+                    if (i == 2) MX_DMA_F16(ks + 1, 2)
+                    if (i == 3) MX_DMA_F16(ks + 1, 3)
+                }
+                if (j == 0) {
+                    if (i == 4) { MX_DMA_SA(ss, 0) MX_DMA_SA(ss, 1) }
+                    if (i == 5) { MX_DMA_SA(ss, 2) MX_DMA_SA(ss, 3) }
+                    if (i == 6) MX_DMA_SA(ss, 4)
+                    if (i == 7) MX_DMA_SA(ss, 5)
+                }
+                if (j == 1) {
+                    if (i == 4) { MX_DMA_SW(ss, 0) MX_DMA_SW(ss, 1) }
+                    if (i == 5) { MX_DMA_SW(ss, 2) MX_DMA_SW(ss, 3) }
+                    if (i == 6) MX_DMA_SW(ss, 4)
+                    if (i == 7) MX_DMA_SW(ss, 5)
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // M: the two block-scaled terms of this super-step (side data complete since the barrier of F3)
+        // M: the two block-scaled terms of this super-step (side data complete since the barrier of F3). Two column halves: the
+        // B fragments of two column blocks (22 registers) stay resident while the eight row blocks stream past them (the A
+        // fragments are read twice; all four column blocks resident cost 44 registers and spilled).
         __builtin_amdgcn_sched_barrier(0);
         {
             const unsigned char* sA = rsm + MX_SA_OFF;
             const unsigned char* sW = rsm + MX_SW_OFF;
-            i32x8 w4[4], wl6[4];
-            unsigned wsc[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int rec = sw_col + jj * 16;
-                const u32x4 a = *reinterpret_cast<const u32x4*>(sW + rec * 16);
-                const u32x4 l0 = *reinterpret_cast<const u32x4*>(sW + 16384 + rec * 16);
-                const u32x2 l1 = *reinterpret_cast<const u32x2*>(sW + 32768 + rec * 8);
-                wsc[jj] = *reinterpret_cast<const unsigned*>(sW + 40960 + rec * 4);
-                w4[jj] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
-                wl6[jj] = i32x8{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, 0, 0};
-            }
-            u32x4 l_n = *reinterpret_cast<const u32x4*>(sA + sa_row * 16);
-            u32x4 h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + sa_row * 16);
-            unsigned s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + sa_row * 4);
+            for (int jh = 0; jh < 2; ++jh) {
+                i32x8 w4[2], wl6[2];
+                unsigned wsc[2];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const u32x4 l = l_n, h = h_n;
-                const unsigned asc = s_n;
-                if (i < 7) {                             // the next row block's fragments are read under this one's MFMAs
-                    const int rec = sa_row + (i + 1) * 16;
-                    l_n = *reinterpret_cast<const u32x4*>(sA + rec * 16);
-                    h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + rec * 16);
-                    s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + rec * 4);
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int rec = sw_col + (jh * 2 + jj) * 16;
+                    const u32x4 a = *reinterpret_cast<const u32x4*>(sW + rec * 16);
+                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(sW + 16384 + rec * 16);
+                    const u32x2 l1 = *reinterpret_cast<const u32x2*>(sW + 32768 + rec * 8);
+                    wsc[jj] = *reinterpret_cast<const unsigned*>(sW + 40960 + rec * 4);
+                    w4[jj] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+                    wl6[jj] = i32x8{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, 0, 0};
                 }
-                const i32x8 al = i32x8{(int)l.x, (int)l.y, (int)l.z, (int)l.w, 0, 0, 0, 0};
-                const i32x8 ah = i32x8{(int)h.x, (int)h.y, (int)h.z, (int)h.w, 0, 0, 0, 0};
+                u32x4 l_n = *reinterpret_cast<const u32x4*>(sA + sa_row * 16);
+                u32x4 h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + sa_row * 16);
+                unsigned s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + sa_row * 4);
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)           // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
-                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, w4[jj], acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4 l = l_n, h = h_n;
+                    const unsigned asc = s_n;
+                    if (i < 7) {                             // the next row block's fragments are read under this one's MFMAs
+                        const int rec = sa_row + (i + 1) * 16;
+                        l_n = *reinterpret_cast<const u32x4*>(sA + rec * 16);
+                        h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + rec * 16);
+                        s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + rec * 4);
+                    }
+                    const i32x8 al = i32x8{(int)l.x, (int)l.y, (int)l.z, (int)l.w, 0, 0, 0, 0};
+                    const i32x8 ah = i32x8{(int)h.x, (int)h.y, (int)h.z, (int)h.w, 0, 0, 0, 0};
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj)           // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
-                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, wl6[jj], acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int jj = 0; jj < 2; ++jj)       // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
+                        acc[i][jh * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, w4[jj], acc[i][jh * 2 + jj], 4, 4, 0, asc, 0, wsc[jj]);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)       // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
+                        acc[i][jh * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, wl6[jj], acc[i][jh * 2 + jj], 4, 2, 1, asc, 1, wsc[jj]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
-#undef MX_ISSUE_F16
-#undef MX_ISSUE_SIDE_A
-#undef MX_ISSUE_SIDE_W
+#undef MX_DMA_F16
+#undef MX_DMA_SA
+#undef MX_DMA_SW
 #undef MX_KSTEP
 
     const int rows_valid = len - t0;
+    float ebias[4], esc[4], esh[4];
+    {
+        const float* prm = reinterpret_cast<const float*>(rsm + MX_PRM_OFF);       // written before the first barrier of the K-loop
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cl = wn * 64 + j * 16 + (lane & 15);
+            ebias[j] = prm[cl];
+            esc[j] = prm[256 + cl];
+            esh[j] = prm[512 + cl];
+        }
+    }
     if constexpr (OUT == MX_OUT_STATS) {
         // fused StatsPooling (stats_pooling.py:231-240): per column the sum and the sum of squares of the wave's 128 rows, taken in
         // fp32 relative to a pivot (row 0 of the block: a constant column -- a dead ReLU unit -- gives exactly 0 and 0), then fp64
@@ -401,53 +444,75 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
     } else {
         __syncthreads();                                 // every fragment read is done: the LDS becomes the store staging area
         float* et = reinterpret_cast<float*>(rsm);
+        const bool affine = p.scale != nullptr;
 #pragma unroll
-        for (int pass = 0; pass < 4; ++pass) {           // rows wm*128 + pass*32 .. +31 of both wave rows -> 64 staged rows
+        for (int pass = 0; pass < 2; ++pass) {           // rows wm*128 + pass*64 .. +63 of both wave rows -> 128 staged rows (130 KiB)
 #pragma unroll
-            for (int ih = 0; ih < 2; ++ih) {
-                const int i = pass * 2 + ih;
+            for (int ih = 0; ih < 4; ++ih) {
+                const int i = pass * 4 + ih;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int col = wn * 64 + j * 16 + (lane & 15);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int srow = wm * 32 + ih * 16 + q4 * 4 + r;
-                        et[srow * MX_EPI_PITCH + col] = mx_act(acc[i][j][r] + ebias[j], ACT) * esc[j] + esh[j];
+                        const int srow = wm * 64 + ih * 16 + q4 * 4 + r;
+                        float v = mx_act(acc[i][j][r] + ebias[j], ACT);
+                        if (affine) v = v * esc[j] + esh[j];          // (absent when the BatchNorm is folded into the next layer)
+                        et[srow * MX_EPI_PITCH + col] = v;
                     }
                 }
             }
             __syncthreads();
             if constexpr (OUT == MX_OUT_PLANES) {
-                // one thread per (staged row, 32-column chunk): the wave's 64 lanes are 64 rows of ONE chunk, so every store
-                // instruction writes consecutive records of a plane
-                const int cidx = wave, srow = lane;
-                const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
-                const int chunk = (n0 >> 5) + cidx;
-                if (m < rows_valid && chunk < p.nch_out) {
-                    float v[32];
+                // (1) one thread per (staged row, 32-column chunk) encodes it: the wave's 64 lanes are 64 consecutive rows of ONE
+                //     chunk (chunk = wave), so the e2m1 / scale stores write consecutive records; the half piece goes back into the
+                //     staging image, in place. (2) the wave streams its chunk's half pieces out as 16-byte pieces of consecutive
+                //     records: 1 KiB of consecutive bytes per store instruction (store issue is per instruction).
+                const int chunk = (n0 >> 5) + wave;
+                const bool chunk_ok = chunk < p.nch_out;
+                const int64_t rec0 = ((int64_t)b * p.nch_out + chunk) * p.T + t0;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const f32x4 t = *reinterpret_cast<const f32x4*>(et + srow * MX_EPI_PITCH + cidx * 32 + k * 4);
-                        v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+                for (int hsel = 0; hsel < 2; ++hsel) {
+                    const int srow = hsel * 64 + lane;
+                    const int m = hsel * 128 + pass * 64 + lane;
+                    float* src = et + srow * MX_EPI_PITCH + wave * 32;
+                    if (m < rows_valid && chunk_ok) {
+                        float v[32];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const f32x4 t = *reinterpret_cast<const f32x4*>(src + k * 4);
+                            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+                        }
+                        u32x4 hp[4], l4, h4;
+                        unsigned sw_;
+                        mx_encode32(v, hp, l4, h4, sw_);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(src + k * 4) = hp[k];
+                        const int64_t rec = rec0 + m;
+                        __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));
+                        __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));
+                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));
                     }
-                    u32x4 hp[4], l4, h4;
-                    unsigned sw_;
-                    mx_encode32(v, hp, l4, h4, sw_);
-                    const int64_t rec = ((int64_t)b * p.nch_out + chunk) * p.T + (t0 + m);
-                    u32x4* dh = reinterpret_cast<u32x4*>(p.yh + rec * 64);
+                }
+                // the half pieces were written by this wave's own lanes: LDS operations of a wave complete in order
+                if (chunk_ok) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(hp[k], dh + k);
-                    __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));
-                    __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));
-                    __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));
+                    for (int n = 0; n < 8; ++n) {
+                        const int srow = n * 16 + (lane >> 2);
+                        const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
+                        if (m < rows_valid) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(et + srow * MX_EPI_PITCH + wave * 32) + (lane & 3) * 16);
+                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));
+                        }
+                    }
                 }
             } else {
                 const int nl = lane * 4;
                 const int n = n0 + nl;
 #pragma unroll
-                for (int sp = 0; sp < 8; ++sp) {
+                for (int sp = 0; sp < 16; ++sp) {
                     const int srow = sp * 8 + wave;
-                    const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
+                    const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
                     if (m < rows_valid) {
                         const f32x4 v = *reinterpret_cast<const f32x4*>(et + srow * MX_EPI_PITCH + nl);
                         float* yp = p.yf + ((int64_t)b * p.T + t0 + m) * p.ldy + n;

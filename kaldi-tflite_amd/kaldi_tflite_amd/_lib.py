@@ -10,8 +10,11 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# KTF_LIBRARY: measurement hook only (a probe build of the same ABI, `make -C csrc probe`); unset = the in-tree product library
-LIB_PATH = os.environ.get("KTF_LIBRARY") or os.path.join(_HERE, "libktf_hip.so")
+# The product loads the in-tree library. KTF_LIBRARY names another build of the same ABI (probe / timing-ablation builds of
+# tools/) and is honoured ONLY together with KTF_ALLOW_LIBRARY_OVERRIDE=1, so that a variable left over in a shell cannot
+# silently swap the library; bench.py records the path that was loaded.
+_OVERRIDE = os.environ.get("KTF_LIBRARY") if os.environ.get("KTF_ALLOW_LIBRARY_OVERRIDE") == "1" else None
+LIB_PATH = _OVERRIDE or os.path.join(_HERE, "libktf_hip.so")
 
 KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
 GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2, GEMM_F16MX = 0, 1, 2, 3, 4, 5
