@@ -7,15 +7,15 @@ tdnn6 -> LDA/length-norm) over one batch of synthetic 10 s / 16 kHz utterances t
 Workload (config.workload): the BASELINE "8 192 utterances over 8 GPUs" configuration = 1 024 utterances per GPU
 (weak scaling: per-GPU batch fixed), 0008_sitw_v2_1a topology with seeded random weights, dither 0.
 
-The timed arithmetic (`dtype`) defaults to "f16x2": half-precision MFMA passes with fp32 accumulation — two per product
-where the weight residual matters (tdnn1; the high-variance half of tdnn2's / tdnn3's input features), ONE elsewhere (their
-other half; the two layers in front of the pooling: weights rounded to nearest half, the constant part of the rounding error
-moved into the fp32 bias) — activations stored as one half plane of ReLU outputs, in order of decreasing variance, with the
-BatchNorm folded into the next layer. The input means / variances this needs are measured by XvectorExtractor.calibrate on
-four utterances that are neither timed nor checked (`--full-residual`, `--two-pass-everywhere` are the A/Bs). The fastest
-form that meets north_star's <= 1e-4 max-abs deviation (the line carries the measured deviation of the timed model at the full
-10 s size and `tolerance_ok`). `--gemm bf16x3` (split-bf16, 4e-6) and `--gemm f32` (exact) are the tighter modes;
-one-pass bf16 / f16 are side legs outside the tolerance.
+The timed arithmetic (`dtype`) defaults to "f16mx" (csrc/tdnn_mx.hip): ONE half-precision MFMA pass plus two block-scaled
+(OCP MX) residual passes at four times the half rate on v_mfma_scale_f32_16x16x128_f8f6f4 -- x_h w_h + fp4(x - x_h) fp4(w) +
+fp4(x_h) fp6(w - w_h), one power-of-two scale per 32 K elements -- 1.5 MFMA passes per algorithmic flop with ~15 significant
+bits on both operands and NO calibration. It is the fastest mode that meets north_star's <= 1e-4 max-abs deviation ON EVERY
+INPUT: the line's `max_abs_dev_vs_fp64_oracle` is the maximum over stationary noise (the timed workload), utterances with quiet
+blocks AND the reference's own end-to-end speech recording (whole and in 10 s chunks), and `timed_batch_vs_f32` compares all
+1024 timed x-vectors with the exact fp32 kernels. `--gemm bf16x3` (split-bf16) and `--gemm f32` (exact) are the tighter
+modes (bf16x3 carries its own roofline block in `other_configs`); `--gemm f16x2` is round 2's calibrated half-precision form,
+which passes on noise and is 4-7e-4 on speech (reported with tolerance_ok false), like one-pass bf16 / f16.
 
     python bench.py                      # 1 GPU
     python bench.py --gpus 8             # starts 8 ranks itself (torch.distributed.run) when WORLD_SIZE is unset
@@ -61,7 +61,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--gemm", default="f16x2", choices=["bf16", "f16", "bf16x3", "f16x2", "f16mx", "f32"])
+    ap.add_argument("--gemm", default="f16mx", choices=["bf16", "f16", "bf16x3", "f16x2", "f16mx", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other modes, latency, PLDA)")
@@ -190,10 +190,6 @@ def main(argv=None):
                    "collective_backend": backend, "fused_pooling": "atomic" if args.atomic_pooling else "reproducible"},
     }
     # ---- roofline of the dominant kernel: TDNN GEMM launches (5 per step), algorithmic FLOPs / measured duration
-    flops_per_step = B * T * FLOP_PER_FRAME_TDNN
-    gemm_ms_per_step = gemm_stats["total_ms"] / args.steps
-    achieved = flops_per_step / (gemm_ms_per_step * 1e-3) / 1e12
-    peak = PEAK_TFLOPS[args.gemm]
     passes = float(MFMA_PASSES[args.gemm])
     if args.gemm == "f16x2" and not args.two_pass_everywhere and mdl.xvec._xbar:
         # MAC per frame: tdnn1 76 800, tdnn2 / tdnn3 786 432 each, tdnn4 262 144, tdnn5 768 000; the last one_pass_tail of them run one pass
@@ -205,42 +201,23 @@ def main(argv=None):
             elif i >= 1 and mdl.xvec.lo_fraction > 0 and mdl.xvec.k_interleaved:      # tdnn2 / tdnn3: residual for the high-variance half only
                 per[i] = 2.0 - mdl.xvec.lo_fraction
         passes = sum(m * q for m, q in zip(mac, per)) / float(sum(mac))
-    out["roofline"] = {
-        "bound": "mfma", "kernel": KERNELS[args.gemm],
-        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
-        "mfma_passes_per_flop": passes,
-        "mfma_issue_equivalent": achieved * passes,
-        "frac_mfma_issue_equivalent": achieved * passes / peak,
-        "launches_per_step": gemm_stats["launches"] // args.steps, "avg_launch_ms": gemm_stats["total_ms"] / max(gemm_stats["launches"], 1),
-        "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],
-        "algorithmic_flop_per_step": flops_per_step,
-        "per_layer_tflops": {k: _layer_flops(k, B, T) / (v * 1e-3) / 1e12 for k, v in gemm_stats["per_layer_ms"].items()},
-        "note": ("achieved / frac count ALGORITHMIC flops (SURVEY 8d: 5 359 616 per voiced frame); this mode issues "
-                 f"{passes:.3g} 16-bit MFMA passes per algorithmic flop, so the matrix pipe is busy at frac_mfma_issue_equivalent")
-                if passes > 1 else "",
-    }
+    out["roofline"] = _roofline(args.gemm, gemm_stats, args.steps, B, T, passes)
     # HBM traffic of those launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE),
     # committed under profiles/: it cannot be collected from inside this process
-    tpath = os.path.join(ROOT, "profiles", f"r2_traffic_{args.gemm}.json")
-    if B == 1024 and os.path.exists(tpath):
-        with open(tpath) as f:
-            tj = json.load(f)
-        nl = max(out["roofline"]["launches_per_step"], 1)
-        out["roofline"]["traffic"] = tj["tdnn_gemm_bytes_per_step_corrected"] / nl
-        alg = tj.get("tdnn_gemm_algorithmic_bytes_per_step")
-        out["roofline"]["traffic_note"] = (f"HBM bytes per launch = PMC bytes per step ({os.path.relpath(tpath, ROOT)}: "
-                                           f"{tj['tdnn_gemm_bytes_per_step_corrected']:.4g}) / {nl} GEMM launches"
-                                           + (f"; algorithmic {alg / nl:.4g} per launch" if alg else ""))
+    if B == 1024:
+        _attach_traffic(out["roofline"], args.gemm)
     out["mfcc"] = _bench_mfcc(torch, mdl, wav, ops)
     # side measurements and the CPU baseline belong to the single-GPU run only (rank 0 at N = 1)
     if world == 1 and not args.no_parity:
         # the deviation of the TIMED mode from the fp64 CPU oracle at the full utterance length: part of the headline
-        dev_info = _parity_sample(torch, ktf, synth, cfg, w, [args.gemm] if args.no_extra else ["f32", "bf16x3", "f16x2", "f16", "bf16"], dev, N,
-                                  calibrate=not args.two_pass_everywhere)
-        out["max_abs_dev_vs_fp64_oracle"] = dev_info[args.gemm]
+        modes = [args.gemm] if args.no_extra else sorted({"f32", "bf16x3", "f16mx", "f16x2", "f16", "bf16", args.gemm})
+        dev_info = _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N, calibrate=not args.two_pass_everywhere)
+        out["max_abs_dev_vs_fp64_oracle"] = dev_info[args.gemm]["max"]
+        out["max_abs_dev_by_input"] = dev_info[args.gemm]
         out["tolerance"] = TOLERANCE
-        out["tolerance_ok"] = bool(dev_info[args.gemm] <= TOLERANCE)
+        out["tolerance_ok"] = bool(dev_info[args.gemm]["max"] <= TOLERANCE)
         out["parity_sample"] = dev_info["sample"]
+        out["timed_batch_vs_f32"] = _timed_batch_vs_f32(torch, ktf, synth, cfg, w, wav, y if world == 1 else mdl(wav))
         if not args.no_extra:
             out["other_configs"] = _other_configs(torch, ktf, synth, cfg, w, wav, args.gemm, dev, dev_info, mdl)
         if not args.no_cpu_baseline:
@@ -295,6 +272,7 @@ class _GemmProfiler:
         return {"total_ms": total, "launches": len(self.events), "per_layer_ms": {k: v / steps for k, v in per.items()}}
 
 
+
 def _bench_mfcc(torch, mdl, wav, ops, iters=10):
     """Secondary BASELINE metric: MFCC frames/s per GPU (fused Framing+MFCC kernel alone) against both of its ceilings:
     HBM (760 algorithmic bytes per frame) and VALU (~25 kFLOP per frame at the fp32 vector peak)."""
@@ -324,21 +302,80 @@ def _bench_mfcc(torch, mdl, wav, ops, iters=10):
 
 
 def _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N, calibrate=True):
-    """max-abs deviation from the fp64 CPU oracle (the checker) at the FULL utterance length: one all-voiced utterance of
-    the bench workload and one with quiet blocks (ragged), per GEMM mode."""
+    """max-abs deviation from the fp64 CPU oracle (the checker), per GEMM mode, over three kinds of input at the FULL utterance
+    length: stationary noise as timed (all-voiced), noise with quiet blocks (ragged), and the reference's end-to-end speech
+    recording (testdata/librispeech_2.wav = tests/golden/e2e_0008.npz: 22.5 s whole, and its first two 10 s chunks). A mode is
+    `tolerance_ok` only if the maximum over ALL of them is inside the tolerance."""
     import numpy as np
     from oracle import ktf_oracle as O
-    wav = np.concatenate([synth.make_wav(2, N, seed=1234), synth.make_wav(2, N, seed=4242, ragged=True)], 0)
-    want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
-    res = {"sample": f"4 utterances x {N} samples (two all-voiced as timed, two with 30 % quiet 0.5 s blocks), 0008 topology, fp64 NumPy oracle"}
+    whole, chunks = synth.speech_wavs(N)
+    inputs = {"noise_as_timed": synth.make_wav(2, N, seed=1234), "noise_quiet_blocks": synth.make_wav(2, N, seed=4242, ragged=True),
+              "speech_22s": whole, "speech_10s_chunks": chunks}
+    want = {k: O.xvector_forward(v, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64) for k, v in inputs.items()}
+    res = {"sample": f"fp64 NumPy oracle, 0008 topology, weights seed 4321: 2 + 2 synthetic utterances x {N} samples (all-voiced as timed / 30 % quiet "
+                     f"0.5 s blocks) + the reference's e2e speech recording (359 665 samples whole, and as two {N}-sample chunks)"}
     for g in modes:
         m = synth.build_extractor(ktf, cfg, w, gemm=g, calibrate=calibrate)
-        m.xvec.min_tiles = {}          # two utterances would be routed to the fp32 kernels: measure the mode's own
-        got = m(torch.as_tensor(wav, device=dev)).cpu().numpy()
-        res[g] = float(np.abs(got - want).max())
+        m.xvec.min_tiles = {}          # a few utterances would be routed to the fp32 kernels: measure the mode's own
+        r = {}
+        for k, v in inputs.items():
+            got = m(torch.as_tensor(v, device=dev)).cpu().numpy().reshape(v.shape[0], -1)
+            r[k] = float(np.abs(got - want[k]).max())
+        r["max"] = max(r.values())
+        res[g] = r
         del m
     torch.cuda.empty_cache()
     return res
+
+
+def _timed_batch_vs_f32(torch, ktf, synth, cfg, w, wav, y):
+    """Every x-vector of the TIMED batch against the exact fp32 kernels on the same waveforms (fp32 is 2e-6 from the fp64 oracle):
+    the maximum, and high quantiles of the per-utterance maxima -- the tolerance claim on all B x 128 timed numbers, not on a sample."""
+    m = synth.build_extractor(ktf, cfg, w, gemm="f32")
+    ref = m(wav)
+    per_utt = (y.double() - ref.double()).abs().amax(dim=1)
+    q = torch.quantile(per_utt, torch.tensor([0.5, 0.99, 0.999], dtype=torch.float64, device=per_utt.device))
+    del m
+    torch.cuda.empty_cache()
+    return {"utterances": int(per_utt.numel()), "max": float(per_utt.max()), "median": float(q[0]), "p99": float(q[1]), "p99.9": float(q[2]),
+            "tolerance_ok": bool(float(per_utt.max()) <= TOLERANCE)}
+
+
+def _roofline(gemm, gemm_stats, steps, B, T, passes):
+    flops_per_step = B * T * FLOP_PER_FRAME_TDNN
+    gemm_ms_per_step = gemm_stats["total_ms"] / steps
+    achieved = flops_per_step / (gemm_ms_per_step * 1e-3) / 1e12
+    peak = PEAK_TFLOPS[gemm]
+    return {
+        "bound": "mfma", "kernel": KERNELS[gemm],
+        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+        "mfma_passes_per_flop": passes,
+        "mfma_issue_equivalent": achieved * passes,
+        "frac_mfma_issue_equivalent": achieved * passes / peak,
+        "launches_per_step": gemm_stats["launches"] // steps, "avg_launch_ms": gemm_stats["total_ms"] / max(gemm_stats["launches"], 1),
+        "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],
+        "algorithmic_flop_per_step": flops_per_step,
+        "per_layer_tflops": {k: _layer_flops(k, B, T) / (v * 1e-3) / 1e12 for k, v in gemm_stats["per_layer_ms"].items()},
+        "note": ("achieved / frac count ALGORITHMIC flops (SURVEY 8d: 5 359 616 per voiced frame); this mode issues "
+                 f"{passes:.3g} 16-bit-rate MFMA passes per algorithmic flop, so the matrix pipe is busy at frac_mfma_issue_equivalent")
+                if passes > 1 else "",
+    }
+
+
+def _attach_traffic(roof, gemm):
+    """HBM traffic of the GEMM launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950, WRITE_SIZE) committed
+    under profiles/: it cannot be collected from inside this process."""
+    for tpath in (os.path.join(ROOT, "profiles", "r3", f"traffic_{gemm}.json"), os.path.join(ROOT, "profiles", f"r2_traffic_{gemm}.json")):
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            nl = max(roof["launches_per_step"], 1)
+            roof["traffic"] = tj["tdnn_gemm_bytes_per_step_corrected"] / nl
+            alg = tj.get("tdnn_gemm_algorithmic_bytes_per_step")
+            roof["traffic_note"] = (f"HBM bytes per launch = PMC bytes per step ({os.path.relpath(tpath, ROOT)}: "
+                                    f"{tj['tdnn_gemm_bytes_per_step_corrected']:.4g}) / {nl} GEMM launches"
+                                    + (f"; algorithmic {alg / nl:.4g} per launch" if alg else ""))
+            return
 
 
 def _layer_flops(key, B, T):
@@ -364,15 +401,36 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     1024-utterance step in the other GEMM arithmetic modes (each with its deviation from the fp64 oracle), a ragged
     variant of the workload, batch-1 latency (config 2), batch 256 (config 3) and the 1024 x 1024 PLDA trial matrix (config 5)."""
     import numpy as np
+    from kaldi_tflite_amd import ops
     res = {}
     B = wav.shape[0]
-    for g in ("f32", "bf16x3", "f16x2", "f16", "bf16"):
+    T = mdl.framing.numFrames(wav.shape[1])
+    for g in ("f32", "bf16x3", "f16mx", "f16x2", "f16", "bf16"):
         if g == gemm:
             continue
         m = synth.build_extractor(ktf, cfg, w, gemm=g, calibrate=True)
         ms = _time_ms(torch, lambda: m(wav), 5)
-        res[g] = {"x_vectors_per_s": B / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info[g],
-                  "tolerance_ok": bool(dev_info[g] <= TOLERANCE)}
+        res[g] = {"x_vectors_per_s": B / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info[g]["max"],
+                  "max_abs_dev_by_input": {k: v for k, v in dev_info[g].items() if k != "max"},
+                  "tolerance_ok": bool(dev_info[g]["max"] <= TOLERANCE)}
+        if g == "f16x2":
+            res[g]["note"] = ("round 2's calibrated form (one-pass tail + residual prefix, calibrated on stationary noise): inside the "
+                              "tolerance on noise only")
+        if g in ("bf16x3", "f16mx"):      # the modes that are compliant on any input: a driver-timed roofline block of their own
+            prof = _GemmProfiler(ops, torch)
+            for _ in range(3):
+                m(wav)
+            prof.reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                m(wav)
+            torch.cuda.synchronize()
+            ms20 = 1e3 * (time.perf_counter() - t0) / 20
+            res[g].update({"x_vectors_per_s": B / (ms20 * 1e-3), "ms_per_step": ms20, "steps": 20,
+                           "roofline": _roofline(g, prof.finish(), 20, B, T, float(MFMA_PASSES[g]))})
+            if B == 1024:
+                _attach_traffic(res[g]["roofline"], g)
         del m
         torch.cuda.empty_cache()
     # the same step on utterances with silence: 30 % of the 0.5 s blocks are quiet, the VAD drops them, batches are ragged
@@ -404,13 +462,13 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     m256 = synth.build_extractor(ktf, cfg, w, gemm="bf16")
     x256 = wav[:256].contiguous()
     ms = _time_ms(torch, lambda: m256(x256), 10)
-    res["config3_batch256_bf16"] = {"x_vectors_per_s": 256 / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info["bf16"],
-                                    "tolerance_ok": bool(dev_info["bf16"] <= TOLERANCE)}
+    res["config3_batch256_bf16"] = {"x_vectors_per_s": 256 / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info["bf16"]["max"],
+                                    "tolerance_ok": bool(dev_info["bf16"]["max"] <= TOLERANCE)}
     del m256
-    m256 = synth.build_extractor(ktf, cfg, w, gemm="f16x2", calibrate=True)       # the same batch in the fastest mode inside the tolerance
+    m256 = synth.build_extractor(ktf, cfg, w, gemm="f16mx")       # the same batch in the fastest mode inside the tolerance
     ms = _time_ms(torch, lambda: m256(x256), 10)
-    res["config3_batch256_f16x2"] = {"x_vectors_per_s": 256 / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info["f16x2"],
-                                     "tolerance_ok": bool(dev_info["f16x2"] <= TOLERANCE)}
+    res["config3_batch256_f16mx"] = {"x_vectors_per_s": 256 / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info["f16mx"]["max"],
+                                     "tolerance_ok": bool(dev_info["f16mx"]["max"] <= TOLERANCE)}
     del m256
     # BASELINE config 2: batch 1, fp32 — eager launches and the captured hipGraph (XvectorExtractor.compile)
     m1 = synth.build_extractor(ktf, cfg, w, gemm="f32")
