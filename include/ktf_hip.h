@@ -255,6 +255,10 @@ typedef struct KtfTdnnDesc {
                                    * features by decreasing activation variance and folds the constant part of the dropped
                                    * residual into the bias (TDNN.device_weights). Bits 8..23; 0 = every chunk two passes */
 
+/* name of the kernel family the calling thread's last ktf_tdnn* / ktf_tdnn_mx* call launched ("" before the first; a static
+ * string). For the dispatch tests: which kernel a (gemm mode, layer shape) pair runs on is part of the library's contract. */
+const char* ktf_tdnn_last_kernel(void);
+
 /* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
 int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);
 

@@ -27,14 +27,11 @@
 // per utterance (SAME padding = edge replication, layers/tdnn/tdnn.py:246-247 of the reference).
 //
 // Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88, stats_pooling.py:211-240 when fused).
-#include "common.h"
+#include "tdnn_common.h"
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 hfrag8;
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-typedef __attribute__((address_space(3))) void lds_ptr_t;
-typedef __attribute__((address_space(1))) const void glb_ptr_t;
 
 #define MX_TILE 16384                       // one half operand image of a K-step: 256 rows x 64 B
 #define MX_STAGE (2 * MX_TILE)              // A | W
@@ -566,6 +563,7 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     if (stats && !p.stat_slots) (void)0;      // (atomic form: the caller zeroes the sums)
 #define MX_LAUNCH(A, O)                                                                                                \
     {                                                                                                                  \
+        KTF_NOTE_KERNEL("tdnn_mx_kernel");                                                                             \
         KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O>);                                                              \
         hipLaunchKernelGGL((tdnn_mx_kernel<A, O>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
     }

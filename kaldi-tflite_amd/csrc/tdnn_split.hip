@@ -1,0 +1,486 @@
+// The plane kernels: KTF_GEMM_BF16X3 (split-bf16: x = hi + lo, w = hi + lo, three bf16 MFMA passes, fp32-grade accuracy) and
+// KTF_GEMM_F16X2 (half activations as one plane, weights as hi + lo half planes: two passes, or one where the host dropped the
+// residual) on the 256 x 256 ring tile.
+#include "tdnn_ring.h"
+
+// ------------------------------------------------------------------------------------ BF16X3, 256x256 tile
+// Split-bf16 on the 256x256 structure: fp32 activations are staged RAW (256 rows x 32 k x 4 B = 128-byte rows, chunk
+// permutation c ^ ((row>>1)&7)) and split into bf16 hi/lo parts in registers when the fragments are read; the weights are
+// pre-split on the host into two bf16 planes. acc += hi*hi + lo*hi + hi*lo: 48 MFMAs per wave per K-step against 8 DMA
+// instructions, so a plain double buffer (2 x 64 KiB) with one stage in flight covers the DMA latency.
+#define X_STAGE_BYTES (32768 + 2 * R_TILE_BYTES)    // A fp32 + W hi + W lo = 64 KiB
+#define X_LDS_BYTES (2 * X_STAGE_BYTES)             // 128 KiB (epilogue staging 66,560 B fits)
+
+__device__ __forceinline__ void split_bf16x8(const f32x4& v0, const f32x4& v1, bfrag8& hi, bfrag8& lo) {
+    union { bfrag8 f; unsigned u[4]; } H, Lw;
+    const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned short h0 = f2bf(x[2 * e]), h1 = f2bf(x[2 * e + 1]);
+        H.u[e] = (unsigned)h0 | ((unsigned)h1 << 16);
+        const unsigned short l0 = f2bf(x[2 * e] - bf2f(h0)), l1 = f2bf(x[2 * e + 1] - bf2f(h1));
+        Lw.u[e] = (unsigned)l0 | ((unsigned)l1 << 16);
+    }
+    hi = H.f;
+    lo = Lw.f;
+}
+
+// (Activations that already travel as hi / lo bf16 planes -- the model's own route -- run on tdnn_x3s_kernel below, whose K-loop
+// carries no conversion: the in-register split here costs ~190 VALU instructions per wave per K-step, four times redundantly
+// per A tile. This kernel serves callers that hand in fp32 activations.)
+template <int ACT, bool STATS>
+__global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
+                                                       double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = (slot / ntiles) * 8 + xcd;
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * R_BM;
+    if (t0 >= out_len || len <= 0) return;
+    const int n0 = nt * R_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    constexpr int XB = 4;                              // bytes per activation element
+    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * XB;
+    const char* wb = reinterpret_cast<const char*>(p.w);
+    const char* wl = reinterpret_cast<const char*>(p.w_lo);
+    const unsigned ldxb = (unsigned)p.ldx * XB;
+
+    // A staging: chunk q = i*512 + tid (i < 4) -> row q/8, LDS position q%8, global chunk (q%8) ^ ((row>>1)&7)
+    int a_t[4];
+    unsigned a_cb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q >> 3;
+        a_cb[i] = (unsigned)(((q & 7) ^ ((row >> 1) & 7)) * 16);
+        a_t[i] = start + (t0 + row) * p.sub;
+    }
+    // W staging (both planes): chunk q = i*512 + tid (i < 2) -> row q/4, position q%4, global chunk (q%4) ^ ((row>>2)&3)
+    unsigned w_ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q >> 2;
+        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + (unsigned)(((q & 3) ^ ((row >> 2) & 3)) * 16);
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / R_BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * XB;
+#define X_STAGE()                                                                                                      \
+    {                                                                                                                  \
+        unsigned char* st_ = rsm + (is_ks & 1) * X_STAGE_BYTES + wave * 1024;                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                \
+            int r_ = a_t[i] + is_off;                                                                                  \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                      \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            const unsigned vo_ = w_ob[i] + (unsigned)(is_ks * (R_BK * 2));                                             \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + vo_), (lds_ptr_t*)(st_ + 32768 + i * 8192), 16, 0, 0);  \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + 32768 + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+        ++is_ks;                                                                                                       \
+        is_db += R_BK * XB;                                                                                            \
+        if (is_db == dpad_b) {                                                                                         \
+            is_db = 0;                                                                                                 \
+            ++is_c;                                                                                                    \
+            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
+        }                                                                                                              \
+    }
+
+    X_STAGE()
+    const int rswa = ((lane & 31) >> 1) & 7;               // A: 128-B rows
+    const int rswb = ((lane & 31) >> 2) & 3;               // W: 64-B rows
+    const int a_row_off = (wm * 128 + (lane & 31)) * 128;
+    const int b_row_off = (wn * 64 + (lane & 31)) * 64;
+    const int hsel = lane >> 5;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // stage ks landed (nothing else is in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (is_ks < nk) X_STAGE()                            // stage ks+1 -> the buffer every wave finished reading (stage ks-1)
+        const unsigned char* sa = rsm + (ks & 1) * X_STAGE_BYTES;
+        const unsigned char* sh = sa + 32768;
+        const unsigned char* sl = sh + R_TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bfrag8 ah[4], al[4], bh[2], bl[2];
+            const int cb = ((kk * 2 + hsel) ^ rswb) << 4;
+            {
+                const int ca = kk * 4 + 2 * hsel;            // first of the two 16-B chunks holding k = 16kk + 8h .. +7
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const unsigned char* row = sa + a_row_off + i * 32 * 128;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(row + ((ca ^ rswa) << 4));
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(row + (((ca + 1) ^ rswa) << 4));
+                    split_bf16x8(v0, v1, ah[i], al[i]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bh[j] = *reinterpret_cast<const bfrag8*>(sh + b_row_off + j * 32 * 64 + cb);
+                bl[j] = *reinterpret_cast<const bfrag8*>(sl + b_row_off + j * 32 * 64 + cb);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#undef X_STAGE
+    __syncthreads();
+    ring_epilogue<ACT, STATS>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+}
+
+// ------------------------------------------------------------------------------------ BF16X3 on 16x16x32, split planes
+// The plane kernel. Split-bf16 (TERMS = 3): hi / lo activation planes, hi / lo weight planes, acc += hi*hi + lo*hi + hi*lo on
+// v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on this shape than on 32x32x16): 256 x 256 tile, 8 waves of 128 x 64, a
+// stage = A hi | A lo | W hi | W lo (4 x 16 KiB, the chunk permutation of the 16x16x32 bf16 kernel), double buffered.
+// F16 / TERMS = 2 (KTF_GEMM_F16X2): IEEE-half operands, activations as ONE half plane (no residual plane: the A lo DMAs, fragments
+// and the lo*hi pass drop out; the stage keeps its layout), weights as hi + lo half planes: acc += x*w_hi + x*w_lo. TERMS = 1: no
+// weight residual either (w_lo NULL; three 32 KiB stages).
+// Hand-scheduled K-step: the stage's operand DMAs are not issued in one burst behind the barrier (all eight waves then sit in
+// DMA issue and LDS latency together while the matrix pipes idle) but one at a time between groups of MFMAs, and the A fragments
+// of row group g+1 are read while the MFMAs of group g run (two fragment register sets).
+#define XS_STAGE_BYTES (4 * R_TILE_BYTES)                // 64 KiB
+#define XS_LDS_BYTES (2 * XS_STAGE_BYTES)                // 128 KiB
+template <int ACT, bool STATS, bool F16 = false, int TERMS = 3>
+__global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
+                                                       double* __restrict__ stats) {
+    // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused
+    constexpr int NST = (TERMS == 1) ? KTF_X1_STAGES : 2;
+    constexpr int STG = (TERMS == 1) ? 2 * R_TILE_BYTES : (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;      // one pass: A | W
+    constexpr int WOFF = (TERMS == 1 || NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
+    int fill_slot = 0, cur_slot = 0;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int g = (slot / ntiles) * 8 + xcd;
+    const int nt = slot - (slot / ntiles) * ntiles;
+    if (g >= gtiles) return;
+    const int b = g / mtiles, mt = g - b * mtiles;
+    const int n0 = nt * R_BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const char* wh = reinterpret_cast<const char*>(p.w);
+    const char* wl = reinterpret_cast<const char*>(p.w_lo);
+    unsigned a_cb[2], w_ob[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = i * 512 + tid;
+        const int row = q >> 2;
+        const unsigned chunk = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
+        a_cb[i] = chunk;
+        w_ob[i] = p.wtiled ? (unsigned)nt * (unsigned)(p.ktot / R_BK) * (unsigned)R_TILE_BYTES + (unsigned)q * 16u
+                           : (unsigned)(n0 + row) * (unsigned)p.ktot * 2u + chunk;
+    }
+    const unsigned w_step = p.wtiled ? (unsigned)R_TILE_BYTES : (unsigned)(R_BK * 2);      // bytes between consecutive K-steps of W
+    // The W half of stage 0 depends on the kernel arguments only: it is in flight while the utterance length (a dependent
+    // scalar load) and everything derived from it are still on their way (stamps: 1.6-2.0 us from entry to the last DMA of
+    // stage 0, then 0.9 us until it lands, on tiles whose K = 512 loop takes 21 us).
+    if (KTF_X3_WFIRST) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned char* st_ = rsm + wave * 1024;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);
+            if (TERMS > 1) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0);
+        }
+    }
+    // (Tried on top: the A half too, clamped to the buffer instead of the utterance -- valid while ctx[0] <= 0 -- and the
+    // epilogue constants before everything: 0.7 % and 1.5 % slower.)
+    if (KTF_X3_WFIRST) asm volatile("" ::: "memory");
+    const int len = p.lens ? p.lens[b] : (int)p.T;
+    int start;
+    const int out_len = tdnn_out_len(len, p, start);
+    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+    const int t0 = mt * R_BM;
+    if (t0 >= out_len || len <= 0) {
+        if (KTF_X3_WFIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing lands in the LDS of a finished workgroup
+        return;
+    }
+    const char* xh = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;      // (re-pointed by a timing ablation)
+    const char* xl = reinterpret_cast<const char*>(p.x_lo) + ((int64_t)b * p.T * p.ldx) * 2;
+    const unsigned ldxb = (unsigned)p.ldx * 2u;
+    int a_t[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_t[i] = start + (t0 + ((i * 512 + tid) >> 2)) * p.sub;
+
+    f32x4v acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
+
+    const int nk = p.ktot / R_BK;
+    const int lenm1 = len - 1;
+    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
+    const int dpad_b = p.din_pad * 2;
+    // A-piece address = row * x_rm + is_xb + chunk: row-major planes x_rm = row pitch, is_xb = byte offset of the 32-feature chunk in
+    // the row; chunk-major planes x_rm = 64, is_xb = chunk index * T * 64 (branch-free: both are wave-uniform scalars)
+    const unsigned x_rm = p.xchunk ? 64u : ldxb;
+    const unsigned x_cs = p.xchunk ? (unsigned)p.T * 64u : (unsigned)(R_BK * 2);
+    unsigned is_xb = 0;
+#define XS_STAGE()                                                                                                     \
+    {                                                                                                                  \
+        unsigned char* st_ = rsm + fill_slot * STG + wave * 1024;                                                      \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            int r_ = a_t[i] + is_off;                                                                                  \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = (unsigned)r_ * x_rm + a_cb[i] + is_xb;                                                \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
+            if (TERMS == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+        if (!(KTF_X3_WFIRST && is_ks == 0))                  /* stage 0's W half went out at kernel entry */           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
+            const unsigned vo_ = w_ob[i] + (unsigned)is_ks * w_step;                                                   \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);   \
+            if (TERMS > 1) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+        }                                                                                                              \
+        fill_slot = (fill_slot + 1 == NST) ? 0 : fill_slot + 1;                                                        \
+        ++is_ks;                                                                                                       \
+        if (p.kinter) {                                                                                                \
+            if (++is_c == p.nctx) {                                                                                    \
+                is_c = 0;                                                                                              \
+                is_db += R_BK * 2;                                                                                     \
+                is_xb += x_cs;                                                                                         \
+            }                                                                                                          \
+            is_off = p.ctx[is_c];                                                                                      \
+        } else {                                                                                                       \
+            is_db += R_BK * 2;                                                                                         \
+            is_xb += x_cs;                                                                                             \
+            if (is_db == dpad_b) {                                                                                     \
+                is_db = 0;                                                                                             \
+                is_xb = 0;                                                                                             \
+                ++is_c;                                                                                                \
+                is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                            \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+    XS_STAGE()
+    if (NST >= 3 && nk > 1) XS_STAGE()
+    if (NST >= 4 && nk > 2) XS_STAGE()
+    const Epi16Prm eprm = epi16_load(p, n0, wn, lane);      // issued here: the ~1 us of global-load latency hides under the K-loop
+    const int fr = (4 - (((lane & 15) >> 2) & 3)) & 3;
+    const int coff = (((lane >> 4) ^ fr) << 4);
+    const int a_row_off = (wm * 128 + (lane & 15)) * 64 + coff;
+    const int b_row_off = (wn * 64 + (lane & 15)) * 64 + coff;
+    {
+        for (int ks = 0; ks < nk; ++ks) {
+            // stage ks landed: nothing else is in flight (two stages), or only the DMAs of stage ks+1 are (three stages)
+            if (NST == 4 && ks + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // (one-pass form) stages ks + 1, ks + 2 in flight
+            else if (NST >= 3 && ks + 1 < nk) {             // stage ks + 1 may stay in flight: four DMAs per thread, six with a residual plane
+                if (TERMS == 1 || ks + 1 >= p.lo_steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            
+            const unsigned char* sa = rsm + cur_slot * STG;
+            const unsigned char* sw = sa + WOFF;
+            cur_slot = (cur_slot + 1 == NST) ? 0 : cur_slot + 1;
+            const bool refill = is_ks < nk;                     // next stage -> the buffer every wave finished reading
+            unsigned char* st_ = rsm + fill_slot * STG + wave * 1024;
+            // DMA n of the stage: 0,1 = A hi / lo rows 0-127; 2,3 = rows 128-255; 4,5 = W hi / lo rows 0-127; 6,7 = rows 128-255
+#define XS_DMA(n)                                                                                                      \
+    {                                                                                                                  \
+        const char* src_ = ((n) < 4) ? ((((n) & 1) ? xl : xh) + va[(n) >> 1]) : ((((n) & 1) ? wl : wh) + vw[((n) - 4) >> 1]); \
+        __builtin_amdgcn_global_load_lds((glb_ptr_t*)src_,                                                             \
+            (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, \
+            0);                                                                  \
+    }
+            const bool two = TERMS != 2 || ks < p.lo_steps;              // this step has a weight residual (always, outside the 2-pass form)
+            const bool two_next = TERMS != 2 || is_ks < p.lo_steps;     // ... and so has the stage being fetched
+            bfrag8 bh[4], bl[4], af[2][4];                      // af[set][0,1] = hi fragments of the group's two rows, [2,3] = lo
+            // fragment reads in the order the MFMAs consume them (LDS returns in order: the first MFMA waits for two reads, not twelve)
+            af[0][0] = *reinterpret_cast<const bfrag8*>(sa + a_row_off);
+            bh[0] = *reinterpret_cast<const bfrag8*>(sw + b_row_off);
+            __builtin_amdgcn_sched_barrier(0);       // (the scheduler otherwise moves the A read behind the eight B reads)
+#pragma unroll
+            for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
+            __builtin_amdgcn_sched_barrier(0);
+            if (TERMS == 3) af[0][2] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off);
+            if (TERMS > 1 && two) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
+            }
+            af[0][1] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + 16 * 64);
+            if (TERMS == 3) af[0][3] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + 16 * 64);
+            unsigned va[2], vw[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                int r_ = a_t[i] + is_off;
+                r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);
+                va[i] = (unsigned)r_ * x_rm + a_cb[i] + is_xb;
+                vw[i] = w_ob[i] + (unsigned)is_ks * w_step;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int PER_ROW = 4 * TERMS, PER_CHUNK = PER_ROW / 2;      // MFMAs per tile row / per chunk (4 chunks per 2-row group)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int cur = g & 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24 (4c .. 4c+3 of 16)
+                    // 2-pass form: the odd chunks are the residual passes of the group's two rows; a step behind the residual
+                    // prefix skips them (wave-uniform)
+                    if (TERMS != 2 || !(c & 1) || two)
+#pragma unroll
+                    for (int m = PER_CHUNK * c; m < PER_CHUNK * c + PER_CHUNK; ++m) {
+                        const int r = m / PER_ROW, j = m & 3;                  // row, column block
+                        const int t = (TERMS == 3) ? (m % PER_ROW) / 4 : 2 * ((m % PER_ROW) / 4);   // term: 0 hh, 1 lh, 2 hl
+                        f32x4v& cc = acc[2 * g + r][j];
+                        cc = mfma16x16x32<F16>(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c == 0 && g < 3) {
+#pragma unroll
+                        for (int r = 0; r < 2; ++r) {
+                            af[cur ^ 1][r] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + (2 * (g + 1) + r) * 16 * 64);
+                            if (TERMS == 3) af[cur ^ 1][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + (2 * (g + 1) + r) * 16 * 64);
+                        }
+                    }
+                    if (refill) {
+                        const int n = 4 * g + c;                // slot -> DMA index
+                        if (TERMS == 3) {
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
+                            else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
+                        } else if (TERMS == 1) {                   // one pass: no residual plane at all, four DMAs
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(6)
+                        } else {                                   // no residual plane of the activations: six DMAs
+                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) { if (two_next) XS_DMA(5) }
+                            else if (n == 4) XS_DMA(6) else if (n == 5) { if (two_next) XS_DMA(7) }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#undef XS_DMA
+            if (refill) {
+                fill_slot = (fill_slot + 1 == NST) ? 0 : fill_slot + 1;
+                ++is_ks;
+                if (p.kinter) {                  // next context of the same 32 features; after the last one, the next features
+                    if (++is_c == p.nctx) {
+                        is_c = 0;
+                        is_db += R_BK * 2;
+                        is_xb += x_cs;
+                    }
+                    is_off = p.ctx[is_c];
+                } else {
+                    is_db += R_BK * 2;
+                    is_xb += x_cs;
+                    if (is_db == dpad_b) {
+                        is_db = 0;
+                        is_xb = 0;
+                        ++is_c;
+                        is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;
+                    }
+                }
+            }
+        }
+    }
+#undef XS_STAGE
+    if (!STATS) __syncthreads();      // all fragment reads done before the LDS is reused as the store staging area
+    ring_epilogue16<ACT, STATS, F16>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm);
+}
+
+
+// ------------------------------------------------------------------------------------ launcher
+int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t Tout, int64_t ldy, bool split_in, double* stats_sums,
+                      hipStream_t st) {
+    const bool half2 = d->gemm == KTF_GEMM_F16X2;
+    const void* w_lo = p.w_lo;
+    if (half2) {
+        const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
+        const int64_t gtiles = B * (int64_t)mtiles;
+        const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
+        KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
+        KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn: F16X2 fuses ReLU or no activation");
+#define H2_LAUNCH(A, ST)                                                                                               \
+    do {                                                                                                               \
+        KTF_NOTE_KERNEL(w_lo ? "tdnn_x3s_kernel<f16, 2>" : "tdnn_x3s_kernel<f16, 1>");                                 \
+        if (!w_lo) {                                         /* no residual plane: ONE pass, three 32 KiB stages */     \
+            constexpr int lds1_ = KTF_X1_STAGES * 2 * R_TILE_BYTES > 5 * R_TILE_BYTES ? KTF_X1_STAGES * 2 * R_TILE_BYTES : 5 * R_TILE_BYTES;   /* >= the epilogue's staging image */ \
+            KTF_LDS_ONCE(lds1_, tdnn_x3s_kernel<A, ST, true, 1>);                                                      \
+            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, true, 1>), dim3((unsigned)nblocks), dim3(512), lds1_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        } else {                                                                                                       \
+            KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST, true, 2>);                                               \
+            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, true, 2>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        }                                                                                                              \
+    } while (0)
+        if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true); else H2_LAUNCH(KTF_ACT_RELU, false); }
+        else { if (stats_sums) H2_LAUNCH(KTF_ACT_NONE, true); else H2_LAUNCH(KTF_ACT_NONE, false); }
+#undef H2_LAUNCH
+    } else {
+        {
+            const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
+            const int64_t gtiles = B * (int64_t)mtiles;
+            const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
+            KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
+#define X_LAUNCH(A)                                                                                                    \
+    do {                                                                                                               \
+        KTF_NOTE_KERNEL("tdnn_x3r_kernel");                                                                            \
+        if (stats_sums) {                                                                                              \
+            KTF_LDS_ONCE(X_LDS_BYTES, tdnn_x3r_kernel<A, true>);                                                       \
+            hipLaunchKernelGGL((tdnn_x3r_kernel<A, true>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        } else {                                                                                                       \
+            KTF_LDS_ONCE(X_LDS_BYTES, tdnn_x3r_kernel<A, false>);                                                      \
+            hipLaunchKernelGGL((tdnn_x3r_kernel<A, false>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        }                                                                                                              \
+    } while (0)
+#define XS_LAUNCH1(A, ST)                                                                                              \
+    do {                                                                                                               \
+        KTF_NOTE_KERNEL("tdnn_x3s_kernel<bf16, 3>");                                                                   \
+        KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST>); \
+        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+    } while (0)
+#define XS_LAUNCH(A)                                                                                                   \
+    do {                                                                                                               \
+        if (stats_sums) XS_LAUNCH1(A, true); else XS_LAUNCH1(A, false);                                                \
+    } while (0)
+            // hi / lo planes in: the 16x16x32 plane kernel; fp32 activations in: the kernel that splits them in registers
+            if (split_in) {
+                if (d->act == KTF_ACT_NONE) XS_LAUNCH(KTF_ACT_NONE);
+                else if (d->act == KTF_ACT_RELU) XS_LAUNCH(KTF_ACT_RELU);
+                else if (d->act == KTF_ACT_SIGMOID) XS_LAUNCH(KTF_ACT_SIGMOID);
+                else XS_LAUNCH(KTF_ACT_TANH);
+            } else
+            if (d->act == KTF_ACT_NONE) X_LAUNCH(KTF_ACT_NONE);
+            else if (d->act == KTF_ACT_RELU) X_LAUNCH(KTF_ACT_RELU);
+            else if (d->act == KTF_ACT_SIGMOID) X_LAUNCH(KTF_ACT_SIGMOID);
+            else X_LAUNCH(KTF_ACT_TANH);
+#undef XS_LAUNCH
+#undef XS_LAUNCH1
+#undef X_LAUNCH
+        }
+    }
+    KTF_CHECK_LAUNCH("ktf_tdnn");
+    return KTF_OK;
+}

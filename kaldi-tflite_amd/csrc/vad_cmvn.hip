@@ -20,13 +20,7 @@
 #define CMVN_CHUNK 32
 
 // phase stamps of workgroup 0 (probe builds only: tools/vc_phase_probe.py)
-#ifdef KTF_TILE_PROBE
-__device__ long long* ktf_vc_probe_ptr = nullptr;
-extern "C" void ktf_probe_set_vc_buffer(void* p) { (void)hipMemcpyToSymbol(HIP_SYMBOL(ktf_vc_probe_ptr), &p, sizeof(p)); }
-#define VC_PROBE(k) { if (ktf_vc_probe_ptr && blockIdx.x == 0 && threadIdx.x == 0) ktf_vc_probe_ptr[k] = wall_clock64(); }
-#else
 #define VC_PROBE(k)
-#endif
 
 __device__ __forceinline__ float block_sum(float v, float* red /* VC_WAVES floats in LDS */) {
     v = wave_sum(v);

@@ -293,6 +293,11 @@ def vad_cmvn(feats, vad_cfg, cmvn_cfg, out, lens, idx_work, work):
     L.check(rc, "ktf_vad_cmvn")
 
 
+def last_kernel():
+    """Kernel family the calling thread's last ktf_tdnn* / ktf_tdnn_mx* call launched (include/ktf_hip.h)."""
+    return (L.load().ktf_tdnn_last_kernel() or b"").decode()
+
+
 def tdnn_out_len(T, desc):
     return int(L.load().ktf_tdnn_out_len(int(T), C.byref(desc)))
 

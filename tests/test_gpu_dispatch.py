@@ -1,0 +1,123 @@
+"""Which kernel each (GEMM mode, layer shape) runs on (run with `-m gpu`): the dispatcher's map is part of the library's
+contract -- bench.py's roofline names these kernels, and a kernel generation nothing dispatches to has no place in the library
+(tests/test_host_cpu.py::test_library_kernel_families checks the shipped set). ktf_tdnn_last_kernel() reports the family of the
+calling thread's last launch."""
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import kaldi_tflite_amd as ktf
+from kaldi_tflite_amd import ops
+from kaldi_tflite_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+FRAME_LAYERS = ["5x30->512", "3x512->512", "3x512->512", "1x512->512", "1x512->1500"]
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _reduced_modes_reach_their_kernels():
+    old = ktf.models.Sequential.min_tiles
+    ktf.models.Sequential.min_tiles = {}
+    yield
+    ktf.models.Sequential.min_tiles = old
+
+
+def trace(mdl, wav):
+    """[(layer shape, kernel family)] of every TDNN launch of one extraction."""
+    seen = []
+    names = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_mx", "tdnn_mx_stats")
+    orig = {n: getattr(ops, n) for n in names}
+
+    def wrap(fn):
+        def f(x, lens, desc, *a, **k):
+            r = fn(x, lens, desc, *a, **k)
+            seen.append((f"{int(desc.nctx)}x{int(desc.din)}->{int(desc.units)}", ops.last_kernel()))
+            return r
+        return f
+    for n in names:
+        setattr(ops, n, wrap(orig[n]))
+    try:
+        mdl(torch.as_tensor(wav, device="cuda"))
+    finally:
+        for n in names:
+            setattr(ops, n, orig[n])
+    return seen
+
+
+EXPECT = {   # mode -> kernel family of tdnn1 .. tdnn5 for a batch of full-length utterances
+    "f32": ["tdnn_f32t_kernel"] * 5,
+    "bf16": ["tdnn_bf16h_kernel<bf16>", "tdnn_bf16r16_kernel<bf16>", "tdnn_bf16r16_kernel<bf16>", "tdnn_bf16h_kernel<bf16>", "tdnn_bf16h_kernel<bf16>"],
+    "f16": ["tdnn_bf16h_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16h_kernel<f16>", "tdnn_bf16h_kernel<f16>"],
+    "bf16x3": ["tdnn_x3s_kernel<bf16, 3>"] * 5,
+    "f16x2": ["tdnn_x3s_kernel<f16, 2>"] * 5,
+    "f16mx": ["tdnn_mx_kernel"] * 5,
+}
+
+
+@pytest.mark.parametrize("gemm", sorted(EXPECT))
+def test_batch_dispatch(gemm):
+    w = synth.make_weights(seed=4321)
+    mdl = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm=gemm)
+    got = trace(mdl, synth.make_wav(32, 160000, seed=3))
+    frame = [(s, k) for s, k in got if s in FRAME_LAYERS]
+    assert [s for s, _ in frame] == FRAME_LAYERS
+    assert [k for _, k in frame] == EXPECT[gemm], frame
+    # the affine after the pooling (one row per utterance) is exact fp32 in every mode
+    tail = [k for s, k in got if s == "1x3000->512"]
+    assert len(tail) == 1 and tail[0].startswith("tdnn_f32"), got
+
+
+def test_calibrated_f16x2_runs_one_pass_in_front_of_the_pooling():
+    w = synth.make_weights(seed=4321)
+    mdl = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm="f16x2", calibrate=True)
+    got = [k for s, k in trace(mdl, synth.make_wav(32, 160000, seed=3)) if s in FRAME_LAYERS]
+    assert got == ["tdnn_x3s_kernel<f16, 2>"] * 3 + ["tdnn_x3s_kernel<f16, 1>"] * 2
+
+
+def test_single_utterance_dispatch():
+    """One 10 s utterance: every reduced mode hands it to the exact fp32 small-tile kernels (Sequential.min_tiles)."""
+    old = ktf.models.Sequential.min_tiles
+    ktf.models.Sequential.min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
+    try:
+        w = synth.make_weights(seed=4321)
+        wav = synth.make_wav(1, 160000, seed=3)
+        want = None
+        for gemm in ("f32", "bf16x3", "f16mx"):
+            got = trace(synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm=gemm), wav)
+            kernels = [k for _, k in got]
+            assert kernels[0] == "tdnn_f32s_kernel<32, 64>"                     # 30 -> 32 input columns: K-step 32
+            assert all(k.startswith("tdnn_f32s_kernel<64, ") for k in kernels[1:5]), got
+            assert kernels[5] == "tdnn_f32_rowvec_kernel"
+            want = want or kernels
+            assert kernels == want
+    finally:
+        ktf.models.Sequential.min_tiles = old
+
+
+def test_special_shapes():
+    dev = torch.device("cuda")
+    x = torch.randn((4, 300, 64), device=dev)
+    # fp32 activations handed to a split-bf16 layer: the kernel that splits them in registers
+    l = ktf.layers.TDNN(512, context=[-1, 0, 1], name="a", gemm="bf16x3")
+    l.build((None, None, 64))
+    l(x)
+    assert ops.last_kernel() == "tdnn_x3r_kernel"
+    # sigmoid on the 16-bit ring: the 32x32x16 kernel
+    l = ktf.layers.TDNN(512, context=[-1, 0, 1], activation="sigmoid", name="b", gemm="bf16")
+    l.build((None, None, 64))
+    l(x)
+    assert ops.last_kernel() == "tdnn_bf16r_kernel"
+    # a narrow layer (units <= 128)
+    l = ktf.layers.TDNN(96, context=[0], name="c", gemm="bf16")
+    l.build((None, None, 64))
+    l(x)
+    assert ops.last_kernel() in ("tdnn_bf16g_kernel", "tdnn_bf16_kernel<64, true, false>", "tdnn_bf16_kernel<64, false, false>")
+    # the bitwise reference tiles of the fp32 kernels
+    l = ktf.layers.TDNN(512, context=[0], name="d", gemm="f32")
+    l.build((None, None, 64))
+    l.kernelFlags = L.TDNN_REF_TILES
+    l(x)
+    assert ops.last_kernel().startswith("tdnn_f32_kernel<")

@@ -493,3 +493,23 @@ def test_calibrate_from_batchnorm_maps_each_layer_to_the_statistics_in_front_of_
         assert np.array_equal(m._xbar[id(cur[1])], prev[3].moving_mean.astype(np.float64))
         assert np.array_equal(m._xvar[id(cur[1])], prev[3].moving_variance.astype(np.float64))
     assert synth.build_sequential(ktf, w, "bf16x3").calibrate_from_batchnorm() == {}
+
+
+def test_library_kernel_families():
+    """The TDNN GEMM kernel instantiations shipped in libktf_hip.so are exactly the ones the dispatcher can reach (the map itself is
+    pinned on the GPU by tests/test_gpu_dispatch.py): no probe / ablation / superseded generations in the product."""
+    import collections
+    import re
+    import subprocess
+    from kaldi_tflite_amd import _lib
+    out = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    kernels = set(re.findall(r"__device_stub__(tdnn_\w+(?:<[^(]*>)?)\(", out))
+    fam = collections.Counter(k.split("<")[0] for k in kernels)
+    assert set(fam) == {"tdnn_f32_kernel", "tdnn_f32s_kernel", "tdnn_f32t_kernel", "tdnn_f32_rowvec_kernel", "tdnn_bf16_kernel",
+                        "tdnn_bf16g_kernel", "tdnn_bf16r_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16h_kernel", "tdnn_x3r_kernel",
+                        "tdnn_x3s_kernel", "tdnn_mx_kernel"}, fam
+    assert fam["tdnn_x3r_kernel"] == 8                  # 4 activations x {store, pooled}: fp32 activations only
+    assert fam["tdnn_x3s_kernel"] == 8 + 4 + 4          # split-bf16 (4 activations x 2), half two-pass and one-pass (2 x 2 each)
+    assert fam["tdnn_mx_kernel"] == 6                   # {ReLU, none} x {planes, fp32, pooled}
+    assert not any("probe" in k for k in kernels)
+    assert "getenv" not in out
