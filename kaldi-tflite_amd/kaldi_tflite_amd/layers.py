@@ -674,6 +674,8 @@ _GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat1
 class TDNN(Layer):
     """layers/tdnn/tdnn.py:29 — irregular-context 1-D convolution as an implicit-im2col MFMA GEMM."""
 
+    MAX_DEVICE_SETS = 4        # device operand sets kept per layer (keyed by mode / fold / calibration); older ones are evicted
+
     def __init__(self, units, context=[0], subsampling_factor=1, padding="SAME", use_bias=True, kernel_initializer=None,
                  bias_initializer=None, activation=None, name=None, gemm="f32", **kwargs):
         super().__init__(trainable=True, name=name, **kwargs)
@@ -708,6 +710,7 @@ class TDNN(Layer):
         self.bias = None
         self.kernelFlags = 0   # KtfTdnnDesc.flags of this layer's launches (L.TDNN_REF_TILES: bitwise-reference fp32 tiles)
         self._dev = {}
+        self._version = 0      # bumped whenever the weights change: models drop calibration / refuse stale captured graphs
 
     # ---- weights
     def build(self, input_shape):
@@ -724,6 +727,7 @@ class TDNN(Layer):
             if self.useBias:
                 lb = np.sqrt(6.0 / (self.units + 1))
                 self.bias = rng.uniform(-lb, lb, (self.units,)).astype(np.float32)
+            self._version += 1
         self._dev = {}
         self.built = True
 
@@ -754,6 +758,7 @@ class TDNN(Layer):
                 raise ValueError(f"bias shape {bias.shape} != ({self.units},)")
             self.bias = bias
         self._dev = {}
+        self._version += 1
         self.built = True
 
     def kaldi_matrix(self):
@@ -848,6 +853,8 @@ class TDNN(Layer):
             if gemm == L.GEMM_BF16X3:
                 w_lo = (W - w.to(torch.float32)).to(torch.bfloat16)
         bias = ops.to_device_f32(bias64, device) if bias64 is not None else None
+        while len(self._dev) >= self.MAX_DEVICE_SETS:        # re-calibration / mode changes replace operand sets: evict the oldest
+            self._dev.pop(next(iter(self._dev)))
         self._dev[key] = (w, w_lo, bias)
         return self._dev[key]
 

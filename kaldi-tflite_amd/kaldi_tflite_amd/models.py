@@ -79,8 +79,10 @@ class _Workspace:
         self._where = (str(device), torch.cuda.current_stream(device).cuda_stream)
 
     def get(self, role, shape, dtype, device, padded=True):
-        """`padded`: the view has pad columns nobody writes (they must read as finite zeros); a view without them is
-        handed out as is when the role's shape changes."""
+        """`padded`: the view has pad columns nobody writes (they must read as finite zeros): True zeroes the whole view when
+        the role's shape changes, an int zeroes the columns from that index on only; False hands the re-sliced bytes out as
+        they are (every kernel clamps its row reads to lens[b] - 1 and skips utterances with lens[b] == 0, so rows nobody
+        wrote are never read)."""
         if self._where is None or self._where[0] != str(device):
             self.enter(device)
         key = (role,) + self._where
@@ -94,8 +96,9 @@ class _Workspace:
             slot = [torch.zeros((nbytes,), dtype=torch.uint8, device=device), None, None]
             self._arenas[key] = slot
         view = slot[0][:nbytes].view(dtype)[:count].view(shape)
-        if slot[1] is not None and padded:
-            view.zero_()              # a different shape re-slices old bytes: pad columns must read as finite zeros
+        if slot[1] is not None and padded is not False:
+            # a different shape re-slices old bytes: pad columns must read as finite zeros
+            (view if padded is True else view[..., int(padded):]).zero_()
         slot[1], slot[2] = sig, view
         return view
 
@@ -146,6 +149,7 @@ class Sequential:
         self._xbar = {}              # calibrate(): id(layer) -> (D,) float64 mean of the layer's stored input plane
         self._xvar = {}              # ... and its variance
         self._calibrating = None
+        self._cal_sig = None         # weights signature the calibration statistics belong to
         self._build()
 
     def _build(self):
@@ -157,6 +161,11 @@ class Sequential:
             if not l.built:
                 l.build(shape)
             shape = tuple(l.compute_output_shape(shape))
+
+    def weights_signature(self):
+        """Changes whenever a TDNN / BatchNorm layer's weights change (set_weights, a re-build): calibration statistics and
+        captured graphs are tied to it."""
+        return tuple((id(l), l._version) for l in self.layers if isinstance(l, (TDNN, BatchNorm)))
 
     def get_layer(self, name):
         for l in self.layers:
@@ -216,8 +225,8 @@ class Sequential:
         ld = ops.round_up(od, 32)
         B = x_or_planes.shape[1] if x_or_planes.dim() == 4 else x_or_planes.shape[0]
         slots = ops.stats_slots(T) if self.deterministic else 0
-        sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev)
-        sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev)
+        sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev, padded=False)
+        sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev, padded=od if ld != od else False)
         kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
         wt = bool(split and self.w_tiled)
         w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=wt, one_pass_mean=one_pass_mean,
@@ -246,6 +255,8 @@ class Sequential:
             raise NotImplementedError("this layer stack is not supported by the fused ragged runner")
         dev = x.device
         self._ws.enter(dev)
+        if (self._xbar or self._xvar) and self._calibrating is None and self._cal_sig != self.weights_signature():
+            self._xbar, self._xvar = {}, {}      # the weights changed since calibrate(): its statistics describe another network
         gemm = self.batch_gemm(x.shape[0], x.shape[1])
         act_dtype = L.act_torch_dtype(gemm)
         pooled = False
@@ -477,6 +488,7 @@ class Sequential:
             self.run_ragged(x, lens)
             self._xbar = {k: v[0].cpu().numpy() for k, v in self._calibrating.items()}
             self._xvar = {k: v[1].cpu().numpy() for k, v in self._calibrating.items()}
+            self._cal_sig = self.weights_signature()
         finally:
             self._calibrating = None
             self.min_tiles = mt
@@ -496,6 +508,7 @@ class Sequential:
                 bn = prev[3]
                 self._xbar[id(cur[1])] = np.asarray(bn.moving_mean, np.float64).copy()
                 self._xvar[id(cur[1])] = np.asarray(bn.moving_variance, np.float64).copy()
+        self._cal_sig = self.weights_signature()
         return self._xbar
 
     def __call__(self, inputs, training=False):
@@ -662,11 +675,11 @@ class XvectorExtractor:
         feat_dtype = L.act_torch_dtype(self.xvec.batch_gemm(B, T))
         ws = self._ws
         ws.enter(dev)
-        mfcc = ws.get("mfcc", (B, T, D), torch.float32, dev)
-        feats = ws.get("feats", (B, T, ops.round_up(D, 32)), feat_dtype, dev)
-        lens = ws.get("lens", (B,), torch.int32, dev)
-        idx = ws.get("idx", (B, T), torch.int32, dev)
-        work = ws.get("cmvn_work", (B * T * 2 * D + 2 * D,), torch.float32, dev)
+        mfcc = ws.get("mfcc", (B, T, D), torch.float32, dev, padded=False)
+        feats = ws.get("feats", (B, T, ops.round_up(D, 32)), feat_dtype, dev, padded=D if D % 32 else False)
+        lens = ws.get("lens", (B,), torch.int32, dev, padded=False)
+        idx = ws.get("idx", (B, T), torch.int32, dev, padded=False)
+        work = ws.get("cmvn_work", (B * T * 2 * D + 2 * D,), torch.float32, dev, padded=False)
         cfg = L.FrontendCfg.from_buffer_copy(mf._cfg)
         cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift
         cfg.pad_mode = 0 if fr.snipEdges else 1
@@ -752,16 +765,36 @@ class XvectorExtractor:
         dev = static_in.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):                # warm-up on the capture stream: workspaces, tables, LDS opt-ins
-            for _ in range(2):
-                self._extract(static_in)
-            static_out = torch.empty((static_in.shape[0], self.ldaMat.shape[1]), dtype=torch.float32, device=dev)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                self._extract(static_in, out=static_out)
+        # The graph addresses scratch and weights by raw pointer. Scratch: PRIVATE workspaces for the capture (the model's own are
+        # keyed by stream handle, and a later call on a recycled handle could grow -- i.e. free -- an arena the graph still
+        # uses); they live as long as `run`. Weights: strong references to every device operand set the capture touched, and
+        # the weights signature at capture time -- `run` refuses to replay after set_weights / calibrate().
+        own_ws, own_xws = self._ws, self.xvec._ws
+        cap_ws, cap_xws = _Workspace(), _Workspace()
+        self._ws, self.xvec._ws = cap_ws, cap_xws
+        try:
+            with torch.cuda.stream(side):                # warm-up on the capture stream: workspaces, tables, LDS opt-ins
+                for _ in range(2):
+                    self._extract(static_in)
+                static_out = torch.empty((static_in.shape[0], self.ldaMat.shape[1]), dtype=torch.float32, device=dev)
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=side):
+                    self._extract(static_in, out=static_out)
+        finally:
+            self._ws, self.xvec._ws = own_ws, own_xws
         torch.cuda.current_stream(dev).wait_stream(side)
+        sig = (self.xvec.weights_signature(), tuple(sorted(self.xvec._xbar)), self.xvec.lo_fraction, self.xvec.one_pass_tail)
+        keep = [cap_ws, cap_xws, dict(self._post_dev)]
+        for l in self.xvec.layers:
+            if isinstance(l, TDNN):
+                keep.append(dict(l._dev))
+            elif isinstance(l, BatchNorm):
+                keep.append(l._dev)
 
         def run(wav):
+            now = (self.xvec.weights_signature(), tuple(sorted(self.xvec._xbar)), self.xvec.lo_fraction, self.xvec.one_pass_tail)
+            if now != sig:
+                raise RuntimeError("the model's weights or calibration changed after compile(): capture again")
             w, _ = self.framing.device_samples(wav)
             if w.dim() == 1:
                 w = w.unsqueeze(0)
@@ -773,4 +806,5 @@ class XvectorExtractor:
             return y.squeeze(0) if y.shape[0] == 1 else y
 
         run.graph = graph
+        run.keepalive = keep
         return run

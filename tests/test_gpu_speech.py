@@ -90,3 +90,77 @@ def test_f16x2_two_pass_on_speech_is_recorded(seed):
     d = deviations("f16x2", seed, calibrate=False)
     print(f"f16x2 two passes everywhere, seed {seed}: " + ", ".join(f"{k} {v:.2e}" for k, v in d.items()))
     assert max(d.values()) <= 2e-4, d
+
+
+# ----------------------------------------------------------------------------- calibrate_from_batchnorm(), numerically
+def _self_consistent_weights(seed, cal_wavs):
+    """Synthetic 0008 weights whose BatchNorm statistics ARE the network's own activation statistics on `cal_wavs` (what a
+    trained Kaldi model's <StatsMean> / <StatsVar> are): one fp64 oracle pass, layer by layer -- the ReLU outputs' mean / variance
+    become that layer's BatchNorm statistics before the pass continues through it."""
+    w = synth.make_weights(seed=seed)
+    cfg = synth.extractor_cfg()
+    feats = []
+    fcfg = {k: v for k, v in cfg["framing"].items() if k != "dynamic_input_shape"}
+    for wav in cal_wavs:
+        fr = O.framing(wav[None].astype(np.float64), **fcfg)
+        m = O.mfcc(fr, **cfg["mfcc"], dtype=np.float64)
+        vcfg = dict(cfg["vad"]); vcfg["return_indexes"] = True
+        idx = O.vad(m, **vcfg, dtype=np.float64)
+        feats.append(O.cmvn(m[idx[:, 0], idx[:, 1]][None], **cfg["cmvn"], dtype=np.float64))
+    xs = feats
+    for name, ctx, _ in synth.TOPOLOGY:
+        W, b = w[f"{name}.affine"]
+        xs = [O.relu(O.tdnn(x, W, b, list(ctx), dtype=np.float64)) for x in xs]
+        allv = np.concatenate([x[0] for x in xs], 0)
+        mean, var = allv.mean(0), allv.var(0)
+        w[f"{name}.batchnorm"] = (np.float32(1.0), mean.astype(np.float32), var.astype(np.float32))
+        xs = [O.batchnorm(x, 1.0, mean.astype(np.float32), var.astype(np.float32), 1e-3, dtype=np.float64) for x in xs]
+    return w
+
+
+def test_calibrate_from_batchnorm_matches_measured_calibration(tmp_path):
+    """SequentialFromConfig(cfg, nnet3Path, gemm="f16x2") on a model whose BatchNorm statistics are its own (written through the
+    Kaldi nnet3 binary format): calibrate_from_batchnorm() must give the statistics calibrate() measures on the same utterances,
+    hence the same one-pass / residual-prefix route and the same x-vectors. Neither route is a tolerance-compliant mode: on this
+    self-normalised network the form is at 1-2e-4 even on the calibration distribution, and further out on speech (which is why
+    bench.py does not time it); the test pins the agreement of the two routes and the order of magnitude."""
+    cal = np.concatenate([synth.make_wav(2, 160000, seed=777), synth.make_wav(2, 160000, seed=778, ragged=True)], 0)
+    w = _self_consistent_weights(11, list(cal))
+    synth.write_nnet3(str(tmp_path / "final.raw"), w)
+    cfg = synth.extractor_cfg()
+    seq = ktf.models.SequentialFromConfig(synth.model_config(), str(tmp_path / "final.raw"), "cmvn2xvec", gemm="f16x2")
+    from_bn = seq.calibrate_from_batchnorm()
+    assert len(from_bn) == 4                                    # tdnn2 .. tdnn5 read a BatchNorm'd ReLU plane
+    a = ktf.models.XvectorExtractor.from_parts(cfg, seq, w["mean"], w["lda"])
+    b = synth.build_extractor(ktf, cfg, w, gemm="f16x2")
+    b.calibrate(torch.as_tensor(cal, device="cuda"))
+    la = [l for l in a.xvec.layers if isinstance(l, ktf.layers.TDNN)]
+    lb = [l for l in b.xvec.layers if isinstance(l, ktf.layers.TDNN)]
+    for x, y in zip(la[1:5], lb[1:5]):
+        ma, mb = a.xvec._xbar[id(x)], b.xvec._xbar[id(y)]
+        assert np.abs(ma - mb).max() <= 2e-3 * max(1.0, np.abs(mb).max()), "BatchNorm mean != measured mean of the stored plane"
+    noise = np.concatenate([synth.make_wav(1, 160000, seed=1234), synth.make_wav(1, 160000, seed=4242, ragged=True)], 0)
+    whole, chunks = synth.speech_wavs()
+    layers = synth.oracle_layers(w)
+    for name, wav, bound in (("noise", noise, 5e-4), ("speech", chunks, 5e-3)):
+        want = O.xvector_forward(wav, cfg, layers, w["mean"], w["lda"], dtype=np.float64)
+        da = np.abs(a(torch.as_tensor(wav, device="cuda")).cpu().numpy() - want).max()
+        db = np.abs(b(torch.as_tensor(wav, device="cuda")).cpu().numpy() - want).max()
+        print(f"f16x2, BatchNorm statistics = own statistics: {name}: from BatchNorm {da:.2e}, measured {db:.2e}")
+        assert da <= bound and db <= bound
+        assert abs(da - db) <= 0.5 * max(da, db) + 2e-5, "the two calibration routes should agree"
+
+
+def test_calibration_is_dropped_when_the_weights_change():
+    w = synth.make_weights(seed=4321)
+    mdl = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm="f16x2", calibrate=True)
+    assert mdl.xvec._xbar
+    wav = torch.as_tensor(synth.make_wav(2, 32000, seed=5), device="cuda")
+    run = mdl.compile(wav)
+    run(wav)
+    tdnn4 = mdl.xvec.get_layer("tdnn4.affine")
+    tdnn4.set_weights([tdnn4.kaldi_matrix() * 1.5, tdnn4.bias])
+    with pytest.raises(RuntimeError):
+        run(wav)                                            # captured pointers / folded weights are stale
+    mdl(wav)
+    assert not mdl.xvec._xbar, "statistics measured on other weights must not survive set_weights"
