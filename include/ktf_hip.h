@@ -349,6 +349,17 @@ int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T, int32_t D,
                                 int32_t input_period, int32_t output_period, int32_t start, int64_t T_out,
                                 int32_t include_std, float eps, float* out, void* stream);
 
+/* The tail of the extractor in ONE launch: pooled statistics -> the affine after the pooling (tdnn6; sequential.py:68-79, W
+ * (units, ldw) fp32 row-major, rows 16-byte aligned, ldw a multiple of 4 >= in_dim = (include_std ? 2 : 1) * D) -> x - mean -> LDA
+ * A (units, out_dim) + off -> length normalisation (xvector_extractor.py:174-184). Input: fp32 pooled rows (`pooled`, ld_pooled;
+ * stats_pooling.py:231-240 already applied) OR the fp64 sums of ktf_tdnn_stats / ktf_tdnn_mx_stats (`sums`, `slots` as for
+ * ktf_stats_finalize[_slots]; the finalize happens in the kernel). Workspace: `partial` (B, 64, out_dim) fp32, `counters` (B)
+ * uint32 ZEROED once by the caller (the kernel leaves them zero). `h_out` (B, units), optional: the affine's output.
+ * 64 workgroups per utterance; sums in a fixed order: results are reproducible and batch == single bit for bit. */
+int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, const int32_t* lens, int64_t T,
+                      int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
+                      int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
+                      uint32_t* counters, float* y, float* h_out, void* stream);
 /* ------------------------------------------------------------------ x-vector post-processing (a12)
  * models/kaldi/xvector_extractor.py:174-184: y = (x - mean) @ A + off ; y *= sqrt(out)/||y||_2
  * x (B, in) fp32, A (in, out) row-major, off (out). */

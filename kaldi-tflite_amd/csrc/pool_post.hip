@@ -187,6 +187,127 @@ __global__ __launch_bounds__(XP_THREADS) void xvec_post_kernel(const float* __re
     for (int j = tid; j < out_dim; j += XP_THREADS) y[(int64_t)b * out_dim + j] = yo[j] / ratio;
 }
 
+// ------------------------------------------------------------------------------------ fused tail (a11 finalize + tdnn6 + a12)
+// pooled statistics -> affine after the pooling (tdnn6: `units` x `in_dim`, sequential.py:68-79 "stats -> tdnn6") -> x - mean ->
+// LDA (+ offset) -> length normalisation (xvector_extractor.py:174-184), ONE launch instead of finalize + GEMM + post.
+// Per utterance XT_NBLK workgroups: each (1) builds the pooled vector in LDS (from fp32 pooled rows, or from the fp64 slot sums
+// of the fused pooling: the finalize of stats_pooling.py:231-240, slots added in block order), (2) computes its slice of the
+// affine's units -- one wave per unit, lanes over K in 16-byte steps, one fixed butterfly -> deterministic --, (3) writes the
+// slice's contribution to the 128 LDA outputs into its own slot; the workgroup that draws the last ticket adds the slots IN SLOT
+// ORDER, adds the offset and normalises. Same kernel for one utterance and for a batch, so batch == single bit for bit; a
+// single utterance spreads over XT_NBLK CUs instead of running 3000-long fmaf chains on one.
+// Hand-off = the agent-scope release / ticket / acquire recipe of cdna_hip_programming.md section 6 (valid for any placement of
+// the workgroups over XCDs); the last arriver resets the ticket counter (the host hands in a zeroed array once).
+#define XT_NBLK 64
+#define XT_THREADS 256
+__global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __restrict__ pooled, int64_t ld_pooled, const double* __restrict__ sums,
+                                                               int64_t slots, const int32_t* __restrict__ lens, int64_t T, int D, int include_std,
+                                                               float eps, const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+                                                               int in_dim, int units, const float* __restrict__ mean, const float* __restrict__ A,
+                                                               const float* __restrict__ off, int out_dim, float* __restrict__ partial,
+                                                               unsigned* __restrict__ counters, float* __restrict__ y, float* __restrict__ h_out) {
+    extern __shared__ float xt_sm[];          // in_dim_pad | units per block | out_dim | 8
+    const int in_pad = (in_dim + 3) & ~3;
+    float* xs = xt_sm;
+    float* hs = xs + in_pad;
+    float* ys = hs + 16;
+    float* red = ys + out_dim;
+    const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t b = blockIdx.y;
+    // (1) the pooled vector
+    if (pooled) {
+        for (int i = tid; i < in_pad; i += XT_THREADS) xs[i] = i < in_dim ? pooled[b * ld_pooled + i] : 0.0f;
+    } else {
+        const int len = lens ? lens[b] : (int)T;
+        const double n = (double)len;
+        const int used = slots ? (len + 127) >> 7 : 1;
+        for (int c = tid; c < D; c += XT_THREADS) {
+            double sv = 0.0, q = 0.0;
+            if (slots == 0) {
+                sv = sums[(b * 2) * D + c];
+                q = sums[(b * 2 + 1) * D + c];
+            } else {
+                for (int k = 0; k < used; ++k) {
+                    sv += sums[((b * slots + k) * 2) * D + c];
+                    q += sums[((b * slots + k) * 2 + 1) * D + c];
+                }
+            }
+            const double m = sv / n;
+            xs[c] = (float)m;
+            if (include_std) xs[D + c] = (float)sqrt(fmax(q / n - m * m, 0.0) + (double)eps);
+        }
+        for (int i = (include_std ? 2 : 1) * D + tid; i < in_pad; i += XT_THREADS) xs[i] = 0.0f;
+    }
+    __syncthreads();
+    // (2) this workgroup's units of the affine: wave w takes units u0 + w, u0 + w + 4, ...
+    const int upb = (units + XT_NBLK - 1) / XT_NBLK;            // <= 16
+    const int u0 = blk * upb;
+    for (int uu = wave; uu < upb; uu += XT_THREADS / 64) {
+        const int u = u0 + uu;
+        float acc = 0.0f;
+        if (u < units) {
+            const float* wr = W + (int64_t)u * ldw;
+            for (int k = lane * 4; k < in_pad; k += 256) {       // 16 bytes per lane and step, K order fixed per lane
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
+                acc = fmaf(wv.x, xs[k], acc);
+                acc = fmaf(wv.y, xs[k + 1], acc);
+                acc = fmaf(wv.z, xs[k + 2], acc);
+                acc = fmaf(wv.w, xs[k + 3], acc);
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float h = u < units ? acc + (bias ? bias[u] : 0.0f) : 0.0f;
+            hs[uu] = h;
+            if (h_out && u < units) h_out[b * units + u] = h;
+        }
+    }
+    __syncthreads();
+    // (3) contribution of these units to every LDA output, into this workgroup's slot
+    float* slot = partial + (b * XT_NBLK + blk) * out_dim;
+    for (int c = tid; c < out_dim; c += XT_THREADS) {
+        float pacc = 0.0f;
+        for (int i = 0; i < upb; ++i) {
+            const int u = u0 + i;
+            if (u < units) pacc = fmaf(hs[i] - (mean ? mean[u] : 0.0f), A[(int64_t)u * out_dim + c], pacc);
+        }
+        slot[c] = pacc;
+    }
+    // (4) hand-off: every wave's stores drained, one agent-scope release, one ticket
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == XT_NBLK - 1;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+        }
+        red[7] = last ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (red[7] == 0.0f) return;
+    float ss = 0.0f;
+    for (int c = tid; c < out_dim; c += XT_THREADS) {
+        float t = 0.0f;
+        for (int k = 0; k < XT_NBLK; ++k) t += partial[(b * XT_NBLK + k) * out_dim + c];       // slot order: deterministic
+        t += off ? off[c] : 0.0f;
+        ys[c] = t;
+        ss += t * t;
+    }
+    ss = wave_sum(ss);
+    __syncthreads();
+    if (lane == 0) red[wave] = ss;
+    __syncthreads();
+    float tot = 0.0f;
+    for (int w = 0; w < XT_THREADS / 64; ++w) tot += red[w];
+    const float ratio = sqrtf(tot) / sqrtf((float)out_dim);   // xvector_extractor.py:178-181
+    for (int c = tid; c < out_dim; c += XT_THREADS) y[b * out_dim + c] = ys[c] / ratio;
+}
+
 // ------------------------------------------------------------------------------------ PLDA
 template <typename R>
 __device__ __forceinline__ R wsum(R v) {
@@ -390,6 +511,26 @@ extern "C" int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T,
     hipLaunchKernelGGL(stats_pool_windowed_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, T, D, left, right,
                        input_period, output_period, start, T_out, include_std, eps, out);
     KTF_CHECK_LAUNCH("ktf_stats_pool_windowed_f32");
+    return KTF_OK;
+}
+
+extern "C" int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, const int32_t* lens, int64_t T,
+                                 int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
+                                 int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
+                                 uint32_t* counters, float* y, float* h_out, void* stream) {
+    KTF_REQUIRE((pooled != nullptr) != (sums != nullptr), "ktf_xvec_tail_f32: exactly one of pooled / sums");
+    KTF_REQUIRE(W && A && partial && counters && y, "ktf_xvec_tail_f32: null argument");
+    const int in_dim = (include_std ? 2 : 1) * D;
+    KTF_REQUIRE(B >= 0 && B < 65536 && D > 0 && units > 0 && units <= 16 * XT_NBLK && out_dim > 0 && out_dim <= 1024, "ktf_xvec_tail_f32: bad sizes");
+    KTF_REQUIRE(ldw >= ((in_dim + 3) & ~3) && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0, "ktf_xvec_tail_f32: W rows must be 16-byte aligned and padded to a multiple of 4 columns");
+    if (pooled) KTF_REQUIRE(ld_pooled >= in_dim, "ktf_xvec_tail_f32: ld_pooled < in_dim");
+    if (sums && slots) KTF_REQUIRE(slots >= (T + 127) / 128, "ktf_xvec_tail_f32: too few slots");
+    if (B == 0) return KTF_OK;
+    const size_t lds = sizeof(float) * ((size_t)((in_dim + 3) & ~3) + 16 + out_dim + 8);
+    KTF_REQUIRE(lds <= 64 * 1024, "ktf_xvec_tail_f32: dims too large");
+    hipLaunchKernelGGL(xvec_tail_kernel, dim3(XT_NBLK, (unsigned)B), dim3(XT_THREADS), lds, (hipStream_t)stream, pooled, ld_pooled, sums, slots, lens, T,
+                       (int)D, (int)include_std, eps, W, ldw, bias, in_dim, (int)units, mean, A, off, (int)out_dim, partial, counters, y, h_out);
+    KTF_CHECK_LAUNCH("ktf_xvec_tail_f32");
     return KTF_OK;
 }
 

@@ -634,6 +634,7 @@ class BatchNorm(Layer):
         self.gamma, self.moving_mean, self.moving_variance = gamma, mean, var
         self._dev = None
         self._version += 1
+        WEIGHTS_EPOCH[0] += 1
 
     def affine64(self):
         """(scale, shift) of the inference transform y = scale * x + shift, float64."""
@@ -665,6 +666,8 @@ def reshapeKaldiTdnnWeights(weights, units, kernel_width):
     """layers/tdnn/utils.py:22-28: Kaldi (units, K*D) -> keras conv2d kernel (1, K, D, units)."""
     return weights.flatten().reshape((1, -1, kernel_width, units), order="F").transpose([0, 2, 1, 3])
 
+
+WEIGHTS_EPOCH = [0]      # bumped by every set_weights / re-build / calibration in the process: a cheap "anything changed?" for captured graphs
 
 _ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
 _GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat16": L.GEMM_BF16, "bf16x3": L.GEMM_BF16X3,
@@ -728,6 +731,7 @@ class TDNN(Layer):
                 lb = np.sqrt(6.0 / (self.units + 1))
                 self.bias = rng.uniform(-lb, lb, (self.units,)).astype(np.float32)
             self._version += 1
+            WEIGHTS_EPOCH[0] += 1
         self._dev = {}
         self.built = True
 
@@ -759,6 +763,7 @@ class TDNN(Layer):
             self.bias = bias
         self._dev = {}
         self._version += 1
+        WEIGHTS_EPOCH[0] += 1
         self.built = True
 
     def kaldi_matrix(self):

@@ -18,7 +18,7 @@ import torch
 from . import _lib as L
 from . import ops
 from .io import KaldiNnet3Reader, ReadKaldiArray
-from .layers import TDNN, BatchNorm, CMVN, Framing, MFCC, ReLU, StatsPooling, VAD, _GEMM
+from .layers import TDNN, BatchNorm, CMVN, Framing, MFCC, ReLU, StatsPooling, VAD, _GEMM, WEIGHTS_EPOCH
 from .mx import Planes
 
 
@@ -107,6 +107,15 @@ class _Workspace:
 
     def clear(self):
         self._arenas.clear()
+
+
+class DeferredTail:
+    """run_ragged(defer_tail=True): the stack up to the pooling has run; what is left -- (finalize of the pooled sums,) the affine
+    after the pooling -- is handed to the caller, who fuses it with its own post-processing (XvectorExtractor: ktf_xvec_tail_f32)."""
+
+    def __init__(self, layer, B, D, include_std, eps, pooled=None, sums=None, slots=0, lens=None, T=0):
+        self.layer, self.B, self.D, self.include_std, self.eps = layer, B, D, include_std, eps
+        self.pooled, self.sums, self.slots, self.lens, self.T = pooled, sums, slots, lens, T
 
 
 class Sequential:
@@ -215,7 +224,7 @@ class Sequential:
         return gemm
 
     def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0, one_pass_mean=None,
-                        in_perm=None):
+                        in_perm=None, defer_to=None):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
         `split`: the input is a (2,B,T,ld) pair of bf16 planes or ONE (B,T,ld) half plane (F16X2) read by the split-plane
         kernel; `fold`: the preceding BatchNorm folded into this layer's weights. Returns the pooled (1, B, od) view."""
@@ -236,6 +245,9 @@ class Sequential:
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
                    flags=flags | (L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if wt else 0))
         (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
+        if defer_to is not None:         # the caller's fused tail finalizes the sums itself
+            self._deferred = DeferredTail(defer_to, B, D, sp.includeStd, sp.epsilon, sums=sums, slots=slots, lens=lens, T=T)
+            return sbuf[:, :od].unsqueeze(0)
         ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf, slots=slots)
         return sbuf[:, :od].unsqueeze(0)
 
@@ -245,7 +257,17 @@ class Sequential:
         return bool(self.lo_fraction > 0 and self._calibrating is None and id(l) in self._xvar and self.k_interleaved and
                     l.kernelWidth > 1 and l.inputDim >= 64 and left > self.one_pass_tail)
 
-    def run_ragged(self, x, lens=None):
+    def _tail_step(self, steps):
+        """Index of the last step if it is a plain affine (context [0], no activation / BatchNorm) right after a reducing
+        StatsPooling -- the tail XvectorExtractor fuses with its LDA / length-norm step -- else -1."""
+        if len(steps) >= 2 and steps[-1][0] == "tdnn" and steps[-2][0] == "stats":
+            _, l, relu, bn = steps[-1]
+            if (not relu and bn is None and l.activation in (None, "linear") and l.kernelWidth == 1 and l.padding == "SAME"
+                    and l.subsamplingFactor == 1 and l.units <= 1024):
+                return len(steps) - 1
+        return -1
+
+    def run_ragged(self, x, lens=None, defer_tail=False):
         """x: (B, T, D) view of an utterance-strided buffer whose row stride is a multiple of 8 and >= round_up(D, 32)
         (pad columns finite); lens: int32 (B,) valid rows per utterance or None. Returns (B, T', units) for frame-level
         outputs or (B, 1, units) after a reducing StatsPooling. The result is a view of this model's workspace: it is
@@ -259,6 +281,8 @@ class Sequential:
             self._xbar, self._xvar = {}, {}      # the weights changed since calibrate(): its statistics describe another network
         gemm = self.batch_gemm(x.shape[0], x.shape[1])
         act_dtype = L.act_torch_dtype(gemm)
+        tail_at = self._tail_step(steps) if defer_tail else -1
+        self._deferred = None        # set by a pooling step whose consumer is the deferred tail
         pooled = False
         skip = False
         # split-bf16 mode: frame-level activations travel between the wide layers as hi/lo bf16 planes (2,B,T,ld) instead
@@ -280,6 +304,8 @@ class Sequential:
             out_role = f"act{si & 1}" + ("s" if pooled else "")
             if st[0] == "tdnn" and st[1].units % 32:
                 out_role += "p"
+            if si == tail_at and self._deferred is not None:
+                return self._deferred
             if st[0] == "tdnn":
                 _, l, relu, bn = st
                 if relu and l.activation not in (None, "linear"):
@@ -309,7 +335,11 @@ class Sequential:
                     scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
                     d.flags = L.TDNN_DET_STATS if slots else 0
                     ops.tdnn_mx_stats(mxp, lens, d, wh, wq, bias, scale, shift, sums, zero=not slots)
-                    ops.stats_finalize(sums, lens, T, l.units, sp.includeStd, sp.epsilon, sbuf, slots=slots)
+                    if si + 2 == tail_at:            # the caller's fused tail finalizes the sums itself
+                        self._deferred = DeferredTail(steps[tail_at][1], B, l.units, sp.includeStd, sp.epsilon, sums=sums, slots=slots,
+                                                      lens=lens, T=T)
+                    else:
+                        ops.stats_finalize(sums, lens, T, l.units, sp.includeStd, sp.epsilon, sbuf, slots=slots)
                     x = sbuf[:, :od].unsqueeze(0)
                     lens, pooled, skip, mxp = None, True, True, None
                     continue
@@ -355,7 +385,7 @@ class Sequential:
                 in_perm, cur_perm = cur_perm, None
                 if can_pool:
                     x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold, flags=kflag & L.TDNN_X_CHUNKED,
-                                             one_pass_mean=opm, in_perm=in_perm)
+                                             one_pass_mean=opm, in_perm=in_perm, defer_to=steps[tail_at][1] if si + 2 == tail_at else None)
                     lens, pooled, skip = None, True, True
                     continue
                 nl = nxt[1] if nxt is not None and nxt[0] == "tdnn" else None
@@ -403,7 +433,8 @@ class Sequential:
                     ops.split_bf16(src, D, planes)
                 B, T = planes.shape[1], planes.shape[2]
                 if can_pool:
-                    x = self._pooled_by_gemm(l, relu, bn, nxt, planes, lens, gemm, True, dev, T)
+                    x = self._pooled_by_gemm(l, relu, bn, nxt, planes, lens, gemm, True, dev, T,
+                                             defer_to=steps[tail_at][1] if si + 2 == tail_at else None)
                     lens, pooled, skip, planes = None, True, True, None
                     continue
                 kint = bool(self.k_interleaved and l.kernelWidth > 1)
@@ -438,7 +469,8 @@ class Sequential:
                     xdt = L.act_torch_dtype(gemm)
                     if x.dtype != xdt or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
                         x = _padded_copy(x, xdt)
-                    x = self._pooled_by_gemm(l, relu, bn, nxt, x, lens, gemm, False, dev, x.shape[1])
+                    x = self._pooled_by_gemm(l, relu, bn, nxt, x, lens, gemm, False, dev, x.shape[1],
+                                             defer_to=steps[tail_at][1] if si + 2 == tail_at else None)
                     lens, pooled, skip = None, True, True
                     continue
                 g = L.GEMM_F32 if pooled else l.effective_gemm(gemm, relu)
@@ -464,6 +496,8 @@ class Sequential:
                 od = 2 * D if l.includeStd else D
                 sbuf = self._ws.get("pooled", (B, ops.round_up(od, 32)), torch.float32, dev)
                 l.reduce_all(x, D, lens=lens, out=sbuf)
+                if si + 1 == tail_at:
+                    return DeferredTail(steps[tail_at][1], B, D, l.includeStd, l.epsilon, pooled=sbuf)
                 x = sbuf[:, :od].unsqueeze(0)       # (1, B, od): the pooled vectors form ONE B-row matrix
                 lens = None
                 pooled = True
@@ -489,6 +523,7 @@ class Sequential:
             self._xbar = {k: v[0].cpu().numpy() for k, v in self._calibrating.items()}
             self._xvar = {k: v[1].cpu().numpy() for k, v in self._calibrating.items()}
             self._cal_sig = self.weights_signature()
+            WEIGHTS_EPOCH[0] += 1
         finally:
             self._calibrating = None
             self.min_tiles = mt
@@ -509,6 +544,7 @@ class Sequential:
                 self._xbar[id(cur[1])] = np.asarray(bn.moving_mean, np.float64).copy()
                 self._xvar[id(cur[1])] = np.asarray(bn.moving_variance, np.float64).copy()
         self._cal_sig = self.weights_signature()
+        WEIGHTS_EPOCH[0] += 1
         return self._xbar
 
     def __call__(self, inputs, training=False):
@@ -652,6 +688,7 @@ class XvectorExtractor:
         self._post_dev = {}
         self._ws = _Workspace()
         self._graphs = {}
+        self.fuse_tail = True        # pooling finalize + tdnn6 + mean-sub + LDA + length-norm as ONE launch (False: three, for A/B)
         self.last_lens = None
 
     @property
@@ -723,14 +760,30 @@ class XvectorExtractor:
     def _extract(self, inputs, out=None):
         _, feats, lens = self._features(inputs)
         self.last_lens = lens                                          # voiced-frame counts of the last call (workspace view)
-        h = self.xvec.run_ragged(feats, lens)                      # (B, 1, 512)
+        h = self.xvec.run_ragged(feats, lens, defer_tail=self.fuse_tail)          # (B, 1, 512), or the deferred tail
+        dev = feats.device
+        key = str(dev)
+        if key not in self._post_dev:
+            self._post_dev[key] = (ops.to_device_f32(self.xvecGlobalMean, dev), ops.to_device_f32(self.ldaMat, dev),
+                                   ops.to_device_f32(self.ldaOffset.reshape(-1), dev))
+        mean, A, off = self._post_dev[key]
+        if isinstance(h, DeferredTail):
+            # pooling finalize + tdnn6 + mean subtraction + LDA + length normalisation in one launch (ktf_xvec_tail_f32)
+            t = h
+            if t.layer.units == A.shape[0]:
+                w6, _, b6 = t.layer.device_weights(dev, L.GEMM_F32)
+                B = t.B
+                odim = A.shape[1]
+                ws = self._ws
+                partial = ws.get("tail_partial", (B, 64, odim), torch.float32, dev, padded=False)
+                counters = ws.get("tail_cnt", (B,), torch.int32, dev, padded=True)      # zero when (re)allocated; the kernel leaves it zero
+                if out is None:
+                    out = torch.empty((B, odim), dtype=torch.float32, device=dev)
+                return ops.xvec_tail(t.pooled, t.sums, t.slots, t.lens, t.T, t.D, t.include_std, t.eps, w6, b6, t.layer.units, mean, A, off,
+                                     partial, counters, out)
+            raise ValueError(f"LDA input dim {A.shape[0]} != embedding dim {t.layer.units}")
         B = h.shape[0]
         h2 = h.reshape(B, h.shape[-1])
-        key = str(h2.device)
-        if key not in self._post_dev:
-            self._post_dev[key] = (ops.to_device_f32(self.xvecGlobalMean, h2.device), ops.to_device_f32(self.ldaMat, h2.device),
-                                   ops.to_device_f32(self.ldaOffset.reshape(-1), h2.device))
-        mean, A, off = self._post_dev[key]
         if not h2.is_contiguous():
             h2 = h2.contiguous()
         return ops.xvec_post(h2, mean, A, off, out=out)
@@ -791,10 +844,15 @@ class XvectorExtractor:
             elif isinstance(l, BatchNorm):
                 keep.append(l._dev)
 
+        epoch = [WEIGHTS_EPOCH[0]]
+
         def run(wav):
-            now = (self.xvec.weights_signature(), tuple(sorted(self.xvec._xbar)), self.xvec.lo_fraction, self.xvec.one_pass_tail)
-            if now != sig:
-                raise RuntimeError("the model's weights or calibration changed after compile(): capture again")
+            if WEIGHTS_EPOCH[0] != epoch[0] or (self.xvec.lo_fraction, self.xvec.one_pass_tail) != sig[2:]:
+                # some layer in the process changed: is it one of ours? (slow path, only after a set_weights / calibrate somewhere)
+                now = (self.xvec.weights_signature(), tuple(sorted(self.xvec._xbar)), self.xvec.lo_fraction, self.xvec.one_pass_tail)
+                if now != sig:
+                    raise RuntimeError("the model's weights or calibration changed after compile(): capture again")
+                epoch[0] = WEIGHTS_EPOCH[0]
             w, _ = self.framing.device_samples(wav)
             if w.dim() == 1:
                 w = w.unsqueeze(0)

@@ -65,9 +65,12 @@ def test_batch_dispatch(gemm):
     frame = [(s, k) for s, k in got if s in FRAME_LAYERS]
     assert [s for s, _ in frame] == FRAME_LAYERS
     assert [k for _, k in frame] == EXPECT[gemm], frame
-    # the affine after the pooling (one row per utterance) is exact fp32 in every mode
-    tail = [k for s, k in got if s == "1x3000->512"]
-    assert len(tail) == 1 and tail[0].startswith("tdnn_f32"), got
+    # the affine after the pooling is part of the fused tail kernel (ktf_xvec_tail_f32): no GEMM launch of its own ...
+    assert not [k for s, k in got if s == "1x3000->512"], got
+    # ... unless the fusion is switched off: exact fp32 in every mode
+    mdl.fuse_tail = False
+    tail = [k for s, k in trace(mdl, synth.make_wav(32, 160000, seed=3)) if s == "1x3000->512"]
+    assert len(tail) == 1 and tail[0].startswith("tdnn_f32"), tail
 
 
 def test_calibrated_f16x2_runs_one_pass_in_front_of_the_pooling():
@@ -86,7 +89,9 @@ def test_single_utterance_dispatch():
         wav = synth.make_wav(1, 160000, seed=3)
         want = None
         for gemm in ("f32", "bf16x3", "f16mx"):
-            got = trace(synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm=gemm), wav)
+            m1 = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm=gemm)
+            m1.fuse_tail = False
+            got = trace(m1, wav)
             kernels = [k for _, k in got]
             assert kernels[0] == "tdnn_f32s_kernel<32, 64>"                     # 30 -> 32 input columns: K-step 32
             assert all(k.startswith("tdnn_f32s_kernel<64, ") for k in kernels[1:5]), got

@@ -211,3 +211,26 @@ def test_extractor_f16mx_full_topology_10s_vs_oracle(seed):
     assert err <= 1e-4
     for b in range(3):
         assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), got[b]), "batch != single"
+
+
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16mx"])
+def test_fused_tail_equals_the_three_launch_tail(gemm):
+    """ktf_xvec_tail_f32 (pooling finalize + tdnn6 + mean-sub + LDA + length-norm in one launch, 64 workgroups per utterance)
+    against finalize -> fp32 GEMM -> ktf_xvec_post_f32: same x-vectors to fp32 summation-order noise, against the fp64 oracle
+    inside the mode's tolerance, reproducible run to run and batch == single bit for bit (one utterance and a ragged batch)."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321)
+    wav = np.concatenate([synth.make_wav(2, 48000, seed=21), synth.make_wav(3, 48000, seed=22, ragged=True)], 0)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
+    fused = mdl(dev(wav))
+    assert torch.equal(mdl(dev(wav)), fused), "not reproducible"
+    for b in (0, 4):
+        assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), fused[b]), "batch != single"
+    mdl.fuse_tail = False
+    plain = mdl(dev(wav))
+    assert (fused - plain).abs().max().item() <= 1e-5          # fp32 summation order of a 3000-long dot product, x-vector components up to ~4
+    want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+    assert np.abs(fused.cpu().numpy() - want).max() <= 1e-4
+    # graph capture covers the ticket counters (reset by the kernel itself)
+    run = synth.build_extractor(ktf, cfg, w, gemm=gemm).compile(dev(wav))
+    assert torch.equal(run(dev(wav)), fused) and torch.equal(run(dev(wav)), fused)
