@@ -355,11 +355,13 @@ int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T, int32_t D,
  * stats_pooling.py:231-240 already applied) OR the fp64 sums of ktf_tdnn_stats / ktf_tdnn_mx_stats (`sums`, `slots` as for
  * ktf_stats_finalize[_slots]; the finalize happens in the kernel). Workspace: `partial` (B, 64, out_dim) fp32, `counters` (B)
  * uint32 ZEROED once by the caller (the kernel leaves them zero). `h_out` (B, units), optional: the affine's output.
- * 64 workgroups per utterance; sums in a fixed order: results are reproducible and batch == single bit for bit. */
+ * Grid = 64 unit slices x ceil(B / group) utterance groups: a workgroup keeps its slice of W in registers and walks `group`
+ * utterances (1 for a single utterance: 64 CUs share the 6 MB of W; ~32 for a large batch: W is read once per group). units <=
+ * 512, in_dim <= 3072. Sums in a fixed order that does not depend on B or group: reproducible, batch == single bit for bit. */
 int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, const int32_t* lens, int64_t T,
                       int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
                       int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
-                      uint32_t* counters, float* y, float* h_out, void* stream);
+                      uint32_t* counters, float* y, float* h_out, int32_t group, void* stream);
 /* ------------------------------------------------------------------ x-vector post-processing (a12)
  * models/kaldi/xvector_extractor.py:174-184: y = (x - mean) @ A + off ; y *= sqrt(out)/||y||_2
  * x (B, in) fp32, A (in, out) row-major, off (out). */

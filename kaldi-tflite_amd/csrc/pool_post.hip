@@ -200,112 +200,181 @@ __global__ __launch_bounds__(XP_THREADS) void xvec_post_kernel(const float* __re
 // the workgroups over XCDs); the last arriver resets the ticket counter (the host hands in a zeroed array once).
 #define XT_NBLK 64
 #define XT_THREADS 256
-__global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __restrict__ pooled, int64_t ld_pooled, const double* __restrict__ sums,
-                                                               int64_t slots, const int32_t* __restrict__ lens, int64_t T, int D, int include_std,
-                                                               float eps, const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
-                                                               int in_dim, int units, const float* __restrict__ mean, const float* __restrict__ A,
-                                                               const float* __restrict__ off, int out_dim, float* __restrict__ partial,
-                                                               unsigned* __restrict__ counters, float* __restrict__ y, float* __restrict__ h_out) {
-    extern __shared__ float xt_sm[];          // in_dim_pad | units per block | out_dim | 8
-    const int in_pad = (in_dim + 3) & ~3;
-    float* xs = xt_sm;
-    float* hs = xs + in_pad;
-    float* ys = hs + 16;
-    float* red = ys + out_dim;
-    const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t b = blockIdx.y;
-    // (1) the pooled vector
-    if (pooled) {
-        for (int i = tid; i < in_pad; i += XT_THREADS) xs[i] = i < in_dim ? pooled[b * ld_pooled + i] : 0.0f;
-    } else {
-        const int len = lens ? lens[b] : (int)T;
-        const double n = (double)len;
-        const int used = slots ? (len + 127) >> 7 : 1;
-        for (int c = tid; c < D; c += XT_THREADS) {
-            double sv = 0.0, q = 0.0;
-            if (slots == 0) {
-                sv = sums[(b * 2) * D + c];
-                q = sums[(b * 2 + 1) * D + c];
-            } else {
-                for (int k = 0; k < used; ++k) {
-                    sv += sums[((b * slots + k) * 2) * D + c];
-                    q += sums[((b * slots + k) * 2 + 1) * D + c];
-                }
-            }
-            const double m = sv / n;
-            xs[c] = (float)m;
-            if (include_std) xs[D + c] = (float)sqrt(fmax(q / n - m * m, 0.0) + (double)eps);
-        }
-        for (int i = (include_std ? 2 : 1) * D + tid; i < in_pad; i += XT_THREADS) xs[i] = 0.0f;
-    }
-    __syncthreads();
-    // (2) this workgroup's units of the affine: wave w takes units u0 + w, u0 + w + 4, ...
-    const int upb = (units + XT_NBLK - 1) / XT_NBLK;            // <= 16
-    const int u0 = blk * upb;
-    for (int uu = wave; uu < upb; uu += XT_THREADS / 64) {
-        const int u = u0 + uu;
-        float acc = 0.0f;
-        if (u < units) {
-            const float* wr = W + (int64_t)u * ldw;
-            for (int k = lane * 4; k < in_pad; k += 256) {       // 16 bytes per lane and step, K order fixed per lane
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wr + k);
-                acc = fmaf(wv.x, xs[k], acc);
-                acc = fmaf(wv.y, xs[k + 1], acc);
-                acc = fmaf(wv.z, xs[k + 2], acc);
-                acc = fmaf(wv.w, xs[k + 3], acc);
-            }
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) {
-            const float h = u < units ? acc + (bias ? bias[u] : 0.0f) : 0.0f;
-            hs[uu] = h;
-            if (h_out && u < units) h_out[b * units + u] = h;
-        }
-    }
-    __syncthreads();
-    // (3) contribution of these units to every LDA output, into this workgroup's slot
-    float* slot = partial + (b * XT_NBLK + blk) * out_dim;
-    for (int c = tid; c < out_dim; c += XT_THREADS) {
-        float pacc = 0.0f;
-        for (int i = 0; i < upb; ++i) {
-            const int u = u0 + i;
-            if (u < units) pacc = fmaf(hs[i] - (mean ? mean[u] : 0.0f), A[(int64_t)u * out_dim + c], pacc);
-        }
-        slot[c] = pacc;
-    }
-    // (4) hand-off: every wave's stores drained, one agent-scope release, one ticket
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = t == XT_NBLK - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-        }
-        red[7] = last ? 1.0f : 0.0f;
-    }
-    __syncthreads();
-    if (red[7] == 0.0f) return;
+// utterance b: the XT_NBLK slots added IN SLOT ORDER, + offset, length normalisation (xvector_extractor.py:178-181); whole workgroup
+__device__ __forceinline__ void xt_reduce(const float* __restrict__ partial, const float* __restrict__ off, float* __restrict__ y, int64_t b,
+                                          int out_dim, float* ys, float* red) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float ss = 0.0f;
     for (int c = tid; c < out_dim; c += XT_THREADS) {
         float t = 0.0f;
-        for (int k = 0; k < XT_NBLK; ++k) t += partial[(b * XT_NBLK + k) * out_dim + c];       // slot order: deterministic
+        for (int k = 0; k < XT_NBLK; ++k) t += partial[(b * XT_NBLK + k) * out_dim + c];
         t += off ? off[c] : 0.0f;
         ys[c] = t;
         ss += t * t;
     }
     ss = wave_sum(ss);
-    __syncthreads();
     if (lane == 0) red[wave] = ss;
     __syncthreads();
     float tot = 0.0f;
     for (int w = 0; w < XT_THREADS / 64; ++w) tot += red[w];
-    const float ratio = sqrtf(tot) / sqrtf((float)out_dim);   // xvector_extractor.py:178-181
+    const float ratio = sqrtf(tot) / sqrtf((float)out_dim);
     for (int c = tid; c < out_dim; c += XT_THREADS) y[b * out_dim + c] = ys[c] / ratio;
+    __syncthreads();
+}
+#define XT_MAXIT 12                                       // 16-byte K steps per lane: in_dim <= 3072
+// Grid (XT_NBLK unit slices, groups of G utterances). A workgroup keeps its slice of W in REGISTERS (two units per wave, 12 x 4
+// floats per lane and unit) and walks its G utterances: W is read once per (slice, group), so the same kernel serves one
+// utterance (G = 1: 64 workgroups spread the 6 MB of W over 64 CUs) and a large batch (G = 32: W traffic / 32). The arithmetic of
+// an utterance does not depend on G or B.
+__global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __restrict__ pooled, int64_t ld_pooled, const double* __restrict__ sums,
+                                                               int64_t slots, const int32_t* __restrict__ lens, int64_t T, int D, int include_std,
+                                                               float eps, const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
+                                                               int in_dim, int units, const float* __restrict__ mean, const float* __restrict__ A,
+                                                               const float* __restrict__ off, int out_dim, float* __restrict__ partial,
+                                                               unsigned* __restrict__ counters, float* __restrict__ y, float* __restrict__ h_out,
+                                                               int64_t B, int G, int two_phase) {
+    extern __shared__ __attribute__((aligned(16))) float xt_sm[];          // in_dim_pad | 16 unit outputs | out_dim | 8
+    const int in_pad = (in_dim + 3) & ~3;
+    float* xs = xt_sm;
+    float* hs = xs + XT_MAXIT * 256;
+    float* ys = hs + 16;
+    float* red = ys + out_dim;
+    const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int upb = (units + XT_NBLK - 1) / XT_NBLK;            // <= 8: two units per wave
+    const int u0 = blk * upb;
+    // this wave's rows of W: lane l holds columns 4 l + 256 it .. + 3 of each
+    f32x4 wreg[2][XT_MAXIT];
+    float wb[2];
+#pragma unroll
+    for (int uw = 0; uw < 2; ++uw) {
+        const int uu = wave + 4 * uw, u = u0 + uu;
+        const bool live = uu < upb && u < units;
+        wb[uw] = (live && bias) ? bias[u] : 0.0f;
+#pragma unroll
+        for (int it = 0; it < XT_MAXIT; ++it) {
+            const int k = lane * 4 + it * 256;
+            wreg[uw][it] = (live && k < in_pad) ? *reinterpret_cast<const f32x4*>(W + (int64_t)u * ldw + k) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    }
+    // LDA rows of this slice's units and their global-mean entries: registers of thread c (column c of A)
+    float areg[8], mreg[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int u = u0 + i;
+        const bool live = i < upb && u < units && tid < out_dim;
+        areg[i] = live ? A[(int64_t)u * out_dim + tid] : 0.0f;
+        mreg[i] = (live && mean) ? mean[u] : 0.0f;
+    }
+    const int64_t b_lo = (int64_t)blockIdx.y * G, b_hi = b_lo + G < B ? b_lo + G : B;
+    // pooled rows are prefetched one utterance ahead into registers (thread t: elements t + 256 j), so their global-load latency
+    // hides under the previous utterance's arithmetic
+    float xn[XT_MAXIT];
+    if (pooled && b_lo < b_hi) {
+#pragma unroll
+        for (int j = 0; j < XT_MAXIT; ++j) {
+            const int i = tid + 256 * j;
+            xn[j] = i < in_dim ? pooled[b_lo * ld_pooled + i] : 0.0f;
+        }
+    }
+    for (int64_t b = b_lo; b < b_hi; ++b) {
+        // (1) the pooled vector (zeros beyond in_dim up to the 3072 the K loop covers)
+        if (pooled) {
+#pragma unroll
+            for (int j = 0; j < XT_MAXIT; ++j) xs[tid + 256 * j] = xn[j];
+            if (b + 1 < b_hi) {
+#pragma unroll
+                for (int j = 0; j < XT_MAXIT; ++j) {
+                    const int i = tid + 256 * j;
+                    xn[j] = i < in_dim ? pooled[(b + 1) * ld_pooled + i] : 0.0f;
+                }
+            }
+        } else {
+            const int len = lens ? lens[b] : (int)T;
+            const double n = (double)len;
+            const int used = slots ? (len + 127) >> 7 : 1;
+            for (int c = tid; c < D; c += XT_THREADS) {
+                double sv = 0.0, q = 0.0;
+                if (slots == 0) {
+                    sv = sums[(b * 2) * D + c];
+                    q = sums[(b * 2 + 1) * D + c];
+                } else {
+                    for (int k = 0; k < used; ++k) {
+                        sv += sums[((b * slots + k) * 2) * D + c];
+                        q += sums[((b * slots + k) * 2 + 1) * D + c];
+                    }
+                }
+                const double m = sv / n;
+                xs[c] = (float)m;
+                if (include_std) xs[D + c] = (float)sqrt(fmax(q / n - m * m, 0.0) + (double)eps);
+            }
+            for (int i = in_dim + tid; i < XT_MAXIT * 256; i += XT_THREADS) xs[i] = 0.0f;
+        }
+        __syncthreads();
+        // (2) this workgroup's units of the affine: K order fixed per lane, one fixed butterfly
+#pragma unroll
+        for (int uw = 0; uw < 2; ++uw) {
+            const int uu = wave + 4 * uw, u = u0 + uu;
+            float acc = 0.0f;
+#pragma unroll
+            for (int it = 0; it < XT_MAXIT; ++it) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + lane * 4 + it * 256);
+                acc = fmaf(wreg[uw][it].x, xv.x, acc);
+                acc = fmaf(wreg[uw][it].y, xv.y, acc);
+                acc = fmaf(wreg[uw][it].z, xv.z, acc);
+                acc = fmaf(wreg[uw][it].w, xv.w, acc);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0 && uu < upb) {
+                const float h = u < units ? acc + wb[uw] : 0.0f;
+                hs[uu] = h;
+                if (h_out && u < units) h_out[b * units + u] = h;
+            }
+        }
+        __syncthreads();
+        // (3) contribution of these units to every LDA output, into this slice's slot (hs is rewritten only behind the next
+        // utterance's first barrier)
+        if (tid < out_dim) {
+            float pacc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < upb && u0 + i < units) pacc = fmaf(hs[i] - mreg[i], areg[i], pacc);
+            partial[(b * XT_NBLK + blk) * out_dim + tid] = pacc;
+        }
+    }
+    if (two_phase) return;                                 // the reduction is the next launch
+    // (4) hand-off, ONCE per workgroup (an agent-scope release writes the XCD's dirty L2 lines back: microseconds): every wave's
+    // stores drained -> one release -> one ticket per utterance of the group -> (if any was the last) one acquire
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave == 0) {                                       // the tickets of the group's utterances are drawn by parallel lanes (a returned
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // atomic is a memory round trip: 32 in a row cost more than the arithmetic)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int64_t bb = b_lo; bb < b_hi; bb += 64) {
+            const int64_t b = bb + lane;
+            unsigned last = 0;
+            if (b < b_hi) {
+                const unsigned t = __hip_atomic_fetch_add(counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = t == XT_NBLK - 1 ? 1u : 0u;
+                if (last) __hip_atomic_store(counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+                xs[b - b_lo] = last ? 1.0f : 0.0f;
+            }
+            if (__ballot(last != 0)) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+    }
+    __syncthreads();
+    for (int64_t b = b_lo; b < b_hi; ++b)
+        if (xs[b - b_lo] != 0.0f) xt_reduce(partial, off, y, b, out_dim, ys, red);          // workgroup-uniform
+}
+
+// Second phase as a launch of its own (large batches: one agent-scope release per workgroup of the fused form writes the
+// XCD's dirty L2 lines back, which with thousands of workgroups costs more than a kernel boundary). Same arithmetic.
+__global__ __launch_bounds__(XT_THREADS) void xvec_tail_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ off,
+                                                                      float* __restrict__ y, int out_dim) {
+    extern __shared__ __attribute__((aligned(16))) float xr_sm[];
+    xt_reduce(partial, off, y, blockIdx.x, out_dim, xr_sm, xr_sm + out_dim);
 }
 
 // ------------------------------------------------------------------------------------ PLDA
@@ -517,19 +586,25 @@ extern "C" int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T,
 extern "C" int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, const int32_t* lens, int64_t T,
                                  int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
                                  int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
-                                 uint32_t* counters, float* y, float* h_out, void* stream) {
+                                 uint32_t* counters, float* y, float* h_out, int32_t group, void* stream) {
     KTF_REQUIRE((pooled != nullptr) != (sums != nullptr), "ktf_xvec_tail_f32: exactly one of pooled / sums");
     KTF_REQUIRE(W && A && partial && counters && y, "ktf_xvec_tail_f32: null argument");
     const int in_dim = (include_std ? 2 : 1) * D;
-    KTF_REQUIRE(B >= 0 && B < 65536 && D > 0 && units > 0 && units <= 16 * XT_NBLK && out_dim > 0 && out_dim <= 1024, "ktf_xvec_tail_f32: bad sizes");
+    KTF_REQUIRE(B >= 0 && D > 0 && units > 0 && units <= 8 * XT_NBLK && in_dim <= XT_MAXIT * 256 && out_dim > 0 && out_dim <= XT_THREADS && group >= 1 && group <= 1024,
+                "ktf_xvec_tail_f32: sizes outside the kernel (units <= 512, (1 + include_std) * D <= 3072, out_dim <= 256, 1 <= group <= 1024)");
+    KTF_REQUIRE((B + group - 1) / group < 65536 && B < (1ll << 31), "ktf_xvec_tail_f32: too many utterance groups");
     KTF_REQUIRE(ldw >= ((in_dim + 3) & ~3) && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0, "ktf_xvec_tail_f32: W rows must be 16-byte aligned and padded to a multiple of 4 columns");
     if (pooled) KTF_REQUIRE(ld_pooled >= in_dim, "ktf_xvec_tail_f32: ld_pooled < in_dim");
     if (sums && slots) KTF_REQUIRE(slots >= (T + 127) / 128, "ktf_xvec_tail_f32: too few slots");
     if (B == 0) return KTF_OK;
-    const size_t lds = sizeof(float) * ((size_t)((in_dim + 3) & ~3) + 16 + out_dim + 8);
-    KTF_REQUIRE(lds <= 64 * 1024, "ktf_xvec_tail_f32: dims too large");
-    hipLaunchKernelGGL(xvec_tail_kernel, dim3(XT_NBLK, (unsigned)B), dim3(XT_THREADS), lds, (hipStream_t)stream, pooled, ld_pooled, sums, slots, lens, T,
-                       (int)D, (int)include_std, eps, W, ldw, bias, in_dim, (int)units, mean, A, off, (int)out_dim, partial, counters, y, h_out);
+    const size_t lds = sizeof(float) * ((size_t)XT_MAXIT * 256 + 16 + out_dim + 8);
+    const int two_phase = group > 1;        // many workgroups: the slot reduction as a second launch instead of in-kernel tickets
+    hipLaunchKernelGGL(xvec_tail_kernel, dim3(XT_NBLK, (unsigned)((B + group - 1) / group)), dim3(XT_THREADS), lds, (hipStream_t)stream, pooled, ld_pooled,
+                       sums, slots, lens, T, (int)D, (int)include_std, eps, W, ldw, bias, in_dim, (int)units, mean, A, off, (int)out_dim, partial,
+                       counters, y, h_out, B, (int)group, two_phase);
+    if (two_phase)
+        hipLaunchKernelGGL(xvec_tail_reduce_kernel, dim3((unsigned)B), dim3(XT_THREADS), sizeof(float) * (out_dim + 8), (hipStream_t)stream, partial, off, y,
+                           (int)out_dim);
     KTF_CHECK_LAUNCH("ktf_xvec_tail_f32");
     return KTF_OK;
 }

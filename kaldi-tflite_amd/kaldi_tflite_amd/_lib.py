@@ -112,7 +112,7 @@ PROTOTYPES = {
     "ktf_stats_pool": (C.c_int, [_P, _i32, _i64, _i64, _i32, _i64, _P, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_stats_pool_windowed_f32": (C.c_int, [_P, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _f32, _P, _P]),
     "ktf_xvec_post_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P, _P]),
-    "ktf_xvec_tail_f32": (C.c_int, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P, _i32, _P, _P, _P, _i32, _P, _P, _P, _P, _P]),
+    "ktf_xvec_tail_f32": (C.c_int, [_P, _i64, _P, _i64, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P, _i32, _P, _P, _P, _i32, _P, _P, _P, _P, _i32, _P]),
     "ktf_plda_f64": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
     "ktf_plda_f32": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
     "ktf_plda_score_f64": (C.c_int, [_P, _i64, _P, _i64, _i32, _P, _P, _P]),

@@ -263,7 +263,7 @@ class Sequential:
         if len(steps) >= 2 and steps[-1][0] == "tdnn" and steps[-2][0] == "stats":
             _, l, relu, bn = steps[-1]
             if (not relu and bn is None and l.activation in (None, "linear") and l.kernelWidth == 1 and l.padding == "SAME"
-                    and l.subsamplingFactor == 1 and l.units <= 1024):
+                    and l.subsamplingFactor == 1 and l.units <= 512 and l.inputDim <= 3072):
                 return len(steps) - 1
         return -1
 
@@ -773,6 +773,13 @@ class XvectorExtractor:
             if t.layer.units == A.shape[0]:
                 w6, _, b6 = t.layer.device_weights(dev, L.GEMM_F32)
                 B = t.B
+                # utterances per workgroup: one while 64 workgroups per utterance still fill the chip, then groups (W is read once
+                # per group); a large batch also finalizes the pooled sums once (not once per unit slice): same arithmetic either way
+                group = max(1, min(32, (B * 64) // 2048))
+                if t.sums is not None and B > 8:
+                    sbuf = self.xvec._ws.get("pooled", (B, ops.round_up((2 if t.include_std else 1) * t.D, 32)), torch.float32, dev)
+                    ops.stats_finalize(t.sums, t.lens, t.T, t.D, t.include_std, t.eps, sbuf, slots=t.slots)
+                    t.pooled, t.sums = sbuf, None
                 odim = A.shape[1]
                 ws = self._ws
                 partial = ws.get("tail_partial", (B, 64, odim), torch.float32, dev, padded=False)
@@ -780,7 +787,7 @@ class XvectorExtractor:
                 if out is None:
                     out = torch.empty((B, odim), dtype=torch.float32, device=dev)
                 return ops.xvec_tail(t.pooled, t.sums, t.slots, t.lens, t.T, t.D, t.include_std, t.eps, w6, b6, t.layer.units, mean, A, off,
-                                     partial, counters, out)
+                                     partial, counters, out, group=group)
             raise ValueError(f"LDA input dim {A.shape[0]} != embedding dim {t.layer.units}")
         B = h.shape[0]
         h2 = h.reshape(B, h.shape[-1])

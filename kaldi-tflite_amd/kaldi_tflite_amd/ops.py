@@ -496,7 +496,7 @@ def xvec_post(x, mean, A, off, out=None):
     return out
 
 
-def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units, mean, A, off, partial, counters, out, h_out=None):
+def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units, mean, A, off, partial, counters, out, h_out=None, group=1):
     """Fused tail (ktf_xvec_tail_f32): pooled (B, ld) fp32 rows OR fp64 sums -> tdnn6 -> mean-sub -> LDA -> length norm, one launch."""
     lib = L.load()
     B = out.shape[0]
@@ -504,7 +504,7 @@ def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units,
     with torch.cuda.device(src.device):
         rc = lib.ktf_xvec_tail_f32(L.ptr(pooled), pooled.stride(0) if pooled is not None else 0, L.ptr(sums), int(slots), L.ptr(lens), int(T), B,
                                    int(D), int(include_std), float(eps), L.ptr(W), W.stride(0), L.ptr(bias), int(units), L.ptr(mean), L.ptr(A),
-                                   L.ptr(off), A.shape[1], L.ptr(partial), L.ptr(counters), L.ptr(out), L.ptr(h_out), L.stream_ptr())
+                                   L.ptr(off), A.shape[1], L.ptr(partial), L.ptr(counters), L.ptr(out), L.ptr(h_out), int(group), L.stream_ptr())
     L.check(rc, "ktf_xvec_tail_f32")
     return out
 
