@@ -62,7 +62,7 @@ struct MxParams {
     int64_t ldy;
     int64_t T;
     int32_t units, nch_in, nctx, nk, nss, nch_out, stat_slots;
-    int32_t ctx[16];
+    unsigned long long ctx_pk[2];      // the (sorted) context offsets as signed bytes, offset k in byte k
 };
 
 // E8M0 scale byte of an e2m1 block whose largest magnitude is m: the maximum lands in the top binade [4, 8) x scale, one
@@ -212,44 +212,71 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
         a_cb[i] = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
         a_row[i] = t0 + row;
     }
-#define MX_KSTEP(ks_, c_, off_)                                                                                        \
-    const int kk_ = (ks_) < p.nk ? (ks_) : 0;             /* padded K-steps re-read step 0 (their weights are zero) */ \
-    const int c_ = kk_ / p.nctx;                                                                                       \
-    const int off_ = p.ctx[kk_ - c_ * p.nctx];
-    // one 16-byte-per-lane DMA of the half stage of K-step ks_: i = 0, 1 the A image (rows 0-127 / 128-255), 2, 3 the W image
+    // Which (32-feature chunk, context offset) a K-step reads is tracked in scalar registers, advanced once per stage: no division
+    // and no table load sits between the MFMAs (a scalar load there is a ~200-cycle stall of the wave's whole instruction
+    // stream). The context offsets travel as packed signed bytes in two 64-bit kernel arguments.
+    const unsigned long long cpk0 = p.ctx_pk[0], cpk1 = p.ctx_pk[1];
+#define MX_CTX(ci_) ((int)(signed char)(((ci_) < 8 ? cpk0 : cpk1) >> (((ci_) & 7) * 8)))
+    int f_ci = 0, f_off = MX_CTX(0);                      // K-step whose half stage is issued next: context index, offset,
+    unsigned f_base = 0;                                  // ... first record of its chunk (chunk * T)
+    int s_ci = 0;                                         // first K-step of the super-step whose side A is issued next
+    unsigned s_base = 0;
+    unsigned sa_base[4];
+    int sa_off[4];
+    // position of K-step ks_ (the next stage to issue) from the position of ks_ - 1; padded K-steps re-read step 0 (zero weights)
+#define MX_F_ADV(ks_)                                                                                                  \
+    {                                                                                                                  \
+        if ((ks_) < p.nk) {                                                                                            \
+            if (++f_ci == p.nctx) { f_ci = 0; f_base += Tu; }                                                          \
+            f_off = MX_CTX(f_ci);                                                                                      \
+        } else {                                                                                                       \
+            f_base = 0;                                                                                                \
+            f_off = MX_CTX(0);                                                                                         \
+        }                                                                                                              \
+    }
+    // one 16-byte-per-lane DMA of the half stage of K-step ks_: n_ = 0, 1 the A image (rows 0-127 / 128-255), 2, 3 the W image
 #define MX_DMA_F16(ks_, n_)                                                                                            \
     {                                                                                                                  \
         unsigned char* st_ = rsm + ((ks_) & 1) * MX_STAGE + wave * 1024;                                               \
         if ((n_) < 2) {                                                                                                \
-            MX_KSTEP(ks_, c__, off__)                                                                                  \
-            int r_ = a_row[(n_) & 1] + off__;                                                                          \
+            int r_ = a_row[(n_) & 1] + f_off;                                                                          \
             r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 64u + a_cb[(n_) & 1];                           \
+            const unsigned vo_ = (f_base + (unsigned)r_) * 64u + a_cb[(n_) & 1];                                       \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + ((n_) & 1) * 8192), 16, 0, 0); \
         } else {                                                                                                       \
             const unsigned vo_ = (unsigned)(ks_) * (unsigned)MX_TILE + (unsigned)(((n_) & 1) * 512 + tid) * 16u;       \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + MX_TILE + ((n_) & 1) * 8192), 16, 0, 0); \
         }                                                                                                              \
     }
+    // the four K-steps of super-step ss_ (K blocks of its scaled MFMAs): chunk bases and offsets for the side A DMAs
+#define MX_SA_SETUP(ss_)                                                                                               \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int kb_ = 0; kb_ < 4; ++kb_) {                                                          \
+            if (4 * (ss_) + kb_ < p.nk) {                                                                              \
+                sa_base[kb_] = s_base;                                                                                 \
+                sa_off[kb_] = MX_CTX(s_ci);                                                                            \
+                if (++s_ci == p.nctx) { s_ci = 0; s_base += Tu; }                                                      \
+            } else {                                                                                                   \
+                sa_base[kb_] = 0;                                                                                      \
+                sa_off[kb_] = MX_CTX(0);                                                                               \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
     // side A of super-step ss_: n_ = 0..3 the e2m1 pieces (32 KiB: plane, K block, 64-row group by wave), 4, 5 the scale words
 #define MX_DMA_SA(ss_, n_)                                                                                             \
     {                                                                                                                  \
+        const int idx_ = ((n_) < 4 ? (n_) : (n_) - 4) * 8 + wave;                                                      \
+        const int plane_ = idx_ >> 4, kb_ = (n_) < 4 ? (idx_ >> 2) & 3 : idx_ >> 2, rg_ = idx_ & 3;                    \
+        const unsigned base_ = kb_ == 0 ? sa_base[0] : kb_ == 1 ? sa_base[1] : kb_ == 2 ? sa_base[2] : sa_base[3];     \
+        const int off__ = kb_ == 0 ? sa_off[0] : kb_ == 1 ? sa_off[1] : kb_ == 2 ? sa_off[2] : sa_off[3];              \
+        int r_ = t0 + rg_ * 64 + lane + off__;                                                                         \
+        r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
         if ((n_) < 4) {                                                                                                \
-            const int idx_ = (n_) * 8 + wave;                                                                          \
-            const int plane_ = idx_ >> 4, kb_ = (idx_ >> 2) & 3, rg_ = idx_ & 3;                                       \
-            MX_KSTEP(4 * (ss_) + kb_, c__, off__)                                                                      \
-            int r_ = t0 + rg_ * 64 + lane + off__;                                                                     \
-            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 16u;                                            \
+            const unsigned vo_ = (base_ + (unsigned)r_) * 16u;                                                         \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)((plane_ ? x4 : xl4) + vo_),                                  \
                                              (lds_ptr_t*)(rsm + MX_SA_OFF + plane_ * 16384 + (kb_ * 256 + rg_ * 64) * 16), 16, 0, 0); \
         } else {                                                                                                       \
-            const int idx_ = ((n_) - 4) * 8 + wave;                                                                    \
-            const int kb_ = idx_ >> 2, rg_ = idx_ & 3;                                                                 \
-            MX_KSTEP(4 * (ss_) + kb_, c__, off__)                                                                      \
-            int r_ = t0 + rg_ * 64 + lane + off__;                                                                     \
-            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = ((unsigned)c__ * Tu + (unsigned)r_) * 4u;                                             \
+            const unsigned vo_ = (base_ + (unsigned)r_) * 4u;                                                          \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xs + vo_),                                                   \
                                              (lds_ptr_t*)(rsm + MX_SA_OFF + 32768 + (kb_ * 256 + rg_ * 64) * 4), 4, 0, 0); \
         }                                                                                                              \
@@ -262,6 +289,7 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wq + vo_), (lds_ptr_t*)(rsm + MX_SW_OFF + idx_ * 1024), 16, 0, 0); \
     }
     MX_DMA_F16(0, 2) MX_DMA_F16(0, 3) MX_DMA_F16(0, 0) MX_DMA_F16(0, 1)
+    MX_F_ADV(1)
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -323,11 +351,12 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
                 __builtin_amdgcn_sched_barrier(0);
                 if (next) {
                     if (i == 0) MX_DMA_F16(ks + 1, 0)
-                    if (i == 1) MX_DMA_F16(ks + 1, 1)
+                    if (i == 1) { MX_DMA_F16(ks + 1, 1) MX_F_ADV(ks + 2) }
                     if (i == 2) MX_DMA_F16(ks + 1, 2)
                     if (i == 3) MX_DMA_F16(ks + 1, 3)
                 }
                 if (j == 0) {
+                    if (i == 3) MX_SA_SETUP(ss)
                     if (i == 4) { MX_DMA_SA(ss, 0) MX_DMA_SA(ss, 1) }
                     if (i == 5) { MX_DMA_SA(ss, 2) MX_DMA_SA(ss, 3) }
                     if (i == 6) MX_DMA_SA(ss, 4)
@@ -392,7 +421,9 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
 #undef MX_DMA_F16
 #undef MX_DMA_SA
 #undef MX_DMA_SW
-#undef MX_KSTEP
+#undef MX_SA_SETUP
+#undef MX_F_ADV
+#undef MX_CTX
 
     const int rows_valid = len - t0;
     float ebias[4], esc[4], esh[4];
@@ -555,7 +586,10 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     p.units = d->units; p.nch_in = d->din_pad / 32; p.nctx = d->nctx; p.nk = p.nch_in * d->nctx; p.nss = (p.nk + 3) / 4;
     p.nch_out = (d->units + 31) / 32;
     p.stat_slots = (stats && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(T) : 0;
-    for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
+    for (int i = 0; i < d->nctx; ++i) {
+        KTF_REQUIRE(d->ctx[i] >= -128 && d->ctx[i] <= 127, "%s: context offsets outside [-128, 127]", who);
+        p.ctx_pk[i >> 3] |= (unsigned long long)(unsigned char)(signed char)d->ctx[i] << ((i & 7) * 8);
+    }
     const int mtiles = ktf_cdiv(T, 256), ntiles = ktf_cdiv(d->units, 256);
     const int64_t gtiles = B * mtiles;
     const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles;
