@@ -433,6 +433,11 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
                 _attach_traffic(res[g]["roofline"], g)
         del m
         torch.cuda.empty_cache()
+    # the same step with the shipped YAML's dither (data/tflite_models/0008_sitw_v2_1a.yml:43, `dither: 1.0`: on-device Philox + Box-Muller)
+    md = synth.build_extractor(ktf, synth.extractor_cfg(dither=1.0), w, gemm=gemm)
+    ms = _time_ms(torch, lambda: md(wav), 5)
+    res[f"{gemm}_dither_1.0"] = {"x_vectors_per_s": B / (ms * 1e-3), "ms_per_step": ms, "note": "the reference's default front-end option; outputs are random by design"}
+    del md
     # the same step on utterances with silence: 30 % of the 0.5 s blocks are quiet, the VAD drops them, batches are ragged
     quiet = (torch.rand((B, wav.shape[1] // 8000), device=dev, generator=torch.Generator(device=dev).manual_seed(5)) < 0.3)
     quiet[:, 0] = False

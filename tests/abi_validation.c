@@ -1,0 +1,61 @@
+// Host-side sanitizer run of the C-ABI's argument validation (no GPU needed: every call below must be rejected before any
+// HIP call). Build + run: tools/asan_abi.sh
+#include <stdio.h>
+#include <string.h>
+#include "ktf_hip.h"
+static int fails = 0;
+#define EXPECT_EINVAL(call)                                                       \
+    do {                                                                          \
+        int rc_ = (call);                                                         \
+        char buf_[256];                                                           \
+        ktf_last_error(buf_, sizeof buf_);                                        \
+        if (rc_ != KTF_EINVAL) { printf("FAIL %s -> %d\n", #call, rc_); ++fails; } \
+        else printf("ok   %-28.28s : %s\n", #call, buf_);                         \
+    } while (0)
+int main(void) {
+    float f[64] = {0};
+    double d[64] = {0};
+    int32_t l[4] = {1, 1, 1, 1};
+    uint32_t u[4] = {0};
+    KtfTdnnDesc t;
+    memset(&t, 0, sizeof t);
+    t.units = 8; t.din = 8; t.din_pad = 32; t.nctx = 1; t.subsampling = 1; t.gemm = KTF_GEMM_F32;
+    EXPECT_EINVAL(ktf_tdnn(NULL, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.nctx = 17;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.nctx = 2; t.ctx[0] = 1; t.ctx[1] = 0;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.nctx = 1; t.ctx[0] = 0; t.din_pad = 30;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.din_pad = 32; t.subsampling = 0;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.subsampling = 1;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, f, NULL, f, 8, NULL, NULL));       /* scale without shift */
+    EXPECT_EINVAL(ktf_tdnn(f, -1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.gemm = 77;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.gemm = KTF_GEMM_F16MX;
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, NULL, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 8, NULL));     /* no output */
+    t.valid = 1;
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
+    t.valid = 0; t.ctx[0] = 300;
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
+    EXPECT_EINVAL(ktf_tdnn_mx_stats(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL));
+    EXPECT_EINVAL(ktf_mx_planes(NULL, 1, 1, 8, 8, NULL, f, f, f, f, NULL));
+    EXPECT_EINVAL(ktf_mx_planes(f, 1, 1, 8, 4, NULL, f, f, f, f, NULL));
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, d, 0, l, 1, 1, 4, 1, 1e-10f, f, 8, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));   /* pooled and sums */
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, l, 1, 1, 4, 1, 1e-10f, f, 6, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));  /* ldw */
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, l, 1, 1, 4000, 1, 1e-10f, f, 8000, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));
+    EXPECT_EINVAL(ktf_xvec_post_f32(NULL, 1, 8, 4, NULL, f, NULL, f, NULL));
+    EXPECT_EINVAL(ktf_stats_finalize(NULL, NULL, 1, 1, 4, 1, 1e-10f, f, 8, NULL));
+    EXPECT_EINVAL(ktf_stats_finalize_slots(d, 1, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));       /* too few slots */
+    EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
+    EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));
+    EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, 9, NULL, NULL, f, NULL));
+    char small[4];
+    size_t n = ktf_last_error(small, sizeof small);      /* truncation must stay inside the buffer */
+    printf("last_error length %zu, truncated copy '%s'\n", n, small);
+    printf(fails ? "FAILED %d\n" : "all rejected as KTF_EINVAL\n", fails);
+    return fails != 0;
+}

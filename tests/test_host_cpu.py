@@ -513,3 +513,22 @@ def test_library_kernel_families():
     assert fam["tdnn_mx_kernel"] == 6                   # {ReLU, none} x {planes, fp32, pooled}
     assert not any("probe" in k for k in kernels)
     assert "getenv" not in out
+
+
+def test_abi_argument_validation_from_c(tmp_path):
+    """tests/abi_validation.c: a plain C caller hands every TDNN / MX / tail / helper entry point arguments it must refuse; each
+    call has to come back KTF_EINVAL with a message, before any HIP call (runs without a GPU). tools/asan_abi.sh runs the same
+    driver against an AddressSanitizer + UBSan build of the library (opt-in here: KTF_RUN_SANITIZERS=1, ~90 s of compile)."""
+    import os
+    import subprocess
+    from kaldi_tflite_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "abi_validation")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "abi_validation.c"), "-o", exe,
+                    "-L" + libdir, "-l:libktf_hip.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "all rejected as KTF_EINVAL" in out.stdout, out.stdout + out.stderr
+    if os.environ.get("KTF_RUN_SANITIZERS") == "1":
+        san = subprocess.run([os.path.join(root, "tools", "asan_abi.sh")], capture_output=True, text=True)
+        assert san.returncode == 0 and "all rejected as KTF_EINVAL" in san.stdout and "ERROR: AddressSanitizer" not in san.stderr, san.stdout + san.stderr
