@@ -27,8 +27,22 @@ V["no_dma"] = lambda s: V["no_f16_dma"](V["no_side_dma"](s))
 V["no_mfma"] = lambda s: rep(V["no_mx_mfma"](s), "                if (live) {\n                    hfrag8 a_nxt", "                if (false) {\n                    hfrag8 a_nxt")
 V["no_epilogue"] = lambda s: rep(s, "        for (int pass = 0; pass < 2; ++pass) {           // rows wm*128", "        for (int pass = 0; pass < 0; ++pass) {           // rows wm*128")
 
+V["hot_a"] = lambda s: rep(rep(rep(s, "const int64_t ub = (int64_t)b * p.nch_in * p.T;", "const int64_t ub = 0;"),
+                                "        a_row[i] = t0 + row;", "        a_row[i] = row;"),
+                            "        int r_ = t0 + rg_ * 64 + lane + off__;", "        int r_ = rg_ * 64 + lane + off__;")
+V["no_stores"] = lambda s: rep(rep(rep(rep(rep(s,
+    "                        __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));", "                        if (l4.x == 0x12345678u) __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));"),
+    "                        __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));", "                        if (h4.x == 0x12345678u) __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));"),
+    "                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));", "                        if (sw_ == 0x12345678u) __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));"),
+    "                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));", "                            if (v.x == 0x12345678u) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));"),
+    "xxxx", "xxxx") if False else rep(rep(rep(rep(s,
+    "                        __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));", "                        if (l4.x == 0x12345678u) __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));"),
+    "                        __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));", "                        if (h4.x == 0x12345678u) __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));"),
+    "                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));", "                        if (sw_ == 0x12345678u) __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));"),
+    "                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));", "                            if (v.x == 0x12345678u) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));")
+
 names = sys.argv[1:] or list(V)
-objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "pool_post.o")]
+objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "pool_post.o")]
 for n in names:
     path = f"/tmp/tdnn_mx_{n}.hip"
     open(path, "w").write(V[n](src))
