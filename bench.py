@@ -519,8 +519,9 @@ def _usable_cpus():
 def _cpu_baseline(torch, synth, cfg, w, N):
     """SURVEY §8(d) / BASELINE.md §3: the torch-CPU fp32 restatement of the reference's op graph (materialised frames,
     rfft, dense mel matmul, materialised im2col + matmul; constants precomputed once) on the host cores: 3 warm-ups, >= 10
-    timed iterations, median; full extractor at B = 1 (the reference's own batch size) and B = 32, the
-    Framing + MFCC + CMVN configuration (BASELINE config 1) and MFCC alone. The thread count is calibrated first (a short
+    timed iterations, median; the full extractor one utterance at a time (the reference's own batch size) with intra-op
+    threads, and utterance-parallel (one single-threaded extraction per usable core), the Framing + MFCC + CMVN configuration
+    (BASELINE config 1) and MFCC alone. The thread count is calibrated first (a short
     B = 8 run per candidate, ascending, stop when it gets slower): with every logical CPU of a shared 256-thread host in the
     pool, torch's intra-op barriers cost more than the extra cores give (measured here: 7.9 s per utterance at 256 threads
     against tens of milliseconds at 16-64). `cores` = the threads actually used; `value` = the better full-extractor rate."""
@@ -557,24 +558,40 @@ def _cpu_baseline(torch, synth, cfg, w, N):
 
     T = 1 + (N - 400) // 160
     legs = {}
-    for B in (1, 32):
-        wav = torch.as_tensor(synth.make_wav(B, N, seed=1234))
-        s, n = median_s(lambda: ref(wav))
-        legs[f"extractor_B{B}"] = {"x_vectors_per_s": B / s, "median_s": s, "iterations": n}
+    wav = torch.as_tensor(synth.make_wav(1, N, seed=1234))
+    s, n = median_s(lambda: ref(wav))
+    legs["extractor_B1"] = {"x_vectors_per_s": 1 / s, "median_s": s, "iterations": n, "threads": best_t,
+                            "note": "one utterance at a time (the reference's own batch size), intra-op threads"}
+    # utterance-parallel: one single-threaded extraction per core (the per-utterance working set stays in the core's caches; the
+    # batched B = 32 call of rounds 1-2 materialised 196 MB of im2col per layer and ran 3.7 x slower per utterance than B = 1)
+    import concurrent.futures
+    torch.set_num_threads(1)
+    wavs = [torch.as_tensor(synth.make_wav(1, N, seed=2000 + i)) for i in range(2 * avail)]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=avail) as pool:
+        list(pool.map(ref, wavs[:avail]))                 # warm-up
+        rates = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            list(pool.map(ref, wavs))
+            rates.append(len(wavs) / (time.perf_counter() - t0))
+    legs["extractor_utterance_parallel"] = {"x_vectors_per_s": float(np.median(rates)), "workers": avail, "utterances_per_round": len(wavs),
+                                            "rounds": 3, "note": "one intra-op thread per worker, one utterance per worker at a time"}
+    torch.set_num_threads(best_t)
     wav1 = torch.as_tensor(synth.make_wav(1, N, seed=1234))
     s, n = median_s(lambda: ref.features(wav1))
     legs["framing_mfcc_cmvn_B1"] = {"frames_per_s": T / s, "median_s": s, "iterations": n}
     wav32 = torch.as_tensor(synth.make_wav(32, N, seed=1234))
     s, n = median_s(lambda: ref.mfcc(wav32))
     legs["mfcc_only_B32"] = {"frames_per_s": 32 * T / s, "median_s": s, "iterations": n}
-    best = max(legs["extractor_B1"]["x_vectors_per_s"], legs["extractor_B32"]["x_vectors_per_s"])
-    return {"value": best, "unit": "x-vectors/s", "cores": best_t, "kind": "port", "cpu_model": _cpu_model(),
+    par = legs["extractor_utterance_parallel"]["x_vectors_per_s"] > legs["extractor_B1"]["x_vectors_per_s"]
+    best = max(legs["extractor_B1"]["x_vectors_per_s"], legs["extractor_utterance_parallel"]["x_vectors_per_s"])
+    return {"value": best, "unit": "x-vectors/s", "cores": avail if par else best_t, "kind": "port", "cpu_model": _cpu_model(),
             "host_logical_cpus": os.cpu_count(), "usable_cpus": avail,
             "thread_calibration_s_per_8_utterances": {str(k): round(v, 4) for k, v in tried.items()},
             "sample": (f"CPU restatement ({best_t} threads of {avail} usable CPUs): torch-CPU fp32 port of the reference's TF "
                        f"op graph (oracle/ktf_torch_cpu.py; the reference's TensorFlow 2.8 cannot be installed here), {N}-sample "
                        f"utterances of the same workload, 3 warm-ups + >= 10 timed iterations per leg, median; value = best "
-                       f"of B=1 / B=32"),
+                       f"of one utterance at a time with {best_t} intra-op threads / {avail} single-threaded extractions in parallel"),
             "legs": legs}
 
 
