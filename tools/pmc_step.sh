@@ -2,7 +2,7 @@
 # GPU box: SQ counter passes over the default 1024 x 10 s step (tools/x3_step.py, GEMM=<mode>). usage: tools/pmc_step.sh <tag> [mode]
 # (counters only: no trace domains in the same rocprofv3 run; TCP_*/TA_* sets abort rocprofv3 on this image)
 TAG=${1:-step}
-export GEMM=${2:-f16x2}
+export GEMM=${2:-f16mx}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -17,6 +17,6 @@ SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ
 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SALU
 SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE
 LIST
-python3 $REPO/tools/pmc_summary.py $OUT tdnn_x3s > $OUT/summary.txt
+python3 $REPO/tools/pmc_summary.py $OUT tdnn_ > $OUT/summary.txt
 python3 $REPO/tools/pmc_summary.py $OUT frontend512 >> $OUT/summary.txt
 head -60 $OUT/summary.txt

@@ -1,5 +1,6 @@
 import json
-d=json.load(open("gpurun_out/r3e/bench_default.json"))
+import sys
+d=json.load(open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/r3i/bench_default.json"))
 print(d["dtype"], d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["per_layer_ms"])
 print(d["max_abs_dev_by_input"], d["tolerance_ok"], d["timed_batch_vs_f32"])
 for k,v in d["other_configs"].items():
