@@ -251,3 +251,22 @@ def test_fused_tail_does_not_depend_on_the_batch_size():
             assert torch.equal(big[:5], mid) and torch.equal(big[3], one)
         else:           # (reduced modes hand small batches to the fp32 kernels: Sequential.min_tiles; the tail itself is the same)
             assert (big[:5] - mid).abs().max().item() <= 1e-4
+
+
+def test_f16mx_edge_cases():
+    """The MX route on degenerate inputs (module fixture: no hand-over of small batches to the fp32 kernels): utterances of a
+    few frames, one without a single voiced frame (NaN embedding for it, the reference pools over zero frames; the others
+    bit-identical), utterance lengths around the 256-row tile boundary."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+    for n in [400 + 160 * 2, 400 + 160 * 255, 400 + 160 * 256, 400 + 160 * 511]:          # 3, 256, 257, 512 frames
+        wav = synth.make_wav(2, n, seed=n)
+        want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+        assert np.abs(mdl(dev(wav)).cpu().numpy() - want).max() <= 1e-4, n
+    wav = synth.make_wav(3, 32000, seed=5, ragged=True)
+    ref = mdl(dev(wav)).cpu().numpy()
+    wav[1] = 0.0
+    out = mdl(dev(wav)).cpu().numpy()
+    assert np.array_equal(out[[0, 2]], ref[[0, 2]]) and np.isnan(out[1]).all()
+    assert tuple(mdl(torch.zeros((0, 32000), device="cuda")).shape) == (0, 128)

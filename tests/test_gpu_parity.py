@@ -759,7 +759,7 @@ def test_extractor_edge_cases():
     assert np.array_equal(a, b[::-1])
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16x2", 2e-4), ("bf16", 5e-2), ("f16", 1e-3)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16mx", 1e-4), ("f16x2", 2e-4), ("bf16", 5e-2), ("f16", 1e-3)])
 def test_extractor_8khz_callhome_topology(gemm, tol):
     """The reference's second model family (0006_callhome_diarization_v2_1a.yml: 8 kHz, 23-dim MFCC, 128-dim embedding):
     200-sample frames -> nfft 256 takes the generic front-end kernel, tdnn6 has 128 units."""

@@ -152,7 +152,7 @@ def test_long_recording_beyond_38400_frames():
 
 
 # ----------------------------------------------------------------------------- reproducible fused pooling
-@pytest.mark.parametrize("gemm", ["bf16x3", "f16x2", "bf16", "f16"])
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16mx", "f16x2", "bf16", "f16"])
 def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
     """KTF_TDNN_DET_STATS (the models' default): per-128-row partial sums added in block order -> bitwise identical
     x-vectors run after run and batch == single; the fp64-atomic form agrees to the last fp32 bits."""
@@ -173,7 +173,7 @@ def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
 
 
 # ----------------------------------------------------------------------------- hipGraph product path
-@pytest.mark.parametrize("gemm,B,cal", [("f32", 1, False), ("bf16x3", 16, False), ("f16x2", 16, False), ("f16x2", 16, True)])
+@pytest.mark.parametrize("gemm,B,cal", [("f32", 1, False), ("bf16x3", 16, False), ("f16mx", 16, False), ("f16x2", 16, False), ("f16x2", 16, True)])
 def test_compiled_extractor_replays_bitwise(gemm, B, cal):
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
