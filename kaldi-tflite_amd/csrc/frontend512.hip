@@ -126,11 +126,13 @@ __device__ __forceinline__ void transpose4(float2 (&r)[4], int lane) {
     swap_step<BL>(r[2].x, r[3].x, lane); swap_step<BL>(r[2].y, r[3].y, lane);
 }
 
-// Philox-based N(0,1) identical to frontend.hip (dither)
-__device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t i) {
+// Dither (windowing.py:182-183: x += N(0,1) * dither): counter-based Philox4x32-10 keyed by `seed`, counter (frame, lane group);
+// ONE Philox call gives four uniform words = two Box-Muller pairs = FOUR Gaussians (the generic kernel in frontend.hip spends one
+// call and one log / sqrt / cos per sample: 1024 x 998 frames x 400 samples of that cost 3.5 ms per step, four times this).
+__device__ __forceinline__ void gauss_noise5x4(uint64_t seed, uint64_t row, uint32_t i, float (&g)[4]) {
     uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32), c2 = i, c3 = 0x9E3779B9u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll 1
+#pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
         const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0, hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
@@ -140,7 +142,13 @@ __device__ __noinline__ float gauss_noise5(uint64_t seed, uint64_t row, uint32_t
     }
     const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
     const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    return sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+    const float u3 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u4 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * __logf(u1)), rb = sqrtf(-2.0f * __logf(u3));
+    g[0] = ra * cospif(2.0f * u2);
+    g[1] = ra * sinpif(2.0f * u2);
+    g[2] = rb * cospif(2.0f * u4);
+    g[3] = rb * sinpif(2.0f * u4);
 }
 
 #define F5_WAVE_SYNC()                           \
@@ -308,10 +316,15 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         // ---- Windowing.call (windowing.py:180-209)
         if (in_kind != KTF_IN_WINDOWED) {
             if (DITHER) {
-#pragma unroll 1
-                for (int j = 0; j < NV; ++j) {
-                    const int i = lane + KTF_WAVE * j;
-                    if (i < M) v[j] += gauss_noise5(seed, (uint64_t)row, (uint32_t)i) * cfg.dither;
+#pragma unroll
+                for (int q = 0; q < (NV + 3) / 4; ++q) {              // four samples of this lane per Philox call
+                    float g[4];
+                    gauss_noise5x4(seed, (uint64_t)row, (uint32_t)(lane + KTF_WAVE * q), g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int j = 4 * q + e;
+                        if (j < NV && lane + KTF_WAVE * j < M) v[j] += g[e] * cfg.dither;
+                    }
                 }
             }
             if (cfg.remove_dc) {
