@@ -41,6 +41,9 @@ V["no_stores"] = lambda s: rep(rep(rep(rep(rep(s,
     "                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));", "                        if (sw_ == 0x12345678u) __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));"),
     "                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));", "                            if (v.x == 0x12345678u) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));")
 
+V["prio_hi_half"] = lambda s: rep(s, "    for (int ss = 0; ss < p.nss; ++ss) {", "    if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n    for (int ss = 0; ss < p.nss; ++ss) {")
+V["prio_lo_half"] = lambda s: rep(s, "    for (int ss = 0; ss < p.nss; ++ss) {", "    if (wave < 4) __builtin_amdgcn_s_setprio(1);\n    for (int ss = 0; ss < p.nss; ++ss) {")
+
 names = sys.argv[1:] or list(V)
 objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "pool_post.o")]
 for n in names:
