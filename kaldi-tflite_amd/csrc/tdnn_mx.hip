@@ -28,6 +28,7 @@
 //
 // Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88, stats_pooling.py:211-240 when fused).
 #include "tdnn_common.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 hfrag8;
@@ -73,30 +74,29 @@ __device__ __forceinline__ unsigned mx_fp4_scale_byte(float m) {
     return (unsigned)(byte < 1 ? 1 : byte);
 }
 
-// 32 values -> half plane piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word.
-// (v_med3 clamp, v_cvt_pk_f16_f32, packed 16-bit maxima of the half magnitudes, v_cvt_scalef32_pk_fp4_f16 on the packed halves:
-// ~240 vector instructions per 32 values; the plain-C form was ~430.)
+// 32 values, each within [-65504, 65504] (the callers clamp: half planes saturate instead of overflowing to inf) -> half plane
+// piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word.
+// Per pair of values: v_cvt_pk_f16_f32, two v_fma_mix_f32 (residual = value - half, exact), two v_max3_f32 (the maxima of the
+// magnitudes: rounding to half is monotonic, so the largest half magnitude is the half of the largest magnitude), then
+// v_cvt_scalef32_pk_fp4_{f32,f16}: ~135 vector instructions per 32 values (the plain-C form was ~430).
 typedef __attribute__((ext_vector_type(2))) float mx_f2;
 typedef __attribute__((ext_vector_type(2))) _Float16 mx_h2;
-typedef __attribute__((ext_vector_type(2))) unsigned short mx_us2;
 __device__ __forceinline__ void mx_encode32(const float (&v)[32], u32x4 (&hp)[4], u32x4& l4, u32x4& h4, unsigned& sw) {
     float lo[32];
     unsigned hw[16];
-    mx_us2 hmax = {0, 0};
-    float ml = 0.0f;
+    float mv = 0.0f, ml = 0.0f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const float a = __builtin_amdgcn_fmed3f(v[2 * k], -65504.0f, 65504.0f);       // half planes saturate instead of overflowing to inf
-        const float b = __builtin_amdgcn_fmed3f(v[2 * k + 1], -65504.0f, 65504.0f);
+        const float a = v[2 * k], b = v[2 * k + 1];
         const mx_h2 hh = __builtin_convertvector(mx_f2{a, b}, mx_h2);
         hw[k] = __builtin_bit_cast(unsigned, hh);
-        lo[2 * k] = a - (float)hh[0];
-        lo[2 * k + 1] = b - (float)hh[1];
-        hmax = __builtin_elementwise_max(hmax, __builtin_bit_cast(mx_us2, hw[k] & 0x7fff7fffu));
-        ml = __builtin_fmaxf(ml, __builtin_fmaxf(__builtin_fabsf(lo[2 * k]), __builtin_fabsf(lo[2 * k + 1])));
+        // (spelled in assembly: from C the compiler emits v_cvt_f32_f16 + v_sub_f32 and quiets every v_max operand first)
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * k]) : "v"(hw[k]), "v"(a));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * k + 1]) : "v"(hw[k]), "v"(b));
+        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mv) : "v"(a), "v"(b), "v"(mv));
+        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(ml) : "v"(lo[2 * k]), "v"(lo[2 * k + 1]), "v"(ml));
     }
-    const unsigned short hm = hmax[0] > hmax[1] ? hmax[0] : hmax[1];
-    const float mh = (float)__builtin_bit_cast(_Float16, hm);
+    const float mh = (float)(_Float16)mv;
     const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml);
     const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
     unsigned wl[4], wh_[4];
@@ -131,7 +131,7 @@ __global__ void mx_planes_kernel(const float* __restrict__ src, int64_t B, int64
     const float* row = src + (b * T + t) * ld + c * 32;
     float v[32];
 #pragma unroll
-    for (int e = 0; e < 32; ++e) v[e] = (c * 32 + e < D) ? row[e] : 0.0f;
+    for (int e = 0; e < 32; ++e) v[e] = (c * 32 + e < D) ? __builtin_amdgcn_fmed3f(row[e], -65504.0f, 65504.0f) : 0.0f;
     u32x4 hp[4], l4, h4;
     unsigned sw;
     mx_encode32(v, hp, l4, h4, sw);
@@ -475,21 +475,35 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
         const bool affine = p.scale != nullptr;
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {           // rows wm*128 + pass*64 .. +63 of both wave rows -> 128 staged rows (130 KiB)
+            // accumulators -> staging image. The (launch-uniform) `affine` test sits outside the element loops: inside them the
+            // compiler kept it as a branch per element, and those 64 branches per pass were half of the epilogue's time.
+            auto to_staging = [&](auto aff) {
+                constexpr bool AFF = decltype(aff)::value;
 #pragma unroll
-            for (int ih = 0; ih < 4; ++ih) {
-                const int i = pass * 4 + ih;
+                for (int ih = 0; ih < 4; ++ih) {
+                    const int i = pass * 4 + ih;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = wn * 64 + j * 16 + (lane & 15);
+                    for (int j = 0; j < 4; ++j) {
+                        const int col = wn * 64 + j * 16 + (lane & 15);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int srow = wm * 64 + ih * 16 + q4 * 4 + r;
-                        float v = mx_act(acc[i][j][r] + ebias[j], ACT);
-                        if (affine) v = v * esc[j] + esh[j];          // (absent when the BatchNorm is folded into the next layer)
-                        et[srow * MX_EPI_PITCH + col] = v;
+                        for (int r = 0; r < 4; ++r) {
+                            const int srow = wm * 64 + ih * 16 + q4 * 4 + r;
+                            float v = acc[i][j][r] + ebias[j];
+                            if constexpr (OUT == MX_OUT_PLANES) {
+                                // the planes saturate at the largest half (mx_encode32 expects clamped values): one v_med3 does the
+                                // ReLU and the clamp when no affine follows (the BatchNorm is normally folded into the next layer)
+                                if constexpr (AFF) v = __builtin_amdgcn_fmed3f(mx_act(v, ACT) * esc[j] + esh[j], -65504.0f, 65504.0f);
+                                else v = __builtin_amdgcn_fmed3f(v, ACT == KTF_ACT_RELU ? 0.0f : -65504.0f, 65504.0f);
+                            } else {
+                                v = mx_act(v, ACT);
+                                if constexpr (AFF) v = v * esc[j] + esh[j];
+                            }
+                            et[srow * MX_EPI_PITCH + col] = v;
+                        }
                     }
                 }
-            }
+            };
+            if (affine) to_staging(std::true_type{}); else to_staging(std::false_type{});
             __syncthreads();
             if constexpr (OUT == MX_OUT_PLANES) {
                 // (1) one thread per (staged row, 32-column chunk) encodes it: the wave's 64 lanes are 64 consecutive rows of ONE
@@ -524,13 +538,28 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
                 }
                 // the half pieces were written by this wave's own lanes: LDS operations of a wave complete in order
                 if (chunk_ok) {
+                    const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(et + wave * 32) + (lane & 3) * 16;
+                    char* hdst = p.yh + rec0 * 64 + (lane & 3) * 16;
+                    if (rows_valid >= 256) {             // whole tile (uniform): all reads in flight, then the stores back to back
+                        u32x4 hv[8];
 #pragma unroll
-                    for (int n = 0; n < 8; ++n) {
-                        const int srow = n * 16 + (lane >> 2);
-                        const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
-                        if (m < rows_valid) {
-                            const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(et + srow * MX_EPI_PITCH + wave * 32) + (lane & 3) * 16);
-                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));
+                        for (int n = 0; n < 8; ++n)
+                            hv[n] = *reinterpret_cast<const u32x4*>(hsrc + (n * 16 + (lane >> 2)) * (MX_EPI_PITCH * 4));
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) {
+                            const int srow = n * 16 + (lane >> 2);
+                            const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
+                            __builtin_nontemporal_store(hv[n], reinterpret_cast<u32x4*>(hdst + (int64_t)m * 64));
+                        }
+                    } else {
+#pragma unroll
+                        for (int n = 0; n < 8; ++n) {
+                            const int srow = n * 16 + (lane >> 2);
+                            const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
+                            if (m < rows_valid) {
+                                const u32x4 v = *reinterpret_cast<const u32x4*>(hsrc + srow * (MX_EPI_PITCH * 4));
+                                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(hdst + (int64_t)m * 64));
+                            }
                         }
                     }
                 }

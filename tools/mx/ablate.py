@@ -30,19 +30,66 @@ V["no_epilogue"] = lambda s: rep(s, "        for (int pass = 0; pass < 2; ++pass
 V["hot_a"] = lambda s: rep(rep(rep(s, "const int64_t ub = (int64_t)b * p.nch_in * p.T;", "const int64_t ub = 0;"),
                                 "        a_row[i] = t0 + row;", "        a_row[i] = row;"),
                             "        int r_ = t0 + rg_ * 64 + lane + off__;", "        int r_ = rg_ * 64 + lane + off__;")
-V["no_stores"] = lambda s: rep(rep(rep(rep(rep(s,
-    "                        __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));", "                        if (l4.x == 0x12345678u) __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));"),
-    "                        __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));", "                        if (h4.x == 0x12345678u) __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));"),
-    "                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));", "                        if (sw_ == 0x12345678u) __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));"),
-    "                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));", "                            if (v.x == 0x12345678u) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));"),
-    "xxxx", "xxxx") if False else rep(rep(rep(rep(s,
-    "                        __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));", "                        if (l4.x == 0x12345678u) __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));"),
-    "                        __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));", "                        if (h4.x == 0x12345678u) __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));"),
-    "                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));", "                        if (sw_ == 0x12345678u) __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));"),
-    "                            __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));", "                            if (v.x == 0x12345678u) __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64 + (lane & 3) * 16));")
+def _no_stores(s):
+    import re
+    s = re.sub(r"__builtin_nontemporal_store\(([^,]+), (reinterpret_cast<[^;]+)\);", r"if (abl_word(\1) == 0x12345678u) __builtin_nontemporal_store(\1, \2);", s)
+    return rep(s, "#define MX_EPI_PITCH 260", "#define MX_EPI_PITCH 260\nstatic __device__ __forceinline__ unsigned abl_word(unsigned v) { return v; }\n"
+               "template <typename V> static __device__ __forceinline__ unsigned abl_word(V v) { return v.x; }")
+V["no_stores"] = _no_stores
 
 V["prio_hi_half"] = lambda s: rep(s, "    for (int ss = 0; ss < p.nss; ++ss) {", "    if (wave >= 4) __builtin_amdgcn_s_setprio(1);\n    for (int ss = 0; ss < p.nss; ++ss) {")
 V["prio_lo_half"] = lambda s: rep(s, "    for (int ss = 0; ss < p.nss; ++ss) {", "    if (wave < 4) __builtin_amdgcn_s_setprio(1);\n    for (int ss = 0; ss < p.nss; ++ss) {")
+
+# A/B (correct results): the half pieces stored straight from the encoding thread (4 x 16 B at a 64-byte lane stride) instead of
+# through the in-place LDS image and coalesced 1 KiB store instructions
+V["direct_half_stores"] = lambda s: rep(rep(s,
+    "                        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(src + k * 4) = hp[k];\n                        const int64_t rec = rec0 + m;",
+    "                        for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(hp[k], reinterpret_cast<u32x4*>(p.yh + (rec0 + m) * 64) + k);\n                        const int64_t rec = rec0 + m;"),
+    "                if (chunk_ok) {\n                    const unsigned char* hsrc", "                if (false) {\n                    const unsigned char* hsrc")
+# A/B (correct results): ordinary stores instead of nontemporal ones
+import re
+V["plain_stores"] = lambda s: re.sub(r"__builtin_nontemporal_store\(([^,]+), (reinterpret_cast<[^;]+)\);", r"*(\2) = \1;", s)
+
+# instrumented build (correct results): per-workgroup 100 MHz timestamps summed per (output kind, super-step count); dumped by
+# ktf_prof_dump() (tools/mx/prof_phases.py). t_k = start .. end of the K-loop, t_e = epilogue until the last store is issued,
+# t_d = until the stores are acknowledged.
+def _prof(s):
+    s = rep(s, "#define MX_EPI_PITCH 260", "#define MX_EPI_PITCH 260\n__device__ unsigned long long g_prof[48][12];")
+    s = rep(s, "    const int n0 = nt * 256, t0 = mt * 256;", "    const int n0 = nt * 256, t0 = mt * 256;\n    const long long pt0 = wall_clock64();\n    long long pe[5] = {0, 0, 0, 0, 0};")
+    s = rep(s, "    const int rows_valid = len - t0;", "    const long long pt1 = wall_clock64();\n    const int rows_valid = len - t0;")
+    s = rep(s, "            __builtin_amdgcn_s_barrier();\n            asm volatile(\"\" ::: \"memory\");\n            constexpr bool live = true;",
+            "            __builtin_amdgcn_s_barrier();\n            asm volatile(\"\" ::: \"memory\");\n            if (ks == 0) ppro = wall_clock64() - pt0;\n            constexpr bool live = true;")
+    s = rep(s, "    long long pe[5] = {0, 0, 0, 0, 0};", "    long long pe[5] = {0, 0, 0, 0, 0}, ppro = 0;")
+    dump = ("{ const long long pt2 = wall_clock64(); __builtin_amdgcn_s_waitcnt(0); __syncthreads(); const long long pt3 = wall_clock64();"
+            " if (tid == 0) { unsigned long long* g = g_prof[(p.nss < 15 ? p.nss : 15) + 16 * OUT]; atomicAdd(g, (unsigned long long)(pt1 - pt0));"
+            " atomicAdd(g + 1, (unsigned long long)(pt2 - pt1)); atomicAdd(g + 2, (unsigned long long)(pt3 - pt2)); atomicAdd(g + 3, 1ull);"
+            " for (int e = 0; e < 5; ++e) atomicAdd(g + 4 + e, (unsigned long long)pe[e]); atomicAdd(g + 9, (unsigned long long)ppro); } }")
+    s = rep(s, "        }\n        return;\n    } else {", "        }\n        " + dump + "\n        return;\n    } else {")
+    s = rep(s, "            __syncthreads();\n        }\n    }\n}\n\n// x planes (see the head", "            __syncthreads();\n            pe[4] += wall_clock64() - pq;\n        }\n        " + dump + "\n    }\n}\n\n// x planes (see the head")
+    # finer epilogue phases (sums over both passes): skew wait | accumulators -> staging | encode | half stores | closing barrier
+    s = rep(s, "        __syncthreads();                                 // every fragment read is done", "        __syncthreads();\n        pe[0] = wall_clock64() - pt1;\n        long long pq = wall_clock64();     // every fragment read is done")
+    s = rep(s, "            __syncthreads();\n            if constexpr (OUT == MX_OUT_PLANES) {", "            __syncthreads();\n            pe[1] += wall_clock64() - pq; pq = wall_clock64();\n            if constexpr (OUT == MX_OUT_PLANES) {")
+    s = rep(s, "                // the half pieces were written by this wave's own lanes", "                pe[2] += wall_clock64() - pq; pq = wall_clock64();\n                // the half pieces were written by this wave's own lanes")
+    s = rep(s, "            } else {\n                const int nl = lane * 4;", "                pe[3] += wall_clock64() - pq; pq = wall_clock64();\n            } else {\n                const int nl = lane * 4;")
+    s += """
+extern "C" void ktf_prof_dump(void) {
+    unsigned long long h[48][12];
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof), sizeof(h));
+    for (int i = 0; i < 48; ++i)
+        if (h[i][3]) {
+            const double n = (double)h[i][3] * 100.0;
+            printf("out %d nss %2d: %llu tiles  prologue %.2f us  K-loop(+prologue) %.2f us  epilogue %.2f us  store-drain %.2f us | skew %.2f  acc->staging %.2f  encode %.2f  half stores %.2f  closing barrier %.2f\\n",
+                   i / 16, i % 16, h[i][3], h[i][9] / n, h[i][0] / n, h[i][1] / n, h[i][2] / n, h[i][4] / n, h[i][5] / n, h[i][6] / n, h[i][7] / n, h[i][8] / n);
+        }
+    memset(h, 0, sizeof(h));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof(h));
+}
+"""
+    return s
+V["prof"] = _prof
+
+V["head"] = lambda s: subprocess.check_output(["git", "show", "HEAD:kaldi-tflite_amd/csrc/tdnn_mx.hip"], cwd=ROOT).decode()
 
 names = sys.argv[1:] or list(V)
 objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "pool_post.o")]
