@@ -371,50 +371,55 @@ __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, in
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // M: the two block-scaled terms of this super-step (side data complete since the barrier of F3). Two column halves: the
-        // B fragments of two column blocks (22 registers) stay resident while the eight row blocks stream past them (the A
-        // fragments are read twice; all four column blocks resident cost 44 registers and spilled).
+        // M: the two block-scaled terms of this super-step (side data complete since the barrier of F3).
         __builtin_amdgcn_sched_barrier(0);
         {
+            // (the two record indices pass through an empty asm: the fragment addresses are then recomputed here, a few VALU
+            // operations per super-step, instead of living in ~20 loop-invariant registers -- which is what spilled)
+            int sw_rec = sw_col, sa_rec = sa_row;
+            asm volatile("" : "+v"(sw_rec), "+v"(sa_rec));
             const unsigned char* sA = rsm + MX_SA_OFF;
             const unsigned char* sW = rsm + MX_SW_OFF;
+            // the B fragments of all four column blocks stay resident (44 registers) while the eight row blocks stream past them
+            // once: read per column half, the A side crossed the LDS twice and the M-step ran at the LDS's read rate
+            // (3,008 clk of reads against 2,048 clk of MFMA per CU; now 1,856)
+            u32x4 w4[4], wl6a[4];
+            u32x2 wl6b[4];
+            unsigned wsc[4];
 #pragma unroll
-            for (int jh = 0; jh < 2; ++jh) {
-                i32x8 w4[2], wl6[2];
-                unsigned wsc[2];
+            for (int jj = 0; jj < 4; ++jj) {
+                const int rec = sw_rec + jj * 16;
+                w4[jj] = *reinterpret_cast<const u32x4*>(sW + rec * 16);
+                wl6a[jj] = *reinterpret_cast<const u32x4*>(sW + 16384 + rec * 16);
+                wl6b[jj] = *reinterpret_cast<const u32x2*>(sW + 32768 + rec * 8);
+                wsc[jj] = *reinterpret_cast<const unsigned*>(sW + 40960 + rec * 4);
+            }
+            u32x4 l_n = *reinterpret_cast<const u32x4*>(sA + sa_rec * 16);
+            u32x4 h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + sa_rec * 16);
+            unsigned s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + sa_rec * 4);
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int rec = sw_col + (jh * 2 + jj) * 16;
-                    const u32x4 a = *reinterpret_cast<const u32x4*>(sW + rec * 16);
-                    const u32x4 l0 = *reinterpret_cast<const u32x4*>(sW + 16384 + rec * 16);
-                    const u32x2 l1 = *reinterpret_cast<const u32x2*>(sW + 32768 + rec * 8);
-                    wsc[jj] = *reinterpret_cast<const unsigned*>(sW + 40960 + rec * 4);
-                    w4[jj] = i32x8{(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
-                    wl6[jj] = i32x8{(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, 0, 0};
+            for (int i = 0; i < 8; ++i) {
+                const u32x4 l = l_n, h = h_n;
+                const unsigned asc = s_n;
+                if (i < 7) {                             // the next row block's fragments are read under this one's MFMAs
+                    const int rec = sa_rec + (i + 1) * 16;
+                    l_n = *reinterpret_cast<const u32x4*>(sA + rec * 16);
+                    h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + rec * 16);
+                    s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + rec * 4);
                 }
-                u32x4 l_n = *reinterpret_cast<const u32x4*>(sA + sa_row * 16);
-                u32x4 h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + sa_row * 16);
-                unsigned s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + sa_row * 4);
+                const i32x8 al = i32x8{(int)l.x, (int)l.y, (int)l.z, (int)l.w, 0, 0, 0, 0};
+                const i32x8 ah = i32x8{(int)h.x, (int)h.y, (int)h.z, (int)h.w, 0, 0, 0, 0};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const u32x4 l = l_n, h = h_n;
-                    const unsigned asc = s_n;
-                    if (i < 7) {                             // the next row block's fragments are read under this one's MFMAs
-                        const int rec = sa_row + (i + 1) * 16;
-                        l_n = *reinterpret_cast<const u32x4*>(sA + rec * 16);
-                        h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + rec * 16);
-                        s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + rec * 4);
-                    }
-                    const i32x8 al = i32x8{(int)l.x, (int)l.y, (int)l.z, (int)l.w, 0, 0, 0, 0};
-                    const i32x8 ah = i32x8{(int)h.x, (int)h.y, (int)h.z, (int)h.w, 0, 0, 0, 0};
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)       // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
-                        acc[i][jh * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, w4[jj], acc[i][jh * 2 + jj], 4, 4, 0, asc, 0, wsc[jj]);
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)       // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
-                        acc[i][jh * 2 + jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, wl6[jj], acc[i][jh * 2 + jj], 4, 2, 1, asc, 1, wsc[jj]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int jj = 0; jj < 4; ++jj) {     // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
+                    const i32x8 bw = i32x8{(int)w4[jj].x, (int)w4[jj].y, (int)w4[jj].z, (int)w4[jj].w, 0, 0, 0, 0};
+                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, bw, acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);
                 }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {     // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
+                    const i32x8 bw = i32x8{(int)wl6a[jj].x, (int)wl6a[jj].y, (int)wl6a[jj].z, (int)wl6a[jj].w, (int)wl6b[jj].x, (int)wl6b[jj].y, 0, 0};
+                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, bw, acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
