@@ -135,7 +135,7 @@ __global__ __launch_bounds__(MXP_ROWS) void mx_planes_kernel(const float* __rest
     const int rows = (int)(len - t0 < MXP_ROWS ? len - t0 : MXP_ROWS);
     const int tid = threadIdx.x;
     const float* base = src + ((int64_t)b * T + t0) * ld + c * 32;
-    const bool vec = (ld & 3) == 0 && ((uintptr_t)src & 15) == 0 && c * 32 + 32 <= D;
+    const bool vec = (ld & 3) == 0 && ((uintptr_t)src & 15) == 0 && c * 32 + 32 <= ld;      // (pad columns inside the row are read and dropped)
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int q = k * MXP_ROWS + tid, r = q >> 3, e4 = (q & 7) * 4;
@@ -143,7 +143,8 @@ __global__ __launch_bounds__(MXP_ROWS) void mx_planes_kernel(const float* __rest
             float v[4];
             if (vec) {
                 const f32x4 t = *reinterpret_cast<const f32x4*>(base + (int64_t)r * ld + e4);
-                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+                const int nd = D - (c * 32 + e4);          // real columns among these four
+                v[0] = nd > 0 ? t.x : 0.0f; v[1] = nd > 1 ? t.y : 0.0f; v[2] = nd > 2 ? t.z : 0.0f; v[3] = nd > 3 ? t.w : 0.0f;
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = (c * 32 + e4 + e < D) ? base[(int64_t)r * ld + e4 + e] : 0.0f;

@@ -29,20 +29,24 @@ def dev(a, dtype=torch.float32):
     return torch.as_tensor(np.ascontiguousarray(a), device="cuda").to(dtype)
 
 
-def test_mx_planes_match_the_numpy_codecs_bit_for_bit():
+@pytest.mark.parametrize("B,T,D,ld", [(3, 37, 70, 70),        # rows of 70 floats: scalar loads, a partial last chunk, one row block
+                                       (2, 600, 64, 64),       # aligned rows: the 16-byte load path, three row blocks (256 + 256 + 88)
+                                       (2, 300, 30, 32)])      # the extractor's own shape: 30 features in rows of 32
+def test_mx_planes_match_the_numpy_codecs_bit_for_bit(B, T, D, ld):
     """ktf_mx_planes: half plane, e2m1 codes of the residual and of the half value, E8M0 scales -- identical to mx.encode_activations
     (round to nearest even, saturation, the scale rule) on values spanning 40 binades, exact zeros, a zero block and ties."""
     rng = np.random.default_rng(5)
-    B, T, D = 3, 37, 70
     x = (rng.standard_normal((B, T, D)) * np.exp2(rng.integers(-20, 20, (B, T, D)))).astype(np.float32)
-    x[0, 0, :32] = 0.0                                    # a zero block
+    x[0, 0, :min(D, 32)] = 0.0                            # a zero block
     x[0, 1, :8] = [0.25, 0.75, 1.25, 1.75, 2.5, 3.5, 5.0, 7.0]      # e2m1 ties (block max 7 -> scale 2, halves of these)
     x[1, 2, 3] = 1e9                                      # saturates the half plane
     x[rng.random((B, T, D)) < 0.3] = 0.0                  # ReLU-like zeros
-    lens = np.array([T, T - 5, 1], np.int32)
+    lens = np.array([T, T - 5, 1][:B], np.int32)
     p = mx.Planes.empty(B, T, D, "cuda")
-    ops.mx_planes(dev(x), D, dev(lens, torch.int32), p)
-    Dp = 96
+    buf = torch.full((B, T, ld), float("nan"), device="cuda")          # pad columns of the rows must not be read as values
+    buf[:, :, :D] = dev(x)
+    ops.mx_planes(buf[:, :, :D] if ld != D else buf, D, dev(lens, torch.int32), p)
+    Dp = (D + 31) // 32 * 32
     xp = np.zeros((B, T, Dp), np.float32)
     xp[:, :, :D] = x
     xh, cl, ch, sl, sh = mx.encode_activations(xp)
