@@ -19,8 +19,8 @@ V["no_encode"] = lambda s: rep(rep(rep(rep(s,
     "                        __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));", "(void)rec;"),
     "                        __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));", ""),
     "                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));", "")
-V["no_mx_mfma"] = lambda s: rep(s, "            for (int jh = 0; jh < 2; ++jh) {", "            for (int jh = 0; jh < 0; ++jh) {")
-V["no_side_dma"] = lambda s: rep(rep(s, "                if (j == 0) {\n                    if (i == 4)", "                if (false) {\n                    if (i == 4)"),
+V["no_mx_mfma"] = lambda s: rep(s, "            for (int i = 0; i < 8; ++i) {\n                const u32x4 l = l_n, h = h_n;", "            for (int i = 0; i < 0; ++i) {\n                const u32x4 l = l_n, h = h_n;")
+V["no_side_dma"] = lambda s: rep(rep(s, "                if (j == 0) {\n                    if (i == 3) MX_SA_SETUP", "                if (false) {\n                    if (i == 3) MX_SA_SETUP"),
                                  "                if (j == 1) {\n                    if (i == 4)", "                if (false) {\n                    if (i == 4)")
 V["no_f16_dma"] = lambda s: rep(s, "                if (next) {\n                    if (i == 0) MX_DMA_F16", "                if (false) {\n                    if (i == 0) MX_DMA_F16")
 V["no_dma"] = lambda s: V["no_f16_dma"](V["no_side_dma"](s))
@@ -104,6 +104,11 @@ V["3slot"] = lambda s: _3slot()
 V["f_only_3slot"] = lambda s: rep(rep(_f_only_common(_3slot()), "                if (j == 2) {\n                    if (i == 4) MX_LD_SW(ss, 0)", "                if (false) {\n                    if (i == 4) MX_LD_SW(ss, 0)"),
     '            if (j == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");\n            else if (j < 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");\n            else if (last) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");\n            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");',
     '            if (last && j == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");')
+
+V["dma_only"] = V["no_mfma"]
+V["dma_only_stage"] = lambda s: V["no_side_dma"](V["no_mfma"](s))
+V["dma_only_sides"] = lambda s: V["no_f16_dma"](V["no_mfma"](s))
+V["dma_only_none"] = lambda s: V["no_dma"](V["no_mfma"](s))
 
 names = sys.argv[1:] or list(V)
 objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "pool_post.o")]
