@@ -257,6 +257,32 @@ def test_fused_tail_does_not_depend_on_the_batch_size():
             assert (big[:5] - mid).abs().max().item() <= 1e-4
 
 
+def test_large_batches_take_the_gemm_tail_route():
+    """From `fuse_tail_below` utterances on (512) the reduced-precision modes run tdnn6 as an fp32 MFMA GEMM over the batch
+    instead of the one-launch tail: same x-vectors to fp32 summation-order noise as the small-batch route, reproducible, the
+    captured graph replays it bit for bit; the exact fp32 mode keeps the one-launch tail at every size (batch == single)."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321)
+    wav = dev(synth.make_wav(512, 24000, seed=41, ragged=True))
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+    assert mdl.fuse_tail_below == 512
+    big = mdl(wav)
+    assert ops.last_kernel().startswith("tdnn_f32"), ops.last_kernel()          # tdnn6 ran as a GEMM launch
+    assert torch.equal(mdl(wav), big), "not reproducible"
+    mdl.fuse_tail_below = 1 << 30
+    small_route = mdl(wav)
+    assert ops.last_kernel().startswith("tdnn_mx"), ops.last_kernel()           # the last GEMM launch was the pooled layer
+    assert bool(torch.isfinite(big).all()) and (big - small_route).abs().max().item() <= 1e-5
+    run = synth.build_extractor(ktf, cfg, w, gemm="f16mx").compile(wav)
+    assert torch.equal(run(wav), big) and torch.equal(run(wav), big)
+    f32 = synth.build_extractor(ktf, cfg, w, gemm="f32")
+    full = f32(wav)
+    assert ops.last_kernel().startswith("tdnn_f32"), ops.last_kernel()
+    for i in (0, 300, 511):
+        assert torch.equal(f32(wav[i:i + 1]).reshape(-1), full[i]), "fp32 mode: batch != single"
+    assert (full - big).abs().max().item() <= 1e-4
+
+
 def test_f16mx_edge_cases():
     """The MX route on degenerate inputs (module fixture: no hand-over of small batches to the fp32 kernels): utterances of a
     few frames, one without a single voiced frame (NaN embedding for it, the reference pools over zero frames; the others

@@ -226,6 +226,12 @@ SCHEMES = {
     "mx46d": [("exact", "mx:e2m1:e2m3:d")] * 5,
     "mx4_": [("exact", "mx:e2m1:none")] * 5,
     "mx_4": [("exact", "mx:none:e2m1")] * 5,
+    "mx_46": [("exact", "mx:none:e2m1/e2m3")] * 5,          # f16mx without the activation-residual term
+    # ... without it in some layers only (F = full f16mx, N = no activation-residual term)
+    "mx_FNNFF": [("exact", "mx:e2m1:e2m1/e2m3")] + [("exact", "mx:none:e2m1/e2m3")] * 2 + [("exact", "mx:e2m1:e2m1/e2m3")] * 2,
+    "mx_NNNFF": [("exact", "mx:none:e2m1/e2m3")] * 3 + [("exact", "mx:e2m1:e2m1/e2m3")] * 2,
+    "mx_FFFNN": [("exact", "mx:e2m1:e2m1/e2m3")] * 3 + [("exact", "mx:none:e2m1/e2m3")] * 2,
+    "mx_FNFFF": [("exact", "mx:e2m1:e2m1/e2m3")] + [("exact", "mx:none:e2m1/e2m3")] + [("exact", "mx:e2m1:e2m1/e2m3")] * 3,
 }
 
 if __name__ == "__main__":
