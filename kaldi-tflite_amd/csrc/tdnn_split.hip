@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             // DMA n of the stage: 0,1 = A hi / lo rows 0-127; 2,3 = rows 128-255; 4,5 = W hi / lo rows 0-127; 6,7 = rows 128-255
 #define XS_DMA(n)                                                                                                      \
     {                                                                                                                  \
-        const char* src_ = ((n) < 4) ? ((((n) & 1) ? xl : xh) + va[(n) >> 1]) : ((((n) & 1) ? wl : wh) + vw[((n) - 4) >> 1]); \
+        const char* src_ = ((n) < 4) ? ((((n) & 1) ? xl : xh) + va[((n) >> 1) & 1]) : ((((n) & 1) ? wl : wh) + vw[((n) >> 1) & 1]); \
         __builtin_amdgcn_global_load_lds((glb_ptr_t*)src_,                                                             \
             (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, \
             0);                                                                  \
@@ -369,10 +369,10 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                     }
                     if (refill) {
                         const int n = 4 * g + c;                // slot -> DMA index
-                        if (TERMS == 3) {
+                        if constexpr (TERMS == 3) {
                             if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
                             else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
-                        } else if (TERMS == 1) {                   // one pass: no residual plane at all, four DMAs
+                        } else if constexpr (TERMS == 1) {         // one pass: no residual plane at all, four DMAs
                             if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(6)
                         } else {                                   // no residual plane of the activations: six DMAs
                             if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) { if (two_next) XS_DMA(5) }

@@ -112,12 +112,23 @@ V["dma_only_none"] = lambda s: V["no_dma"](V["no_mfma"](s))
 
 names = sys.argv[1:] or list(V)
 objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "pool_post.o")]
+FLAGS = {
+    "flags_O2": ["-O2"],
+    "flags_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "flags_maxocc": ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"],
+    "flags_iter": ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"],
+    "flags_nounroll": ["-fno-unroll-loops"],
+    "flags_noslp": ["-fno-slp-vectorize"],
+    "flags_postra": ["-mllvm", "-enable-post-misched=false"],
+}
+for k in FLAGS:
+    V[k] = lambda s: s
 for n in names:
     path = f"/tmp/tdnn_mx_{n}.hip"
     open(path, "w").write(V[n](src))
     out = os.path.join(ROOT, "kaldi-tflite_amd", "kaldi_tflite_amd", f"libktf_abl_{n}.so")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-I" + CS,
-                           "-c", path, "-o", f"/tmp/tdnn_mx_{n}.o"], cwd=CS)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-I" + CS]
+                          + FLAGS.get(n, []) + ["-c", path, "-o", f"/tmp/tdnn_mx_{n}.o"], cwd=CS)
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + [os.path.join(CS, o) for o in objs]
                           + [f"/tmp/tdnn_mx_{n}.o", "-o", out])
     print("built", out)
