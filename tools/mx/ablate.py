@@ -55,17 +55,17 @@ V["plain_stores"] = lambda s: re.sub(r"__builtin_nontemporal_store\(([^,]+), (re
 # t_d = until the stores are acknowledged.
 def _prof(s):
     s = rep(s, "#define MX_EPI_PITCH 260", "#define MX_EPI_PITCH 260\n__device__ unsigned long long g_prof[48][12];")
-    s = rep(s, "    const int n0 = nt * 256, t0 = mt * 256;", "    const int n0 = nt * 256, t0 = mt * 256;\n    const long long pt0 = wall_clock64();\n    long long pe[5] = {0, 0, 0, 0, 0};")
-    s = rep(s, "    const int rows_valid = len - t0;", "    const long long pt1 = wall_clock64();\n    const int rows_valid = len - t0;")
+    s = rep(s, "    const int n0 = nt * 256, t0 = mt * 256;", "    const int n0 = nt * 256, t0 = mt * 256;\n    const long long pt0 = wall_clock64();\n    const long long pc0 = clock64();\n    long long pe[5] = {0, 0, 0, 0, 0};")
+    s = rep(s, "    const int rows_valid = len - t0;", "    const long long pt1 = wall_clock64();\n    const long long pc1 = clock64();\n    const int rows_valid = len - t0;")
     s = rep(s, "            __builtin_amdgcn_s_barrier();\n            asm volatile(\"\" ::: \"memory\");\n            constexpr bool live = true;",
             "            __builtin_amdgcn_s_barrier();\n            asm volatile(\"\" ::: \"memory\");\n            if (ks == 0) ppro = wall_clock64() - pt0;\n            constexpr bool live = true;")
     s = rep(s, "    long long pe[5] = {0, 0, 0, 0, 0};", "    long long pe[5] = {0, 0, 0, 0, 0}, ppro = 0;")
     dump = ("{ const long long pt2 = wall_clock64(); __builtin_amdgcn_s_waitcnt(0); __syncthreads(); const long long pt3 = wall_clock64();"
             " if (tid == 0) { unsigned long long* g = g_prof[(p.nss < 15 ? p.nss : 15) + 16 * OUT]; atomicAdd(g, (unsigned long long)(pt1 - pt0));"
             " atomicAdd(g + 1, (unsigned long long)(pt2 - pt1)); atomicAdd(g + 2, (unsigned long long)(pt3 - pt2)); atomicAdd(g + 3, 1ull);"
-            " for (int e = 0; e < 5; ++e) atomicAdd(g + 4 + e, (unsigned long long)pe[e]); atomicAdd(g + 9, (unsigned long long)ppro); } }")
+            " for (int e = 0; e < 5; ++e) atomicAdd(g + 4 + e, (unsigned long long)pe[e]); atomicAdd(g + 9, (unsigned long long)ppro); atomicAdd(g + 10, (unsigned long long)(pc1 - pc0)); } }")
     s = rep(s, "        }\n        return;\n    } else {", "        }\n        " + dump + "\n        return;\n    } else {")
-    s = rep(s, "            __syncthreads();\n        }\n    }\n}\n\n// x planes (see the head", "            __syncthreads();\n            pe[4] += wall_clock64() - pq;\n        }\n        " + dump + "\n    }\n}\n\n// x planes (see the head")
+    s = rep(s, "            __syncthreads();\n        }\n    }\n}\n\n// (The tile body is a function", "            __syncthreads();\n            pe[4] += wall_clock64() - pq;\n        }\n        " + dump + "\n    }\n}\n\n// (The tile body is a function")
     # finer epilogue phases (sums over both passes): skew wait | accumulators -> staging | encode | half stores | closing barrier
     s = rep(s, "        __syncthreads();                                 // every fragment read is done", "        __syncthreads();\n        pe[0] = wall_clock64() - pt1;\n        long long pq = wall_clock64();     // every fragment read is done")
     s = rep(s, "            __syncthreads();\n            if constexpr (OUT == MX_OUT_PLANES) {", "            __syncthreads();\n            pe[1] += wall_clock64() - pq; pq = wall_clock64();\n            if constexpr (OUT == MX_OUT_PLANES) {")
@@ -79,8 +79,8 @@ extern "C" void ktf_prof_dump(void) {
     for (int i = 0; i < 48; ++i)
         if (h[i][3]) {
             const double n = (double)h[i][3] * 100.0;
-            printf("out %d nss %2d: %llu tiles  prologue %.2f us  K-loop(+prologue) %.2f us  epilogue %.2f us  store-drain %.2f us | skew %.2f  acc->staging %.2f  encode %.2f  half stores %.2f  closing barrier %.2f\\n",
-                   i / 16, i % 16, h[i][3], h[i][9] / n, h[i][0] / n, h[i][1] / n, h[i][2] / n, h[i][4] / n, h[i][5] / n, h[i][6] / n, h[i][7] / n, h[i][8] / n);
+            printf("out %d nss %2d: %llu tiles  prologue %.2f us  K-loop(+prologue) %.2f us  epilogue %.2f us  store-drain %.2f us | skew %.2f  acc->staging %.2f  encode %.2f  half stores %.2f  closing barrier %.2f | K-loop: %.0f clock64 ticks per 10 ns wall tick x 100 = %.0f MHz\\n",
+                   i / 16, i % 16, h[i][3], h[i][9] / n, h[i][0] / n, h[i][1] / n, h[i][2] / n, h[i][4] / n, h[i][5] / n, h[i][6] / n, h[i][7] / n, h[i][8] / n, (double)h[i][10] / (double)h[i][0], 100.0 * (double)h[i][10] / (double)h[i][0]);
         }
     memset(h, 0, sizeof(h));
     hipMemcpyToSymbol(HIP_SYMBOL(g_prof), h, sizeof(h));
