@@ -316,7 +316,7 @@ def _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N, calibrate=True):
                      f"0.5 s blocks) + the reference's e2e speech recording (359 665 samples whole, and as two {N}-sample chunks)"}
     for g in modes:
         m = synth.build_extractor(ktf, cfg, w, gemm=g, calibrate=calibrate)
-        m.xvec.min_tiles = {}          # a few utterances would be routed to the fp32 kernels: measure the mode's own
+        m.xvec.min_tiles, m.xvec.min_frames = {}, {}          # a few (or short) utterances would be routed to tighter kernels: measure the mode's own
         r = {}
         for k, v in inputs.items():
             got = m(torch.as_tensor(v, device=dev)).cpu().numpy().reshape(v.shape[0], -1)

@@ -136,8 +136,15 @@ class Sequential:
     one_pass_tail = 2           # f16x2: the last N frame-level layers in front of the pooling run ONE half pass (weights rounded to
                                 # nearest half, the constant part of the rounding error moved into the fp32 bias) once calibrate()
                                 # has measured the mean of their input planes; 0 = every layer two passes
-    # batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times)
-    min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
+    # Routing defaults, copied into every instance (`self.min_tiles`, `self.min_frames`: per-model knobs, no shared mutable state).
+    # MIN_TILES: batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times).
+    # MIN_FRAMES: batches whose utterances are shorter than this many frames run the next tighter mode: the block-scaled residuals
+    # of f16mx are zero-mean rounding noise that the statistics pooling averages over the voiced frames, so its deviation grows as
+    # the utterance shrinks (measured on speech windows, tests/test_gpu_margin.py: 10 s 2-5e-5, 3 s 6e-5, 1 s up to 9e-5 of the
+    # 1e-4 tolerance); below 2 s of audio the split-bf16 kernels (7e-6) take the batch.
+    MIN_TILES = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
+    MIN_FRAMES = {"f16mx": 200}
+    SHORT_MODE = {"f16mx": "bf16x3"}
 
     def __init__(self, layers=None, name=None, gemm="f32"):
         self.input = None
@@ -151,6 +158,8 @@ class Sequential:
         if gemm not in _GEMM:
             raise ValueError(f"gemm must be one of {sorted(_GEMM)}")
         self.gemm = gemm
+        self.min_tiles = dict(self.MIN_TILES)
+        self.min_frames = dict(self.MIN_FRAMES)
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"
@@ -217,9 +226,13 @@ class Sequential:
     def batch_gemm(self, B, T):
         """GEMM arithmetic for a batch of B utterances of up to T frames: the model's mode, except that a handful of
         256-row tiles (single utterances) cannot fill the chip on the 256-wide ring kernels -- the exact fp32 kernels have
-        small-tile forms and are faster there (one 10 s utterance: 0.19 ms against 0.20 bf16 / 0.39 split-bf16)."""
-        gemm = _GEMM[self.gemm]
-        if gemm != L.GEMM_F32 and B * ((T + 255) // 256) < self.min_tiles.get(self.gemm, 0):
+        small-tile forms and are faster there (one 10 s utterance: 0.19 ms against 0.20 bf16 / 0.39 split-bf16); and a batch
+        of utterances shorter than `min_frames` frames runs the tighter mode named by SHORT_MODE."""
+        mode = self.gemm
+        if T < self.min_frames.get(mode, 0):             # short utterances: the tighter mode (MIN_FRAMES)
+            mode = self.SHORT_MODE.get(mode, "f32")
+        gemm = _GEMM[mode]
+        if gemm != L.GEMM_F32 and B * ((T + 255) // 256) < self.min_tiles.get(mode, 0):
             gemm = L.GEMM_F32
         return gemm
 
@@ -764,8 +777,8 @@ class XvectorExtractor:
     def _extract(self, inputs, out=None):
         _, feats, lens = self._features(inputs)
         self.last_lens = lens                                          # voiced-frame counts of the last call (workspace view)
-        one_launch = self.fuse_tail and (feats.shape[0] < self.fuse_tail_below or
-                                         self.xvec.batch_gemm(feats.shape[0], feats.shape[1]) == L.GEMM_F32)
+        one_launch = self.fuse_tail and self._tail_fusable() and (feats.shape[0] < self.fuse_tail_below or
+                                                                  self.xvec.batch_gemm(feats.shape[0], feats.shape[1]) == L.GEMM_F32)
         h = self.xvec.run_ragged(feats, lens, defer_tail=one_launch)          # (B, 1, 512), or the deferred tail
         dev = feats.device
         key = str(dev)
@@ -800,6 +813,16 @@ class XvectorExtractor:
         if not h2.is_contiguous():
             h2 = h2.contiguous()
         return ops.xvec_post(h2, mean, A, off, out=out)
+
+    def _tail_fusable(self):
+        """ktf_xvec_tail_f32 serves LDA outputs up to 256 wide (one thread per output), an embedding layer whose width is the LDA's
+        input, and default kernel flags; anything else keeps the three-launch tail (finalize, GEMM, ktf_xvec_post_f32)."""
+        steps = self.xvec._plan() or []
+        at = self.xvec._tail_step(steps)
+        if at < 0:
+            return False
+        layer = steps[at][1]
+        return self.ldaMat.shape[1] <= 256 and layer.units == self.ldaMat.shape[0] and layer.kernelFlags == 0
 
     def calibrate(self, inputs):
         """Extension: `Sequential.calibrate` on the features of these utterances (a handful is enough: the statistic is a

@@ -19,10 +19,11 @@ FRAME_LAYERS = ["5x30->512", "3x512->512", "3x512->512", "1x512->512", "1x512->1
 
 @pytest.fixture(autouse=True, scope="module")
 def _reduced_modes_reach_their_kernels():
-    old = ktf.models.Sequential.min_tiles
-    ktf.models.Sequential.min_tiles = {}
+    S = ktf.models.Sequential           # defaults of models built in this module (instances copy them; no call-time global)
+    old = (S.MIN_TILES, S.MIN_FRAMES)
+    S.MIN_TILES, S.MIN_FRAMES = {}, {}
     yield
-    ktf.models.Sequential.min_tiles = old
+    S.MIN_TILES, S.MIN_FRAMES = old
 
 
 def trace(mdl, wav):
@@ -82,8 +83,9 @@ def test_calibrated_f16x2_runs_one_pass_in_front_of_the_pooling():
 
 def test_single_utterance_dispatch():
     """One 10 s utterance: every reduced mode hands it to the exact fp32 small-tile kernels (Sequential.min_tiles)."""
-    old = ktf.models.Sequential.min_tiles
-    ktf.models.Sequential.min_tiles = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
+    S = ktf.models.Sequential
+    old = S.MIN_TILES
+    S.MIN_TILES = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
     try:
         w = synth.make_weights(seed=4321)
         wav = synth.make_wav(1, 160000, seed=3)
@@ -99,7 +101,7 @@ def test_single_utterance_dispatch():
             want = want or kernels
             assert kernels == want
     finally:
-        ktf.models.Sequential.min_tiles = old
+        S.MIN_TILES = old
 
 
 def test_special_shapes():

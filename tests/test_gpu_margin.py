@@ -1,0 +1,113 @@
+"""Where the headline mode's parity margin is thin (run with `-m gpu` on an MI355X): `f16mx` on SHORT speech windows and on
+weights whose BatchNorm statistics are the network's own.
+
+The block-scaled residual terms of `f16mx` leave zero-mean rounding noise per frame that the statistics pooling averages over
+the voiced frames, so the x-vector deviation grows as the pooled window shrinks: 10 s 2-5e-5, 5 s up to 6e-5, 1 s up to 9e-5 of
+the 1e-4 tolerance (fp64 emulation: tools/emulate_schemes.py `mx4_46`). The diarization recipes the reference documents use
+1.5 s windows (README.md:203-206 of the reference), so that regime is gated here on the reference's own
+speech recording (models/kaldi/xvector_extractor_test.py:70-96, tests/golden/e2e_0008.npz:wav_int16) at a 1 s hop, one batch per
+window length, four weight seeds, against the fp64 oracle:
+
+* the RAW kernels (routing off): every mode that claims the tolerance stays inside 1e-4 at every window length;
+* the SHIPPED routing (`Sequential.MIN_FRAMES`): windows shorter than 200 frames go to the split-bf16 kernels, and what still
+  reaches the `f16mx` kernels stays inside 8e-5;
+* the same on SELF-CONSISTENT BatchNorm weights (tests/_selfbn.py): the closest offline stand-in for trained statistics.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+import kaldi_tflite_amd as ktf
+from kaldi_tflite_amd import ops
+from oracle import ktf_oracle as O
+from _selfbn import self_consistent_weights
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4                  # north_star: max-abs x-vector deviation
+ROUTED_BOUND = 8e-5         # what the shipped routing guarantees on the gated regimes
+SEEDS = [4321, 1, 2, 3]
+WINDOWS_S = [1.0, 1.5, 3.0, 5.0]
+
+
+def windows(sec, hop=1.0):
+    """(n, samples) windows of the reference's speech recording, `hop` seconds apart."""
+    sp = synth.speech_wavs()[0][0]
+    n, h = int(sec * 16000), int(hop * 16000)
+    return np.stack([sp[s:s + n] for s in range(0, len(sp) - n + 1, h)], 0)
+
+
+_weights, _want = {}, {}
+
+
+def weights(kind, seed):
+    if (kind, seed) not in _weights:
+        if kind == "synthetic":
+            _weights[(kind, seed)] = synth.make_weights(seed=seed)
+        else:       # BatchNorm statistics = the network's own statistics on the recording itself
+            _weights[(kind, seed)] = self_consistent_weights(seed, [synth.speech_wavs()[0][0]])
+    return _weights[(kind, seed)]
+
+
+def oracle(kind, seed, sec):
+    if (kind, seed, sec) not in _want:
+        w = weights(kind, seed)
+        _want[(kind, seed, sec)] = O.xvector_forward(windows(sec), synth.extractor_cfg(), synth.oracle_layers(w), w["mean"], w["lda"],
+                                                     dtype=np.float64)
+    return _want[(kind, seed, sec)]
+
+
+def deviations(gemm, kind, seed, routed):
+    """{window seconds: (max-abs deviation over the batch of windows, GEMM kernel family that ran)}"""
+    mdl = synth.build_extractor(ktf, synth.extractor_cfg(), weights(kind, seed), gemm=gemm)
+    mdl.xvec.min_tiles = {}                               # a batch of ~20 windows is a handful of tiles: keep it off the fp32 small-tile route
+    if not routed:
+        mdl.xvec.min_frames = {}
+    out = {}
+    for sec in WINDOWS_S:
+        wav = windows(sec)
+        got = mdl(torch.as_tensor(wav, device="cuda")).cpu().numpy().reshape(wav.shape[0], -1)
+        out[sec] = (float(np.abs(got - oracle(kind, seed, sec)).max()), ops.last_kernel())
+    return out
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("kind", ["synthetic", "self_consistent_bn"])
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16mx"])
+def test_raw_kernels_on_short_speech_windows(gemm, kind, seed):
+    """Routing off: the mode's own kernels at every window length. Inside the tolerance everywhere; f16mx's margin at 1-1.5 s is
+    thin (printed), which is why the shipped routing below does not send such batches to it."""
+    d = deviations(gemm, kind, seed, routed=False)
+    print(f"{gemm} raw, {kind} weights, seed {seed}: " + ", ".join(f"{k:g} s {v[0]:.2e}" for k, v in d.items()))
+    assert max(v[0] for v in d.values()) <= TOL, d
+    if gemm == "bf16x3":
+        assert max(v[0] for v in d.values()) <= 2e-5, d
+
+
+@pytest.mark.parametrize("seed", SEEDS)
+@pytest.mark.parametrize("kind", ["synthetic", "self_consistent_bn"])
+def test_shipped_routing_on_short_speech_windows(kind, seed):
+    """`Sequential.MIN_FRAMES` as shipped: 1 s and 1.5 s windows (98 / 148 frames) run the split-bf16 kernels, 3 s and 5 s windows
+    the f16mx kernels, and every gated regime stays inside 8e-5."""
+    d = deviations("f16mx", kind, seed, routed=True)
+    print(f"f16mx routed, {kind} weights, seed {seed}: " + ", ".join(f"{k:g} s {v[0]:.2e} ({v[1]})" for k, v in d.items()))
+    for sec, (err, kernel) in d.items():
+        short = ktf.models.Sequential.MIN_FRAMES["f16mx"] > 1 + (int(sec * 16000) - 400) // 160
+        assert ("x3" in kernel) == short, (sec, kernel)
+        assert ("mx" in kernel) == (not short), (sec, kernel)
+        assert err <= ROUTED_BOUND, (sec, err, kernel)
+
+
+def test_min_frames_is_a_per_model_knob():
+    """The routing knobs are instance attributes copied from the class defaults: changing one model's does not move another's."""
+    w = weights("synthetic", 4321)
+    a = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm="f16mx")
+    b = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm="f16mx")
+    a.xvec.min_frames, a.xvec.min_tiles = {}, {}
+    assert b.xvec.min_frames == ktf.models.Sequential.MIN_FRAMES and b.xvec.min_tiles == ktf.models.Sequential.MIN_TILES
+    assert a.xvec.batch_gemm(64, 148) == ktf._lib.GEMM_F16MX
+    assert b.xvec.batch_gemm(64, 148) == ktf._lib.GEMM_BF16X3
+    assert b.xvec.batch_gemm(64, 998) == ktf._lib.GEMM_F16MX
+    assert b.xvec.batch_gemm(1, 998) == ktf._lib.GEMM_F32

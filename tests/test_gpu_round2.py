@@ -20,10 +20,11 @@ Ls = ktf.layers
 
 @pytest.fixture(autouse=True, scope="module")
 def _reduced_modes_reach_their_kernels():
-    old = ktf.models.Sequential.min_tiles
-    ktf.models.Sequential.min_tiles = {}
+    S = ktf.models.Sequential           # defaults of models built in this module (instances copy them; no call-time global)
+    old = (S.MIN_TILES, S.MIN_FRAMES)
+    S.MIN_TILES, S.MIN_FRAMES = {}, {}
     yield
-    ktf.models.Sequential.min_tiles = old
+    S.MIN_TILES, S.MIN_FRAMES = old
 
 
 def dev(a, dtype=torch.float32):

@@ -13,6 +13,7 @@ import torch
 import synth
 import kaldi_tflite_amd as ktf
 from oracle import ktf_oracle as O
+from _selfbn import self_consistent_weights as _self_consistent_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -23,10 +24,11 @@ SEEDS = [4321, 1, 2, 3]
 
 @pytest.fixture(autouse=True, scope="module")
 def _reduced_modes_reach_their_kernels():
-    old = ktf.models.Sequential.min_tiles
-    ktf.models.Sequential.min_tiles = {}
+    S = ktf.models.Sequential           # defaults of models built in this module (instances copy them; no call-time global)
+    old = (S.MIN_TILES, S.MIN_FRAMES)
+    S.MIN_TILES, S.MIN_FRAMES = {}, {}
     yield
-    ktf.models.Sequential.min_tiles = old
+    S.MIN_TILES, S.MIN_FRAMES = old
 
 
 _inputs = {}
@@ -93,31 +95,6 @@ def test_f16x2_two_pass_on_speech_is_recorded(seed):
 
 
 # ----------------------------------------------------------------------------- calibrate_from_batchnorm(), numerically
-def _self_consistent_weights(seed, cal_wavs):
-    """Synthetic 0008 weights whose BatchNorm statistics ARE the network's own activation statistics on `cal_wavs` (what a
-    trained Kaldi model's <StatsMean> / <StatsVar> are): one fp64 oracle pass, layer by layer -- the ReLU outputs' mean / variance
-    become that layer's BatchNorm statistics before the pass continues through it."""
-    w = synth.make_weights(seed=seed)
-    cfg = synth.extractor_cfg()
-    feats = []
-    fcfg = {k: v for k, v in cfg["framing"].items() if k != "dynamic_input_shape"}
-    for wav in cal_wavs:
-        fr = O.framing(wav[None].astype(np.float64), **fcfg)
-        m = O.mfcc(fr, **cfg["mfcc"], dtype=np.float64)
-        vcfg = dict(cfg["vad"]); vcfg["return_indexes"] = True
-        idx = O.vad(m, **vcfg, dtype=np.float64)
-        feats.append(O.cmvn(m[idx[:, 0], idx[:, 1]][None], **cfg["cmvn"], dtype=np.float64))
-    xs = feats
-    for name, ctx, _ in synth.TOPOLOGY:
-        W, b = w[f"{name}.affine"]
-        xs = [O.relu(O.tdnn(x, W, b, list(ctx), dtype=np.float64)) for x in xs]
-        allv = np.concatenate([x[0] for x in xs], 0)
-        mean, var = allv.mean(0), allv.var(0)
-        w[f"{name}.batchnorm"] = (np.float32(1.0), mean.astype(np.float32), var.astype(np.float32))
-        xs = [O.batchnorm(x, 1.0, mean.astype(np.float32), var.astype(np.float32), 1e-3, dtype=np.float64) for x in xs]
-    return w
-
-
 def test_calibrate_from_batchnorm_matches_measured_calibration(tmp_path):
     """SequentialFromConfig(cfg, nnet3Path, gemm="f16x2") on a model whose BatchNorm statistics are its own (written through the
     Kaldi nnet3 binary format): calibrate_from_batchnorm() must give the statistics calibrate() measures on the same utterances,

@@ -8,7 +8,7 @@ for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "test
 import numpy as np, torch, synth
 import kaldi_tflite_amd as ktf
 from oracle import ktf_oracle as O
-ktf.models.Sequential.min_tiles = {}
+ktf.models.Sequential.MIN_TILES, ktf.models.Sequential.MIN_FRAMES = {}, {}
 cfg = synth.extractor_cfg()
 # "f16x2" = every layer two passes; "f16x2+cal" = calibrated: the two layers in front of the pooling run one pass (the default of bench.py)
 modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f16x2+cal", "f16x2", "bf16x3", "f32"]

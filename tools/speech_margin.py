@@ -11,7 +11,7 @@ import numpy as np, torch, synth
 import kaldi_tflite_amd as ktf
 from oracle import ktf_oracle as O
 
-ktf.models.Sequential.min_tiles = {}       # every batch runs the mode under test (by default a handful of tiles goes to the fp32 kernels)
+ktf.models.Sequential.MIN_TILES, ktf.models.Sequential.MIN_FRAMES = {}, {}       # every batch runs the mode under test (by default a handful of tiles goes to the fp32 kernels)
 modes = sys.argv[1].split(",") if len(sys.argv) > 1 else ["f16mx"]
 seeds = [int(s) for s in sys.argv[2].split(",")] if len(sys.argv) > 2 else [4321, 1, 2, 3]
 cfg = synth.extractor_cfg()
