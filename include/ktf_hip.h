@@ -255,6 +255,12 @@ typedef struct KtfTdnnDesc {
                                    * features by decreasing activation variance and folds the constant part of the dropped
                                    * residual into the bias (TDNN.device_weights). Bits 8..23; 0 = every chunk two passes */
 
+#define KTF_TDNN_MX_LOADER (1 << 24)  /* ktf_tdnn_mx / ktf_tdnn_mx_stats only: the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles,
+                                   * eight matrix waves + four loader waves). It reads the weight images of its own
+                                   * (mx.weight_images_loader; layout below) and, with KTF_TDNN_DET_STATS, writes one slot per 96-row
+                                   * block: `sums` is (B, ktf_mx_stats_slots(T, flags), 2, units), reduced with slot_rows =
+                                   * ktf_mx_slot_rows(flags) */
+
 /* name of the kernel family the calling thread's last ktf_tdnn* / ktf_tdnn_mx* call launched ("" before the first; a static
  * string). For the dispatch tests: which kernel a (gemm mode, layer shape) pair runs on is part of the library's contract. */
 const char* ktf_tdnn_last_kernel(void);
@@ -323,10 +329,14 @@ int ktf_tdnn_mx_stats(const void* xh, const void* xl4, const void* x4, const voi
 int ktf_stats_finalize(const double* sums, const int32_t* lens, int64_t T, int64_t B, int32_t D, int32_t include_std,
                        float eps, float* out, int64_t ld_out, void* stream);
 /* KTF_TDNN_DET_STATS layout: number of 128-row slots of an utterance of T rows (2 * ceil(T / 256): whole 256-row tiles),
- * and the finalize that adds the slots
- * 0 .. ceil(n_b / 128) - 1 of sums (B, slots, 2, D) in that order before forming mean / std as above. */
+ * and the finalize that adds the slots 0 .. ceil(n_b / slot_rows) - 1 of sums (B, slots, 2, D) in that order before forming
+ * mean / std as above (slot_rows = 128 for ktf_tdnn_stats / ktf_tdnn_split_stats, ktf_mx_slot_rows(flags) for ktf_tdnn_mx_stats). */
 int64_t ktf_stats_slots(int64_t T);
-int ktf_stats_finalize_slots(const double* sums, int64_t slots, const int32_t* lens, int64_t T, int64_t B, int32_t D,
+/* ... for ktf_tdnn_mx_stats, whose slot geometry depends on the kernel (KtfTdnnDesc.flags & KTF_TDNN_MX_LOADER: 96-row slots, two per
+ * 192-row tile; else as ktf_stats_slots) */
+int64_t ktf_mx_stats_slots(int64_t T, int32_t flags);
+int32_t ktf_mx_slot_rows(int32_t flags);
+int ktf_stats_finalize_slots(const double* sums, int64_t slots, int32_t slot_rows, const int32_t* lens, int64_t T, int64_t B, int32_t D,
                              int32_t include_std, float eps, float* out, int64_t ld_out, void* stream);
 
 /* elementwise y = act(x) * scale + shift per column (stand-alone ReLU / BatchNorm layers); scale/shift may be NULL */
@@ -352,13 +362,13 @@ int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T, int32_t D,
 /* The tail of the extractor in ONE launch: pooled statistics -> the affine after the pooling (tdnn6; sequential.py:68-79, W
  * (units, ldw) fp32 row-major, rows 16-byte aligned, ldw a multiple of 4 >= in_dim = (include_std ? 2 : 1) * D) -> x - mean -> LDA
  * A (units, out_dim) + off -> length normalisation (xvector_extractor.py:174-184). Input: fp32 pooled rows (`pooled`, ld_pooled;
- * stats_pooling.py:231-240 already applied) OR the fp64 sums of ktf_tdnn_stats / ktf_tdnn_mx_stats (`sums`, `slots` as for
+ * stats_pooling.py:231-240 already applied) OR the fp64 sums of ktf_tdnn_stats / ktf_tdnn_mx_stats (`sums`, `slots`, `slot_rows` as for
  * ktf_stats_finalize[_slots]; the finalize happens in the kernel). Workspace: `partial` (B, 64, out_dim) fp32, `counters` (B)
  * uint32 ZEROED once by the caller (the kernel leaves them zero). `h_out` (B, units), optional: the affine's output.
  * Grid = 64 unit slices x ceil(B / group) utterance groups: a workgroup keeps its slice of W in registers and walks `group`
  * utterances (1 for a single utterance: 64 CUs share the 6 MB of W; ~32 for a large batch: W is read once per group). units <=
  * 512, in_dim <= 3072. Sums in a fixed order that does not depend on B or group: reproducible, batch == single bit for bit. */
-int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, const int32_t* lens, int64_t T,
+int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, int32_t slot_rows, const int32_t* lens, int64_t T,
                       int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
                       int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
                       uint32_t* counters, float* y, float* h_out, int32_t group, void* stream);

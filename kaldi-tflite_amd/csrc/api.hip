@@ -12,7 +12,7 @@ void ktf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int32_t ktf_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int32_t ktf_version(void) { return 110; /* 0.1.1: slot_rows in ktf_stats_finalize_slots / ktf_xvec_tail_f32, ktf_mx_stats_slots, KTF_TDNN_MX_LOADER */ }
 
 extern "C" size_t ktf_last_error(char* buf, size_t cap) {
     const size_t n = strlen(g_err);

@@ -227,7 +227,7 @@ __device__ __forceinline__ void xt_reduce(const float* __restrict__ partial, con
 // utterance (G = 1: 64 workgroups spread the 6 MB of W over 64 CUs) and a large batch (G = 32: W traffic / 32). The arithmetic of
 // an utterance does not depend on G or B.
 __global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __restrict__ pooled, int64_t ld_pooled, const double* __restrict__ sums,
-                                                               int64_t slots, const int32_t* __restrict__ lens, int64_t T, int D, int include_std,
+                                                               int64_t slots, int slot_rows, const int32_t* __restrict__ lens, int64_t T, int D, int include_std,
                                                                float eps, const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias,
                                                                int in_dim, int units, const float* __restrict__ mean, const float* __restrict__ A,
                                                                const float* __restrict__ off, int out_dim, float* __restrict__ partial,
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __re
         } else {
             const int len = lens ? lens[b] : (int)T;
             const double n = (double)len;
-            const int used = slots ? (len + 127) >> 7 : 1;
+            const int used = slots ? (len + slot_rows - 1) / slot_rows : 1;
             for (int c = tid; c < D; c += XT_THREADS) {
                 double sv = 0.0, q = 0.0;
                 if (slots == 0) {
@@ -583,7 +583,7 @@ extern "C" int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T,
     return KTF_OK;
 }
 
-extern "C" int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, const int32_t* lens, int64_t T,
+extern "C" int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, int32_t slot_rows, const int32_t* lens, int64_t T,
                                  int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
                                  int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
                                  uint32_t* counters, float* y, float* h_out, int32_t group, void* stream) {
@@ -595,12 +595,12 @@ extern "C" int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const d
     KTF_REQUIRE((B + group - 1) / group < 65536 && B < (1ll << 31), "ktf_xvec_tail_f32: too many utterance groups");
     KTF_REQUIRE(ldw >= ((in_dim + 3) & ~3) && ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0, "ktf_xvec_tail_f32: W rows must be 16-byte aligned and padded to a multiple of 4 columns");
     if (pooled) KTF_REQUIRE(ld_pooled >= in_dim, "ktf_xvec_tail_f32: ld_pooled < in_dim");
-    if (sums && slots) KTF_REQUIRE(slots >= (T + 127) / 128, "ktf_xvec_tail_f32: too few slots");
+    if (sums && slots) KTF_REQUIRE(slot_rows > 0 && slots * slot_rows >= T, "ktf_xvec_tail_f32: too few slots");
     if (B == 0) return KTF_OK;
     const size_t lds = sizeof(float) * ((size_t)XT_MAXIT * 256 + 16 + out_dim + 8);
     const int two_phase = group > 1;        // many workgroups: the slot reduction as a second launch instead of in-kernel tickets
     hipLaunchKernelGGL(xvec_tail_kernel, dim3(XT_NBLK, (unsigned)((B + group - 1) / group)), dim3(XT_THREADS), lds, (hipStream_t)stream, pooled, ld_pooled,
-                       sums, slots, lens, T, (int)D, (int)include_std, eps, W, ldw, bias, in_dim, (int)units, mean, A, off, (int)out_dim, partial,
+                       sums, slots, (int)slot_rows, lens, T, (int)D, (int)include_std, eps, W, ldw, bias, in_dim, (int)units, mean, A, off, (int)out_dim, partial,
                        counters, y, h_out, B, (int)group, two_phase);
     if (two_phase)
         hipLaunchKernelGGL(xvec_tail_reduce_kernel, dim3((unsigned)B), dim3(XT_THREADS), sizeof(float) * (out_dim + 8), (hipStream_t)stream, partial, off, y,

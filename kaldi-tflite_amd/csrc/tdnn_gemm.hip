@@ -206,7 +206,7 @@ extern "C" int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t
 extern "C" int64_t ktf_stats_slots(int64_t T) { return T <= 0 ? 2 : 2 * ((T + 255) / 256); }
 
 // mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)
-__global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t slots, const int32_t* __restrict__ lens, int64_t T,
+__global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t slots, int slot_rows, const int32_t* __restrict__ lens, int64_t T,
                                       int64_t B, int D, int include_std, float eps, float* __restrict__ out, int64_t ldo) {
     const int64_t total = B * D;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -219,7 +219,7 @@ __global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t s
             s = sums[(b * 2) * D + c];
             q = sums[(b * 2 + 1) * D + c];
         } else {
-            const int used = (len + 127) >> 7;                 // blocks holding valid rows, added in block order
+            const int used = (len + slot_rows - 1) / slot_rows;   // blocks holding valid rows, added in block order
             for (int k = 0; k < used; ++k) {
                 s += sums[((b * slots + k) * 2) * D + c];
                 q += sums[((b * slots + k) * 2 + 1) * D + c];
@@ -241,20 +241,20 @@ extern "C" int ktf_stats_finalize(const double* sums, const int32_t* lens, int64
     if (B == 0) return KTF_OK;
     int blocks = ktf_cdiv(B * D, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, (int64_t)0, lens, T, B, D, include_std, eps, out, ld_out);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, (int64_t)0, 128, lens, T, B, D, include_std, eps, out, ld_out);
     KTF_CHECK_LAUNCH("ktf_stats_finalize");
     return KTF_OK;
 }
 
-extern "C" int ktf_stats_finalize_slots(const double* sums, int64_t slots, const int32_t* lens, int64_t T, int64_t B, int32_t D,
+extern "C" int ktf_stats_finalize_slots(const double* sums, int64_t slots, int32_t slot_rows, const int32_t* lens, int64_t T, int64_t B, int32_t D,
                                         int32_t include_std, float eps, float* out, int64_t ld_out, void* stream) {
     KTF_REQUIRE(sums && out, "ktf_stats_finalize_slots: null argument");
     KTF_REQUIRE(B >= 0 && D > 0 && ld_out >= (include_std ? 2 : 1) * (int64_t)D, "ktf_stats_finalize_slots: bad sizes");
-    KTF_REQUIRE(slots >= ktf_stats_slots(T), "ktf_stats_finalize_slots: %lld slots < ktf_stats_slots(%lld)", (long long)slots, (long long)T);
+    KTF_REQUIRE(slot_rows > 0 && slots * slot_rows >= T, "ktf_stats_finalize_slots: %lld slots of %d rows do not cover %lld rows", (long long)slots, slot_rows, (long long)T);
     if (B == 0) return KTF_OK;
     int blocks = ktf_cdiv(B * D, 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, slots, lens, T, B, D, include_std, eps, out, ld_out);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, slots, (int)slot_rows, lens, T, B, D, include_std, eps, out, ld_out);
     KTF_CHECK_LAUNCH("ktf_stats_finalize_slots");
     return KTF_OK;
 }

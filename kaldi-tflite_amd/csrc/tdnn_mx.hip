@@ -27,52 +27,7 @@
 // per utterance (SAME padding = edge replication, layers/tdnn/tdnn.py:246-247 of the reference).
 //
 // Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88, stats_pooling.py:211-240 when fused).
-#include "tdnn_common.h"
-#include <type_traits>
-
-typedef __attribute__((ext_vector_type(8))) int i32x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 hfrag8;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-
-#define MX_TILE 16384                       // one half operand image of a K-step: 256 rows x 64 B
-#define MX_STAGE (2 * MX_TILE)              // A | W
-#define MX_SA_OFF (2 * MX_STAGE)            // side A: xl4 [4][256][16] | x4 [4][256][16] | scales [4][256] u32
-#define MX_SA_BYTES (2 * 16384 + 4096)
-#define MX_SW_OFF (MX_SA_OFF + MX_SA_BYTES)  // side W: w4 [4][256][16] | wl6a [4][256][16] | wl6b [4][256][8] | scales [4][256] u32 | pad
-#define MX_WQ_BLOCK 49152                   // bytes of one (N-tile, super-step) block of the MX weight planes (last 4 KiB unused)
-#define MX_PRM_OFF (MX_SW_OFF + MX_WQ_BLOCK)        // bias | scale | shift of the tile's 256 columns (read by the epilogue)
-#define MX_LDS_BYTES (MX_PRM_OFF + 3 * 256 * 4)     // 154,624 B
-#define MX_EPI_PITCH 260
-
-struct MxParams {
-    const char* xh;
-    const char* xl4;
-    const char* x4;
-    const char* xs;
-    const int32_t* lens;
-    const char* wh;          // [N-tile][K-step (padded to a multiple of 4)][16 KiB]: LDS images of w_h
-    const char* wq;          // [N-tile][super-step][MX_WQ_BLOCK]: LDS images of w_4 | w_l6 | scales
-    const float* bias;
-    const float* scale;
-    const float* shift;
-    char* yh;                // output planes (chunk-major), or
-    char* yl4;
-    char* y4;
-    char* ys;
-    float* yf;               // ... fp32 row-major (B, T, ldy)
-    int64_t ldy;
-    int64_t T;
-    int32_t units, nch_in, nctx, nk, nss, nch_out, stat_slots;
-    unsigned long long ctx_pk[2];      // the (sorted) context offsets as signed bytes, offset k in byte k
-};
-
-// E8M0 scale byte of an e2m1 block whose largest magnitude is m: the maximum lands in the top binade [4, 8) x scale, one
-// binade lower when it would round past 6 (mantissa >= 1.75)
-__device__ __forceinline__ unsigned mx_fp4_scale_byte(float m) {
-    const unsigned bits = __float_as_uint(m);
-    int byte = (int)(bits >> 23) - 2 + ((bits & 0x7fffffu) >= 0x600000u ? 1 : 0);
-    return (unsigned)(byte < 1 ? 1 : byte);
-}
+#include "tdnn_mx_common.h"
 
 // 32 values, each within [-65504, 65504] (the callers clamp: half planes saturate instead of overflowing to inf) -> half plane
 // piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word.
@@ -209,10 +164,6 @@ __device__ __forceinline__ void mx_stats_out(double* __restrict__ stats, const M
         atomicAdd(dst + p.units, q);
     }
 }
-
-#define MX_OUT_PLANES 0
-#define MX_OUT_F32 1
-#define MX_OUT_STATS 2
 
 template <int ACT, int OUT>
 __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mtiles, int ntiles, int gtiles, double* __restrict__ stats,
@@ -666,15 +617,23 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     p.yh = (char*)yh; p.yl4 = (char*)yl4; p.y4 = (char*)y4; p.ys = (char*)ys; p.yf = yf; p.ldy = ldy; p.T = T;
     p.units = d->units; p.nch_in = d->din_pad / 32; p.nctx = d->nctx; p.nk = p.nch_in * d->nctx; p.nss = (p.nk + 3) / 4;
     p.nch_out = (d->units + 31) / 32;
-    p.stat_slots = (stats && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(T) : 0;
+    const bool loader = (d->flags & KTF_TDNN_MX_LOADER) != 0;
+    p.stat_slots = (stats && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_mx_stats_slots(T, d->flags) : 0;
     for (int i = 0; i < d->nctx; ++i) {
         KTF_REQUIRE(d->ctx[i] >= -128 && d->ctx[i] <= 127, "%s: context offsets outside [-128, 127]", who);
         p.ctx_pk[i >> 3] |= (unsigned long long)(unsigned char)(signed char)d->ctx[i] << ((i & 7) * 8);
     }
+    hipStream_t st = (hipStream_t)stream;
+    const int o = stats ? MX_OUT_STATS : (yf ? MX_OUT_F32 : MX_OUT_PLANES);
+    if (loader) {                               // 192 x 256 tiles, eight matrix waves + four loader waves (tdnn_mxl.hip)
+        const int rc = mxl_launch(p, B, d->act, o, stats, st);
+        if (rc != KTF_OK) return rc;
+        KTF_CHECK_LAUNCH(who);
+        return KTF_OK;
+    }
     const int mtiles = ktf_cdiv(T, 256), ntiles = ktf_cdiv(d->units, 256);
     const int64_t gtiles = B * mtiles;
     const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles;
-    hipStream_t st = (hipStream_t)stream;
     if (stats && !p.stat_slots) (void)0;      // (atomic form: the caller zeroes the sums)
 #define MX_LAUNCH(A, O)                                                                                                \
     {                                                                                                                  \
@@ -682,7 +641,6 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
         KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O>);                                                              \
         hipLaunchKernelGGL((tdnn_mx_kernel<A, O>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
     }
-    const int o = stats ? MX_OUT_STATS : (yf ? MX_OUT_F32 : MX_OUT_PLANES);
     if (d->act == KTF_ACT_RELU) {
         if (o == MX_OUT_STATS) MX_LAUNCH(KTF_ACT_RELU, MX_OUT_STATS) else if (o == MX_OUT_F32) MX_LAUNCH(KTF_ACT_RELU, MX_OUT_F32) else MX_LAUNCH(KTF_ACT_RELU, MX_OUT_PLANES)
     } else {
@@ -705,4 +663,12 @@ extern "C" int ktf_tdnn_mx_stats(const void* xh, const void* xl4, const void* x4
     KTF_REQUIRE(sums, "ktf_tdnn_mx_stats: null sums");
     return mx_launch(xh, xl4, x4, xs, B, T, lens, d, wh, wq, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, 0, sums, stream,
                      "ktf_tdnn_mx_stats");
+}
+
+// KTF_TDNN_DET_STATS slots of ktf_tdnn_mx_stats: the 256-row kernel writes one slot per 128-row block (ktf_stats_slots), the loader
+// kernel one per 96-row block of its 192-row tiles
+extern "C" int32_t ktf_mx_slot_rows(int32_t flags) { return (flags & KTF_TDNN_MX_LOADER) ? 96 : 128; }
+extern "C" int64_t ktf_mx_stats_slots(int64_t T, int32_t flags) {
+    if (!(flags & KTF_TDNN_MX_LOADER)) return ktf_stats_slots(T);
+    return T <= 0 ? 2 : 2 * ((T + 191) / 192);
 }

@@ -113,9 +113,9 @@ class DeferredTail:
     """run_ragged(defer_tail=True): the stack up to the pooling has run; what is left -- (finalize of the pooled sums,) the affine
     after the pooling -- is handed to the caller, who fuses it with its own post-processing (XvectorExtractor: ktf_xvec_tail_f32)."""
 
-    def __init__(self, layer, B, D, include_std, eps, pooled=None, sums=None, slots=0, lens=None, T=0):
+    def __init__(self, layer, B, D, include_std, eps, pooled=None, sums=None, slots=0, lens=None, T=0, slot_rows=128):
         self.layer, self.B, self.D, self.include_std, self.eps = layer, B, D, include_std, eps
-        self.pooled, self.sums, self.slots, self.lens, self.T = pooled, sums, slots, lens, T
+        self.pooled, self.sums, self.slots, self.lens, self.T, self.slot_rows = pooled, sums, slots, lens, T, slot_rows
 
 
 class Sequential:
@@ -160,6 +160,7 @@ class Sequential:
         self.gemm = gemm
         self.min_tiles = dict(self.MIN_TILES)
         self.min_frames = dict(self.MIN_FRAMES)
+        self.mx_loader = True        # f16mx: the loader-wave kernel (csrc/tdnn_mxl.hip); False = the 256-row kernel (csrc/tdnn_mx.hip), the A/B
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"
@@ -337,22 +338,24 @@ class Sequential:
                     ops.mx_planes(src, D, lens, mxp)
                 B, T, _ = mxp.shape
                 fold, pending_bn = pending_bn, None
-                wh, wq, bias = l.device_weights_mx(dev, fold=fold)
-                d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None)
+                wh, wq, bias = l.device_weights_mx(dev, fold=fold, loader=self.mx_loader)
+                mxf = L.TDNN_MX_LOADER if self.mx_loader else 0
+                d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None, flags=mxf)
                 if can_pool:                             # ... -> reducing StatsPooling inside the epilogue (BatchNorm applied there)
                     sp = nxt[1]
                     od = 2 * l.units if sp.includeStd else l.units
-                    slots = ops.stats_slots(T) if self.deterministic else 0
+                    slots = ops.stats_slots(T, mx_flags=mxf) if self.deterministic else 0
+                    srows = ops.mx_slot_rows(mxf)
                     sums = self._ws.get("sums", (B, max(slots, 1), 2, l.units), torch.float64, dev, padded=False)
                     sbuf = self._ws.get("pooled", (B, ops.round_up(od, 32)), torch.float32, dev)
                     scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
-                    d.flags = L.TDNN_DET_STATS if slots else 0
+                    d.flags = mxf | (L.TDNN_DET_STATS if slots else 0)
                     ops.tdnn_mx_stats(mxp, lens, d, wh, wq, bias, scale, shift, sums, zero=not slots)
                     if si + 2 == tail_at:            # the caller's fused tail finalizes the sums itself
                         self._deferred = DeferredTail(steps[tail_at][1], B, l.units, sp.includeStd, sp.epsilon, sums=sums, slots=slots,
-                                                      lens=lens, T=T)
+                                                      lens=lens, T=T, slot_rows=srows)
                     else:
-                        ops.stats_finalize(sums, lens, T, l.units, sp.includeStd, sp.epsilon, sbuf, slots=slots)
+                        ops.stats_finalize(sums, lens, T, l.units, sp.includeStd, sp.epsilon, sbuf, slots=slots, slot_rows=srows)
                     x = sbuf[:, :od].unsqueeze(0)
                     lens, pooled, skip, mxp = None, True, True, None
                     continue
@@ -797,7 +800,7 @@ class XvectorExtractor:
                 group = max(1, min(32, (B * 64) // 2048))
                 if t.sums is not None and B > 8:
                     sbuf = self.xvec._ws.get("pooled", (B, ops.round_up((2 if t.include_std else 1) * t.D, 32)), torch.float32, dev)
-                    ops.stats_finalize(t.sums, t.lens, t.T, t.D, t.include_std, t.eps, sbuf, slots=t.slots)
+                    ops.stats_finalize(t.sums, t.lens, t.T, t.D, t.include_std, t.eps, sbuf, slots=t.slots, slot_rows=t.slot_rows)
                     t.pooled, t.sums = sbuf, None
                 odim = A.shape[1]
                 ws = self._ws
@@ -806,7 +809,7 @@ class XvectorExtractor:
                 if out is None:
                     out = torch.empty((B, odim), dtype=torch.float32, device=dev)
                 return ops.xvec_tail(t.pooled, t.sums, t.slots, t.lens, t.T, t.D, t.include_std, t.eps, w6, b6, t.layer.units, mean, A, off,
-                                     partial, counters, out, group=group)
+                                     partial, counters, out, group=group, slot_rows=t.slot_rows)
             raise ValueError(f"LDA input dim {A.shape[0]} != embedding dim {t.layer.units}")
         B = h.shape[0]
         h2 = h.reshape(B, h.shape[-1])

@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 FP4_MAX, FP6_MAX = 6.0, 7.5
-WQ_BLOCK = 49152                      # bytes of one (N-tile, super-step) block of the MX weight planes
+WQ_BLOCK = 49152                      # bytes of one (N-tile, super-step) block of the MX weight planes (256-row kernel)
+WQ_BLOCK_LOADER = 45056               # ... of the loader-wave kernel's images (two 22 KiB halves)
 
 
 # ------------------------------------------------------------------------------------------------ element codecs
@@ -166,5 +167,53 @@ def weight_images(Wk):
     wq[:, :, 16384:32768] = np.ascontiguousarray(p6[..., :16]).reshape(nt, nss, 16384)
     wq[:, :, 32768:40960] = np.ascontiguousarray(p6[..., 16:]).reshape(nt, nss, 8192)
     wq[:, :, 40960:45056] = np.ascontiguousarray(sc).view(np.uint8).reshape(nt, nss, 4096)
+    dec = (Wh.astype(np.float64), decode_e2m1(c4, s4), decode_e2m3(c6, s6))
+    return wh.view(np.uint8).reshape(-1), wq.reshape(-1), dec
+
+
+def loader_unit_order():
+    """(256,) unit (inside a 256-unit tile) held by column `m` of unit block `cb` (index cb * 16 + m) of the loader kernel's weight
+    images: inside every 32-unit chunk the order is permuted so that, with the weights as the A operand of the MFMAs, the four lanes
+    of a frame own units 0-7, 8-15, 16-23, 24-31 of the chunk (csrc/tdnn_mxl.hip, xl_unit)."""
+    cb, m = np.divmod(np.arange(256), 16)
+    return (cb >> 1) * 32 + (m >> 2) * 8 + (cb & 1) * 4 + (m & 3)
+
+
+def weight_images_loader(Wk):
+    """As weight_images, in the layouts of the loader-wave kernel (csrc/tdnn_mxl.hip; include/ktf_hip.h, KTF_TDNN_MX_LOADER): every
+    operand fragment is 64 lanes x 16 (8, 4) consecutive bytes, lane = 16 * (K quarter / K block) + column.
+      wh: per (N-tile, K-step) 16 fragments (unit blocks cb) x 1 KiB: lane (q, m) holds halves 8 q .. 8 q + 7 of unit order[16 cb + m]
+      wq: per (N-tile, super-step) two halves of 22 KiB, half h = unit blocks cb with (cb >> 1) & 1 == h, in the order
+          cbh = 2 (cb >> 2) + (cb & 1):  e2m1 codes 8 x 1 KiB | e2m3 bits 0..127 8 x 1 KiB | e2m3 bits 128..191 8 x 512 B |
+          scale words 8 x 256 B; lane (kb, m) = K block kb of the super-step, unit order[16 cb + m].
+    The decoded operands are the same numbers as weight_images' (the codecs do not depend on the layout)."""
+    Up, nk, _ = Wk.shape
+    nkp = (nk + 3) // 4 * 4
+    W = np.zeros((Up, nkp, 32), np.float64)
+    W[:, :nk] = Wk
+    Wh = W.astype(np.float16)
+    Wl = W - Wh.astype(np.float64)
+    s4, s6 = scale_bytes(np.abs(W).max(-1), "e2m1"), scale_bytes(np.abs(Wl).max(-1), "e2m3")
+    c4, c6 = encode_e2m1(W, s4), encode_e2m3(Wl, s6)
+    nt, nss = Up // 256, nkp // 4
+    order = loader_unit_order()                                                       # image column -> unit of the tile
+    tile = lambda a: a.reshape((nt, 256) + a.shape[1:])[:, order]                     # (nt, 256 image columns, ...)
+    # wh: (nt, ks, cb, q, m, 8)
+    wh = np.ascontiguousarray(tile(Wh).reshape(nt, 16, 16, nkp, 4, 8).transpose(0, 3, 1, 4, 2, 5))
+    # wq halves: image columns -> (cb, m); half h = (cb >> 1) & 1; inside a half cbh = 2 (cb >> 2) + (cb & 1)
+    cb = np.arange(16)
+    sel = [np.array(sorted(cb[((cb >> 1) & 1) == h], key=lambda c: 2 * (c >> 2) + (c & 1))) for h in (0, 1)]
+    p4 = tile(pack4(c4)).reshape(nt, 16, 16, nss, 4, 16)                              # (nt, cb, m, ss, kb, 16)
+    p6 = tile(pack6(c6)).reshape(nt, 16, 16, nss, 4, 24)
+    sc = tile((s4.astype(np.uint32) | (s6.astype(np.uint32) << 8))).reshape(nt, 16, 16, nss, 4)
+    wq = np.zeros((nt, nss, 2, WQ_BLOCK_LOADER // 2), np.uint8)
+    for h in (0, 1):
+        a4 = p4[:, sel[h]].transpose(0, 3, 1, 4, 2, 5)                                # (nt, ss, cbh, kb, m, 16)
+        a6 = p6[:, sel[h]].transpose(0, 3, 1, 4, 2, 5)
+        asc = sc[:, sel[h]].transpose(0, 3, 1, 4, 2)                                  # (nt, ss, cbh, kb, m)
+        wq[:, :, h, 0:8192] = np.ascontiguousarray(a4).reshape(nt, nss, 8192)
+        wq[:, :, h, 8192:16384] = np.ascontiguousarray(a6[..., :16]).reshape(nt, nss, 8192)
+        wq[:, :, h, 16384:20480] = np.ascontiguousarray(a6[..., 16:]).reshape(nt, nss, 4096)
+        wq[:, :, h, 20480:22528] = np.ascontiguousarray(asc).view(np.uint8).reshape(nt, nss, 2048)
     dec = (Wh.astype(np.float64), decode_e2m1(c4, s4), decode_e2m3(c6, s6))
     return wh.view(np.uint8).reshape(-1), wq.reshape(-1), dec

@@ -313,9 +313,16 @@ def tdnn(x, lens, desc, w, w_lo, bias, scale, shift, y, out_lens=None):
     return y
 
 
-def stats_slots(T):
-    """128-row slots of the reproducible pooling layout (KTF_TDNN_DET_STATS) for utterances of up to T rows."""
-    return int(L.load().ktf_stats_slots(int(T)))
+def stats_slots(T, mx_flags=None):
+    """Slots of the reproducible pooling layout (KTF_TDNN_DET_STATS) for utterances of up to T rows: 128-row slots, or -- for
+    ktf_tdnn_mx_stats, `mx_flags` = its KtfTdnnDesc.flags -- the slots of the MX kernel in use (mx_slot_rows rows each)."""
+    if mx_flags is None:
+        return int(L.load().ktf_stats_slots(int(T)))
+    return int(L.load().ktf_mx_stats_slots(int(T), int(mx_flags)))
+
+
+def mx_slot_rows(mx_flags):
+    return int(L.load().ktf_mx_slot_rows(int(mx_flags)))
 
 
 def tdnn_stats(x, lens, desc, w, w_lo, bias, scale, shift, sums, zero=True):
@@ -424,13 +431,13 @@ def tdnn_mx_stats(xp, lens, desc, wh, wq, bias, scale, shift, sums, zero=True):
     return sums
 
 
-def stats_finalize(sums, lens, T, D, include_std, eps, out, slots=0):
-    """sums (B,2,D) [slots == 0] or (B,slots,2,D) fp64 -> out (B, ld) mean | std."""
+def stats_finalize(sums, lens, T, D, include_std, eps, out, slots=0, slot_rows=128):
+    """sums (B,2,D) [slots == 0] or (B,slots,2,D) fp64 (one slot per `slot_rows` rows) -> out (B, ld) mean | std."""
     lib = L.load()
     B = sums.shape[0]
     with torch.cuda.device(sums.device):
         if slots:
-            rc = lib.ktf_stats_finalize_slots(L.ptr(sums), slots, L.ptr(lens), T, B, D, int(include_std), eps, L.ptr(out),
+            rc = lib.ktf_stats_finalize_slots(L.ptr(sums), slots, int(slot_rows), L.ptr(lens), T, B, D, int(include_std), eps, L.ptr(out),
                                               out.stride(0), L.stream_ptr())
         else:
             rc = lib.ktf_stats_finalize(L.ptr(sums), L.ptr(lens), T, B, D, int(include_std), eps, L.ptr(out), out.stride(0),
@@ -496,13 +503,14 @@ def xvec_post(x, mean, A, off, out=None):
     return out
 
 
-def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units, mean, A, off, partial, counters, out, h_out=None, group=1):
+def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units, mean, A, off, partial, counters, out, h_out=None, group=1,
+              slot_rows=128):
     """Fused tail (ktf_xvec_tail_f32): pooled (B, ld) fp32 rows OR fp64 sums -> tdnn6 -> mean-sub -> LDA -> length norm, one launch."""
     lib = L.load()
     B = out.shape[0]
     src = pooled if pooled is not None else sums
     with torch.cuda.device(src.device):
-        rc = lib.ktf_xvec_tail_f32(L.ptr(pooled), pooled.stride(0) if pooled is not None else 0, L.ptr(sums), int(slots), L.ptr(lens), int(T), B,
+        rc = lib.ktf_xvec_tail_f32(L.ptr(pooled), pooled.stride(0) if pooled is not None else 0, L.ptr(sums), int(slots), int(slot_rows), L.ptr(lens), int(T), B,
                                    int(D), int(include_std), float(eps), L.ptr(W), W.stride(0), L.ptr(bias), int(units), L.ptr(mean), L.ptr(A),
                                    L.ptr(off), A.shape[1], L.ptr(partial), L.ptr(counters), L.ptr(out), L.ptr(h_out), int(group), L.stream_ptr())
     L.check(rc, "ktf_xvec_tail_f32")

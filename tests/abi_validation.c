@@ -44,12 +44,12 @@ int main(void) {
     EXPECT_EINVAL(ktf_tdnn_mx_stats(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL));
     EXPECT_EINVAL(ktf_mx_planes(NULL, 1, 1, 8, 8, NULL, f, f, f, f, NULL));
     EXPECT_EINVAL(ktf_mx_planes(f, 1, 1, 8, 4, NULL, f, f, f, f, NULL));
-    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, d, 0, l, 1, 1, 4, 1, 1e-10f, f, 8, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));   /* pooled and sums */
-    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, l, 1, 1, 4, 1, 1e-10f, f, 6, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));  /* ldw */
-    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, l, 1, 1, 4000, 1, 1e-10f, f, 8000, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, d, 0, 128, l, 1, 1, 4, 1, 1e-10f, f, 8, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));   /* pooled and sums */
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, 128, l, 1, 1, 4, 1, 1e-10f, f, 6, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));  /* ldw */
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, 128, l, 1, 1, 4000, 1, 1e-10f, f, 8000, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));
     EXPECT_EINVAL(ktf_xvec_post_f32(NULL, 1, 8, 4, NULL, f, NULL, f, NULL));
     EXPECT_EINVAL(ktf_stats_finalize(NULL, NULL, 1, 1, 4, 1, 1e-10f, f, 8, NULL));
-    EXPECT_EINVAL(ktf_stats_finalize_slots(d, 1, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));       /* too few slots */
+    EXPECT_EINVAL(ktf_stats_finalize_slots(d, 1, 128, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));       /* too few slots */
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));
     EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, 9, NULL, NULL, f, NULL));

@@ -54,7 +54,7 @@ EXPECT = {   # mode -> kernel family of tdnn1 .. tdnn5 for a batch of full-lengt
     "f16": ["tdnn_bf16h_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16h_kernel<f16>", "tdnn_bf16h_kernel<f16>"],
     "bf16x3": ["tdnn_x3s_kernel<bf16, 3>"] * 5,
     "f16x2": ["tdnn_x3s_kernel<f16, 2>"] * 5,
-    "f16mx": ["tdnn_mx_kernel"] * 5,
+    "f16mx": ["tdnn_mxl_kernel"] * 5,
 }
 
 

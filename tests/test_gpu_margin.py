@@ -8,7 +8,9 @@ the 1e-4 tolerance (fp64 emulation: tools/emulate_schemes.py `mx4_46`). The diar
 speech recording (models/kaldi/xvector_extractor_test.py:70-96, tests/golden/e2e_0008.npz:wav_int16) at a 1 s hop, one batch per
 window length, four weight seeds, against the fp64 oracle:
 
-* the RAW kernels (routing off): every mode that claims the tolerance stays inside 1e-4 at every window length;
+* the RAW kernels (routing off): split-bf16 stays inside 2e-5 at every window length; `f16mx` is inside 1e-4 from 3 s on and
+  OUTSIDE it on 1 s windows (measured 7-12e-5 at 1 s, 6-8e-5 at 1.5 s, 4-6e-5 at 3 s and 5 s): bounded here at 1.5e-4 so that a
+  regression shows, and the reason for the routing;
 * the SHIPPED routing (`Sequential.MIN_FRAMES`): windows shorter than 200 frames go to the split-bf16 kernels, and what still
   reaches the `f16mx` kernels stays inside 8e-5;
 * the same on SELF-CONSISTENT BatchNorm weights (tests/_selfbn.py): the closest offline stand-in for trained statistics.
@@ -77,13 +79,17 @@ def deviations(gemm, kind, seed, routed):
 @pytest.mark.parametrize("kind", ["synthetic", "self_consistent_bn"])
 @pytest.mark.parametrize("gemm", ["bf16x3", "f16mx"])
 def test_raw_kernels_on_short_speech_windows(gemm, kind, seed):
-    """Routing off: the mode's own kernels at every window length. Inside the tolerance everywhere; f16mx's margin at 1-1.5 s is
-    thin (printed), which is why the shipped routing below does not send such batches to it."""
+    """Routing off: the mode's own kernels at every window length. split-bf16: inside 2e-5 everywhere. f16mx: inside the
+    tolerance from 3 s on; on 1 s / 1.5 s windows its block-scaled rounding noise is averaged over too few frames (up to 1.2e-4
+    measured at 1 s): bounded at 1.5e-4, and the shipped routing below keeps such batches off it."""
     d = deviations(gemm, kind, seed, routed=False)
     print(f"{gemm} raw, {kind} weights, seed {seed}: " + ", ".join(f"{k:g} s {v[0]:.2e}" for k, v in d.items()))
-    assert max(v[0] for v in d.values()) <= TOL, d
     if gemm == "bf16x3":
         assert max(v[0] for v in d.values()) <= 2e-5, d
+        return
+    for sec, (err, _) in d.items():
+        frames = 1 + (int(sec * 16000) - 400) // 160
+        assert err <= (TOL if frames >= ktf.models.Sequential.MIN_FRAMES["f16mx"] else 1.5e-4), (sec, err)
 
 
 @pytest.mark.parametrize("seed", SEEDS)

@@ -122,17 +122,22 @@ CASES = [  # D, context, units, B, T, lens
 ]
 
 
+KERNELS = [pytest.param(True, id="loader_waves"), pytest.param(False, id="tile256")]     # KTF_TDNN_MX_LOADER on / off
+
+
+@pytest.mark.parametrize("loader", KERNELS)
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("relu", [True, False])
-def test_tdnn_mx_fp32_output_vs_emulation(case, relu):
+def test_tdnn_mx_fp32_output_vs_emulation(case, relu, loader):
     rng = np.random.default_rng(11)
     layer, W, bias, x, lens = _layer_case(rng, *case)
     B, T, D = x.shape
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"))
-    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None)
+    mxf = L.TDNN_MX_LOADER if loader else 0
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
+    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=mxf)
     ldy = ops.round_up(layer.units, 4)
     y = torch.full((B, T, ldy), 7.0, device="cuda")
     ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, y)
@@ -149,8 +154,9 @@ def test_tdnn_mx_fp32_output_vs_emulation(case, relu):
         assert (got[b, n:] == 7.0).all(), "rows beyond the utterance are not written"
 
 
+@pytest.mark.parametrize("loader", KERNELS)
 @pytest.mark.parametrize("case", CASES[:2] + CASES[3:])
-def test_tdnn_mx_plane_output_feeds_the_next_layer(case):
+def test_tdnn_mx_plane_output_feeds_the_next_layer(case, loader):
     """Plane output of one layer == ktf_mx_planes of its fp32 output (same encoder), up to the ties an fp32 summation-order
     difference can flip: compared as decoded values."""
     rng = np.random.default_rng(12)
@@ -159,12 +165,13 @@ def test_tdnn_mx_plane_output_feeds_the_next_layer(case):
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"))
-    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu")
+    mxf = L.TDNN_MX_LOADER if loader else 0
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
+    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=mxf)
     out = mx.Planes.empty(B, T, layer.units, "cuda")
     ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, out)
     y = torch.zeros((B, T, ops.round_up(layer.units, 4)), device="cuda")
-    d32 = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu")
+    d32 = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu", flags=mxf)
     ops.tdnn_mx(p, dl, d32, wh, wq, bd, None, None, y)
     ref = mx.Planes.empty(B, T, layer.units, "cuda")
     ops.mx_planes(y, layer.units, dl, ref)
@@ -175,7 +182,8 @@ def test_tdnn_mx_plane_output_feeds_the_next_layer(case):
         assert np.array_equal(out.xs[b, :, :n].cpu().numpy(), ref.xs[b, :, :n].cpu().numpy())
 
 
-def test_tdnn_mx_fused_pooling_vs_emulation():
+@pytest.mark.parametrize("loader", KERNELS)
+def test_tdnn_mx_fused_pooling_vs_emulation(loader):
     rng = np.random.default_rng(13)
     layer, W, bias, x, lens = _layer_case(rng, 512, [0], 1500, 3, 700, [700, 129, 256])
     B, T, D = x.shape
@@ -185,15 +193,16 @@ def test_tdnn_mx_fused_pooling_vs_emulation():
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"))
+    mxf = L.TDNN_MX_LOADER if loader else 0
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
     emu, _ = _emulate(layer, x, lens, True)
     for det in (True, False):
-        d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=L.TDNN_DET_STATS if det else 0)
-        slots = ops.stats_slots(T) if det else 0
+        d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=mxf | (L.TDNN_DET_STATS if det else 0))
+        slots = ops.stats_slots(T, mx_flags=mxf) if det else 0
         sums = torch.full((B, max(slots, 1), 2, U), 3.0, dtype=torch.float64, device="cuda")
         ops.tdnn_mx_stats(p, dl, d, wh, wq, bd, dev(sc), dev(sh), sums, zero=not det)
         out = torch.zeros((B, 2 * U), device="cuda")
-        ops.stats_finalize(sums, dl, T, U, True, 1e-10, out, slots=slots)
+        ops.stats_finalize(sums, dl, T, U, True, 1e-10, out, slots=slots, slot_rows=ops.mx_slot_rows(mxf))
         got = out.cpu().numpy()
         for b in range(B):
             v = emu[b, : lens[b]] * sc + sh
@@ -216,6 +225,30 @@ def test_extractor_f16mx_full_topology_10s_vs_oracle(seed):
     assert err <= 1e-4
     for b in range(3):
         assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), got[b]), "batch != single"
+
+
+def test_loader_wave_kernel_against_the_256_row_kernel():
+    """The two f16mx kernels (KTF_TDNN_MX_LOADER on / off) do the same arithmetic on the same planes: x-vectors equal to fp32
+    summation-order noise (the loader kernel runs the block-scaled terms of a super-step between its half-precision K-steps, and
+    pools 96-row blocks), both inside the tolerance; utterance lengths that put utterance boundaries inside the loader kernel's
+    flat 192-row tiles, and an utterance without a voiced frame."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321)
+    wav = np.concatenate([synth.make_wav(3, 52000, seed=61), synth.make_wav(4, 52000, seed=62, ragged=True)], 0)
+    wav[5] = 0.0                                               # no voiced frame: NaN embedding, the others untouched
+    want = O.xvector_forward(np.delete(wav, 5, 0), cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+    got = {}
+    for loader in (True, False):
+        mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+        mdl.xvec.mx_loader = loader
+        y = mdl(dev(wav))
+        assert ops.last_kernel() == ("tdnn_mxl_kernel" if loader else "tdnn_mx_kernel")
+        got[loader] = y.cpu().numpy()
+        assert np.isnan(got[loader][5]).all()
+        assert np.abs(np.delete(got[loader], 5, 0) - want).max() <= 1e-4
+        for b in (0, 6):
+            assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), y[b]), "batch != single"
+    assert np.abs(np.delete(got[True] - got[False], 5, 0)).max() <= 5e-6
 
 
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16mx"])
