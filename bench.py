@@ -50,7 +50,7 @@ KERNELS = {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=
            "bf16x3": "tdnn_x3r_kernel<.., SPLIT> (tdnn2-4) + tdnn_x3s_kernel (tdnn5 + pooling) + tdnn_x3r_kernel (tdnn1)",
            "f16x2": "tdnn_x3s_kernel<.., F16, TERMS = 2> (tdnn1-3; tdnn2 / tdnn3 with a residual prefix of half their K-steps) and "
                     "<.., TERMS = 1> (tdnn4, tdnn5 with fused pooling); --full-residual / --two-pass-everywhere are the A/Bs",
-           "f16mx": "tdnn_mxl_kernel (csrc/tdnn_mxl.hip: 192 x 256 tile, 8 matrix + 4 loader waves): v_mfma_f32_16x16x32_f16 + 2 x v_mfma_scale_f32_16x16x128_f8f6f4 (fp4 x fp4, fp4 x fp6) per 128 K",
+           "f16mx": "tdnn_mx_kernel (csrc/tdnn_mx.hip): v_mfma_f32_16x16x32_f16 + 2 x v_mfma_scale_f32_16x16x128_f8f6f4 (fp4 x fp4, fp4 x fp6) per 128 K",
            "f32": "tdnn_f32t_kernel", "f16": "tdnn_bf16r16_kernel<.., F16> + tdnn_bf16h_kernel<.., F16>"}
 
 
@@ -66,7 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other modes, latency, PLDA)")
     ap.add_argument("--no-parity", action="store_true", help="measurement runs of timing-only ablation builds (tools/mx): no oracle comparison, no finite check")
-    ap.add_argument("--mx-tile256", action="store_true", help="A/B: f16mx on the 256 x 256 eight-wave kernel (csrc/tdnn_mx.hip) instead of the loader-wave kernel")
+    ap.add_argument("--mx-loader", action="store_true", help="A/B: f16mx on the loader-wave kernel (csrc/tdnn_mxl.hip) instead of the 256 x 256 eight-wave kernel")
     ap.add_argument("--atomic-pooling", action="store_true", help="fp64-atomic fused pooling instead of the reproducible form")
     ap.add_argument("--ctx-major-k", action="store_true", help="A/B: weights in (context, feature) K order instead of the chunk-interleaved one")
     ap.add_argument("--row-major-w", action="store_true", help="A/B: row-major weights instead of the LDS-image tiles")
@@ -128,7 +128,7 @@ def main(argv=None):
     if args.full_residual:
         mdl.xvec.lo_fraction = 0.0
     mdl.xvec.deterministic = not args.atomic_pooling
-    mdl.xvec.mx_loader = not args.mx_tile256
+    mdl.xvec.mx_loader = args.mx_loader
     mdl.xvec.k_interleaved = not args.ctx_major_k
     mdl.xvec.w_tiled = not args.row_major_w
     mdl.xvec.chunked = not args.row_major_x
@@ -204,8 +204,8 @@ def main(argv=None):
                 per[i] = 2.0 - mdl.xvec.lo_fraction
         passes = sum(m * q for m, q in zip(mac, per)) / float(sum(mac))
     out["roofline"] = _roofline(args.gemm, gemm_stats, args.steps, B, T, passes)
-    if args.gemm == "f16mx" and args.mx_tile256:
-        out["roofline"]["kernel"] = "tdnn_mx_kernel (csrc/tdnn_mx.hip: 256 x 256 tile, 8 waves; --mx-tile256 A/B)"
+    if args.gemm == "f16mx" and args.mx_loader:
+        out["roofline"]["kernel"] = "tdnn_mxl_kernel (csrc/tdnn_mxl.hip: 192 x 256 tile, 8 matrix + 4 loader waves; --mx-loader A/B)"
     # HBM traffic of those launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE),
     # committed under profiles/: it cannot be collected from inside this process
     if B == 1024:

@@ -63,48 +63,99 @@ struct MxlParams {
     uint32_t total_rows;                             // B * T
 };
 
-// maximum over the four lanes that hold one frame (lane ^ 16, lane ^ 32)
-__device__ __forceinline__ float xl_frame_max(float v) {
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+// registers (a, b, c, d) of the four lanes of a frame (lane quarter q = 0..3) hold element [register][q]: afterwards lane quarter q
+// holds elements [q][0..3] (a 4 x 4 transpose between register index and lane quarter)
+__device__ __forceinline__ void xl_transpose4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1];
+    r = __builtin_amdgcn_permlane16_swap(c, d, false, false); c = r[0]; d = r[1];
+    r = __builtin_amdgcn_permlane32_swap(a, c, false, false); a = r[0]; c = r[1];
+    r = __builtin_amdgcn_permlane32_swap(b, d, false, false); b = r[0]; d = r[1];
 }
 
-// eight consecutive values of a 32-value block (this lane's quarter; the other three quarters sit in lanes ^ 16, ^ 32, ^ 48), each
-// within [-65504, 65504] -> this lane's 16 bytes of the half piece, its dword of the two e2m1 records, the block's scale word.
-// Same arithmetic as mx_encode32 (tdnn_mx.hip) and mx.encode_activations.
-__device__ __forceinline__ void xl_encode8(const float (&v)[8], u32x4& hp, unsigned& l4, unsigned& h4, unsigned& sw) {
+// Plane encoder. Eight consecutive values of a 32-value block (this lane's quarter; the other three quarters sit in lanes ^ 16, ^ 32,
+// ^ 48), each within [-65504, 65504] -> this lane's 16 bytes of the half piece, its dword of the two e2m1 records, the block's scale
+// word. Same arithmetic as mx_encode32 (tdnn_mx.hip) and mx.encode_activations. The work is one long dependency chain (values ->
+// half -> residual -> maxima -> two cross-lane steps -> scale -> conversions) and a wave has at most one partner on its SIMD, so
+// TWO blocks (N = 2: two row blocks of the tile) are encoded with their chains interleaved statement by statement: alone a block
+// took ~600 clk for ~70 instructions.
+template <int N>
+__device__ __forceinline__ void xl_encode8(const float (&v)[N][8], u32x4 (&hp)[N], unsigned (&l4)[N], unsigned (&h4)[N], unsigned (&sw)[N]) {
     typedef __attribute__((ext_vector_type(2))) float f2;
     typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-    float lo[8];
-    unsigned hw[4];
-    float mv = 0.0f, ml = 0.0f;
+    float lo[N][8];
+    unsigned hw[N][4];
+    float mv[N], ml[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) { mv[n] = 0.0f; ml[n] = 0.0f; }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float a = v[2 * k], b = v[2 * k + 1];
-        const h2 hh = __builtin_convertvector(f2{a, b}, h2);
-        hw[k] = __builtin_bit_cast(unsigned, hh);
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * k]) : "v"(hw[k]), "v"(a));
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * k + 1]) : "v"(hw[k]), "v"(b));
-        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mv) : "v"(a), "v"(b), "v"(mv));
-        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(ml) : "v"(lo[2 * k]), "v"(lo[2 * k + 1]), "v"(ml));
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const float a = v[n][2 * k], b = v[n][2 * k + 1];
+            const h2 hh = __builtin_convertvector(f2{a, b}, h2);
+            hw[n][k] = __builtin_bit_cast(unsigned, hh);
+            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[n][2 * k]) : "v"(hw[n][k]), "v"(a));
+            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[n][2 * k + 1]) : "v"(hw[n][k]), "v"(b));
+            asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mv[n]) : "v"(a), "v"(b), "v"(mv[n]));
+            asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(ml[n]) : "v"(lo[n][2 * k]), "v"(lo[n][2 * k + 1]), "v"(ml[n]));
+        }
     }
-    mv = xl_frame_max(mv);
-    ml = xl_frame_max(ml);
-    const float mh = (float)(_Float16)mv;
-    const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml);
-    const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
-    unsigned x = 0, y = 0;
+    // the maxima over the four lanes of a frame: all 2 N values per cross-lane step
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        unsigned o[N][2][2];
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            if (step == 0) {
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(mv[n]), __float_as_uint(mv[n]), false, false);
+                o[n][0][0] = r[0]; o[n][0][1] = r[1];
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ml[n]), __float_as_uint(ml[n]), false, false);
+                o[n][1][0] = r[0]; o[n][1][1] = r[1];
+            } else {
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mv[n]), __float_as_uint(mv[n]), false, false);
+                o[n][0][0] = r[0]; o[n][0][1] = r[1];
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ml[n]), __float_as_uint(ml[n]), false, false);
+                o[n][1][0] = r[0]; o[n][1][1] = r[1];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {      // (magnitudes: plain v_max_f32 -- from C the compiler quiets both operands of every fmaxf first)
+            asm("v_max_f32 %0, %1, %2" : "=v"(mv[n]) : "v"(o[n][0][0]), "v"(o[n][0][1]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(ml[n]) : "v"(o[n][1][0]), "v"(o[n][1][1]));
+        }
+    }
+    float sh[N], sl[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float mh = (float)(_Float16)mv[n];
+        const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml[n]);
+        sh[n] = __uint_as_float(bh << 23);
+        sl[n] = __uint_as_float(bl << 23);
+        sw[n] = bl | (bh << 8);
+    }
+    // every conversion writes one byte of a register of its own (a chain of four through one register runs at the instruction's latency)
+    unsigned xb[N][4], yb[N][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            xb[n][k] = 0;
+            yb[n][k] = 0;
+        }
+    }
 #define XL_ENC_S(s_)                                                                                                   \
-    x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(x, lo[2 * s_], lo[2 * s_ + 1], sl, s_);                               \
-    y = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(y, __builtin_bit_cast(h2, hw[s_]), sh, s_);
+    _Pragma("unroll") for (int n = 0; n < N; ++n) {                                                                    \
+        xb[n][s_] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(xb[n][s_], lo[n][2 * s_], lo[n][2 * s_ + 1], sl[n], s_);  \
+        yb[n][s_] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(yb[n][s_], __builtin_bit_cast(h2, hw[n][s_]), sh[n], s_); \
+    }
     XL_ENC_S(0) XL_ENC_S(1) XL_ENC_S(2) XL_ENC_S(3)
 #undef XL_ENC_S
-    l4 = x;
-    h4 = y;
-    hp = u32x4{hw[0], hw[1], hw[2], hw[3]};
-    sw = bl | (bh << 8);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        l4[n] = (xb[n][0] | xb[n][1]) | (xb[n][2] | xb[n][3]);
+        h4[n] = (yb[n][0] | yb[n][1]) | (yb[n][2] | yb[n][3]);
+        hp[n] = u32x4{hw[n][0], hw[n][1], hw[n][2], hw[n][3]};
+    }
 }
 
 __device__ __forceinline__ float xl_act(float v, int act) { return act == KTF_ACT_RELU ? fmaxf(v, 0.0f) : v; }
@@ -193,12 +244,19 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
                     t = t0 + row;
                 }
                 const int len = p.lens ? p.lens[b] : T;
-                const unsigned base = (unsigned)b * (unsigned)(p.nch_in * T);
+                const unsigned base = (unsigned)(b - b0) * (unsigned)(p.nch_in * T);       // relative to utterance b0 (32-bit byte offsets below)
                 const int lm1 = len > 0 ? len - 1 : 0;
                 if (w) { sb[k] = base; st[k] = t; sl_[k] = lm1; } else { hb[k] = base; ht[k] = t; hl[k] = lm1; }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the lens loads: from here on the vector-memory counter counts DMAs only)
+        // the planes from the first record of utterance b0 on: uniform bases + 32-bit per-lane byte offsets (a tile spans at most
+        // 192 + T rows: offsets stay below 2^32 while T * din_pad * 2 < 2^31, which the launcher requires)
+        const uint64_t u0 = (uint64_t)b0 * (uint64_t)(p.nch_in * T);
+        const char* xh0 = p.xh + u0 * 64u;
+        const char* xl0 = p.xl4 + u0 * 16u;
+        const char* x40 = p.x4 + u0 * 16u;
+        const char* xs0 = p.xs + u0 * 4u;
         const unsigned hpos = (unsigned)((((lane & 3) ^ ((4 - (((lane >> 2) >> 2) & 3)) & 3)) * 16));   // this lane's 16-byte piece of its row
         // half stages walk the K-steps in order: context index, offset, first record of the chunk (chunk * T)
         int h_ci = 0;
@@ -216,8 +274,8 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
             _Pragma("unroll") for (int k_ = 0; k_ < 3; ++k_) {                                                         \
                 int r_ = ht[k_] + h_off;                                                                               \
                 r_ = r_ < 0 ? 0 : (r_ > hl[k_] ? hl[k_] : r_);                                                         \
-                const uint64_t vo_ = (uint64_t)(hb[k_] + h_cT + (unsigned)r_) * 64u + hpos;                            \
-                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(p.xh + vo_), (lds_ptr_t*)(st__ + (l + 4 * k_) * 1024), 16, 0, 0); \
+                const unsigned vo_ = (hb[k_] + h_cT + (unsigned)r_) * 64u + hpos;                                      \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh0 + vo_), (lds_ptr_t*)(st__ + (l + 4 * k_) * 1024), 16, 0, 0); \
             }                                                                                                          \
             if ((ks_) + 1 < p.nk) {                                                                                    \
                 if (++h_ci == p.nctx) { h_ci = 0; h_cT += (unsigned)T; }                                               \
@@ -255,13 +313,13 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
             unsigned char* sa__ = rsm + XL_SA_OFF + (buf_) * XL_SA_BYTES;                                              \
             int r_ = st[k_] + s_off;                                                                                   \
             r_ = r_ < 0 ? 0 : (r_ > sl_[k_] ? sl_[k_] : r_);                                                           \
-            const uint64_t rec_ = (uint64_t)(sb[k_] + (s_ks < p.nk ? s_cT : 0u) + (unsigned)r_);                       \
+            const unsigned rec_ = sb[k_] + (s_ks < p.nk ? s_cT : 0u) + (unsigned)r_;                                   \
             if (kind_ == 0)                                                                                            \
-                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(p.xl4 + rec_ * 16u), (lds_ptr_t*)(sa__ + (l + 4 * k_) * 1024), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl0 + rec_ * 16u), (lds_ptr_t*)(sa__ + (l + 4 * k_) * 1024), 16, 0, 0); \
             else if (kind_ == 1)                                                                                       \
-                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(p.x4 + rec_ * 16u), (lds_ptr_t*)(sa__ + 12288 + (l + 4 * k_) * 1024), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(x40 + rec_ * 16u), (lds_ptr_t*)(sa__ + 12288 + (l + 4 * k_) * 1024), 16, 0, 0); \
             else                                                                                                       \
-                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(p.xs + rec_ * 4u), (lds_ptr_t*)(sa__ + 24576 + (l + 4 * k_) * 256), 4, 0, 0); \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xs0 + rec_ * 4u), (lds_ptr_t*)(sa__ + 24576 + (l + 4 * k_) * 256), 4, 0, 0); \
         }
         // side W of super-step ss_, half h_: pieces l, l + 4, ... of its 22 KiB
 #define XL_SW(ss_, h_)                                                                                                 \
@@ -325,11 +383,6 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
         prm[512 + tid] = (nv && p.shift) ? p.shift[n] : 0.0f;
     }
     f32x4 acc[6][4];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
     const int r16 = lane & 15, q4 = lane >> 4;
     const int fr = (4 - ((r16 >> 2) & 3)) & 3;
     const int a_off = wm * 6144 + r16 * 64 + ((q4 ^ fr) << 4);        // A half fragment of row block 0 (+ 1 KiB per block)
@@ -405,21 +458,36 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
         XL_BARRIER()                                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                             \
     }
+    const float* prm = reinterpret_cast<const float*>(rsm + XL_PRM_OFF);
+    XL_PHASE()                                       // opens F0 of super-step 0; the epilogue constants are in place
+    // the accumulators start at the bias of their units
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 b4;
+        if constexpr (SWAP) {
+            b4 = *reinterpret_cast<const f32x4*>(prm + xl_unit(wn * 4 + j, q4 * 4));
+        } else {
+            const float bv = prm[xl_unit(wn * 4 + j, r16)];
+            b4 = f32x4{bv, bv, bv, bv};
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[i][j] = b4;
+    }
     for (int ss = 0; ss < p.nss; ++ss) {
         const int buf = ss & 1;
-        XL_PHASE() XL_F(0)
+        XL_F(0)
         XL_PHASE() XL_M(buf, 0)
         XL_PHASE() XL_F(1)
         XL_PHASE() XL_F(0)
         XL_PHASE() XL_M(buf, 1)
         XL_PHASE() XL_F(1)
+        if (ss + 1 < p.nss) XL_PHASE()
     }
     __builtin_amdgcn_sched_barrier(0);
 #undef XL_F
 #undef XL_M
 #undef XL_PHASE
 
-    const float* prm = reinterpret_cast<const float*>(rsm + XL_PRM_OFF);
     if constexpr (OUT == MX_OUT_STATS) {
         // fused StatsPooling (stats_pooling.py:231-240): per unit the sum and the sum of squares of the wave's rows, in fp32 relative
         // to a pivot (row 0 of the wave's block: a constant column -- a dead ReLU unit -- gives exactly 0 and 0), then fp64.
@@ -429,8 +497,8 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ul = xl_unit(wn * 4 + j, r16);
-            const float ebias = prm[ul], esc = prm[256 + ul], esh = prm[512 + ul];
-            const float v0 = xl_act(acc[0][j][0] + ebias, ACT) * esc + esh;
+            const float esc = prm[256 + ul], esh = prm[512 + ul];
+            const float v0 = xl_act(acc[0][j][0], ACT) * esc + esh;
             const float pv = __shfl(v0, lane & 15, 64);
             float s32 = 0.0f, q32 = 0.0f;
             int cnt = 0;
@@ -438,7 +506,7 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
             for (int i = 0; i < 6; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = xl_act(acc[i][j][r] + ebias, ACT) * esc + esh;
+                    const float v = xl_act(acc[i][j][r], ACT) * esc + esh;
                     if (rv >= 96 || i * 16 + q4 * 4 + r < rv) {
                         const float u = v - pv;
                         s32 += u;
@@ -470,9 +538,8 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
         // Accumulator (i, jj)[r] = frame 16 i + r16 of the wave's rows, unit xl_unit(4 wn + jj, 4 q4 + r): for output chunk c of the
         // wave (unit blocks 2 c, 2 c + 1) this lane holds units 8 q4 .. 8 q4 + 7 of the chunk.
         // the rows: (utterance, frame) of this lane's frame in every row block, and whether it is a valid row
-        unsigned rec_i[6];                           // record of (b, chunk 0, t) in the OUTPUT planes: b * nch_out * T + t
+        unsigned rec_i[6];                           // planes: record of (b, chunk 0, t): b * nch_out * T + t; fp32 rows: b * T + t
         unsigned ok = 0;                             // bit i: row block i's frame is valid
-        int64_t frow[6];                             // b * T + t (fp32 output rows)
         {
             int b, t;
             const int row0 = wm * 96 + r16;
@@ -490,47 +557,75 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
                 const bool inb = b < q.B;
                 const int len = inb ? (p.lens ? p.lens[b] : T) : 0;
                 if (i < nblk && t < len) ok |= 1u << i;
-                rec_i[i] = (unsigned)b * (unsigned)(p.nch_out * T) + (unsigned)t;
-                frow[i] = (int64_t)b * T + t;
+                rec_i[i] = (unsigned)(b - b0) * (unsigned)(OUT == MX_OUT_PLANES ? p.nch_out * T : T) + (unsigned)t;   // relative to utterance b0
                 t += 16;
             }
         }
         const bool affine = p.scale != nullptr;
         if constexpr (OUT == MX_OUT_PLANES) {
+            // per chunk: the half pieces leave per row block (16 bytes per lane: 1 KiB of consecutive records per store); the e2m1
+            // dwords and the scale words of row blocks 0-3 are transposed between register index and lane quarter so that lane quarter
+            // q stores the whole 16-byte record of row block q (row = lane of the wave's block), those of row blocks 4, 5 pairwise
+            // (8 bytes per lane): 12 store instructions per chunk instead of 24
+            const uint64_t o0 = (uint64_t)b0 * (uint64_t)(p.nch_out * T);        // uniform bases + 32-bit per-lane byte offsets
+            char* yh0 = p.yh + o0 * 64u;
+            char* yl0 = p.yl4 + o0 * 16u;
+            char* y40 = p.y4 + o0 * 16u;
+            char* ys0 = p.ys + o0 * 4u;
+            const unsigned recA = q4 == 0 ? rec_i[0] : q4 == 1 ? rec_i[1] : q4 == 2 ? rec_i[2] : rec_i[3];
+            const unsigned recB = (q4 & 1) ? rec_i[5] : rec_i[4];
+            const bool okA = (ok >> q4) & 1u, okB = (ok >> (4 + (q4 & 1))) & 1u;
+            // (no BatchNorm affine on this path: a plane output feeds a layer of the route, which folds it into its weights; the
+            // launcher refuses scale / shift here -- a second, affine copy of this epilogue cost registers: spills whose reloads wait
+            // on `vmcnt`, i.e. on the plane stores in flight)
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
                 const int chunk = (n0 >> 5) + wn * 2 + c;
                 if (chunk >= p.nch_out) continue;    // (wave-uniform)
-                const int ul = wn * 64 + c * 32 + q4 * 8;
-                float eb[8], es[8], eh[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) eb[e] = prm[ul + e];
-                if (affine) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { es[e] = prm[256 + ul + e]; eh[e] = prm[512 + ul + e]; }
-                }
                 const unsigned crec = (unsigned)chunk * (unsigned)T;
+                unsigned l4r[6], h4r[6], swr[6];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    if (i >= nblk) continue;         // (wave-uniform)
-                    float v[8];
+                for (int i2 = 0; i2 < 6; i2 += 2) {
+                    float v[2][8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float x = acc[i][2 * c + (e >> 2)][e & 3] + eb[e];
-                        // the planes saturate at the largest half: one v_med3 does the ReLU and the clamp when no affine follows
-                        if (affine) x = __builtin_amdgcn_fmed3f(xl_act(x, ACT) * es[e] + eh[e], -65504.0f, 65504.0f);
-                        else x = __builtin_amdgcn_fmed3f(x, ACT == KTF_ACT_RELU ? 0.0f : -65504.0f, 65504.0f);
-                        v[e] = x;
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)      // the planes saturate at the largest half: one v_med3 does the ReLU and the clamp
+                            v[n][e] = __builtin_amdgcn_fmed3f(acc[i2 + n][2 * c + (e >> 2)][e & 3], ACT == KTF_ACT_RELU ? 0.0f : -65504.0f, 65504.0f);
+                    u32x4 hp[2];
+                    unsigned l4p[2], h4p[2], swp[2];
+                    xl_encode8<2>(v, hp, l4p, h4p, swp);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int i = i2 + n;
+                        l4r[i] = l4p[n]; h4r[i] = h4p[n]; swr[i] = swp[n];
+                        if ((ok >> i) & 1u) {
+                            unsigned rr = rec_i[i];
+                            asm volatile("" : "+v"(rr));      // (the address is formed here, not hoisted and kept in registers)
+                            __builtin_nontemporal_store(hp[n], reinterpret_cast<u32x4*>(yh0 + ((rr + crec) * 64u + (unsigned)q4 * 16u)));
+                        }
                     }
-                    u32x4 hp;
-                    unsigned l4, h4, sw;
-                    xl_encode8(v, hp, l4, h4, sw);
-                    if ((ok >> i) & 1u) {
-                        const uint64_t rec = (uint64_t)(rec_i[i] + crec);
-                        __builtin_nontemporal_store(hp, reinterpret_cast<u32x4*>(p.yh + rec * 64u + (unsigned)q4 * 16u));
-                        __builtin_nontemporal_store(l4, reinterpret_cast<unsigned*>(p.yl4 + rec * 16u + (unsigned)q4 * 4u));
-                        __builtin_nontemporal_store(h4, reinterpret_cast<unsigned*>(p.y4 + rec * 16u + (unsigned)q4 * 4u));
-                        if (q4 == 0) __builtin_nontemporal_store(sw, reinterpret_cast<unsigned*>(p.ys + rec * 4u));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                xl_transpose4(l4r[0], l4r[1], l4r[2], l4r[3]);
+                xl_transpose4(h4r[0], h4r[1], h4r[2], h4r[3]);
+                if (okA) {
+                    const unsigned rec = recA + crec;
+                    const unsigned sw = q4 == 0 ? swr[0] : q4 == 1 ? swr[1] : q4 == 2 ? swr[2] : swr[3];
+                    __builtin_nontemporal_store(u32x4{l4r[0], l4r[1], l4r[2], l4r[3]}, reinterpret_cast<u32x4*>(yl0 + rec * 16u));
+                    __builtin_nontemporal_store(u32x4{h4r[0], h4r[1], h4r[2], h4r[3]}, reinterpret_cast<u32x4*>(y40 + rec * 16u));
+                    __builtin_nontemporal_store(sw, reinterpret_cast<unsigned*>(ys0 + rec * 4u));
+                }
+                {   // row blocks 4, 5: even lane quarters end up with dwords (q, q + 1) of block 4, odd ones with (q - 1, q) of block 5
+                    auto r = __builtin_amdgcn_permlane16_swap(l4r[4], l4r[5], false, false);
+                    const u32x2 lw = u32x2{r[0], r[1]};
+                    r = __builtin_amdgcn_permlane16_swap(h4r[4], h4r[5], false, false);
+                    const u32x2 hw2 = u32x2{r[0], r[1]};
+                    if (okB) {
+                        const unsigned rec = recB + crec;
+                        __builtin_nontemporal_store(lw, reinterpret_cast<u32x2*>(yl0 + (rec * 16u + (unsigned)(q4 >> 1) * 8u)));
+                        __builtin_nontemporal_store(hw2, reinterpret_cast<u32x2*>(y40 + (rec * 16u + (unsigned)(q4 >> 1) * 8u)));
+                        if (q4 < 2) __builtin_nontemporal_store((q4 & 1) ? swr[5] : swr[4], reinterpret_cast<unsigned*>(ys0 + rec * 4u));
                     }
                 }
             }
@@ -541,19 +636,19 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
             for (int jj = 0; jj < 4; ++jj) {
                 const int ul = xl_unit(wn * 4 + jj, q4 * 4);
                 const int n = n0 + ul;
-                float eb[4], es[4], eh[4];
+                float es[4], eh[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { eb[e] = prm[ul + e]; es[e] = prm[256 + ul + e]; eh[e] = prm[512 + ul + e]; }
+                for (int e = 0; e < 4; ++e) { es[e] = prm[256 + ul + e]; eh[e] = prm[512 + ul + e]; }
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
                     if (!((ok >> i) & 1u)) continue;
                     float v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        v[e] = xl_act(acc[i][jj][e] + eb[e], ACT);
+                        v[e] = xl_act(acc[i][jj][e], ACT);
                         if (affine) v[e] = v[e] * es[e] + eh[e];
                     }
-                    float* yp = p.yf + frow[i] * p.ldy + n;
+                    float* yp = p.yf + ((int64_t)b0 * T + (int64_t)rec_i[i]) * p.ldy + n;
                     if (vec && n + 4 <= p.units) {
                         *reinterpret_cast<f32x4*>(yp) = f32x4{v[0], v[1], v[2], v[3]};
                     } else {
@@ -573,6 +668,8 @@ int mxl_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stat
     q.m = p;
     q.stats = stats;
     q.B = (int32_t)B;
+    KTF_REQUIRE(!(out_kind == MX_OUT_PLANES && p.scale), "ktf_tdnn_mx: the loader kernel writes planes without scale / shift (fold the BatchNorm into the "
+                "next layer, or clear KTF_TDNN_MX_LOADER)");
     KTF_REQUIRE(B * p.T < (1ll << 31) && B * p.T * (int64_t)(p.nch_in > p.nch_out ? p.nch_in : p.nch_out) < (1ll << 32),
                 "ktf_tdnn_mx: batch too large for the loader kernel's 32-bit record indices (B * T * D / 32 must be below 2^32)");
     q.total_rows = (uint32_t)(B * p.T);

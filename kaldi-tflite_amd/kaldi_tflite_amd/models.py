@@ -160,7 +160,9 @@ class Sequential:
         self.gemm = gemm
         self.min_tiles = dict(self.MIN_TILES)
         self.min_frames = dict(self.MIN_FRAMES)
-        self.mx_loader = True        # f16mx: the loader-wave kernel (csrc/tdnn_mxl.hip); False = the 256-row kernel (csrc/tdnn_mx.hip), the A/B
+        self.mx_loader = False       # f16mx: True = the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles on the flat row space, eight
+                                     # matrix + four loader waves, plane epilogue from registers); False = the 256 x 256 eight-wave kernel
+                                     # (csrc/tdnn_mx.hip), which is 4-6 % faster on the 0008 shapes: the default
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"

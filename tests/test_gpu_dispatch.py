@@ -54,7 +54,7 @@ EXPECT = {   # mode -> kernel family of tdnn1 .. tdnn5 for a batch of full-lengt
     "f16": ["tdnn_bf16h_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16h_kernel<f16>", "tdnn_bf16h_kernel<f16>"],
     "bf16x3": ["tdnn_x3s_kernel<bf16, 3>"] * 5,
     "f16x2": ["tdnn_x3s_kernel<f16, 2>"] * 5,
-    "f16mx": ["tdnn_mxl_kernel"] * 5,
+    "f16mx": ["tdnn_mx_kernel"] * 5,
 }
 
 
@@ -72,6 +72,15 @@ def test_batch_dispatch(gemm):
     mdl.fuse_tail = False
     tail = [k for s, k in trace(mdl, synth.make_wav(32, 160000, seed=3)) if s == "1x3000->512"]
     assert len(tail) == 1 and tail[0].startswith("tdnn_f32"), tail
+
+
+def test_f16mx_loader_kernel_dispatch():
+    """`Sequential.mx_loader`: every frame-level layer of an f16mx model on the loader-wave kernel (csrc/tdnn_mxl.hip)."""
+    w = synth.make_weights(seed=4321)
+    mdl = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm="f16mx")
+    mdl.xvec.mx_loader = True
+    got = [k for s, k in trace(mdl, synth.make_wav(32, 160000, seed=3)) if s in FRAME_LAYERS]
+    assert got == ["tdnn_mxl_kernel"] * 5, got
 
 
 def test_calibrated_f16x2_runs_one_pass_in_front_of_the_pooling():

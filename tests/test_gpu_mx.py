@@ -248,7 +248,7 @@ def test_loader_wave_kernel_against_the_256_row_kernel():
         assert np.abs(np.delete(got[loader], 5, 0) - want).max() <= 1e-4
         for b in (0, 6):
             assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), y[b]), "batch != single"
-    assert np.abs(np.delete(got[True] - got[False], 5, 0)).max() <= 5e-6
+    assert np.abs(np.delete(got[True] - got[False], 5, 0)).max() <= 1e-5
 
 
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16mx"])
