@@ -64,6 +64,7 @@ def parse_args(argv=None):
     ap.add_argument("--gemm", default="f16mx", choices=["bf16", "f16", "bf16x3", "f16x2", "f16mx", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--dump-xvectors", default=None, help="rank 0 saves the x-vectors of the last timed step (all ranks' when gathered) as .npy (tests)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other modes, latency, PLDA)")
     ap.add_argument("--no-parity", action="store_true", help="measurement runs of timing-only ablation builds (tools/mx): no oracle comparison, no finite check")
     ap.add_argument("--mx-loader", action="store_true", help="A/B: f16mx on the loader-wave kernel (csrc/tdnn_mxl.hip) instead of the 256 x 256 eight-wave kernel")
@@ -175,6 +176,8 @@ def main(argv=None):
         if world > 1:
             torch.distributed.destroy_process_group()
         return
+    if args.dump_xvectors:
+        np.save(args.dump_xvectors, y.detach().cpu().numpy())
 
     value = world * B * args.steps / dt
     out = {
@@ -235,13 +238,17 @@ class _GemmProfiler:
     """Brackets every ktf_tdnn launch of the frame-level layers with HIP events on the launch stream."""
 
     NAMES = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_mx", "tdnn_mx_stats")
+    AUX = ("mx_planes", "split_bf16")      # conversions a mode needs in front of its first GEMM: timed too, reported separately
 
     def __init__(self, ops, torch):
         self.ops, self.torch = ops, torch
         self.events = []
-        self.orig = {n: getattr(ops, n) for n in self.NAMES}
+        self.orig = {n: getattr(ops, n) for n in self.NAMES + self.AUX}
+        self.aux_events = []
         for n in self.NAMES:
             setattr(ops, n, self._wrap(n))
+        for n in self.AUX:
+            setattr(ops, n, self._wrap_aux(n))
 
     def _wrap(self, name):
         orig, prof, torch = self.orig[name], self, self.torch
@@ -260,20 +267,38 @@ class _GemmProfiler:
 
         return wrapped
 
+    def _wrap_aux(self, name):
+        orig, prof, torch = self.orig[name], self, self.torch
+
+        def wrapped(*a, **k):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = orig(*a, **k)
+            e.record()
+            prof.aux_events.append((name, s, e))
+            return r
+
+        return wrapped
+
     def reset(self):
         """Drops the launches recorded so far (the warm-up)."""
         self.events = []
+        self.aux_events = []
 
     def finish(self):
-        for n in self.NAMES:
+        for n in self.NAMES + self.AUX:
             setattr(self.ops, n, self.orig[n])
+        aux = {}
+        for name, s, e in self.aux_events:
+            aux[name] = aux.get(name, 0.0) + s.elapsed_time(e)
         total, per = 0.0, {}
         for name, s, e in self.events:
             ms = s.elapsed_time(e)
             total += ms
             per[name] = per.get(name, 0.0) + ms
         steps = max(len(self.events) // 5, 1)
-        return {"total_ms": total, "launches": len(self.events), "per_layer_ms": {k: v / steps for k, v in per.items()}}
+        return {"total_ms": total, "launches": len(self.events), "per_layer_ms": {k: v / steps for k, v in per.items()},
+                "aux_ms_per_step": {k: v / steps for k, v in aux.items()}}
 
 
 
@@ -358,6 +383,7 @@ def _roofline(gemm, gemm_stats, steps, B, T, passes):
         "frac_mfma_issue_equivalent": achieved * passes / peak,
         "launches_per_step": gemm_stats["launches"] // steps, "avg_launch_ms": gemm_stats["total_ms"] / max(gemm_stats["launches"], 1),
         "gemm_ms_per_step": gemm_ms_per_step, "per_layer_ms": gemm_stats["per_layer_ms"],
+        "input_conversion_ms_per_step": gemm_stats.get("aux_ms_per_step", {}),      # ktf_mx_planes / ktf_split_bf16: part of the mode's cost, not of `achieved`
         "algorithmic_flop_per_step": flops_per_step,
         "per_layer_tflops": {k: _layer_flops(k, B, T) / (v * 1e-3) / 1e12 for k, v in gemm_stats["per_layer_ms"].items()},
         "note": ("achieved / frac count ALGORITHMIC flops (SURVEY 8d: 5 359 616 per voiced frame); this mode issues "

@@ -677,7 +677,8 @@ _GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat1
 class TDNN(Layer):
     """layers/tdnn/tdnn.py:29 — irregular-context 1-D convolution as an implicit-im2col MFMA GEMM."""
 
-    MAX_DEVICE_SETS = 4        # device operand sets kept per layer (keyed by mode / fold / calibration); older ones are evicted
+    MAX_DEVICE_SETS = 4        # device operand sets kept per layer AND DEVICE (keyed by mode / fold / calibration): the oldest set of
+                               # the same device is evicted; sets on other devices (other ranks' streams may be reading them) stay
 
     def __init__(self, units, context=[0], subsampling_factor=1, padding="SAME", use_bias=True, kernel_initializer=None,
                  bias_initializer=None, activation=None, name=None, gemm="f32", **kwargs):
@@ -858,8 +859,9 @@ class TDNN(Layer):
             if gemm == L.GEMM_BF16X3:
                 w_lo = (W - w.to(torch.float32)).to(torch.bfloat16)
         bias = ops.to_device_f32(bias64, device) if bias64 is not None else None
-        while len(self._dev) >= self.MAX_DEVICE_SETS:        # re-calibration / mode changes replace operand sets: evict the oldest
-            self._dev.pop(next(iter(self._dev)))
+        mine = [k for k in self._dev if k[0] == str(device)]
+        while len(mine) >= self.MAX_DEVICE_SETS:             # re-calibration / mode changes replace operand sets: evict this device's oldest
+            self._dev.pop(mine.pop(0))
         self._dev[key] = (w, w_lo, bias)
         return self._dev[key]
 
@@ -964,6 +966,13 @@ class TDNN(Layer):
         ok = self.units > 128 and (a in (None, "linear") or (a == "relu" and not relu))
         if gemm == L.GEMM_F16MX:             # SAME padding without subsampling only
             ok = ok and self.padding == "SAME" and self.subsamplingFactor == 1
+        if not ok and not getattr(self, "_warned_fp32_fallback", False):
+            import warnings
+            self._warned_fp32_fallback = True
+            mode = {L.GEMM_F16: "f16", L.GEMM_F16X2: "f16x2", L.GEMM_F16MX: "f16mx"}[gemm]
+            warnings.warn(f"TDNN layer '{self.name}' (units {self.units}, padding {self.padding}, subsampling {self.subsamplingFactor}, "
+                          f"activation {self.activation}) is outside what the '{mode}' kernels serve: it runs on the exact fp32 kernels "
+                          f"(several times slower per flop; results are the more accurate ones)", RuntimeWarning, stacklevel=3)
         return gemm if ok else L.GEMM_F32
 
     def prepare_input(self, x, gemm):

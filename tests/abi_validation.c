@@ -42,6 +42,13 @@ int main(void) {
     t.valid = 0; t.ctx[0] = 300;
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
     EXPECT_EINVAL(ktf_tdnn_mx_stats(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL));
+    t.ctx[0] = 0; t.flags = KTF_TDNN_MX_LOADER;                                                            /* the loader-wave kernel ... */
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, f, f, f, f, f, f, NULL, 0, NULL));     /* ... writes planes without scale / shift */
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 70000, 40000, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL)); /* ... 32-bit row space */
+    EXPECT_EINVAL(ktf_stats_finalize_slots(d, 4, 0, NULL, 500, 1, 4, 1, 1e-10f, f, 8, NULL));             /* slot_rows */
+    if (ktf_mx_slot_rows(KTF_TDNN_MX_LOADER) != 96 || ktf_mx_slot_rows(0) != 128 || ktf_mx_stats_slots(998, KTF_TDNN_MX_LOADER) != 12 ||
+        ktf_mx_stats_slots(998, 0) != ktf_stats_slots(998)) { printf("FAIL: ktf_mx_slot_rows / ktf_mx_stats_slots\n"); ++fails; }
+    t.flags = 0;
     EXPECT_EINVAL(ktf_mx_planes(NULL, 1, 1, 8, 8, NULL, f, f, f, f, NULL));
     EXPECT_EINVAL(ktf_mx_planes(f, 1, 1, 8, 4, NULL, f, f, f, f, NULL));
     EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, d, 0, 128, l, 1, 1, 4, 1, 1e-10f, f, 8, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));   /* pooled and sums */

@@ -519,7 +519,8 @@ def test_library_kernel_families():
 def test_abi_argument_validation_from_c(tmp_path):
     """tests/abi_validation.c: a plain C caller hands every TDNN / MX / tail / helper entry point arguments it must refuse; each
     call has to come back KTF_EINVAL with a message, before any HIP call (runs without a GPU). tools/asan_abi.sh runs the same
-    driver against an AddressSanitizer + UBSan build of the library (opt-in here: KTF_RUN_SANITIZERS=1, ~90 s of compile)."""
+    driver against an AddressSanitizer + UBSan build of the library (built in ~30 s on 8 cores and cached under $TMPDIR, keyed by a
+    checksum of the sources; KTF_SKIP_SANITIZERS=1 skips it)."""
     import os
     import subprocess
     from kaldi_tflite_amd import _lib
@@ -530,6 +531,6 @@ def test_abi_argument_validation_from_c(tmp_path):
                     "-L" + libdir, "-l:libktf_hip.so", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "all rejected as KTF_EINVAL" in out.stdout, out.stdout + out.stderr
-    if os.environ.get("KTF_RUN_SANITIZERS") == "1":
-        san = subprocess.run([os.path.join(root, "tools", "asan_abi.sh")], capture_output=True, text=True)
+    if os.environ.get("KTF_SKIP_SANITIZERS") != "1" and os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        san = subprocess.run(["bash", os.path.join(root, "tools", "asan_abi.sh")], capture_output=True, text=True, timeout=900)
         assert san.returncode == 0 and "all rejected as KTF_EINVAL" in san.stdout and "ERROR: AddressSanitizer" not in san.stderr, san.stdout + san.stderr

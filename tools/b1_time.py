@@ -35,4 +35,4 @@ g = lambda: g_(wav)
 for _ in range(20):
     g()
 graph = med(g)
-print(f"{os.environ.get('KTF_LIBRARY', 'default'):>60s}  eager {eager:.4f} ms   graph {graph:.4f} ms   checksum {float(y.double().sum()):.9f}")
+print(f"{os.path.basename(ktf._lib.LIB_PATH):>60s}  eager {eager:.4f} ms   graph {graph:.4f} ms   checksum {float(y.double().sum()):.9f}")

@@ -99,12 +99,7 @@ def _f_only_common(s):
     s = rep(s, "                if (j == 0) {\n                    if (i == 3) MX_SA_SETUP(ss)", "                if (false) {\n                    if (i == 3) MX_SA_SETUP(ss)")
     return rep(s, "            for (int i = 0; i < 8; ++i) {\n                const u32x4 l = l_n, h = h_n;", "            for (int i = 0; i < 0; ++i) {\n                const u32x4 l = l_n, h = h_n;")
 V["f_only_2slot"] = lambda s: rep(_f_only_common(_head()), "                if (j == 1) {\n                    if (i == 4) { MX_DMA_SW", "                if (false) {\n                    if (i == 4) { MX_DMA_SW")
-_3slot = lambda: open(os.path.join(ROOT, "tools", "mx", "experiments", "tdnn_mx_3slot.hip.txt")).read()
-V["3slot"] = lambda s: _3slot()
-V["f_only_3slot"] = lambda s: rep(rep(_f_only_common(_3slot()), "                if (j == 2) {\n                    if (i == 4) MX_LD_SW(ss, 0)", "                if (false) {\n                    if (i == 4) MX_LD_SW(ss, 0)"),
-    '            if (j == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");\n            else if (j < 3) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");\n            else if (last) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");\n            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");',
-    '            if (last && j == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");\n            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");')
-
+# (the three-slot ring variants were built from a full copy of the kernel: kept as tools/mx/experiments/tdnn_mx_3slot.patch)
 V["dma_only"] = V["no_mfma"]
 V["dma_only_stage"] = lambda s: V["no_side_dma"](V["no_mfma"](s))
 V["dma_only_sides"] = lambda s: V["no_f16_dma"](V["no_mfma"](s))

@@ -41,4 +41,4 @@ def both():
     main.wait_stream(side)
 
 t_both = timeit(both)
-print(f"{os.path.basename(os.environ.get('KTF_LIBRARY', 'default'))}: features(512) {t_fe:.3f} ms, TDNN stack(512) {t_gemm:.3f} ms, sum {t_fe + t_gemm:.3f}, on two streams {t_both:.3f} ms")
+print(f"{os.path.basename(ktf._lib.LIB_PATH)}: features(512) {t_fe:.3f} ms, TDNN stack(512) {t_gemm:.3f} ms, sum {t_fe + t_gemm:.3f}, on two streams {t_both:.3f} ms")

@@ -19,4 +19,4 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(8): mdl(wav)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
 st = prof.finish()
-print(os.path.basename(os.environ.get("KTF_LIBRARY", "default")), f"{dt*1e3:.3f} ms/step", {k: round(v, 3) for k, v in st["per_layer_ms"].items()})
+print(os.path.basename(ktf._lib.LIB_PATH), f"{dt*1e3:.3f} ms/step", {k: round(v, 3) for k, v in st["per_layer_ms"].items()})
