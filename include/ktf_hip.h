@@ -371,7 +371,9 @@ int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T, int32_t D,
 int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, int32_t slot_rows, const int32_t* lens, int64_t T,
                       int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
                       int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
-                      uint32_t* counters, float* y, float* h_out, int32_t group, void* stream);
+                      uint32_t* counters, float* y, float* h_out, int32_t group, int32_t flags, void* stream);
+#define KTF_TAIL_SKIP_EMPTY 1     /* ktf_xvec_tail_f32 flags: utterances with lens[b] == 0 are skipped and their rows of y left as they are
+                                   * (the second, tighter pass over the short utterances of a batch: XvectorExtractor.route_short_utterances) */
 /* ------------------------------------------------------------------ x-vector post-processing (a12)
  * models/kaldi/xvector_extractor.py:174-184: y = (x - mean) @ A + off ; y *= sqrt(out)/||y||_2
  * x (B, in) fp32, A (in, out) row-major, off (out). */

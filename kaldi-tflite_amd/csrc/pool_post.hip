@@ -232,7 +232,7 @@ __global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __re
                                                                int in_dim, int units, const float* __restrict__ mean, const float* __restrict__ A,
                                                                const float* __restrict__ off, int out_dim, float* __restrict__ partial,
                                                                unsigned* __restrict__ counters, float* __restrict__ y, float* __restrict__ h_out,
-                                                               int64_t B, int G, int two_phase) {
+                                                               int64_t B, int G, int two_phase, int skip_empty) {
     extern __shared__ __attribute__((aligned(16))) float xt_sm[];          // in_dim_pad | 16 unit outputs | out_dim | 8
     const int in_pad = (in_dim + 3) & ~3;
     float* xs = xt_sm;
@@ -240,6 +240,12 @@ __global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __re
     float* ys = hs + 16;
     float* red = ys + out_dim;
     const int blk = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (skip_empty && lens) {                                   // KTF_TAIL_SKIP_EMPTY: a group without a single voiced utterance leaves at once
+        const int64_t lo = (int64_t)blockIdx.y * G, hi = lo + G < B ? lo + G : B;
+        bool any = false;
+        for (int64_t b = lo; b < hi; ++b) any |= lens[b] > 0;
+        if (!any) return;
+    }
     const int upb = (units + XT_NBLK - 1) / XT_NBLK;            // <= 8: two units per wave
     const int u0 = blk * upb;
     // this wave's rows of W: lane l holds columns 4 l + 256 it .. + 3 of each
@@ -288,8 +294,10 @@ __global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __re
                     xn[j] = i < in_dim ? pooled[(b + 1) * ld_pooled + i] : 0.0f;
                 }
             }
+            if (skip_empty && lens && lens[b] <= 0) continue;  // (workgroup-uniform; no barrier of this iteration has been reached)
         } else {
             const int len = lens ? lens[b] : (int)T;
+            if (skip_empty && len <= 0) continue;              // (workgroup-uniform; no barrier of this iteration has been reached)
             const double n = (double)len;
             const int used = slots ? (len + slot_rows - 1) / slot_rows : 1;
             for (int c = tid; c < D; c += XT_THREADS) {
@@ -372,8 +380,10 @@ __global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __re
 // Second phase as a launch of its own (large batches: one agent-scope release per workgroup of the fused form writes the
 // XCD's dirty L2 lines back, which with thousands of workgroups costs more than a kernel boundary). Same arithmetic.
 __global__ __launch_bounds__(XT_THREADS) void xvec_tail_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ off,
-                                                                      float* __restrict__ y, int out_dim) {
+                                                                      float* __restrict__ y, int out_dim, const int32_t* __restrict__ lens,
+                                                                      int skip_empty) {
     extern __shared__ __attribute__((aligned(16))) float xr_sm[];
+    if (skip_empty && lens && lens[blockIdx.x] <= 0) return;
     xt_reduce(partial, off, y, blockIdx.x, out_dim, xr_sm, xr_sm + out_dim);
 }
 
@@ -586,7 +596,7 @@ extern "C" int ktf_stats_pool_windowed_f32(const float* x, int64_t B, int64_t T,
 extern "C" int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const double* sums, int64_t slots, int32_t slot_rows, const int32_t* lens, int64_t T,
                                  int64_t B, int32_t D, int32_t include_std, float eps, const float* W, int64_t ldw, const float* bias,
                                  int32_t units, const float* mean, const float* A, const float* off, int32_t out_dim, float* partial,
-                                 uint32_t* counters, float* y, float* h_out, int32_t group, void* stream) {
+                                 uint32_t* counters, float* y, float* h_out, int32_t group, int32_t flags, void* stream) {
     KTF_REQUIRE((pooled != nullptr) != (sums != nullptr), "ktf_xvec_tail_f32: exactly one of pooled / sums");
     KTF_REQUIRE(W && A && partial && counters && y, "ktf_xvec_tail_f32: null argument");
     const int in_dim = (include_std ? 2 : 1) * D;
@@ -598,13 +608,15 @@ extern "C" int ktf_xvec_tail_f32(const float* pooled, int64_t ld_pooled, const d
     if (sums && slots) KTF_REQUIRE(slot_rows > 0 && slots * slot_rows >= T, "ktf_xvec_tail_f32: too few slots");
     if (B == 0) return KTF_OK;
     const size_t lds = sizeof(float) * ((size_t)XT_MAXIT * 256 + 16 + out_dim + 8);
+    const int skip = (flags & KTF_TAIL_SKIP_EMPTY) ? 1 : 0;
+    KTF_REQUIRE(!skip || lens, "ktf_xvec_tail_f32: KTF_TAIL_SKIP_EMPTY needs lens");
     const int two_phase = group > 1;        // many workgroups: the slot reduction as a second launch instead of in-kernel tickets
     hipLaunchKernelGGL(xvec_tail_kernel, dim3(XT_NBLK, (unsigned)((B + group - 1) / group)), dim3(XT_THREADS), lds, (hipStream_t)stream, pooled, ld_pooled,
                        sums, slots, (int)slot_rows, lens, T, (int)D, (int)include_std, eps, W, ldw, bias, in_dim, (int)units, mean, A, off, (int)out_dim, partial,
-                       counters, y, h_out, B, (int)group, two_phase);
+                       counters, y, h_out, B, (int)group, two_phase, skip);
     if (two_phase)
         hipLaunchKernelGGL(xvec_tail_reduce_kernel, dim3((unsigned)B), dim3(XT_THREADS), sizeof(float) * (out_dim + 8), (hipStream_t)stream, partial, off, y,
-                           (int)out_dim);
+                           (int)out_dim, lens, skip);
     KTF_CHECK_LAUNCH("ktf_xvec_tail_f32");
     return KTF_OK;
 }

@@ -20,6 +20,7 @@ KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
 GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2, GEMM_F16MX = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED, TDNN_X_CHUNKED, TDNN_Y_CHUNKED = 1, 2, 4, 8, 16, 32   # KtfTdnnDesc.flags
+TAIL_SKIP_EMPTY = 1                 # ktf_xvec_tail_f32 flags
 TDNN_MX_LOADER = 1 << 24          # ktf_tdnn_mx*: the loader-wave kernel (csrc/tdnn_mxl.hip) and its weight images
 
 
@@ -115,7 +116,7 @@ PROTOTYPES = {
     "ktf_stats_pool": (C.c_int, [_P, _i32, _i64, _i64, _i32, _i64, _P, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_stats_pool_windowed_f32": (C.c_int, [_P, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _f32, _P, _P]),
     "ktf_xvec_post_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P, _P]),
-    "ktf_xvec_tail_f32": (C.c_int, [_P, _i64, _P, _i64, _i32, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P, _i32, _P, _P, _P, _i32, _P, _P, _P, _P, _i32, _P]),
+    "ktf_xvec_tail_f32": (C.c_int, [_P, _i64, _P, _i64, _i32, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P, _i32, _P, _P, _P, _i32, _P, _P, _P, _P, _i32, _i32, _P]),
     "ktf_plda_f64": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
     "ktf_plda_f32": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _i32, _P, _P, _P]),
     "ktf_plda_score_f64": (C.c_int, [_P, _i64, _P, _i64, _i32, _P, _P, _P]),

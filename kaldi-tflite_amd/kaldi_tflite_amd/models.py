@@ -140,10 +140,11 @@ class Sequential:
     # MIN_TILES: batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times).
     # MIN_FRAMES: batches whose utterances are shorter than this many frames run the next tighter mode: the block-scaled residuals
     # of f16mx are zero-mean rounding noise that the statistics pooling averages over the voiced frames, so its deviation grows as
-    # the utterance shrinks (measured on speech windows, tests/test_gpu_margin.py: 10 s 2-5e-5, 3 s 6e-5, 1 s up to 9e-5 of the
-    # 1e-4 tolerance); below 2 s of audio the split-bf16 kernels (7e-6) take the batch.
+    # the utterance shrinks (measured on speech windows with BatchNorm statistics that are the network's own, tests/test_gpu_margin.py:
+    # 10 s 2-5e-5, 5 s 5-6.5e-5, 3 s 6-7.5e-5, 1.5 s up to 1.2e-4 -- outside the 1e-4 tolerance); below 4 s the split-bf16 kernels
+    # (1.5e-5) take the batch, and XvectorExtractor applies the same rule per utterance on the device (route_short_utterances).
     MIN_TILES = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
-    MIN_FRAMES = {"f16mx": 200}
+    MIN_FRAMES = {"f16mx": 400}
     SHORT_MODE = {"f16mx": "bf16x3"}
 
     def __init__(self, layers=None, name=None, gemm="f32"):
@@ -226,14 +227,15 @@ class Sequential:
                 return None
         return steps
 
-    def batch_gemm(self, B, T):
+    def batch_gemm(self, B, T, mode=None):
         """GEMM arithmetic for a batch of B utterances of up to T frames: the model's mode, except that a handful of
         256-row tiles (single utterances) cannot fill the chip on the 256-wide ring kernels -- the exact fp32 kernels have
         small-tile forms and are faster there (one 10 s utterance: 0.19 ms against 0.20 bf16 / 0.39 split-bf16); and a batch
         of utterances shorter than `min_frames` frames runs the tighter mode named by SHORT_MODE."""
-        mode = self.gemm
-        if T < self.min_frames.get(mode, 0):             # short utterances: the tighter mode (MIN_FRAMES)
-            mode = self.SHORT_MODE.get(mode, "f32")
+        if mode is None:
+            mode = self.gemm
+            if T < self.min_frames.get(mode, 0):         # short utterances: the tighter mode (MIN_FRAMES)
+                mode = self.SHORT_MODE.get(mode, "f32")
         gemm = _GEMM[mode]
         if gemm != L.GEMM_F32 and B * ((T + 255) // 256) < self.min_tiles.get(mode, 0):
             gemm = L.GEMM_F32
@@ -283,11 +285,12 @@ class Sequential:
                 return len(steps) - 1
         return -1
 
-    def run_ragged(self, x, lens=None, defer_tail=False):
+    def run_ragged(self, x, lens=None, defer_tail=False, mode=None):
         """x: (B, T, D) view of an utterance-strided buffer whose row stride is a multiple of 8 and >= round_up(D, 32)
         (pad columns finite); lens: int32 (B,) valid rows per utterance or None. Returns (B, T', units) for frame-level
         outputs or (B, 1, units) after a reducing StatsPooling. The result is a view of this model's workspace: it is
-        overwritten by the model's next call on the same stream (`__call__` hands out an owned copy)."""
+        overwritten by the model's next call on the same stream (`__call__` hands out an owned copy). `mode`: run this call in
+        that arithmetic instead of the model's (XvectorExtractor's second pass over short utterances)."""
         steps = self._plan()
         if steps is None:
             raise NotImplementedError("this layer stack is not supported by the fused ragged runner")
@@ -295,7 +298,7 @@ class Sequential:
         self._ws.enter(dev)
         if (self._xbar or self._xvar) and self._calibrating is None and self._cal_sig != self.weights_signature():
             self._xbar, self._xvar = {}, {}      # the weights changed since calibrate(): its statistics describe another network
-        gemm = self.batch_gemm(x.shape[0], x.shape[1])
+        gemm = self.batch_gemm(x.shape[0], x.shape[1], mode=mode)
         act_dtype = L.act_torch_dtype(gemm)
         tail_at = self._tail_step(steps) if defer_tail else -1
         self._deferred = None        # set by a pooling step whose consumer is the deferred tail
@@ -711,6 +714,8 @@ class XvectorExtractor:
                                      # batch (0.10 ms at 1024 utterances, against 0.28 ms for the fused launch's vector arithmetic).
                                      # The exact fp32 mode keeps the one route at every size: its x-vectors do not depend on the
                                      # batch an utterance arrives in, bit for bit.
+        self.route_short_utterances = True    # utterances with fewer voiced frames than the mode's Sequential.MIN_FRAMES go through the
+                                              # tighter SHORT_MODE kernels, decided per utterance on the device (see _extract)
         self.last_lens = None
 
     @property
@@ -782,9 +787,39 @@ class XvectorExtractor:
     def _extract(self, inputs, out=None):
         _, feats, lens = self._features(inputs)
         self.last_lens = lens                                          # voiced-frame counts of the last call (workspace view)
-        one_launch = self.fuse_tail and self._tail_fusable() and (feats.shape[0] < self.fuse_tail_below or
-                                                                  self.xvec.batch_gemm(feats.shape[0], feats.shape[1]) == L.GEMM_F32)
-        h = self.xvec.run_ragged(feats, lens, defer_tail=one_launch)          # (B, 1, 512), or the deferred tail
+        B, T = feats.shape[0], feats.shape[1]
+        seq = self.xvec
+        nshort = seq.min_frames.get(seq.gemm, 0)
+        if not (self.route_short_utterances and nshort > 0 and T >= nshort and seq.gemm in seq.SHORT_MODE
+                and seq.batch_gemm(B, T) == _GEMM[seq.gemm]):
+            return self._xvectors(feats, lens, out)
+        # Per-utterance routing on the DEVICE (no host read of the lengths, graph-capturable): the batch runs in the model's mode with
+        # the utterances of fewer than `nshort` voiced frames masked out (length 0: their tiles leave at once), then once more in the
+        # tighter mode with only those utterances live; the second tail writes just their rows. With no short utterance in the batch
+        # the second pass is a handful of launches whose workgroups all leave at their first instruction.
+        ws = self._ws
+        lens_main = ws.get("lens_main", (B,), torch.int32, feats.device, padded=False)
+        lens_short = ws.get("lens_short", (B,), torch.int32, feats.device, padded=False)
+        zero = torch.zeros((), dtype=torch.int32, device=feats.device)
+        torch.where(lens >= nshort, lens, zero, out=lens_main)
+        torch.where(lens < nshort, lens, zero, out=lens_short)
+        y = self._xvectors(feats, lens_main, out)
+        short_mode = seq.SHORT_MODE[seq.gemm]
+        if self._tail_fusable() and self.fuse_tail:
+            self._xvectors(feats, lens_short, y, mode=short_mode, skip_empty=True)
+        else:                                                          # (tails that write every row: select afterwards)
+            y2 = self._xvectors(feats, lens_short, None, mode=short_mode)
+            y.copy_(torch.where((lens_short > 0)[:, None], y2, y))
+        return y
+
+    def _xvectors(self, feats, lens, out=None, mode=None, skip_empty=False):
+        """CMVN'd features + voiced-frame counts -> x-vectors (B, lda_dim). `mode`: the TDNN arithmetic of this pass (default: the
+        model's); `skip_empty`: utterances with lens == 0 are not computed and their rows of `out` stay (fused tail only)."""
+        one_launch = self.fuse_tail and self._tail_fusable() and (skip_empty or feats.shape[0] < self.fuse_tail_below or
+                                                                  self.xvec.batch_gemm(feats.shape[0], feats.shape[1], mode=mode) == L.GEMM_F32)
+        if skip_empty and not one_launch:
+            raise RuntimeError("internal: skip_empty needs the fused tail")
+        h = self.xvec.run_ragged(feats, lens, defer_tail=one_launch, mode=mode)          # (B, 1, 512), or the deferred tail
         dev = feats.device
         key = str(dev)
         if key not in self._post_dev:
@@ -811,7 +846,7 @@ class XvectorExtractor:
                 if out is None:
                     out = torch.empty((B, odim), dtype=torch.float32, device=dev)
                 return ops.xvec_tail(t.pooled, t.sums, t.slots, t.lens, t.T, t.D, t.include_std, t.eps, w6, b6, t.layer.units, mean, A, off,
-                                     partial, counters, out, group=group, slot_rows=t.slot_rows)
+                                     partial, counters, out, group=group, slot_rows=t.slot_rows, skip_empty=skip_empty)
             raise ValueError(f"LDA input dim {A.shape[0]} != embedding dim {t.layer.units}")
         B = h.shape[0]
         h2 = h.reshape(B, h.shape[-1])

@@ -504,7 +504,7 @@ def xvec_post(x, mean, A, off, out=None):
 
 
 def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units, mean, A, off, partial, counters, out, h_out=None, group=1,
-              slot_rows=128):
+              slot_rows=128, skip_empty=False):
     """Fused tail (ktf_xvec_tail_f32): pooled (B, ld) fp32 rows OR fp64 sums -> tdnn6 -> mean-sub -> LDA -> length norm, one launch."""
     lib = L.load()
     B = out.shape[0]
@@ -512,7 +512,8 @@ def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units,
     with torch.cuda.device(src.device):
         rc = lib.ktf_xvec_tail_f32(L.ptr(pooled), pooled.stride(0) if pooled is not None else 0, L.ptr(sums), int(slots), int(slot_rows), L.ptr(lens), int(T), B,
                                    int(D), int(include_std), float(eps), L.ptr(W), W.stride(0), L.ptr(bias), int(units), L.ptr(mean), L.ptr(A),
-                                   L.ptr(off), A.shape[1], L.ptr(partial), L.ptr(counters), L.ptr(out), L.ptr(h_out), int(group), L.stream_ptr())
+                                   L.ptr(off), A.shape[1], L.ptr(partial), L.ptr(counters), L.ptr(out), L.ptr(h_out), int(group),
+                                   L.TAIL_SKIP_EMPTY if skip_empty else 0, L.stream_ptr())
     L.check(rc, "ktf_xvec_tail_f32")
     return out
 

@@ -51,9 +51,10 @@ int main(void) {
     t.flags = 0;
     EXPECT_EINVAL(ktf_mx_planes(NULL, 1, 1, 8, 8, NULL, f, f, f, f, NULL));
     EXPECT_EINVAL(ktf_mx_planes(f, 1, 1, 8, 4, NULL, f, f, f, f, NULL));
-    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, d, 0, 128, l, 1, 1, 4, 1, 1e-10f, f, 8, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));   /* pooled and sums */
-    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, 128, l, 1, 1, 4, 1, 1e-10f, f, 6, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));  /* ldw */
-    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, 128, l, 1, 1, 4000, 1, 1e-10f, f, 8000, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, NULL));
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, d, 0, 128, l, 1, 1, 4, 1, 1e-10f, f, 8, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, 0, NULL));   /* pooled and sums */
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, 128, l, 1, 1, 4, 1, 1e-10f, f, 6, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, 0, NULL));  /* ldw */
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, 128, l, 1, 1, 4000, 1, 1e-10f, f, 8000, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, 0, NULL));
+    EXPECT_EINVAL(ktf_xvec_tail_f32(f, 8, NULL, 0, 128, NULL, 1, 1, 4, 1, 1e-10f, f, 8, NULL, 8, NULL, f, NULL, 4, f, u, f, NULL, 1, KTF_TAIL_SKIP_EMPTY, NULL));   /* skip without lens */
     EXPECT_EINVAL(ktf_xvec_post_f32(NULL, 1, 8, 4, NULL, f, NULL, f, NULL));
     EXPECT_EINVAL(ktf_stats_finalize(NULL, NULL, 1, 1, 4, 1, 1e-10f, f, 8, NULL));
     EXPECT_EINVAL(ktf_stats_finalize_slots(d, 1, 128, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));       /* too few slots */
