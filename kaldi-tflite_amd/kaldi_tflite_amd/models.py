@@ -715,7 +715,9 @@ class XvectorExtractor:
                                      # The exact fp32 mode keeps the one route at every size: its x-vectors do not depend on the
                                      # batch an utterance arrives in, bit for bit.
         self.route_short_utterances = True    # utterances with fewer voiced frames than the mode's Sequential.MIN_FRAMES go through the
-                                              # tighter SHORT_MODE kernels, decided per utterance on the device (see _extract)
+                                              # tighter SHORT_MODE kernels, decided per utterance from the device's frame counts (_extract)
+        self._short_count = None              # pinned int32: short utterances of the batch in flight
+        self.last_short_count = 0             # ... of the last call
         self.last_lens = None
 
     @property
@@ -793,17 +795,32 @@ class XvectorExtractor:
         if not (self.route_short_utterances and nshort > 0 and T >= nshort and seq.gemm in seq.SHORT_MODE
                 and seq.batch_gemm(B, T) == _GEMM[seq.gemm]):
             return self._xvectors(feats, lens, out)
-        # Per-utterance routing on the DEVICE (no host read of the lengths, graph-capturable): the batch runs in the model's mode with
-        # the utterances of fewer than `nshort` voiced frames masked out (length 0: their tiles leave at once), then once more in the
-        # tighter mode with only those utterances live; the second tail writes just their rows. With no short utterance in the batch
-        # the second pass is a handful of launches whose workgroups all leave at their first instruction.
+        # Per-utterance routing: the batch runs in the model's mode with the utterances of fewer than `nshort` voiced frames masked out
+        # (length 0: their tiles leave at once), then once more in the tighter mode with only those utterances live; the second tail
+        # writes just their rows. The masks are made on the device. Whether the second pass is enqueued at all is decided on the host
+        # from ONE int32 (the number of short utterances) that travels to pinned memory behind the VAD / CMVN launch: the host waits
+        # for that copy's event AFTER it has enqueued the whole first pass, i.e. while the GPU has milliseconds of GEMMs queued -- no
+        # bubble on the device, and a batch without short utterances (the usual case) costs nothing. Under graph capture there is no
+        # host to ask: both passes are captured, and the second one's workgroups leave at their first instruction when nothing is short.
         ws = self._ws
         lens_main = ws.get("lens_main", (B,), torch.int32, feats.device, padded=False)
         lens_short = ws.get("lens_short", (B,), torch.int32, feats.device, padded=False)
         zero = torch.zeros((), dtype=torch.int32, device=feats.device)
         torch.where(lens >= nshort, lens, zero, out=lens_main)
         torch.where(lens < nshort, lens, zero, out=lens_short)
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not capturing:
+            if self._short_count is None:
+                self._short_count = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._short_count.copy_((lens_short > 0).sum(dtype=torch.int32).reshape(1), non_blocking=True)
+            counted = torch.cuda.Event()
+            counted.record()
         y = self._xvectors(feats, lens_main, out)
+        if not capturing:
+            counted.synchronize()
+            self.last_short_count = int(self._short_count[0])
+            if self.last_short_count == 0:
+                return y
         short_mode = seq.SHORT_MODE[seq.gemm]
         if self._tail_fusable() and self.fuse_tail:
             self._xvectors(feats, lens_short, y, mode=short_mode, skip_empty=True)

@@ -162,6 +162,7 @@ def test_vad_shortened_utterances_are_routed_on_the_device(seed):
     mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
     mdl.xvec.min_tiles = {}
     y = mdl(torch.as_tensor(wav, device="cuda"))
+    assert mdl.last_short_count == 3
     lens = mdl.last_lens.cpu().numpy()
     assert lens[0] > 400 and lens[2] > 400 and lens[5] == 0 and all(0 < lens[i] < 400 for i in (1, 3, 4)), lens
     got = y.cpu().numpy()
@@ -195,6 +196,8 @@ def test_device_routing_on_the_large_batch_tail_route():
     y = mdl(torch.as_tensor(wav, device="cuda"))
     lens = mdl.last_lens.cpu().numpy()
     assert (lens[short] < 400).all() and (lens[~short] >= 400).all()
+    assert mdl.last_short_count == int(short.sum())
+    assert mdl(torch.as_tensor(wav[~short], device="cuda")).shape[0] == int((~short).sum()) and mdl.last_short_count == 0       # nothing short: one pass
     ref = synth.build_extractor(ktf, cfg, w, gemm="bf16x3")
     ref.route_short_utterances = False
     yb = ref(torch.as_tensor(wav, device="cuda"))
