@@ -304,7 +304,7 @@ class _GemmProfiler:
 
 
 
-def _bench_mfcc(torch, mdl, wav, ops, iters=10):
+def _bench_mfcc(torch, mdl, wav, ops, iters=20, warm=5):
     """Secondary BASELINE metric: MFCC frames/s per GPU (fused Framing+MFCC kernel alone) against both of its ceilings:
     HBM (760 algorithmic bytes per frame) and VALU (~25 kFLOP per frame at the fp32 vector peak)."""
     from kaldi_tflite_amd import _lib as L
@@ -315,7 +315,8 @@ def _bench_mfcc(torch, mdl, wav, ops, iters=10):
     cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift
     out = torch.empty((B, T, mf.numMfccs), dtype=torch.float32, device=wav.device)
     tabs = mf.tables(wav.device)
-    ops.frontend(wav, L.IN_WAV, cfg, tabs, L.OUT_MFCC, N, B, T, out=out)
+    for _ in range(warm):          # (the clock ramps up over the first launches after an idle gap: 0.92 ms cold against 0.77 sustained)
+        ops.frontend(wav, L.IN_WAV, cfg, tabs, L.OUT_MFCC, N, B, T, out=out)
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -340,19 +341,31 @@ def _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N, calibrate=True):
     import numpy as np
     from oracle import ktf_oracle as O
     whole, chunks = synth.speech_wavs(N)
+
+    def windows(sec):          # windows of the speech recording at a 1 s hop (tests/test_gpu_margin.py)
+        n = int(sec * 16000)
+        return np.stack([whole[0, s0:s0 + n] for s0 in range(0, whole.shape[1] - n + 1, 16000)], 0)
     inputs = {"noise_as_timed": synth.make_wav(2, N, seed=1234), "noise_quiet_blocks": synth.make_wav(2, N, seed=4242, ragged=True),
-              "speech_22s": whole, "speech_10s_chunks": chunks}
+              "speech_22s": whole, "speech_10s_chunks": chunks, "speech_5s_windows": windows(5.0), "speech_1.5s_windows": windows(1.5)}
     want = {k: O.xvector_forward(v, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64) for k, v in inputs.items()}
     res = {"sample": f"fp64 NumPy oracle, 0008 topology, weights seed 4321: 2 + 2 synthetic utterances x {N} samples (all-voiced as timed / 30 % quiet "
-                     f"0.5 s blocks) + the reference's e2e speech recording (359 665 samples whole, and as two {N}-sample chunks)"}
+                     f"0.5 s blocks) + the reference's e2e speech recording (359 665 samples whole, as two {N}-sample chunks, and as 5 s and "
+                     f"1.5 s windows at a 1 s hop: 18 + 21 utterances). Each mode runs AS SHIPPED (Sequential.MIN_FRAMES and "
+                     f"XvectorExtractor.route_short_utterances send utterances below 400 voiced frames of an f16mx model through the "
+                     f"split-bf16 kernels); only the small-batch hand-over to the fp32 kernels (min_tiles) is off"}
     for g in modes:
         m = synth.build_extractor(ktf, cfg, w, gemm=g, calibrate=calibrate)
-        m.xvec.min_tiles, m.xvec.min_frames = {}, {}          # a few (or short) utterances would be routed to tighter kernels: measure the mode's own
+        m.xvec.min_tiles = {}          # a few utterances would be handed to the fp32 kernels: measure the mode's own (routing by length stays)
         r = {}
         for k, v in inputs.items():
             got = m(torch.as_tensor(v, device=dev)).cpu().numpy().reshape(v.shape[0], -1)
             r[k] = float(np.abs(got - want[k]).max())
         r["max"] = max(r.values())
+        if g == "f16mx":               # for the record: the f16mx kernels themselves on the short windows (what the routing is for)
+            m.xvec.min_frames, m.route_short_utterances = {}, False
+            v = inputs["speech_1.5s_windows"]
+            got = m(torch.as_tensor(v, device=dev)).cpu().numpy().reshape(v.shape[0], -1)
+            r["unrouted_kernels_on_speech_1.5s_windows"] = float(np.abs(got - want["speech_1.5s_windows"]).max())
         res[g] = r
         del m
     torch.cuda.empty_cache()
