@@ -49,6 +49,105 @@ __device__ __forceinline__ unsigned mx_fp4_scale_byte(float m) {
 }
 
 
+// unit (inside the 256-unit tile) that column `m` of unit block `cb` of the weight images holds: inside each 32-unit chunk the
+// order is permuted so that, with the weights as the A operand, lane quarter q4 of a frame owns units 8 q4 .. 8 q4 + 7 of the chunk
+__device__ __forceinline__ int mx_unit(int cb, int m) { return (cb >> 1) * 32 + (m >> 2) * 8 + (cb & 1) * 4 + (m & 3); }
+
+// registers (a, b, c, d) of the four lanes of a frame (lane quarter q = 0..3) hold element [register][q]: afterwards lane quarter q
+// holds elements [q][0..3] (a 4 x 4 transpose between register index and lane quarter)
+__device__ __forceinline__ void mx_transpose4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
+    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1];
+    r = __builtin_amdgcn_permlane16_swap(c, d, false, false); c = r[0]; d = r[1];
+    r = __builtin_amdgcn_permlane32_swap(a, c, false, false); a = r[0]; c = r[1];
+    r = __builtin_amdgcn_permlane32_swap(b, d, false, false); b = r[0]; d = r[1];
+}
+
+// Plane encoder. Eight consecutive values of a 32-value block (this lane's quarter; the other three quarters sit in lanes ^ 16, ^ 32,
+// ^ 48), each within [-65504, 65504] -> this lane's 16 bytes of the half piece, its dword of the two e2m1 records, the block's scale
+// word. Same arithmetic as mx_encode32 (tdnn_mx.hip, ktf_mx_planes) and mx.encode_activations. The work is one long dependency chain (values ->
+// half -> residual -> maxima -> two cross-lane steps -> scale -> conversions) and a wave has at most one partner on its SIMD, so
+// TWO blocks (N = 2: two row blocks of the tile) are encoded with their chains interleaved statement by statement: alone a block
+// took ~600 clk for ~70 instructions.
+template <int N>
+__device__ __forceinline__ void mx_encode8(const float (&v)[N][8], u32x4 (&hp)[N], unsigned (&l4)[N], unsigned (&h4)[N], unsigned (&sw)[N]) {
+    typedef __attribute__((ext_vector_type(2))) float f2;
+    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+    float lo[N][8];
+    unsigned hw[N][4];
+    float mv[N], ml[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) { mv[n] = 0.0f; ml[n] = 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            const float a = v[n][2 * k], b = v[n][2 * k + 1];
+            const h2 hh = __builtin_convertvector(f2{a, b}, h2);
+            hw[n][k] = __builtin_bit_cast(unsigned, hh);
+            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[n][2 * k]) : "v"(hw[n][k]), "v"(a));
+            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[n][2 * k + 1]) : "v"(hw[n][k]), "v"(b));
+            asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mv[n]) : "v"(a), "v"(b), "v"(mv[n]));
+            asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(ml[n]) : "v"(lo[n][2 * k]), "v"(lo[n][2 * k + 1]), "v"(ml[n]));
+        }
+    }
+    // the maxima over the four lanes of a frame: all 2 N values per cross-lane step
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        unsigned o[N][2][2];
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            if (step == 0) {
+                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(mv[n]), __float_as_uint(mv[n]), false, false);
+                o[n][0][0] = r[0]; o[n][0][1] = r[1];
+                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ml[n]), __float_as_uint(ml[n]), false, false);
+                o[n][1][0] = r[0]; o[n][1][1] = r[1];
+            } else {
+                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mv[n]), __float_as_uint(mv[n]), false, false);
+                o[n][0][0] = r[0]; o[n][0][1] = r[1];
+                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ml[n]), __float_as_uint(ml[n]), false, false);
+                o[n][1][0] = r[0]; o[n][1][1] = r[1];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {      // (magnitudes: plain v_max_f32 -- from C the compiler quiets both operands of every fmaxf first)
+            asm("v_max_f32 %0, %1, %2" : "=v"(mv[n]) : "v"(o[n][0][0]), "v"(o[n][0][1]));
+            asm("v_max_f32 %0, %1, %2" : "=v"(ml[n]) : "v"(o[n][1][0]), "v"(o[n][1][1]));
+        }
+    }
+    float sh[N], sl[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        const float mh = (float)(_Float16)mv[n];
+        const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml[n]);
+        sh[n] = __uint_as_float(bh << 23);
+        sl[n] = __uint_as_float(bl << 23);
+        sw[n] = bl | (bh << 8);
+    }
+    // every conversion writes one byte of a register of its own (a chain of four through one register runs at the instruction's latency)
+    unsigned xb[N][4], yb[N][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+            xb[n][k] = 0;
+            yb[n][k] = 0;
+        }
+    }
+#define MX_ENC8_S(s_)                                                                                                   \
+    _Pragma("unroll") for (int n = 0; n < N; ++n) {                                                                    \
+        xb[n][s_] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(xb[n][s_], lo[n][2 * s_], lo[n][2 * s_ + 1], sl[n], s_);  \
+        yb[n][s_] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(yb[n][s_], __builtin_bit_cast(h2, hw[n][s_]), sh[n], s_); \
+    }
+    MX_ENC8_S(0) MX_ENC8_S(1) MX_ENC8_S(2) MX_ENC8_S(3)
+#undef MX_ENC8_S
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        l4[n] = (xb[n][0] | xb[n][1]) | (xb[n][2] | xb[n][3]);
+        h4[n] = (yb[n][0] | yb[n][1]) | (yb[n][2] | yb[n][3]);
+        hp[n] = u32x4{hw[n][0], hw[n][1], hw[n][2], hw[n][3]};
+    }
+}
+
 #define MX_OUT_PLANES 0
 #define MX_OUT_F32 1
 #define MX_OUT_STATS 2

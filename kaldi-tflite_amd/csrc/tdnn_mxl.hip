@@ -63,106 +63,7 @@ struct MxlParams {
     uint32_t total_rows;                             // B * T
 };
 
-// registers (a, b, c, d) of the four lanes of a frame (lane quarter q = 0..3) hold element [register][q]: afterwards lane quarter q
-// holds elements [q][0..3] (a 4 x 4 transpose between register index and lane quarter)
-__device__ __forceinline__ void xl_transpose4(unsigned& a, unsigned& b, unsigned& c, unsigned& d) {
-    auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false); a = r[0]; b = r[1];
-    r = __builtin_amdgcn_permlane16_swap(c, d, false, false); c = r[0]; d = r[1];
-    r = __builtin_amdgcn_permlane32_swap(a, c, false, false); a = r[0]; c = r[1];
-    r = __builtin_amdgcn_permlane32_swap(b, d, false, false); b = r[0]; d = r[1];
-}
-
-// Plane encoder. Eight consecutive values of a 32-value block (this lane's quarter; the other three quarters sit in lanes ^ 16, ^ 32,
-// ^ 48), each within [-65504, 65504] -> this lane's 16 bytes of the half piece, its dword of the two e2m1 records, the block's scale
-// word. Same arithmetic as mx_encode32 (tdnn_mx.hip) and mx.encode_activations. The work is one long dependency chain (values ->
-// half -> residual -> maxima -> two cross-lane steps -> scale -> conversions) and a wave has at most one partner on its SIMD, so
-// TWO blocks (N = 2: two row blocks of the tile) are encoded with their chains interleaved statement by statement: alone a block
-// took ~600 clk for ~70 instructions.
-template <int N>
-__device__ __forceinline__ void xl_encode8(const float (&v)[N][8], u32x4 (&hp)[N], unsigned (&l4)[N], unsigned (&h4)[N], unsigned (&sw)[N]) {
-    typedef __attribute__((ext_vector_type(2))) float f2;
-    typedef __attribute__((ext_vector_type(2))) _Float16 h2;
-    float lo[N][8];
-    unsigned hw[N][4];
-    float mv[N], ml[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) { mv[n] = 0.0f; ml[n] = 0.0f; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            const float a = v[n][2 * k], b = v[n][2 * k + 1];
-            const h2 hh = __builtin_convertvector(f2{a, b}, h2);
-            hw[n][k] = __builtin_bit_cast(unsigned, hh);
-            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[n][2 * k]) : "v"(hw[n][k]), "v"(a));
-            asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[n][2 * k + 1]) : "v"(hw[n][k]), "v"(b));
-            asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mv[n]) : "v"(a), "v"(b), "v"(mv[n]));
-            asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(ml[n]) : "v"(lo[n][2 * k]), "v"(lo[n][2 * k + 1]), "v"(ml[n]));
-        }
-    }
-    // the maxima over the four lanes of a frame: all 2 N values per cross-lane step
-#pragma unroll
-    for (int step = 0; step < 2; ++step) {
-        unsigned o[N][2][2];
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            if (step == 0) {
-                auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(mv[n]), __float_as_uint(mv[n]), false, false);
-                o[n][0][0] = r[0]; o[n][0][1] = r[1];
-                r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ml[n]), __float_as_uint(ml[n]), false, false);
-                o[n][1][0] = r[0]; o[n][1][1] = r[1];
-            } else {
-                auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(mv[n]), __float_as_uint(mv[n]), false, false);
-                o[n][0][0] = r[0]; o[n][0][1] = r[1];
-                r = __builtin_amdgcn_permlane32_swap(__float_as_uint(ml[n]), __float_as_uint(ml[n]), false, false);
-                o[n][1][0] = r[0]; o[n][1][1] = r[1];
-            }
-        }
-#pragma unroll
-        for (int n = 0; n < N; ++n) {      // (magnitudes: plain v_max_f32 -- from C the compiler quiets both operands of every fmaxf first)
-            asm("v_max_f32 %0, %1, %2" : "=v"(mv[n]) : "v"(o[n][0][0]), "v"(o[n][0][1]));
-            asm("v_max_f32 %0, %1, %2" : "=v"(ml[n]) : "v"(o[n][1][0]), "v"(o[n][1][1]));
-        }
-    }
-    float sh[N], sl[N];
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        const float mh = (float)(_Float16)mv[n];
-        const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml[n]);
-        sh[n] = __uint_as_float(bh << 23);
-        sl[n] = __uint_as_float(bl << 23);
-        sw[n] = bl | (bh << 8);
-    }
-    // every conversion writes one byte of a register of its own (a chain of four through one register runs at the instruction's latency)
-    unsigned xb[N][4], yb[N][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-        for (int n = 0; n < N; ++n) {
-            xb[n][k] = 0;
-            yb[n][k] = 0;
-        }
-    }
-#define XL_ENC_S(s_)                                                                                                   \
-    _Pragma("unroll") for (int n = 0; n < N; ++n) {                                                                    \
-        xb[n][s_] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(xb[n][s_], lo[n][2 * s_], lo[n][2 * s_ + 1], sl[n], s_);  \
-        yb[n][s_] = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(yb[n][s_], __builtin_bit_cast(h2, hw[n][s_]), sh[n], s_); \
-    }
-    XL_ENC_S(0) XL_ENC_S(1) XL_ENC_S(2) XL_ENC_S(3)
-#undef XL_ENC_S
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-        l4[n] = (xb[n][0] | xb[n][1]) | (xb[n][2] | xb[n][3]);
-        h4[n] = (yb[n][0] | yb[n][1]) | (yb[n][2] | yb[n][3]);
-        hp[n] = u32x4{hw[n][0], hw[n][1], hw[n][2], hw[n][3]};
-    }
-}
-
 __device__ __forceinline__ float xl_act(float v, int act) { return act == KTF_ACT_RELU ? fmaxf(v, 0.0f) : v; }
-
-// unit (inside the 256-unit tile) that column `m` of unit block `cb` of the weight images holds: inside each 32-unit chunk the
-// order is permuted so that, with the weights as the A operand, lane quarter q4 of a frame owns units 8 q4 .. 8 q4 + 7 of the chunk
-__device__ __forceinline__ int xl_unit(int cb, int m) { return (cb >> 1) * 32 + (m >> 2) * 8 + (cb & 1) * 4 + (m & 3); }
 
 #define XL_WAIT_VM(n_) asm volatile("s_waitcnt vmcnt(" #n_ ")" ::: "memory")
 #define XL_BARRIER()                                                                                                   \
@@ -465,9 +366,9 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
     for (int j = 0; j < 4; ++j) {
         f32x4 b4;
         if constexpr (SWAP) {
-            b4 = *reinterpret_cast<const f32x4*>(prm + xl_unit(wn * 4 + j, q4 * 4));
+            b4 = *reinterpret_cast<const f32x4*>(prm + mx_unit(wn * 4 + j, q4 * 4));
         } else {
-            const float bv = prm[xl_unit(wn * 4 + j, r16)];
+            const float bv = prm[mx_unit(wn * 4 + j, r16)];
             b4 = f32x4{bv, bv, bv, bv};
         }
 #pragma unroll
@@ -496,7 +397,7 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
         if (rv <= 0) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ul = xl_unit(wn * 4 + j, r16);
+            const int ul = mx_unit(wn * 4 + j, r16);
             const float esc = prm[256 + ul], esh = prm[512 + ul];
             const float v0 = xl_act(acc[0][j][0], ACT) * esc + esh;
             const float pv = __shfl(v0, lane & 15, 64);
@@ -535,7 +436,7 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
         }
         return;
     } else {
-        // Accumulator (i, jj)[r] = frame 16 i + r16 of the wave's rows, unit xl_unit(4 wn + jj, 4 q4 + r): for output chunk c of the
+        // Accumulator (i, jj)[r] = frame 16 i + r16 of the wave's rows, unit mx_unit(4 wn + jj, 4 q4 + r): for output chunk c of the
         // wave (unit blocks 2 c, 2 c + 1) this lane holds units 8 q4 .. 8 q4 + 7 of the chunk.
         // the rows: (utterance, frame) of this lane's frame in every row block, and whether it is a valid row
         unsigned rec_i[6];                           // planes: record of (b, chunk 0, t): b * nch_out * T + t; fp32 rows: b * T + t
@@ -594,7 +495,7 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
                             v[n][e] = __builtin_amdgcn_fmed3f(acc[i2 + n][2 * c + (e >> 2)][e & 3], ACT == KTF_ACT_RELU ? 0.0f : -65504.0f, 65504.0f);
                     u32x4 hp[2];
                     unsigned l4p[2], h4p[2], swp[2];
-                    xl_encode8<2>(v, hp, l4p, h4p, swp);
+                    mx_encode8<2>(v, hp, l4p, h4p, swp);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) {
                         const int i = i2 + n;
@@ -607,8 +508,8 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                xl_transpose4(l4r[0], l4r[1], l4r[2], l4r[3]);
-                xl_transpose4(h4r[0], h4r[1], h4r[2], h4r[3]);
+                mx_transpose4(l4r[0], l4r[1], l4r[2], l4r[3]);
+                mx_transpose4(h4r[0], h4r[1], h4r[2], h4r[3]);
                 if (okA) {
                     const unsigned rec = recA + crec;
                     const unsigned sw = q4 == 0 ? swr[0] : q4 == 1 ? swr[1] : q4 == 2 ? swr[2] : swr[3];
@@ -634,7 +535,7 @@ __global__ __launch_bounds__(768) void tdnn_mxl_kernel(MxlParams q) {
             const bool vec = (p.ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(p.yf) & 15) == 0;
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
-                const int ul = xl_unit(wn * 4 + jj, q4 * 4);
+                const int ul = mx_unit(wn * 4 + jj, q4 * 4);
                 const int n = n0 + ul;
                 float es[4], eh[4];
 #pragma unroll

@@ -33,7 +33,7 @@ V["hot_a"] = lambda s: rep(rep(rep(s, "const int64_t ub = (int64_t)b * p.nch_in 
 def _no_stores(s):
     import re
     s = re.sub(r"__builtin_nontemporal_store\(([^,]+), (reinterpret_cast<[^;]+)\);", r"if (abl_word(\1) == 0x12345678u) __builtin_nontemporal_store(\1, \2);", s)
-    return rep(s, "#define MX_EPI_PITCH 260", "#define MX_EPI_PITCH 260\nstatic __device__ __forceinline__ unsigned abl_word(unsigned v) { return v; }\n"
+    return rep(s, '#include "tdnn_mx_common.h"', '#include "tdnn_mx_common.h"\nstatic __device__ __forceinline__ unsigned abl_word(unsigned v) { return v; }\n'
                "template <typename V> static __device__ __forceinline__ unsigned abl_word(V v) { return v.x; }")
 V["no_stores"] = _no_stores
 
@@ -54,7 +54,7 @@ V["plain_stores"] = lambda s: re.sub(r"__builtin_nontemporal_store\(([^,]+), (re
 # ktf_prof_dump() (tools/mx/prof_phases.py). t_k = start .. end of the K-loop, t_e = epilogue until the last store is issued,
 # t_d = until the stores are acknowledged.
 def _prof(s):
-    s = rep(s, "#define MX_EPI_PITCH 260", "#define MX_EPI_PITCH 260\n__device__ unsigned long long g_prof[48][12];")
+    s = rep(s, '#include "tdnn_mx_common.h"', '#include "tdnn_mx_common.h"\n__device__ unsigned long long g_prof[48][12];')
     s = rep(s, "    const int n0 = nt * 256, t0 = mt * 256;", "    const int n0 = nt * 256, t0 = mt * 256;\n    const long long pt0 = wall_clock64();\n    const long long pc0 = clock64();\n    long long pe[5] = {0, 0, 0, 0, 0};")
     s = rep(s, "    const int rows_valid = len - t0;", "    const long long pt1 = wall_clock64();\n    const long long pc1 = clock64();\n    const int rows_valid = len - t0;")
     s = rep(s, "            __builtin_amdgcn_s_barrier();\n            asm volatile(\"\" ::: \"memory\");\n            constexpr bool live = true;",
@@ -106,7 +106,7 @@ V["dma_only_sides"] = lambda s: V["no_f16_dma"](V["no_mfma"](s))
 V["dma_only_none"] = lambda s: V["no_dma"](V["no_mfma"](s))
 
 names = sys.argv[1:] or list(V)
-objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "pool_post.o")]
+objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "tdnn_mxl.o", "pool_post.o")]
 FLAGS = {
     "flags_O2": ["-O2"],
     "flags_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
