@@ -65,10 +65,13 @@ extern "C" {
                              *   y = x_h * w_h + x_l4 * w_4 + x_4 * w_l6
                              * (x_h, w_h half; x_l4 = e2m1 image of x - x_h; w_4 = e2m1 image of w; x_4 = e2m1 image of x_h;
                              * w_l6 = e2m3 image of w - w_h; one E8M0 scale per 32 K elements). 1.5 MFMA passes per algorithmic
-                             * flop with ~15 significant bits on BOTH operands: 1.5e-5 .. 3.7e-5 max-abs x-vector deviation on
-                             * speech, noise and modulated noise alike, with no calibration and no dependence on the input
-                             * distribution (KTF_GEMM_F16X2's two half passes are 7e-5 .. 1e-4 on 10 s of speech). Through
-                             * ktf_tdnn_mx / ktf_tdnn_mx_stats on the four-plane activation format ktf_mx_planes produces */
+                             * flop with ~15 significant bits on BOTH operands, no calibration. What is left is zero-mean rounding
+                             * noise per frame that the statistics pooling averages, so the max-abs x-vector deviation depends on
+                             * the voiced length: 1.2e-5 on 10 s of noise, 2-5e-5 on 10 s of speech, 4-6.5e-5 on 5 s, up to 1.2e-4
+                             * on 1-1.5 s (tests/test_gpu_margin.py; KTF_GEMM_F16X2's two half passes are 7e-5 .. 1e-4 on 10 s of
+                             * speech). The host side (Sequential.MIN_FRAMES, XvectorExtractor.route_short_utterances) sends
+                             * utterances below 400 voiced frames through KTF_GEMM_BF16X3. Through ktf_tdnn_mx / ktf_tdnn_mx_stats
+                             * on the four-plane activation format ktf_mx_planes produces */
 
 /* activations fused into the ktf_tdnn epilogue */
 #define KTF_ACT_NONE 0
@@ -197,6 +200,13 @@ int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D, const KtfV
                  void* out, int32_t out_dtype, int64_t ldo, int32_t* lens, int32_t* idx_work, float* work,
                  void* stream);
 
+/* Per-utterance routing by voiced length (no reference counterpart: the reference runs one utterance at a time in fp32). lens (B) ->
+ * lens_main[b] = lens[b] >= min_frames ? lens[b] : 0 and lens_short[b] = 0 < lens[b] < min_frames ? lens[b] : 0. host_flag (optional):
+ * two int32 in PINNED, device-visible host memory: [0] = number of short utterances, then [1] = seq (system-scope release), for a host
+ * that polls [1] instead of synchronising the stream. */
+int ktf_route_short(const int32_t* lens, int64_t B, int32_t min_frames, int32_t* lens_main, int32_t* lens_short, int32_t* host_flag,
+                    int32_t seq, void* stream);
+
 /* ------------------------------------------------------------------ TDNN stack (a9, a10)
  * TDNN.call   layers/tdnn/tdnn.py:251-280 (gather im2col + conv2d 1xK + bias + activation)
  * ReLU / BatchNorm (inference affine)  models/kaldi/sequential.py:72-74, layers/normalization/batchnorm.py:78-88
@@ -315,7 +325,17 @@ int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, vo
  *          [40 Ki, 44 Ki)   q * 4 : uint32, byte 0 = E8M0 scale of the e2m1 block, byte 1 = of the e2m3 block
  *          [44 Ki, 48 Ki)   unused
  * SAME padding, subsampling 1, ReLU or no activation; scale / shift as in ktf_tdnn (NULL when the BatchNorm is folded into
- * the next layer, TDNN.device_weights_mx). */
+ * the next layer, TDNN.device_weights_mx).
+ * With KtfTdnnDesc.flags & KTF_TDNN_MX_LOADER the call runs the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles over the flat row
+ * space b * T + t, eight matrix + four loader waves) on the SAME activation planes and on weight images of its own
+ * (mx.weight_images_loader): every operand fragment is 64 lanes x 16 (8, 4) consecutive bytes, and inside each 32-unit chunk the image
+ * columns hold the units in the order (m >> 2) * 8 + (cb & 1) * 4 + (m & 3) for column m of unit block cb:
+ *   wh : block (nt * nkp + ks) * 16 KiB: 16 unit-block fragments x 1 KiB, lane (q, m) = halves 8 q .. 8 q + 7 of the block's unit m
+ *   wq : block (nt * nkp / 4 + ss) * 44 KiB = two halves of 22 KiB (unit blocks with (cb >> 1) & 1 == h, in the order
+ *        2 (cb >> 2) + (cb & 1)): e2m1 codes 8 x 1 KiB | e2m3 bits 0..127 8 x 1 KiB | e2m3 bits 128..191 8 x 512 B | scale words
+ *        8 x 256 B, lane (kb, m) = K block kb of the super-step, unit m of the block.
+ * It needs B * T < 2^31 and B * T * ceil(D / 32) < 2^32, writes planes only without scale / shift, and its KTF_TDNN_DET_STATS slots are
+ * 96 rows each (ktf_mx_stats_slots / ktf_mx_slot_rows). */
 int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, int64_t ld_src, const int32_t* lens, void* xh, void* xl4,
                   void* x4, void* xs, void* stream);
 int ktf_tdnn_mx(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,

@@ -471,3 +471,42 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     KTF_CHECK_LAUNCH("ktf_vad_cmvn");
     return KTF_OK;
 }
+
+// ------------------------------------------------------------------------------------ per-utterance routing by voiced length
+// XvectorExtractor.route_short_utterances: lens (B) -> lens_main (utterances of at least `min_frames` voiced frames keep their length,
+// the others 0) and lens_short (the complement; utterances without a voiced frame stay 0 in both), and -- for the host, which
+// decides whether the second pass is enqueued at all -- the number of short utterances, written to PINNED HOST memory followed by
+// the call's sequence number (system-scope release): the host polls the sequence number while the GPU works through the first
+// pass's launches; no copy, no event, no stream synchronisation. One workgroup.
+__global__ __launch_bounds__(1024) void route_short_kernel(const int32_t* __restrict__ lens, int64_t B, int32_t min_frames, int32_t* __restrict__ lens_main,
+                                                           int32_t* __restrict__ lens_short, int32_t* host_flag, int32_t seq) {
+    __shared__ int part[16];
+    int n = 0;
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        const int len = lens[b];
+        const bool is_short = len > 0 && len < min_frames;
+        lens_main[b] = len >= min_frames ? len : 0;
+        lens_short[b] = is_short ? len : 0;
+        n += is_short ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0 && host_flag) {
+        int tot = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += part[w];
+        __hip_atomic_store(host_flag, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(host_flag + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+extern "C" int ktf_route_short(const int32_t* lens, int64_t B, int32_t min_frames, int32_t* lens_main, int32_t* lens_short, int32_t* host_flag,
+                               int32_t seq, void* stream) {
+    KTF_REQUIRE(lens && lens_main && lens_short, "ktf_route_short: null argument");
+    KTF_REQUIRE(B >= 0 && min_frames >= 0, "ktf_route_short: bad size");
+    if (B == 0 && !host_flag) return KTF_OK;
+    hipLaunchKernelGGL(route_short_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lens, B, min_frames, lens_main, lens_short, host_flag, seq);
+    KTF_CHECK_LAUNCH("ktf_route_short");
+    return KTF_OK;
+}

@@ -716,8 +716,9 @@ class XvectorExtractor:
                                      # batch an utterance arrives in, bit for bit.
         self.route_short_utterances = True    # utterances with fewer voiced frames than the mode's Sequential.MIN_FRAMES go through the
                                               # tighter SHORT_MODE kernels, decided per utterance from the device's frame counts (_extract)
-        self._short_count = None              # pinned int32: short utterances of the batch in flight
-        self.last_short_count = 0             # ... of the last call
+        self._short_flag = None               # pinned int32[2]: short utterances of the batch in flight, call sequence number
+        self._short_seq = 0
+        self.last_short_count = 0             # short utterances of the last call
         self.last_lens = None
 
     @property
@@ -797,28 +798,26 @@ class XvectorExtractor:
             return self._xvectors(feats, lens, out)
         # Per-utterance routing: the batch runs in the model's mode with the utterances of fewer than `nshort` voiced frames masked out
         # (length 0: their tiles leave at once), then once more in the tighter mode with only those utterances live; the second tail
-        # writes just their rows. The masks are made on the device. Whether the second pass is enqueued at all is decided on the host
-        # from ONE int32 (the number of short utterances) that travels to pinned memory behind the VAD / CMVN launch: the host waits
-        # for that copy's event AFTER it has enqueued the whole first pass, i.e. while the GPU has milliseconds of GEMMs queued -- no
-        # bubble on the device, and a batch without short utterances (the usual case) costs nothing. Under graph capture there is no
-        # host to ask: both passes are captured, and the second one's workgroups leave at their first instruction when nothing is short.
+        # writes just their rows. The masks are made on the device (ktf_route_short, one small launch behind VAD / CMVN). Whether the
+        # second pass is enqueued at all is decided on the host from ONE int32, the number of short utterances, which that kernel
+        # writes straight into pinned host memory: the host reads it AFTER it has enqueued the whole first pass, i.e. while the GPU has
+        # milliseconds of GEMMs queued -- no copy, no event, no bubble on the device, and a batch without short utterances (the usual
+        # case) costs one 5 us launch. Under graph capture there is no host to ask: both passes are captured, and the second one's
+        # workgroups leave at their first instruction when nothing is short.
         ws = self._ws
         lens_main = ws.get("lens_main", (B,), torch.int32, feats.device, padded=False)
         lens_short = ws.get("lens_short", (B,), torch.int32, feats.device, padded=False)
-        zero = torch.zeros((), dtype=torch.int32, device=feats.device)
-        torch.where(lens >= nshort, lens, zero, out=lens_main)
-        torch.where(lens < nshort, lens, zero, out=lens_short)
         capturing = torch.cuda.is_current_stream_capturing()
-        if not capturing:
-            if self._short_count is None:
-                self._short_count = torch.zeros(1, dtype=torch.int32).pin_memory()
-            self._short_count.copy_((lens_short > 0).sum(dtype=torch.int32).reshape(1), non_blocking=True)
-            counted = torch.cuda.Event()
-            counted.record()
+        if capturing:
+            ops.route_short(lens, nshort, lens_main, lens_short)
+        else:
+            if self._short_flag is None:
+                self._short_flag = torch.zeros(2, dtype=torch.int32).pin_memory()     # [count, sequence number]: written by the kernel
+            self._short_seq = (self._short_seq % 0x3FFFFFFF) + 1
+            ops.route_short(lens, nshort, lens_main, lens_short, self._short_flag, self._short_seq)
         y = self._xvectors(feats, lens_main, out)
         if not capturing:
-            counted.synchronize()
-            self.last_short_count = int(self._short_count[0])
+            self.last_short_count = self._await_short_count(feats.device)
             if self.last_short_count == 0:
                 return y
         short_mode = seq.SHORT_MODE[seq.gemm]
@@ -828,6 +827,20 @@ class XvectorExtractor:
             y2 = self._xvectors(feats, lens_short, None, mode=short_mode)
             y.copy_(torch.where((lens_short > 0)[:, None], y2, y))
         return y
+
+    def _await_short_count(self, dev):
+        """The number of short utterances ktf_route_short wrote to pinned memory for this call: the host polls the sequence number
+        (the GPU is busy with the first pass's launches meanwhile); after 2 s without it, one stream synchronisation."""
+        import time
+        flag, want = self._short_flag, self._short_seq
+        t0 = time.perf_counter()
+        while int(flag[1]) != want:
+            if time.perf_counter() - t0 > 2.0:
+                torch.cuda.current_stream(dev).synchronize()
+                if int(flag[1]) != want:
+                    raise RuntimeError("ktf_route_short: the short-utterance count did not reach the host")
+                break
+        return int(flag[0])
 
     def _xvectors(self, feats, lens, out=None, mode=None, skip_empty=False):
         """CMVN'd features + voiced-frame counts -> x-vectors (B, lda_dim). `mode`: the TDNN arithmetic of this pass (default: the

@@ -298,6 +298,16 @@ def last_kernel():
     return (L.load().ktf_tdnn_last_kernel() or b"").decode()
 
 
+def route_short(lens, min_frames, lens_main, lens_short, host_flag=None, seq=0):
+    """lens -> (lens_main, lens_short) by voiced length (ktf_route_short); host_flag: pinned int32[2] CPU tensor that receives the number
+    of short utterances and then `seq`."""
+    lib = L.load()
+    with torch.cuda.device(lens.device):
+        rc = lib.ktf_route_short(L.ptr(lens), lens.shape[0], int(min_frames), L.ptr(lens_main), L.ptr(lens_short),
+                                 host_flag.data_ptr() if host_flag is not None else None, int(seq), L.stream_ptr())
+    L.check(rc, "ktf_route_short")
+
+
 def tdnn_out_len(T, desc):
     return int(L.load().ktf_tdnn_out_len(int(T), C.byref(desc)))
 

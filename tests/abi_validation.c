@@ -58,6 +58,7 @@ int main(void) {
     EXPECT_EINVAL(ktf_xvec_post_f32(NULL, 1, 8, 4, NULL, f, NULL, f, NULL));
     EXPECT_EINVAL(ktf_stats_finalize(NULL, NULL, 1, 1, 4, 1, 1e-10f, f, 8, NULL));
     EXPECT_EINVAL(ktf_stats_finalize_slots(d, 1, 128, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));       /* too few slots */
+    EXPECT_EINVAL(ktf_route_short(NULL, 1, 400, l, l, NULL, 0, NULL));
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));
     EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, 9, NULL, NULL, f, NULL));
