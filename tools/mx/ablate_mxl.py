@@ -78,7 +78,7 @@ V["l_prof"] = _prof
 def _prof_epi(s):
     s = _prof(s)
     s = rep(s, "        const bool affine = p.scale != nullptr;", "        const bool affine = p.scale != nullptr;\n        long long xe_t = XP_T(); const long long xe_rows = xe_t - xp_k; long long xe_enc = 0, xe_st = 0;")
-    s = rep(s, "                xl_transpose4(l4r[0], l4r[1], l4r[2], l4r[3]);", "                { const long long t_ = XP_T(); xe_enc += t_ - xe_t; xe_t = t_; }\n                xl_transpose4(l4r[0], l4r[1], l4r[2], l4r[3]);")
+    s = rep(s, "                mx_transpose4(l4r[0], l4r[1], l4r[2], l4r[3]);", "                { const long long t_ = XP_T(); xe_enc += t_ - xe_t; xe_t = t_; }\n                mx_transpose4(l4r[0], l4r[1], l4r[2], l4r[3]);")
     s = rep(s, "            }\n        } else {\n            // fp32 rows (B, T, ldy)",
             "            }\n            { const long long t_ = XP_T(); xe_st += t_ - xe_t; xe_t = t_; }\n"
             "            if (wave == 0 && lane == 0) { unsigned long long* g = g_xprof[(p.nss < 15 ? p.nss : 15) + 16 * OUT]; atomicAdd(g + 13, (unsigned long long)xe_rows); atomicAdd(g + 14, (unsigned long long)xe_enc); atomicAdd(g + 15, (unsigned long long)xe_st); }\n"
@@ -99,40 +99,7 @@ for _n, _c in ():
 
 
 
-# A/B (correct results, instrumented): the cross-lane maxima of the plane encoder by ds_bpermute (__shfl_xor) instead of v_permlane*_swap
-def _prof_shfl(s):
-    s = rep(s, """    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
-    r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(r[0]), "v"(r[1]));
-    return v;""", """    float o = __shfl_xor(v, 16, 64);
-    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
-    o = __shfl_xor(v, 32, 64);
-    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(o));
-    return v;""")
-    return _prof(s)
 
-
-V["l_prof_shfl"] = _prof_shfl
-
-
-# timing only (instrumented): no cross-lane maxima at all
-def _prof_nomax(s):
-    s = rep(s, """    mv = xl_frame_max(mv);
-    ml = xl_frame_max(ml);""", "")
-    return _prof(s)
-
-
-V["l_prof_nomax"] = _prof_nomax
-
-
-# timing only (instrumented): no fp4 conversions
-def _prof_nocvt(s):
-    s = rep(s, """    XL_ENC_S(0) XL_ENC_S(1) XL_ENC_S(2) XL_ENC_S(3)""", "    x = __float_as_uint(lo[0] + lo[3] + sl); y = hw[1] + hw[2] + __float_as_uint(sh);")
-    return _prof(s)
-
-
-V["l_prof_nocvt"] = _prof_nocvt
 
 if __name__ == "__main__":
     names = sys.argv[1:] or list(V)

@@ -10,6 +10,7 @@ from kaldi_tflite_amd import ops, _lib
 g = torch.Generator(device="cuda").manual_seed(1234)
 wav = torch.clamp(torch.round(1000.0 * torch.randn((1024, 160000), generator=g, device="cuda")), -32767, 32767)
 m = synth.build_extractor(ktf, synth.extractor_cfg(), synth.make_weights(seed=4321), gemm="f16mx")
+m.xvec.mx_loader = True          # (the 256-row kernel is the default)
 for _ in range(3): m(wav)
 lib = _lib.load()
 print("library:", _lib.LIB_PATH)
