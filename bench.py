@@ -67,6 +67,7 @@ def parse_args(argv=None):
     ap.add_argument("--dump-xvectors", default=None, help="rank 0 saves the x-vectors of the last timed step (all ranks' when gathered) as .npy (tests)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other modes, latency, PLDA)")
     ap.add_argument("--no-parity", action="store_true", help="measurement runs of timing-only ablation builds (tools/mx): no oracle comparison, no finite check")
+    ap.add_argument("--mx-slab", action="store_true", help="A/B: f16mx layers with context offsets on the slab form of the 256 x 256 kernel (csrc/tdnn_mxs.hip)")
     ap.add_argument("--mx-loader", action="store_true", help="A/B: f16mx on the loader-wave kernel (csrc/tdnn_mxl.hip) instead of the 256 x 256 eight-wave kernel")
     ap.add_argument("--no-short-routing", action="store_true", help="A/B: without the device-side second pass over utterances below MIN_FRAMES voiced frames")
     ap.add_argument("--atomic-pooling", action="store_true", help="fp64-atomic fused pooling instead of the reproducible form")
@@ -131,6 +132,7 @@ def main(argv=None):
         mdl.xvec.lo_fraction = 0.0
     mdl.xvec.deterministic = not args.atomic_pooling
     mdl.xvec.mx_loader = args.mx_loader
+    mdl.xvec.mx_slab = args.mx_slab
     mdl.route_short_utterances = not args.no_short_routing
     mdl.xvec.k_interleaved = not args.ctx_major_k
     mdl.xvec.w_tiled = not args.row_major_w

@@ -270,6 +270,10 @@ typedef struct KtfTdnnDesc {
                                    * (mx.weight_images_loader; layout below) and, with KTF_TDNN_DET_STATS, writes one slot per 96-row
                                    * block: `sums` is (B, ktf_mx_stats_slots(T, flags), 2, units), reduced with slot_rows =
                                    * ktf_mx_slot_rows(flags) */
+#define KTF_TDNN_MX_SLAB (1 << 25)    /* ktf_tdnn_mx / ktf_tdnn_mx_stats only (ignored with KTF_TDNN_MX_LOADER): layers with 2+ context
+                                   * offsets, all within [-4, 4], run the slab form of the 256 x 256 kernel (csrc/tdnn_mxs.hip): a
+                                   * 32-feature chunk's rows are fetched once per tile and shared by the chunk's K-steps. Same weight
+                                   * images, tiles, slots and results as without the flag; other layers are unaffected */
 
 /* name of the kernel family the calling thread's last ktf_tdnn* / ktf_tdnn_mx* call launched ("" before the first; a static
  * string). For the dispatch tests: which kernel a (gemm mode, layer shape) pair runs on is part of the library's contract. */

@@ -29,49 +29,6 @@
 // Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88, stats_pooling.py:211-240 when fused).
 #include "tdnn_mx_common.h"
 
-// 32 values, each within [-65504, 65504] (the callers clamp: half planes saturate instead of overflowing to inf) -> half plane
-// piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word.
-// Per pair of values: v_cvt_pk_f16_f32, two v_fma_mix_f32 (residual = value - half, exact), two v_max3_f32 (the maxima of the
-// magnitudes: rounding to half is monotonic, so the largest half magnitude is the half of the largest magnitude), then
-// v_cvt_scalef32_pk_fp4_{f32,f16}: ~135 vector instructions per 32 values (the plain-C form was ~430).
-typedef __attribute__((ext_vector_type(2))) float mx_f2;
-typedef __attribute__((ext_vector_type(2))) _Float16 mx_h2;
-__device__ __forceinline__ void mx_encode32(const float (&v)[32], u32x4 (&hp)[4], u32x4& l4, u32x4& h4, unsigned& sw) {
-    float lo[32];
-    unsigned hw[16];
-    float mv = 0.0f, ml = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float a = v[2 * k], b = v[2 * k + 1];
-        const mx_h2 hh = __builtin_convertvector(mx_f2{a, b}, mx_h2);
-        hw[k] = __builtin_bit_cast(unsigned, hh);
-        // (spelled in assembly: from C the compiler emits v_cvt_f32_f16 + v_sub_f32 and quiets every v_max operand first)
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * k]) : "v"(hw[k]), "v"(a));
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * k + 1]) : "v"(hw[k]), "v"(b));
-        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mv) : "v"(a), "v"(b), "v"(mv));
-        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(ml) : "v"(lo[2 * k]), "v"(lo[2 * k + 1]), "v"(ml));
-    }
-    const float mh = (float)(_Float16)mv;
-    const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml);
-    const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
-    unsigned wl[4], wh_[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {            // dword k = elements 8k .. 8k+7, byte s = elements 8k+2s, 8k+2s+1
-        unsigned x = 0, y = 0;
-#define MX_ENC_S(s_)                                                                                                   \
-        x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(x, lo[8 * k + 2 * s_], lo[8 * k + 2 * s_ + 1], sl, s_);           \
-        y = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(y, __builtin_bit_cast(mx_h2, hw[4 * k + s_]), sh, s_);
-        MX_ENC_S(0) MX_ENC_S(1) MX_ENC_S(2) MX_ENC_S(3)
-#undef MX_ENC_S
-        wl[k] = x;
-        wh_[k] = y;
-        hp[k] = u32x4{hw[4 * k], hw[4 * k + 1], hw[4 * k + 2], hw[4 * k + 3]};
-    }
-    l4 = u32x4{wl[0], wl[1], wl[2], wl[3]};
-    h4 = u32x4{wh_[0], wh_[1], wh_[2], wh_[3]};
-    sw = bl | (bh << 8);
-}
-
 // ------------------------------------------------------------------------------------ fp32 features -> MX planes
 // One workgroup per (utterance, 32-feature chunk, 256 rows); rows at or beyond lens[b] are left unwritten (consumers clamp rows
 // to len - 1). Both directions cross the LDS so that every global access is a run of consecutive bytes: the rows come in as
@@ -151,20 +108,6 @@ extern "C" int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, 
 }
 
 // ------------------------------------------------------------------------------------ the GEMM
-__device__ __forceinline__ float mx_act(float v, int act) { return act == KTF_ACT_RELU ? fmaxf(v, 0.0f) : v; }
-
-__device__ __forceinline__ void mx_stats_out(double* __restrict__ stats, const MxParams& p, int b, int slot, int n, double s, double q) {
-    if (p.stat_slots > 0) {
-        double* dst = stats + (((int64_t)b * p.stat_slots + slot) * 2) * p.units + n;
-        dst[0] = s;
-        dst[p.units] = q;
-    } else {
-        double* dst = stats + ((int64_t)b * 2) * p.units + n;
-        atomicAdd(dst, s);
-        atomicAdd(dst + p.units, q);
-    }
-}
-
 template <int ACT, int OUT>
 __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mtiles, int ntiles, int gtiles, double* __restrict__ stats,
                                         unsigned char* rsm) {
@@ -419,167 +362,7 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
 #undef MX_F_ADV
 #undef MX_CTX
 
-    const int rows_valid = len - t0;
-    float ebias[4], esc[4], esh[4];
-    {
-        const float* prm = reinterpret_cast<const float*>(rsm + MX_PRM_OFF);       // written before the first barrier of the K-loop
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int cl = wn * 64 + j * 16 + (lane & 15);
-            ebias[j] = prm[cl];
-            esc[j] = prm[256 + cl];
-            esh[j] = prm[512 + cl];
-        }
-    }
-    if constexpr (OUT == MX_OUT_STATS) {
-        // fused StatsPooling (stats_pooling.py:231-240): per column the sum and the sum of squares of the wave's 128 rows, taken in
-        // fp32 relative to a pivot (row 0 of the block: a constant column -- a dead ReLU unit -- gives exactly 0 and 0), then fp64
-        const int rv = rows_valid - wm * 128;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float v0 = mx_act(acc[0][j][0] + ebias[j], ACT) * esc[j] + esh[j];
-            const float pv = __shfl(v0, lane & 15, 64);
-            float s32 = 0.0f, q32 = 0.0f;
-            int cnt = 0;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = mx_act(acc[i][j][r] + ebias[j], ACT) * esc[j] + esh[j];
-                    if (rv >= 128 || i * 16 + q4 * 4 + r < rv) {
-                        const float u = v - pv;
-                        s32 += u;
-                        q32 = fmaf(u, u, q32);
-                        ++cnt;
-                    }
-                }
-            }
-            const double pd = (double)pv, sd = (double)s32, nd = (double)cnt;
-            double s = sd + nd * pd;
-            double q = (double)q32 + 2.0 * pd * sd + nd * pd * pd;
-            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-            if (lane < 16 && n < p.units) mx_stats_out(stats, p, b, (t0 >> 7) + wm, n, s, q);
-        }
-        return;
-    } else {
-        __syncthreads();                                 // every fragment read is done: the LDS becomes the store staging area
-        float* et = reinterpret_cast<float*>(rsm);
-        const bool affine = p.scale != nullptr;
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {           // rows wm*128 + pass*64 .. +63 of both wave rows -> 128 staged rows (130 KiB)
-            // accumulators -> staging image. The (launch-uniform) `affine` test sits outside the element loops: inside them the
-            // compiler kept it as a branch per element, and those 64 branches per pass were half of the epilogue's time.
-            auto to_staging = [&](auto aff) {
-                constexpr bool AFF = decltype(aff)::value;
-#pragma unroll
-                for (int ih = 0; ih < 4; ++ih) {
-                    const int i = pass * 4 + ih;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int col = wn * 64 + j * 16 + (lane & 15);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int srow = wm * 64 + ih * 16 + q4 * 4 + r;
-                            float v = acc[i][j][r] + ebias[j];
-                            if constexpr (OUT == MX_OUT_PLANES) {
-                                // the planes saturate at the largest half (mx_encode32 expects clamped values): one v_med3 does the
-                                // ReLU and the clamp when no affine follows (the BatchNorm is normally folded into the next layer)
-                                if constexpr (AFF) v = __builtin_amdgcn_fmed3f(mx_act(v, ACT) * esc[j] + esh[j], -65504.0f, 65504.0f);
-                                else v = __builtin_amdgcn_fmed3f(v, ACT == KTF_ACT_RELU ? 0.0f : -65504.0f, 65504.0f);
-                            } else {
-                                v = mx_act(v, ACT);
-                                if constexpr (AFF) v = v * esc[j] + esh[j];
-                            }
-                            et[srow * MX_EPI_PITCH + col] = v;
-                        }
-                    }
-                }
-            };
-            if (affine) to_staging(std::true_type{}); else to_staging(std::false_type{});
-            __syncthreads();
-            if constexpr (OUT == MX_OUT_PLANES) {
-                // (1) one thread per (staged row, 32-column chunk) encodes it: the wave's 64 lanes are 64 consecutive rows of ONE
-                //     chunk (chunk = wave), so the e2m1 / scale stores write consecutive records; the half piece goes back into the
-                //     staging image, in place. (2) the wave streams its chunk's half pieces out as 16-byte pieces of consecutive
-                //     records: 1 KiB of consecutive bytes per store instruction (store issue is per instruction).
-                const int chunk = (n0 >> 5) + wave;
-                const bool chunk_ok = chunk < p.nch_out;
-                const int64_t rec0 = ((int64_t)b * p.nch_out + chunk) * p.T + t0;
-#pragma unroll
-                for (int hsel = 0; hsel < 2; ++hsel) {
-                    const int srow = hsel * 64 + lane;
-                    const int m = hsel * 128 + pass * 64 + lane;
-                    float* src = et + srow * MX_EPI_PITCH + wave * 32;
-                    if (m < rows_valid && chunk_ok) {
-                        float v[32];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const f32x4 t = *reinterpret_cast<const f32x4*>(src + k * 4);
-                            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
-                        }
-                        u32x4 hp[4], l4, h4;
-                        unsigned sw_;
-                        mx_encode32(v, hp, l4, h4, sw_);
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(src + k * 4) = hp[k];
-                        const int64_t rec = rec0 + m;
-                        __builtin_nontemporal_store(l4, reinterpret_cast<u32x4*>(p.yl4 + rec * 16));
-                        __builtin_nontemporal_store(h4, reinterpret_cast<u32x4*>(p.y4 + rec * 16));
-                        __builtin_nontemporal_store(sw_, reinterpret_cast<unsigned*>(p.ys + rec * 4));
-                    }
-                }
-                // the half pieces were written by this wave's own lanes: LDS operations of a wave complete in order
-                if (chunk_ok) {
-                    const unsigned char* hsrc = reinterpret_cast<const unsigned char*>(et + wave * 32) + (lane & 3) * 16;
-                    char* hdst = p.yh + rec0 * 64 + (lane & 3) * 16;
-                    if (rows_valid >= 256) {             // whole tile (uniform): all reads in flight, then the stores back to back
-                        u32x4 hv[8];
-#pragma unroll
-                        for (int n = 0; n < 8; ++n)
-                            hv[n] = *reinterpret_cast<const u32x4*>(hsrc + (n * 16 + (lane >> 2)) * (MX_EPI_PITCH * 4));
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) {
-                            const int srow = n * 16 + (lane >> 2);
-                            const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
-                            __builtin_nontemporal_store(hv[n], reinterpret_cast<u32x4*>(hdst + (int64_t)m * 64));
-                        }
-                    } else {
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) {
-                            const int srow = n * 16 + (lane >> 2);
-                            const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
-                            if (m < rows_valid) {
-                                const u32x4 v = *reinterpret_cast<const u32x4*>(hsrc + srow * (MX_EPI_PITCH * 4));
-                                __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(hdst + (int64_t)m * 64));
-                            }
-                        }
-                    }
-                }
-            } else {
-                const int nl = lane * 4;
-                const int n = n0 + nl;
-#pragma unroll
-                for (int sp = 0; sp < 16; ++sp) {
-                    const int srow = sp * 8 + wave;
-                    const int m = (srow >> 6) * 128 + pass * 64 + (srow & 63);
-                    if (m < rows_valid) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(et + srow * MX_EPI_PITCH + nl);
-                        float* yp = p.yf + ((int64_t)b * p.T + t0 + m) * p.ldy + n;
-                        if (n + 4 <= p.units && (p.ldy & 3) == 0) {
-                            *reinterpret_cast<f32x4*>(yp) = v;
-                        } else {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e)
-                                if (n + e < p.units) yp[e] = v[e];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
+#include "tdnn_mx_epilogue.inc"
 }
 
 // (The tile body is a function of its own: a persistent form -- one workgroup per CU looping over tiles, tried for the pooled
@@ -631,10 +414,15 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
         KTF_CHECK_LAUNCH(who);
         return KTF_OK;
     }
+    if ((d->flags & KTF_TDNN_MX_SLAB) && mxs_applies(d)) {   // multi-context layers on activation slabs (tdnn_mxs.hip); same images, same tiles
+        const int rc = mxs_launch(p, B, d->act, o, stats, st);
+        if (rc != KTF_OK) return rc;
+        KTF_CHECK_LAUNCH(who);
+        return KTF_OK;
+    }
     const int mtiles = ktf_cdiv(T, 256), ntiles = ktf_cdiv(d->units, 256);
     const int64_t gtiles = B * mtiles;
     const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles;
-    if (stats && !p.stat_slots) (void)0;      // (atomic form: the caller zeroes the sums)
 #define MX_LAUNCH(A, O)                                                                                                \
     {                                                                                                                  \
         KTF_NOTE_KERNEL("tdnn_mx_kernel");                                                                             \

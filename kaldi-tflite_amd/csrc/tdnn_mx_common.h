@@ -1,5 +1,5 @@
-// Shared by the two KTF_GEMM_F16MX kernels (tdnn_mx.hip: 256 x 256 tile on eight waves; tdnn_mxl.hip: 192 x 256 tile on eight matrix
-// waves + four loader waves): operand types, the parameter block, the E8M0 scale rule.
+// Shared by the KTF_GEMM_F16MX kernels (tdnn_mx.hip: 256 x 256 tile on eight waves, tdnn_mxs.hip its slab form; tdnn_mxl.hip: 192 x 256
+// tile on eight matrix waves + four loader waves): operand types, the parameter block, the E8M0 scale rule.
 #pragma once
 #include "tdnn_common.h"
 #include <type_traits>
@@ -152,5 +152,66 @@ __device__ __forceinline__ void mx_encode8(const float (&v)[N][8], u32x4 (&hp)[N
 #define MX_OUT_F32 1
 #define MX_OUT_STATS 2
 
+// 32 values, each within [-65504, 65504] (the callers clamp: half planes saturate instead of overflowing to inf) -> half plane
+// piece (64 B), e2m1 images of the residual and of the half value (16 B each), scale word.
+// Per pair of values: v_cvt_pk_f16_f32, two v_fma_mix_f32 (residual = value - half, exact), two v_max3_f32 (the maxima of the
+// magnitudes: rounding to half is monotonic, so the largest half magnitude is the half of the largest magnitude), then
+// v_cvt_scalef32_pk_fp4_{f32,f16}: ~135 vector instructions per 32 values (the plain-C form was ~430).
+typedef __attribute__((ext_vector_type(2))) float mx_f2;
+typedef __attribute__((ext_vector_type(2))) _Float16 mx_h2;
+__device__ __forceinline__ void mx_encode32(const float (&v)[32], u32x4 (&hp)[4], u32x4& l4, u32x4& h4, unsigned& sw) {
+    float lo[32];
+    unsigned hw[16];
+    float mv = 0.0f, ml = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float a = v[2 * k], b = v[2 * k + 1];
+        const mx_h2 hh = __builtin_convertvector(mx_f2{a, b}, mx_h2);
+        hw[k] = __builtin_bit_cast(unsigned, hh);
+        // (spelled in assembly: from C the compiler emits v_cvt_f32_f16 + v_sub_f32 and quiets every v_max operand first)
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo[2 * k]) : "v"(hw[k]), "v"(a));
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lo[2 * k + 1]) : "v"(hw[k]), "v"(b));
+        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(mv) : "v"(a), "v"(b), "v"(mv));
+        asm("v_max3_f32 %0, |%1|, |%2|, %3" : "=v"(ml) : "v"(lo[2 * k]), "v"(lo[2 * k + 1]), "v"(ml));
+    }
+    const float mh = (float)(_Float16)mv;
+    const unsigned bh = mx_fp4_scale_byte(mh), bl = mx_fp4_scale_byte(ml);
+    const float sh = __uint_as_float(bh << 23), sl = __uint_as_float(bl << 23);
+    unsigned wl[4], wh_[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {            // dword k = elements 8k .. 8k+7, byte s = elements 8k+2s, 8k+2s+1
+        unsigned x = 0, y = 0;
+#define MX_ENC_S(s_)                                                                                                   \
+        x = __builtin_amdgcn_cvt_scalef32_pk_fp4_f32(x, lo[8 * k + 2 * s_], lo[8 * k + 2 * s_ + 1], sl, s_);           \
+        y = __builtin_amdgcn_cvt_scalef32_pk_fp4_f16(y, __builtin_bit_cast(mx_h2, hw[4 * k + s_]), sh, s_);
+        MX_ENC_S(0) MX_ENC_S(1) MX_ENC_S(2) MX_ENC_S(3)
+#undef MX_ENC_S
+        wl[k] = x;
+        wh_[k] = y;
+        hp[k] = u32x4{hw[4 * k], hw[4 * k + 1], hw[4 * k + 2], hw[4 * k + 3]};
+    }
+    l4 = u32x4{wl[0], wl[1], wl[2], wl[3]};
+    h4 = u32x4{wh_[0], wh_[1], wh_[2], wh_[3]};
+    sw = bl | (bh << 8);
+}
+
+// ------------------------------------------------------------------------------------ shared by the epilogues (tdnn_mx_epilogue.inc)
+__device__ __forceinline__ float mx_act(float v, int act) { return act == KTF_ACT_RELU ? fmaxf(v, 0.0f) : v; }
+
+__device__ __forceinline__ void mx_stats_out(double* __restrict__ stats, const MxParams& p, int b, int slot, int n, double s, double q) {
+    if (p.stat_slots > 0) {
+        double* dst = stats + (((int64_t)b * p.stat_slots + slot) * 2) * p.units + n;
+        dst[0] = s;
+        dst[p.units] = q;
+    } else {
+        double* dst = stats + ((int64_t)b * 2) * p.units + n;
+        atomicAdd(dst, s);
+        atomicAdd(dst + p.units, q);
+    }
+}
+
 // tdnn_mxl.hip: the loader-wave kernel (include/ktf_hip.h, KTF_TDNN_MX_LOADER); `p` as filled by mx_launch
 int mxl_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);
+// tdnn_mxs.hip: the slab form of the 256 x 256 kernel for layers with context offsets (KTF_TDNN_MX_SLAB)
+bool mxs_applies(const KtfTdnnDesc* d);
+int mxs_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);

@@ -164,6 +164,7 @@ class Sequential:
         self.mx_loader = False       # f16mx: True = the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles on the flat row space, eight
                                      # matrix + four loader waves, plane epilogue from registers); False = the 256 x 256 eight-wave kernel
                                      # (csrc/tdnn_mx.hip), which is 4-6 % faster on the 0008 shapes: the default
+        self.mx_slab = False         # f16mx, 256-row kernel: multi-context layers on activation slabs (csrc/tdnn_mxs.hip, KTF_TDNN_MX_SLAB)
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"
@@ -344,7 +345,7 @@ class Sequential:
                 B, T, _ = mxp.shape
                 fold, pending_bn = pending_bn, None
                 wh, wq, bias = l.device_weights_mx(dev, fold=fold, loader=self.mx_loader)
-                mxf = L.TDNN_MX_LOADER if self.mx_loader else 0
+                mxf = L.TDNN_MX_LOADER if self.mx_loader else (L.TDNN_MX_SLAB if self.mx_slab else 0)
                 d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None, flags=mxf)
                 if can_pool:                             # ... -> reducing StatsPooling inside the epilogue (BatchNorm applied there)
                     sp = nxt[1]

@@ -119,28 +119,42 @@ CASES = [  # D, context, units, B, T, lens
     (30, [-2, -1, 0, 1, 2], 512, 2, 270, [270, 3]),         # 5 K-steps padded to 8
     (512, [0], 1500, 1, 256, [256]),
     (96, [-3, 0, 3], 200, 3, 513, [513, 256, 1]),           # 9 K-steps padded to 12; three M-tiles; one N-tile with pad units
+    (160, [-4, 4], 256, 2, 260, [260, 5]),                  # two contexts at the slab kernel's largest offsets; 10 K-steps
+    (64, [-5, 0, 1, 5], 100, 2, 300, [258, 300]),           # offsets beyond the slab kernel's range: the gathering kernel runs
 ]
 
 
-KERNELS = [pytest.param(True, id="loader_waves"), pytest.param(False, id="tile256")]     # KTF_TDNN_MX_LOADER on / off
+KERNELS = ["loader_waves", "tile256", "slab"]     # KTF_TDNN_MX_LOADER / no flag / KTF_TDNN_MX_SLAB
 
 
-@pytest.mark.parametrize("loader", KERNELS)
+def _kernel(kernel, layer):
+    """(flags, loader weight images?, kernel family that must run) of a KERNELS entry for `layer`."""
+    if kernel == "loader_waves":
+        return L.TDNN_MX_LOADER, True, "tdnn_mxl_kernel"
+    if kernel == "slab":
+        ctx = list(layer.context)
+        applies = len(ctx) >= 2 and min(ctx) >= -4 and max(ctx) <= 4
+        return L.TDNN_MX_SLAB, False, "tdnn_mxs_kernel" if applies else "tdnn_mx_kernel"
+    return 0, False, "tdnn_mx_kernel"
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("relu", [True, False])
-def test_tdnn_mx_fp32_output_vs_emulation(case, relu, loader):
+def test_tdnn_mx_fp32_output_vs_emulation(case, relu, kernel):
     rng = np.random.default_rng(11)
     layer, W, bias, x, lens = _layer_case(rng, *case)
     B, T, D = x.shape
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    mxf = L.TDNN_MX_LOADER if loader else 0
+    mxf, loader, family = _kernel(kernel, layer)
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
     d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=mxf)
     ldy = ops.round_up(layer.units, 4)
     y = torch.full((B, T, ldy), 7.0, device="cuda")
     ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, y)
+    assert ops.last_kernel() == family
     got = y.cpu().numpy()
     emu, exact = _emulate(layer, x, lens, relu)
     for b in range(B):
@@ -154,9 +168,9 @@ def test_tdnn_mx_fp32_output_vs_emulation(case, relu, loader):
         assert (got[b, n:] == 7.0).all(), "rows beyond the utterance are not written"
 
 
-@pytest.mark.parametrize("loader", KERNELS)
-@pytest.mark.parametrize("case", CASES[:2] + CASES[3:])
-def test_tdnn_mx_plane_output_feeds_the_next_layer(case, loader):
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("case", CASES[:2] + CASES[3:5])
+def test_tdnn_mx_plane_output_feeds_the_next_layer(case, kernel):
     """Plane output of one layer == ktf_mx_planes of its fp32 output (same encoder), up to the ties an fp32 summation-order
     difference can flip: compared as decoded values."""
     rng = np.random.default_rng(12)
@@ -165,11 +179,12 @@ def test_tdnn_mx_plane_output_feeds_the_next_layer(case, loader):
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    mxf = L.TDNN_MX_LOADER if loader else 0
+    mxf, loader, family = _kernel(kernel, layer)
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
     d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=mxf)
     out = mx.Planes.empty(B, T, layer.units, "cuda")
     ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, out)
+    assert ops.last_kernel() == family
     y = torch.zeros((B, T, ops.round_up(layer.units, 4)), device="cuda")
     d32 = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu", flags=mxf)
     ops.tdnn_mx(p, dl, d32, wh, wq, bd, None, None, y)
@@ -182,10 +197,11 @@ def test_tdnn_mx_plane_output_feeds_the_next_layer(case, loader):
         assert np.array_equal(out.xs[b, :, :n].cpu().numpy(), ref.xs[b, :, :n].cpu().numpy())
 
 
-@pytest.mark.parametrize("loader", KERNELS)
-def test_tdnn_mx_fused_pooling_vs_emulation(loader):
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("shape", [(512, [0], 1500), (96, [-2, 0, 2], 300)], ids=["tdnn5", "three_contexts"])
+def test_tdnn_mx_fused_pooling_vs_emulation(kernel, shape):
     rng = np.random.default_rng(13)
-    layer, W, bias, x, lens = _layer_case(rng, 512, [0], 1500, 3, 700, [700, 129, 256])
+    layer, W, bias, x, lens = _layer_case(rng, *shape, 3, 700, [700, 129, 256])
     B, T, D = x.shape
     U = layer.units
     sc = rng.uniform(0.5, 2.0, U).astype(np.float32)
@@ -193,7 +209,7 @@ def test_tdnn_mx_fused_pooling_vs_emulation(loader):
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    mxf = L.TDNN_MX_LOADER if loader else 0
+    mxf, loader, family = _kernel(kernel, layer)
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
     emu, _ = _emulate(layer, x, lens, True)
     for det in (True, False):
@@ -201,6 +217,7 @@ def test_tdnn_mx_fused_pooling_vs_emulation(loader):
         slots = ops.stats_slots(T, mx_flags=mxf) if det else 0
         sums = torch.full((B, max(slots, 1), 2, U), 3.0, dtype=torch.float64, device="cuda")
         ops.tdnn_mx_stats(p, dl, d, wh, wq, bd, dev(sc), dev(sh), sums, zero=not det)
+        assert ops.last_kernel() == family
         out = torch.zeros((B, 2 * U), device="cuda")
         ops.stats_finalize(sums, dl, T, U, True, 1e-10, out, slots=slots, slot_rows=ops.mx_slot_rows(mxf))
         got = out.cpu().numpy()
@@ -249,6 +266,33 @@ def test_loader_wave_kernel_against_the_256_row_kernel():
         for b in (0, 6):
             assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), y[b]), "batch != single"
     assert np.abs(np.delete(got[True] - got[False], 5, 0)).max() <= 1e-5
+
+
+def test_slab_kernel_is_bit_identical_to_the_gathering_kernel():
+    """KTF_TDNN_MX_SLAB changes what the K-loop FETCHES (a chunk's rows once per tile instead of once per context offset), not what it
+    computes: same operands into the same MFMAs in the same order, so the x-vectors are equal bit for bit."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=977)
+    wav = np.concatenate([synth.make_wav(3, 52000, seed=71), synth.make_wav(5, 52000, seed=72, ragged=True)], 0)
+    got = {}
+    for slab in (False, True):
+        mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+        mdl.xvec.mx_slab = slab
+        seen = []
+        real = ops.tdnn_mx
+
+        def spy(*a, **k):
+            r = real(*a, **k)
+            seen.append(ops.last_kernel())
+            return r
+        ops.tdnn_mx = spy
+        try:
+            got[slab] = mdl(dev(wav))
+        finally:
+            ops.tdnn_mx = real
+        assert seen[:3] == (["tdnn_mxs_kernel"] * 3 if slab else ["tdnn_mx_kernel"] * 3), seen    # tdnn1-3 have contexts, tdnn4 none
+        assert seen[3] == "tdnn_mx_kernel"
+    assert torch.equal(got[True], got[False])
 
 
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16mx"])

@@ -106,7 +106,7 @@ V["dma_only_sides"] = lambda s: V["no_f16_dma"](V["no_mfma"](s))
 V["dma_only_none"] = lambda s: V["no_dma"](V["no_mfma"](s))
 
 names = sys.argv[1:] or list(V)
-objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "tdnn_mxl.o", "pool_post.o")]
+objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "tdnn_mxl.o", "tdnn_mxs.o", "pool_post.o")]
 FLAGS = {
     "flags_O2": ["-O2"],
     "flags_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],

@@ -104,7 +104,7 @@ for _n, _c in ():
 if __name__ == "__main__":
     names = sys.argv[1:] or list(V)
     flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function -Wno-unused-result -Wno-unused-value".split()
-    objs = [os.path.join(CS, f) for f in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "tdnn_mx.o", "pool_post.o")]
+    objs = [os.path.join(CS, f) for f in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "tdnn_mx.o", "tdnn_mxs.o", "pool_post.o")]
     for n in names:
         scratch = os.path.join(CS, f"_abl_{n}.hip")
         open(scratch, "w").write(V[n](src))
