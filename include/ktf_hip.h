@@ -78,6 +78,18 @@ extern "C" {
 #define KTF_ACT_RELU 1
 #define KTF_ACT_SIGMOID 2
 #define KTF_ACT_TANH 3
+/* the rest of tf.keras.activations of the reference's TensorFlow (2.8; layers/tdnn/tdnn.py:117-118 accepts any of its names):
+ * ktf_tdnn with KTF_GEMM_F32 and an fp32 output runs them as a second launch over the rows it wrote (ktf_activation_f32); the 16-bit
+ * and MX kernels fuse KTF_ACT_NONE / KTF_ACT_RELU only (the host runs such layers on the fp32 kernels) */
+#define KTF_ACT_ELU 4            /* x > 0 ? x : exp(x) - 1 */
+#define KTF_ACT_SELU 5           /* 1.0507 * (x > 0 ? x : 1.67326 * (exp(x) - 1)) */
+#define KTF_ACT_SOFTPLUS 6       /* log(exp(x) + 1) */
+#define KTF_ACT_SOFTSIGN 7       /* x / (|x| + 1) */
+#define KTF_ACT_SWISH 8          /* x * sigmoid(x) */
+#define KTF_ACT_GELU 9           /* 0.5 x (1 + erf(x / sqrt 2)): approximate=False, the default */
+#define KTF_ACT_EXPONENTIAL 10   /* exp(x) */
+#define KTF_ACT_HARD_SIGMOID 11  /* clip(0.2 x + 0.5, 0, 1) */
+#define KTF_ACT_SOFTMAX 12       /* over the units of a row (axis = -1) */
 
 int32_t ktf_version(void);
 /* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
@@ -363,7 +375,14 @@ int32_t ktf_mx_slot_rows(int32_t flags);
 int ktf_stats_finalize_slots(const double* sums, int64_t slots, int32_t slot_rows, const int32_t* lens, int64_t T, int64_t B, int32_t D,
                              int32_t include_std, float eps, float* out, int64_t ld_out, void* stream);
 
-/* elementwise y = act(x) * scale + shift per column (stand-alone ReLU / BatchNorm layers); scale/shift may be NULL */
+/* in place over the rows t < lens[b] of y (B, T, ld) fp32 (lens NULL: all T rows): y = act(y) * scale + shift per column, any KTF_ACT_*
+ * (KTF_ACT_SOFTMAX: over the D units of each row, then the affine); scale / shift may be NULL (both or neither). The pass ktf_tdnn
+ * appends for activations its epilogues do not fuse; rows at and beyond lens[b] are not touched. */
+int ktf_activation_f32(float* y, int64_t B, int64_t T, int32_t D, int64_t ld, const int32_t* lens, int32_t act, const float* scale,
+                       const float* shift, void* stream);
+
+/* elementwise y = act(x) * scale + shift per column (stand-alone ReLU / BatchNorm layers; any KTF_ACT_* but KTF_ACT_SOFTMAX);
+ * scale/shift may be NULL */
 int ktf_affine_act_f32(const float* x, int64_t rows, int32_t D, int32_t act, const float* scale, const float* shift,
                        float* y, void* stream);
 /* dtype conversion / column padding: dst (rows, ld_dst) <- src (rows, D) with zero fill of the pad columns */

@@ -12,7 +12,7 @@ void ktf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int32_t ktf_version(void) { return 110; /* 0.1.1: slot_rows in ktf_stats_finalize_slots / ktf_xvec_tail_f32, ktf_mx_stats_slots, KTF_TDNN_MX_LOADER */ }
+extern "C" int32_t ktf_version(void) { return 111; /* 0.1.1 + KTF_TDNN_MX_SLAB, KTF_ACT_ELU .. KTF_ACT_SOFTMAX, ktf_activation_f32 */ }
 
 extern "C" size_t ktf_last_error(char* buf, size_t cap) {
     const size_t n = strlen(g_err);

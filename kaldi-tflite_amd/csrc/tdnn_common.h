@@ -79,6 +79,22 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// The rest of tf.keras.activations (TF 2.8: the names layers/tdnn/tdnn.py:117-118 resolves), elementwise ones; the GEMM epilogues
+// fuse KTF_ACT_NONE .. KTF_ACT_TANH only, these run as a pass over the layer's output rows (act_rows_kernel, tdnn_gemm.hip).
+__device__ __forceinline__ float apply_act_ext(float v, int act) {
+    switch (act) {
+        case KTF_ACT_ELU: return v > 0.0f ? v : expm1f(v);
+        case KTF_ACT_SELU: return 1.05070098735548049342f * (v > 0.0f ? v : 1.67326324235437728481f * expm1f(v));
+        case KTF_ACT_SOFTPLUS: return fmaxf(v, 0.0f) + log1pf(expf(-fabsf(v)));
+        case KTF_ACT_SOFTSIGN: return v / (fabsf(v) + 1.0f);
+        case KTF_ACT_SWISH: return v / (1.0f + expf(-v));
+        case KTF_ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+        case KTF_ACT_EXPONENTIAL: return expf(v);
+        case KTF_ACT_HARD_SIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.0f), 1.0f);
+        default: return apply_act(v, act);
+    }
+}
+
 // Epilogue for the 32x32 accumulator layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 __device__ __forceinline__ void store_tile32(const f32x16& acc, const TdnnParams& p, int64_t out_row0, int rows_valid,
                                              int m_base, int n_base, int lane) {

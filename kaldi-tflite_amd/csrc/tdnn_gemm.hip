@@ -11,11 +11,62 @@ __global__ void affine_act_kernel(const float* __restrict__ x, int64_t total, in
                                   float* __restrict__ y) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int d = (int)(e % D);
-        float v = apply_act(x[e], act);
+        float v = apply_act_ext(x[e], act);
         if (scale) v *= scale[d];
         if (shift) v += shift[d];
         y[e] = v;
     }
+}
+
+// One wave per output row, in place: y = act(y) * scale + shift over the rows a TDNN launch wrote (out rows of utterance b =
+// ceil((lens[b] - trim) / sub), trim / sub from the layer's padding and subsampling; the stand-alone entry point passes 0 / 1).
+__global__ __launch_bounds__(256) void act_rows_kernel(float* __restrict__ y, int64_t B, int64_t T, int D, int64_t ld,
+                                                      const int32_t* __restrict__ lens, int64_t Tin, int trim, int sub, int act,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B * T) return;
+    const int64_t b = row / T, t = row - b * T;
+    const int64_t n = (lens ? (int64_t)lens[b] : Tin) - trim;
+    const int64_t rows = n <= 0 ? 0 : (n + sub - 1) / sub;
+    if (t >= rows) return;
+    float* r = y + row * ld;
+    float inv = 1.0f, mx = 0.0f;
+    if (act == KTF_ACT_SOFTMAX) {
+        mx = -INFINITY;
+        for (int d = lane; d < D; d += 64) mx = fmaxf(mx, r[d]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float s = 0.0f;
+        for (int d = lane; d < D; d += 64) s += expf(r[d] - mx);
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        inv = 1.0f / s;
+    }
+    for (int d = lane; d < D; d += 64) {
+        float v = act == KTF_ACT_SOFTMAX ? expf(r[d] - mx) * inv : apply_act_ext(r[d], act);
+        if (scale) v = v * scale[d] + shift[d];
+        r[d] = v;
+    }
+}
+
+static int act_rows_launch(float* y, int64_t B, int64_t T, int32_t D, int64_t ld, const int32_t* lens, int64_t Tin, int trim, int sub,
+                           int act, const float* scale, const float* shift, hipStream_t st) {
+    const int64_t rows = B * T;
+    if (rows == 0) return KTF_OK;
+    KTF_REQUIRE((rows + 3) / 4 < (1ll << 31), "activation pass: too many rows");
+    hipLaunchKernelGGL(act_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, y, B, T, D, ld, lens, Tin, trim, sub, act, scale, shift);
+    return KTF_OK;
+}
+
+extern "C" int ktf_activation_f32(float* y, int64_t B, int64_t T, int32_t D, int64_t ld, const int32_t* lens, int32_t act,
+                                  const float* scale, const float* shift, void* stream) {
+    KTF_REQUIRE(y, "ktf_activation_f32: null argument");
+    KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ld >= D, "ktf_activation_f32: bad sizes");
+    KTF_REQUIRE(act >= KTF_ACT_NONE && act <= KTF_ACT_SOFTMAX, "ktf_activation_f32: bad activation %d", act);
+    KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_activation_f32: scale and shift go together");
+    const int rc = act_rows_launch(y, B, T, D, ld, lens, T, 0, 1, act, scale, shift, (hipStream_t)stream);
+    if (rc != KTF_OK) return rc;
+    KTF_CHECK_LAUNCH("ktf_activation_f32");
+    return KTF_OK;
 }
 
 template <typename S>
@@ -84,7 +135,10 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     KTF_REQUIRE(d->din_pad >= d->din && d->din_pad % 32 == 0 && d->din_pad <= ldx, "ktf_tdnn: din_pad %d must be a multiple of 32 with din <= din_pad <= ldx", d->din_pad);
     KTF_REQUIRE(ldx % 8 == 0, "ktf_tdnn: ldx must be a multiple of 8");
     KTF_REQUIRE(ldy >= d->units, "ktf_tdnn: ldy < units");
-    KTF_REQUIRE(d->act >= KTF_ACT_NONE && d->act <= KTF_ACT_TANH, "ktf_tdnn: bad activation %d", d->act);
+    KTF_REQUIRE(d->act >= KTF_ACT_NONE && d->act <= KTF_ACT_SOFTMAX, "ktf_tdnn: bad activation %d", d->act);
+    const bool act_pass = d->act > KTF_ACT_TANH;        // not fused by any epilogue: a second launch over the rows written
+    if (act_pass) KTF_REQUIRE(d->gemm == KTF_GEMM_F32 && d->y_dtype == KTF_F32 && y && !stats_sums,
+                              "ktf_tdnn: activation %d runs with KTF_GEMM_F32 and an fp32 output only (no fused pooling)", d->act);
     KTF_REQUIRE(d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F16, "ktf_tdnn: bad y_dtype");
     KTF_REQUIRE(d->y_dtype != KTF_F16 || d->gemm == KTF_GEMM_F16 || half2, "ktf_tdnn: half output needs KTF_GEMM_F16 or KTF_GEMM_F16X2");
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_tdnn: scale and shift go together");
@@ -101,7 +155,8 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.x_lo = x_lo; p.y_lo = y_lo;
     p.out_lens = out_lens; p.T = T; p.ldx = ldx; p.ldy = ldy; p.Tout = Tout;
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
-    p.act = d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
+    p.act = act_pass ? KTF_ACT_NONE : d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
+    if (act_pass) p.scale = p.shift = nullptr;          // (the BatchNorm affine follows the activation: applied by the pass)
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
     {
         const int pre = (d->flags >> 8) & 0xffff;             // KTF_TDNN_LO_PREFIX(chunks) = (chunks + 1) << 8
@@ -124,7 +179,13 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     hipStream_t st = (hipStream_t)stream;
     if (d->gemm == KTF_GEMM_F32) {
         KTF_REQUIRE(d->x_dtype == KTF_F32 && d->w_dtype == KTF_F32, "ktf_tdnn: F32 gemm needs fp32 x and w");
-        return tdnn_launch_f32(p, d, B, Tout, st);
+        const int rc = tdnn_launch_f32(p, d, B, Tout, st);
+        if (rc != KTF_OK || !act_pass) return rc;
+        const int trim = d->valid ? (d->ctx[0] < 0 ? -d->ctx[0] : 0) + (d->ctx[d->nctx - 1] > 0 ? d->ctx[d->nctx - 1] : 0) : 0;
+        const int rc2 = act_rows_launch((float*)y, B, Tout, d->units, ldy, lens, T, trim, d->subsampling, d->act, scale, shift, st);
+        if (rc2 != KTF_OK) return rc2;
+        KTF_CHECK_LAUNCH("ktf_tdnn (activation pass)");
+        return KTF_OK;
     }
     if (half2) return tdnn_launch_split(p, d, B, Tout, ldy, false, stats_sums, st);
     if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3 || d->gemm == KTF_GEMM_F16) {
@@ -263,7 +324,7 @@ extern "C" int ktf_affine_act_f32(const float* x, int64_t rows, int32_t D, int32
                                   const float* shift, float* y, void* stream) {
     KTF_REQUIRE(x && y, "ktf_affine_act_f32: null argument");
     KTF_REQUIRE(rows >= 0 && D > 0, "ktf_affine_act_f32: bad sizes");
-    KTF_REQUIRE(act >= KTF_ACT_NONE && act <= KTF_ACT_TANH, "ktf_affine_act_f32: bad activation");
+    KTF_REQUIRE(act >= KTF_ACT_NONE && act < KTF_ACT_SOFTMAX, "ktf_affine_act_f32: bad activation %d (KTF_ACT_SOFTMAX: ktf_activation_f32)", act);
     const int64_t total = rows * D;
     if (total == 0) return KTF_OK;
     int blocks = ktf_cdiv(total, 256);

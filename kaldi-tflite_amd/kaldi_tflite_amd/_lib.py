@@ -19,6 +19,8 @@ LIB_PATH = _OVERRIDE or os.path.join(_HERE, "libktf_hip.so")
 KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
 GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2, GEMM_F16MX = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+(ACT_ELU, ACT_SELU, ACT_SOFTPLUS, ACT_SOFTSIGN, ACT_SWISH, ACT_GELU, ACT_EXPONENTIAL, ACT_HARD_SIGMOID,
+ ACT_SOFTMAX) = range(4, 13)         # run as a pass of their own (ktf_activation_f32)
 TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED, TDNN_X_CHUNKED, TDNN_Y_CHUNKED = 1, 2, 4, 8, 16, 32   # KtfTdnnDesc.flags
 TAIL_SKIP_EMPTY = 1                 # ktf_xvec_tail_f32 flags
 TDNN_MX_SLAB = 1 << 25            # ktf_tdnn_mx*: multi-context layers on the slab form of the 256-row kernel (csrc/tdnn_mxs.hip)
@@ -114,6 +116,7 @@ PROTOTYPES = {
     "ktf_mx_slot_rows": (_i32, [_i32]),
     "ktf_stats_finalize_slots": (C.c_int, [_P, _i64, _i32, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_affine_act_f32": (C.c_int, [_P, _i64, _i32, _i32, _P, _P, _P, _P]),
+    "ktf_activation_f32": (C.c_int, [_P, _i64, _i64, _i32, _i64, _P, _i32, _P, _P, _P]),
     "ktf_convert_pad": (C.c_int, [_P, _i32, _i64, _i32, _i64, _P, _i32, _i64, _P]),
     "ktf_stats_pool": (C.c_int, [_P, _i32, _i64, _i64, _i32, _i64, _P, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_stats_pool_windowed_f32": (C.c_int, [_P, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _f32, _P, _P]),

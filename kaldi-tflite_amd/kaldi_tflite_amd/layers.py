@@ -669,7 +669,11 @@ def reshapeKaldiTdnnWeights(weights, units, kernel_width):
 
 WEIGHTS_EPOCH = [0]      # bumped by every set_weights / re-build / calibration in the process: a cheap "anything changed?" for captured graphs
 
-_ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
+# every name tf.keras.activations.get resolves in the reference's TensorFlow (2.8; layers/tdnn/tdnn.py:117-118). The GEMM epilogues
+# fuse the first four; the others run as a second launch over the layer's output (ktf_tdnn does that itself, fp32 kernels only)
+_ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH,
+         "elu": L.ACT_ELU, "selu": L.ACT_SELU, "softplus": L.ACT_SOFTPLUS, "softsign": L.ACT_SOFTSIGN, "swish": L.ACT_SWISH,
+         "gelu": L.ACT_GELU, "exponential": L.ACT_EXPONENTIAL, "hard_sigmoid": L.ACT_HARD_SIGMOID, "softmax": L.ACT_SOFTMAX}
 _GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat16": L.GEMM_BF16, "bf16x3": L.GEMM_BF16X3,
          "f16": L.GEMM_F16, "float16": L.GEMM_F16, "f16x2": L.GEMM_F16X2, "f16mx": L.GEMM_F16MX}
 
@@ -960,9 +964,11 @@ class TDNN(Layer):
     def effective_gemm(self, gemm, relu=False):
         """The half-precision mode runs on the ring kernels only (units > 128, ReLU or no activation); any other layer
         of an "f16" model is evaluated by the exact fp32 kernel instead."""
+        a = self.activation.lower() if isinstance(self.activation, str) else self.activation
+        if _ACTS[a] > L.ACT_TANH:            # activations no epilogue fuses: the fp32 kernels + an activation pass, in every mode
+            return L.GEMM_F32
         if gemm not in (L.GEMM_F16, L.GEMM_F16X2, L.GEMM_F16MX):
             return gemm
-        a = self.activation.lower() if isinstance(self.activation, str) else self.activation
         ok = self.units > 128 and (a in (None, "linear") or (a == "relu" and not relu))
         if gemm == L.GEMM_F16MX:             # SAME padding without subsampling only
             ok = ok and self.padding == "SAME" and self.subsamplingFactor == 1
@@ -995,6 +1001,8 @@ class TDNN(Layer):
             raise ValueError(f"expected input feature dim {self.inputDim}, got {x.shape[-1]}")
         gemm = self.effective_gemm(_GEMM[self.gemm])
         B, T, D = x.shape
+        if gemm == L.GEMM_F16MX:
+            return self._call_mx(x)
         # the 16-bit ring kernels want an output row stride that is a multiple of 8 (16-byte stores); the pad columns
         # are sliced off again
         ldy = ops.round_up(self.units, 8) if gemm in (L.GEMM_BF16, L.GEMM_F16) else self.units
@@ -1003,6 +1011,21 @@ class TDNN(Layer):
             y = self.forward(self.prepare_input(x.reshape(1, B, D), gemm), gemm=gemm, ldy=ldy)
             return y[:, :, : self.units].reshape(B, 1, self.units)
         return self.forward(self.prepare_input(x, gemm), gemm=gemm, ldy=ldy)[:, :, : self.units]
+
+
+    def _call_mx(self, x):
+        """A stand-alone call of an "f16mx" layer (inside a Sequential the planes travel from layer to layer instead): fp32 rows ->
+        the four MX planes -> csrc/tdnn_mx.hip -> fp32 rows."""
+        from . import mx
+        B, T, D = x.shape
+        src = x if (x.dtype == torch.float32 and x.stride(2) == 1 and x.stride(0) == T * x.stride(1)) else x.to(torch.float32).contiguous()
+        planes = mx.Planes.empty(B, T, D, x.device)
+        ops.mx_planes(src, D, None, planes)
+        wh, wq, bias = self.device_weights_mx(x.device, loader=False)
+        d = self.desc(L.GEMM_F16MX, torch.float16, torch.float32)
+        y = torch.empty((B, T, ops.round_up(self.units, 4)), dtype=torch.float32, device=x.device)
+        ops.tdnn_mx(planes, None, d, wh, wq, bias, None, None, y)
+        return y[:, :, : self.units]
 
 
 # =============================================================================== stats

@@ -447,7 +447,7 @@ class Sequential:
                 continue
             if pending_bn is not None:
                 raise RuntimeError("internal: a deferred BatchNorm reached a layer that cannot fold it")
-            if use_planes and st[0] == "tdnn" and not pooled and l.units > 128:
+            if use_planes and st[0] == "tdnn" and not pooled and l.units > 128 and l.effective_gemm(gemm, relu) == gemm:
                 if planes is None:                                   # first wide layer: split its fp32 input once
                     B, T, D = x.shape
                     planes = self._ws.get("split_in", (2, B, T, ops.round_up(D, 32)), torch.bfloat16, dev)
@@ -468,7 +468,8 @@ class Sequential:
                 out_lens = None
                 if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
                     out_lens = torch.empty_like(lens)
-                keep = nxt is not None and nxt[0] == "tdnn" and nxt[1].units > 128        # the consumer reads planes too
+                keep = (nxt is not None and nxt[0] == "tdnn" and nxt[1].units > 128 and         # the consumer reads planes too
+                        nxt[1].effective_gemm(gemm, nxt[2]) == gemm)
                 if keep:
                     ybuf = self._ws.get(out_role, (2, B, Tout, ldy), torch.bfloat16, dev, padded=ldy != l.units)
                     d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None, flags=kflag)

@@ -467,6 +467,17 @@ def affine_act(x, act, scale=None, shift=None):
     return y
 
 
+def activation_(y, lens, act, scale=None, shift=None):
+    """In place over the rows t < lens[b] of y (B, T, D) fp32: y = act(y) * scale + shift (any L.ACT_*, softmax over D)."""
+    lib = L.load()
+    B, T, D = y.shape
+    assert y.dtype == torch.float32 and y.stride(2) == 1 and y.stride(0) == T * y.stride(1)
+    with torch.cuda.device(y.device):
+        rc = lib.ktf_activation_f32(L.ptr(y), B, T, D, y.stride(1), L.ptr(lens), act, L.ptr(scale), L.ptr(shift), L.stream_ptr())
+    L.check(rc, "ktf_activation_f32")
+    return y
+
+
 def convert_pad(src, D, dst):
     """src (..., ld_src) / dst (..., ld_dst) 2-D-viewable row-major tensors; copies D columns, zero-fills the pad."""
     lib = L.load()

@@ -27,7 +27,7 @@ import numpy as np
 
 __all__ = [
     "framing", "pad_waveform", "window_function", "windowing", "mel_bank", "filterbank", "dct_matrix", "dct",
-    "lifter_coeffs", "mfcc", "vad", "cmvn", "tdnn", "relu", "batchnorm", "stats_pooling",
+    "lifter_coeffs", "mfcc", "vad", "cmvn", "tdnn", "keras_activation", "relu", "batchnorm", "stats_pooling",
     "xvector_post", "plda", "sequential_forward", "xvector_forward",
 ]
 
@@ -359,16 +359,44 @@ def tdnn(x, W, b=None, context=(0,), subsampling_factor=1, padding="SAME", activ
     if b is not None:
         y = y + np.asarray(b, dtype=dtype)
     if activation is not None:
-        a = activation.lower()
-        if a == "relu":
-            y = np.maximum(y, 0)
-        elif a == "sigmoid":
-            y = 1.0 / (1.0 + np.exp(-y))
-        elif a == "tanh":
-            y = np.tanh(y)
-        elif a != "linear":
-            raise ValueError(f"unsupported activation {activation}")
+        y = keras_activation(y, activation)
     return y.astype(dtype)
+
+
+def keras_activation(y, name):
+    """tf.keras.activations.get(name) of the reference's TensorFlow (setup.py:49: 2.8.0; layers/tdnn/tdnn.py:117-118, 278-279), by the
+    definitions of keras/activations.py and keras/backend.py of that release: elu alpha 1; selu alpha 1.67326324, scale 1.05070098;
+    hard_sigmoid = clip(0.2 x + 0.5, 0, 1); gelu approximate=False; softmax over the last axis."""
+    a = name.lower()
+    if a == "linear":
+        return y
+    if a == "relu":
+        return np.maximum(y, 0)
+    if a == "sigmoid":
+        return 1.0 / (1.0 + np.exp(-y))
+    if a == "tanh":
+        return np.tanh(y)
+    if a == "elu":
+        return np.where(y > 0, y, np.expm1(np.minimum(y, 0)))
+    if a == "selu":
+        return 1.05070098735548049342 * np.where(y > 0, y, 1.67326324235437728481 * np.expm1(np.minimum(y, 0)))
+    if a == "softplus":
+        return np.maximum(y, 0) + np.log1p(np.exp(-np.abs(y)))
+    if a == "softsign":
+        return y / (np.abs(y) + 1.0)
+    if a == "swish":
+        return y / (1.0 + np.exp(-y))
+    if a == "gelu":
+        from scipy.special import erf
+        return 0.5 * y * (1.0 + erf(y / np.sqrt(2.0)))
+    if a == "exponential":
+        return np.exp(y)
+    if a == "hard_sigmoid":
+        return np.clip(0.2 * y + 0.5, 0.0, 1.0)
+    if a == "softmax":
+        e = np.exp(y - y.max(axis=-1, keepdims=True))
+        return e / e.sum(axis=-1, keepdims=True)
+    raise ValueError(f"Unknown activation function: {name}")
 
 
 def relu(x):

@@ -34,6 +34,11 @@ int main(void) {
     EXPECT_EINVAL(ktf_tdnn(f, -1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
     t.gemm = 77;
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.gemm = KTF_GEMM_BF16; t.act = KTF_ACT_SELU; t.x_dtype = KTF_BF16; t.w_dtype = KTF_BF16; t.y_dtype = KTF_BF16;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));       /* an unfused activation outside fp32 */
+    t.gemm = KTF_GEMM_F32; t.act = KTF_ACT_SOFTMAX + 1; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    t.act = KTF_ACT_NONE;
     t.gemm = KTF_GEMM_F16MX;
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, NULL, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 8, NULL));     /* no output */
@@ -61,7 +66,12 @@ int main(void) {
     EXPECT_EINVAL(ktf_route_short(NULL, 1, 400, l, l, NULL, 0, NULL));
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));
-    EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, 9, NULL, NULL, f, NULL));
+    EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, 99, NULL, NULL, f, NULL));
+    EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, KTF_ACT_SOFTMAX, NULL, NULL, f, NULL));                     /* a row operation: ktf_activation_f32 */
+    EXPECT_EINVAL(ktf_activation_f32(NULL, 1, 1, 4, 4, NULL, KTF_ACT_ELU, NULL, NULL, NULL));
+    EXPECT_EINVAL(ktf_activation_f32(f, 1, 1, 8, 4, NULL, KTF_ACT_ELU, NULL, NULL, NULL));               /* ld < D */
+    EXPECT_EINVAL(ktf_activation_f32(f, 1, 1, 4, 4, NULL, KTF_ACT_SOFTMAX + 1, NULL, NULL, NULL));
+    EXPECT_EINVAL(ktf_activation_f32(f, 1, 1, 4, 4, NULL, KTF_ACT_GELU, f, NULL, NULL));                  /* scale without shift */
     char small[4];
     size_t n = ktf_last_error(small, sizeof small);      /* truncation must stay inside the buffer */
     printf("last_error length %zu, truncated copy '%s'\n", n, small);

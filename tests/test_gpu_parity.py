@@ -307,6 +307,93 @@ def test_tdnn_options_vs_oracle(gemm, tol):
         assert err < tol, (gemm, B, T, D, U, ctx, sub, pad, act, err)
 
 
+KERAS_ACTIVATIONS = ["elu", "selu", "softplus", "softsign", "swish", "gelu", "exponential", "hard_sigmoid", "softmax", "linear"]
+
+
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16mx"])
+@pytest.mark.parametrize("act", KERAS_ACTIVATIONS)
+def test_tdnn_every_keras_activation_vs_oracle(act, gemm):
+    """layers/tdnn/tdnn.py:117-118 resolves ANY tf.keras.activations name (TF 2.8). The GEMM epilogues fuse relu / sigmoid / tanh; the
+    others run on the fp32 kernels + an activation pass over the rows written, whatever the layer's mode: same tolerance as fp32.
+    Ragged batch with VALID padding and subsampling: rows beyond an utterance's output length stay untouched."""
+    import warnings
+    rng = np.random.default_rng(21)
+    for (B, T, D, U, ctx, sub, pad) in [(3, 150, 40, 200, [-2, 0, 2], 1, "SAME"), (2, 141, 64, 33, [-3, 1], 2, "VALID"), (4, 1, 96, 150, [0], 1, "SAME")]:
+        x = rng.standard_normal((B, T, D)).astype(np.float32)
+        W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+        b = rng.standard_normal(U).astype(np.float32)
+        t = Ls.TDNN(U, context=list(ctx), subsampling_factor=sub, padding=pad, activation=act, gemm=gemm)
+        t.build(x.shape)
+        t.set_weights([W, b])
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore", RuntimeWarning)
+            got = host(t(x))
+        want = O.tdnn(x, W, b, ctx, sub, pad, act, dtype=np.float64)
+        assert got.shape == want.shape
+        fused = act == "linear" and U > 128         # the mode's own kernels (a stand-alone "f16mx" layer: planes in, fp32 rows out)
+        tol = {"f32": 2e-5, "bf16x3": 2e-4, "f16mx": 2e-3}[gemm] if fused else 2e-5
+        assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (act, gemm, B, T, D, U)
+        if fused and gemm == "f16mx":
+            from kaldi_tflite_amd import ops
+            assert ops.last_kernel() == "tdnn_mx_kernel"
+    # ragged, through the C-ABI wrapper: rows at and beyond the output length of an utterance are not written
+    B, T, D, U, ctx = 3, 90, 32, 64, [-2, 0, 2]
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    W = (rng.standard_normal((U, 3 * D)) / np.sqrt(3 * D)).astype(np.float32)
+    b = rng.standard_normal(U).astype(np.float32)
+    t = Ls.TDNN(U, context=ctx, padding="VALID", activation=act, gemm="f32")
+    t.build(x.shape)
+    t.set_weights([W, b])
+    lens = [90, 41, 3]
+    out = torch.full((B, t.outputTimesteps(T), U), 7.0, device="cuda")
+    out_lens = torch.zeros(B, dtype=torch.int32, device="cuda")
+    t.forward(dev(x), lens=dev(np.array(lens), torch.int32), gemm=Ls.L.GEMM_F32, out=out, out_lens=out_lens)
+    got = host(out)
+    assert out_lens.tolist() == [86, 37, 0]
+    for bi, n in enumerate([86, 37, 0]):
+        want = O.tdnn(x[bi:bi + 1, : lens[bi]], W, b, ctx, 1, "VALID", act, dtype=np.float64)[0] if n else np.zeros((0, U))
+        assert np.abs(got[bi, :n] - want).max(initial=0.0) < 2e-5 * max(1.0, np.abs(want).max(initial=0.0))
+        assert (got[bi, n:] == 7.0).all()
+
+
+@pytest.mark.parametrize("gemm,tol", [("f32", 3e-5), ("bf16x3", 3e-4), ("f16mx", 2e-3)])
+def test_sequential_with_unfused_activations_between_wide_layers(gemm, tol):
+    """A stack whose middle layers carry activations no epilogue fuses: the 16-bit / MX routes hand exactly those layers to the fp32
+    kernels (planes are not kept for a consumer that cannot read them) and pick the route up again behind them."""
+    import warnings
+    rng = np.random.default_rng(31)
+    B, T, D = 3, 260, 40
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    spec = [(256, [-2, 0, 2], None, True), (192, [-1, 0, 1], "gelu", False), (256, [0], "softmax", False), (160, [-3, 0, 3], None, True), (64, [0], "selu", False)]
+    built, olayers, din = [], [], D
+    for i, (U, ctx, act, relu) in enumerate(spec):
+        W = (rng.standard_normal((U, len(ctx) * din)) / np.sqrt(len(ctx) * din)).astype(np.float32)
+        b = (0.1 * rng.standard_normal(U)).astype(np.float32)
+        l = Ls.TDNN(U, context=ctx, activation=act, name=f"t{i}.affine")
+        built.append((l, W, b))
+        olayers.append({"kind": "tdnn", "W": W, "b": b, "context": ctx, "activation": act})
+        if relu:
+            built.append((Ls.ReLU(name=f"t{i}.relu"), None, None))
+            olayers.append({"kind": "relu"})
+        din = U
+    mdl = ktf.models.Sequential([ktf.models.Input(shape=(None, D))] + [l for l, _, _ in built], gemm=gemm)
+    for l, W, b in built:
+        if W is not None:
+            l.set_weights([W, b])
+    mdl.min_tiles, mdl.min_frames = {}, {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        got = host(mdl(x, training=False))
+    want = O.sequential_forward(olayers, x, dtype=np.float64)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max())
+
+
+def test_unknown_activation_is_refused_like_keras():
+    with pytest.raises(ValueError, match="Unknown activation function"):
+        Ls.TDNN(8, activation="relu7")
+
+
 def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
     """The fp32 path runs on LDS-DMA-staged kernels: 128x128 tiles (two workgroups per CU), 64-row tiles when there are
     few workgroups (a single utterance), and a row-vector fmaf chain for <= 8 output rows (tdnn6). All sum in K order

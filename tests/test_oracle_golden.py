@@ -138,6 +138,36 @@ def test_tdnn_narrow():
     assert G.rmse(want, got) <= 5e-4
 
 
+def test_keras_activation_known_answers():
+    """oracle.keras_activation against the closed forms of tf.keras.activations (TF 2.8: keras/activations.py) at points whose values
+    are textbook constants -- TensorFlow itself is not installable here, so these pin the definitions (alpha / scale of selu, the 0.2
+    slope of hard_sigmoid, the erf form of gelu)."""
+    x = np.array([-3.0, -1.0, 0.0, 1.0, 3.0])
+    e = np.e
+    want = {
+        "linear": x,
+        "relu": [0, 0, 0, 1, 3],
+        "sigmoid": 1 / (1 + np.exp(-x)),
+        "tanh": np.tanh(x),
+        "elu": [e ** -3 - 1, 1 / e - 1, 0, 1, 3],
+        "selu": [1.0507009873554805 * 1.6732632423543772 * (e ** -3 - 1), -1.1113307378125625, 0, 1.0507009873554805, 3.1521029620664414],
+        "softplus": [0.04858735157374196, 0.31326168751822286, np.log(2), 1.3132616875182228, 3.048587351573742],
+        "softsign": [-0.75, -0.5, 0, 0.5, 0.75],
+        "swish": [-0.14227761953270035, -0.2689414213699951, 0, 0.7310585786300049, 2.8577223804673],
+        "gelu": [-3 * 0.0013498980316301, -0.158655253931457, 0, 0.841344746068543, 3 * 0.9986501019683699],      # x * Phi(x), Phi from tables
+        "exponential": [e ** -3, 1 / e, 1, e, e ** 3],
+        "hard_sigmoid": [0, 0.3, 0.5, 0.7, 1],
+    }
+    for name, w in want.items():
+        assert np.allclose(O.keras_activation(x, name), np.asarray(w, dtype=np.float64), rtol=0, atol=1e-12), name
+    sm = O.keras_activation(np.array([[1.0, 2.0, 3.0], [0.0, 0.0, 0.0]]), "softmax")
+    assert np.allclose(sm, [[0.09003057317038046, 0.24472847105479767, 0.6652409557748219], [1 / 3] * 3], atol=1e-15)
+    big = O.keras_activation(np.array([[1000.0, 1000.0]]), "softmax")           # shifted by the row maximum: no overflow
+    assert np.allclose(big, 0.5)
+    with pytest.raises(ValueError):
+        O.keras_activation(x, "relu7")
+
+
 def test_stats_pooling_goldens():
     # layers/stats/stats_pooling_test.py:26,48-88  RMSE <= 4e-6
     for name in G.STATS_CONFIGS:
