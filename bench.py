@@ -449,6 +449,7 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     variant of the workload, batch-1 latency (config 2), batch 256 (config 3) and the 1024 x 1024 PLDA trial matrix (config 5)."""
     import numpy as np
     from kaldi_tflite_amd import ops
+    from oracle import ktf_oracle as O          # (the checker of the batch-1 x-vector below; never the thing measured)
     res = {}
     B = wav.shape[0]
     T = mdl.framing.numFrames(wav.shape[1])
@@ -522,13 +523,21 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     res["config3_batch256_f16mx"] = {"x_vectors_per_s": 256 / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info["f16mx"]["max"],
                                      "tolerance_ok": bool(dev_info["f16mx"]["max"] <= TOLERANCE)}
     del m256
-    # BASELINE config 2: batch 1, fp32 — eager launches and the captured hipGraph (XvectorExtractor.compile)
-    m1 = synth.build_extractor(ktf, cfg, w, gemm="f32")
+    # BASELINE config 2: batch 1 — eager launches and the captured hipGraph (XvectorExtractor.compile), per mode: "f32" (the exact
+    # fp32 small-tile kernels; batch == single bitwise) and the timed mode (a batch this small runs the bf16-pair small tiles,
+    # KTF_GEMM_BF16X4: Sequential.small_tile_pairs)
     one = wav[:1].contiguous()
-    res["config2_batch1_fp32_latency_ms"] = {"eager": _time_ms(torch, lambda: m1(one), 50)}
-    run = m1.compile(one)
-    res["config2_batch1_fp32_latency_ms"]["hipgraph"] = _time_ms(torch, lambda: run(one), 50)
-    res["config2_batch1_fp32_latency_ms"]["hipgraph_bitwise_equal_eager"] = bool(torch.equal(run(one), m1(one)))
+    want1 = O.xvector_forward(one.cpu().numpy(), cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+    res["config2_batch1_latency_ms"] = {}
+    for mode in dict.fromkeys(("f32", gemm)):
+        m1 = synth.build_extractor(ktf, cfg, w, gemm=mode)
+        r = {"eager": _time_ms(torch, lambda: m1(one), 50)}
+        run = m1.compile(one)
+        r["hipgraph"] = _time_ms(torch, lambda: run(one), 50)
+        r["hipgraph_bitwise_equal_eager"] = bool(torch.equal(run(one), m1(one)))
+        r["max_abs_dev_vs_fp64_oracle"] = float(np.abs(m1(one).cpu().numpy().reshape(1, -1) - want1).max())
+        res["config2_batch1_latency_ms"][mode] = r
+        del m1, run
     # BASELINE config 5: 1024 x 1024 PLDA trial matrix on the x-vectors of this batch
     rng = np.random.default_rng(31)
     dim, nb = 128, 1024

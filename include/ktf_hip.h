@@ -42,6 +42,9 @@ extern "C" {
 #define KTF_BF16 1
 #define KTF_F16 2           /* IEEE half: same 16-bit MFMA rate as bf16, 3 more mantissa bits (activations of this
                              * network are BatchNorm-scaled, far inside the half range) */
+#define KTF_BF16P 3         /* a bf16 PAIR in an fp32-sized slot: bits 0-15 = bf16(v) (round to nearest even), bits 16-31 =
+                             * bf16(v - bf16(v)): 16 mantissa bits, the shapes / strides / padding of fp32 (zero = 0x00000000).
+                             * Operands of KTF_GEMM_BF16X4; KTF_GEMM_F32 and KTF_GEMM_BF16X4 can write it (y_dtype) */
 
 /* GEMM arithmetic of ktf_tdnn */
 #define KTF_GEMM_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity path) */
@@ -72,6 +75,10 @@ extern "C" {
                              * speech). The host side (Sequential.MIN_FRAMES, XvectorExtractor.route_short_utterances) sends
                              * utterances below 400 voiced frames through KTF_GEMM_BF16X3. Through ktf_tdnn_mx / ktf_tdnn_mx_stats
                              * on the four-plane activation format ktf_mx_planes produces */
+#define KTF_GEMM_BF16X4 6   /* all four bf16 products of (x_hi + x_lo)(w_hi + w_lo), fp32 accumulate, on SMALL tiles (64 x 32..96,
+                             * csrc/tdnn_pair.hip): x and w of KTF_BF16P, y KTF_F32 or KTF_BF16P, through ktf_tdnn (w_lo NULL). For
+                             * batches too small to fill the chip on 256-row tiles -- a single utterance -- where it replaces the
+                             * fp32 small-tile kernels in every mode but KTF_GEMM_F32: x-vectors ~1e-5 from the fp64 oracle */
 
 /* activations fused into the ktf_tdnn epilogue */
 #define KTF_ACT_NONE 0
@@ -368,6 +375,10 @@ int ktf_stats_finalize(const double* sums, const int32_t* lens, int64_t T, int64
  * and the finalize that adds the slots 0 .. ceil(n_b / slot_rows) - 1 of sums (B, slots, 2, D) in that order before forming
  * mean / std as above (slot_rows = 128 for ktf_tdnn_stats / ktf_tdnn_split_stats, ktf_mx_slot_rows(flags) for ktf_tdnn_mx_stats). */
 int64_t ktf_stats_slots(int64_t T);
+/* ... of ktf_tdnn_stats for a GEMM mode: KTF_GEMM_BF16X4 (x, w of KTF_BF16P; the small-tile kernel) writes one slot per 64-row tile
+ * (ceil(T / 64) slots of ktf_tdnn_slot_rows(gemm) = 64 rows), every other mode ktf_stats_slots(T) slots of 128 rows */
+int64_t ktf_tdnn_stats_slots(int64_t T, int32_t gemm);
+int32_t ktf_tdnn_slot_rows(int32_t gemm);
 /* ... for ktf_tdnn_mx_stats, whose slot geometry depends on the kernel (KtfTdnnDesc.flags & KTF_TDNN_MX_LOADER: 96-row slots, two per
  * 192-row tile; else as ktf_stats_slots) */
 int64_t ktf_mx_stats_slots(int64_t T, int32_t flags);

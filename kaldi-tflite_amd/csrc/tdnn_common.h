@@ -46,7 +46,16 @@ struct TdnnParams {
     int32_t kinter;         // KTF_TDNN_K_INTERLEAVED: K runs (32-wide feature chunk, context, feature) instead of (context, feature)
     int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
     int32_t lo_steps;       // F16X2: K-steps [0, lo_steps) run two passes, the rest one (KTF_TDNN_LO_PREFIX); >= ktot / 32: all of them
+    int32_t y_pair;         // fp32-sized output slots hold the KTF_BF16P pair of the value (y_dtype is KTF_F32 to the store paths)
 };
+
+// KTF_BF16P: bf16(v) in the low half, bf16(v - bf16(v)) in the high half of a 32-bit slot (tdnn_pair.hip), returned as the float
+// with that bit pattern so that the fp32 store paths carry it
+__device__ __forceinline__ float ktf_pair(float v) {
+    const unsigned hi = f2bf(v);
+    const unsigned lo = f2bf(v - bf2f((unsigned short)hi));
+    return __uint_as_float(hi | (lo << 16));
+}
 
 // Adds (slots == 0) or stores (slots > 0: block `slot` of utterance b is written by exactly one wave) a column's partial sums.
 __device__ __forceinline__ void stats_out(double* __restrict__ stats, const TdnnParams& p, int b, int slot, int n, double s, double q) {
@@ -109,6 +118,7 @@ __device__ __forceinline__ void store_tile32(const f32x16& acc, const TdnnParams
         if (m < rows_valid) {
             float v = apply_act(acc[r] + bias, p.act);
             if (p.scale) v = v * sc + sh;
+            if (p.y_pair) v = ktf_pair(v);
             const int64_t off = (out_row0 + m) * p.ldy + n;
             if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off] = v;
             else reinterpret_cast<unsigned short*>(p.y)[off] = f2bf(v);
@@ -138,6 +148,7 @@ __device__ __forceinline__ void store_tile32_t(const f32x16& acc, const TdnnPara
             const float bias = (nv && p.bias) ? p.bias[n + e] : 0.0f;
             v[e] = apply_act(acc[q * 4 + e] + bias, ACT);
             if (p.scale) v[e] = v[e] * (nv ? p.scale[n + e] : 1.0f) + (nv ? p.shift[n + e] : 0.0f);
+            if (p.y_pair) v[e] = ktf_pair(v[e]);
         }
         if (p.y_dtype == KTF_F32) {
             float* yp = reinterpret_cast<float*>(p.y) + rowoff + n;
@@ -164,6 +175,7 @@ extern thread_local const char* g_ktf_last_kernel;
 
 // per-family launchers (validation of the family's own constraints + launch); `p` is filled by tdnn_gemm.hip
 int tdnn_launch_f32(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t Tout, hipStream_t st);
+int tdnn_launch_x4(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t Tout, double* stats, hipStream_t st);   // tdnn_pair.hip
 int tdnn_launch_16(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t Tout, int64_t ldy, double* stats_sums, hipStream_t st);
 int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t Tout, int64_t ldy, bool split_in, double* stats_sums,
                       hipStream_t st);

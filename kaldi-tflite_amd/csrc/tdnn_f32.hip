@@ -349,6 +349,7 @@ __global__ __launch_bounds__(64 * 4 * (BN / 16 / NB)) void tdnn_f32s_kernel(Tdnn
             if (m < rows_valid) {
                 float v = apply_act(acc[j][r] + bias, p.act);
                 if (p.scale) v = v * sc + sh;
+                if (p.y_pair) v = ktf_pair(v);
                 const int64_t off = (out_row0 + m) * p.ldy + n;
                 if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off] = v;
                 else reinterpret_cast<unsigned short*>(p.y)[off] = f2bf(v);
@@ -395,6 +396,7 @@ __device__ __forceinline__ void f32t_epilogue(f32x4v (&acc)[2][4], const TdnnPar
             for (int e = 0; e < 4; ++e) {
                 v[e] = apply_act(acc[i][j][e] + bias[e], ACT);
                 if (p.scale) v[e] = v[e] * sc[e] + sh[e];
+                if (p.y_pair) v[e] = ktf_pair(v[e]);
             }
             const int64_t off = (out_row0 + m) * p.ldy + n;
             if (p.y_dtype == KTF_F32) {
@@ -632,6 +634,7 @@ __global__ __launch_bounds__(64) void tdnn_f32_rowvec_kernel(TdnnParams p) {
         const float sh = p.shift ? p.shift[n] : 0.0f;
         float v = apply_act(acc + bias, p.act);
         if (p.scale) v = v * sc + sh;
+        if (p.y_pair) v = ktf_pair(v);
         const int64_t off = ((int64_t)b * p.Tout + t) * p.ldy + n;
         if (p.y_dtype == KTF_F32) reinterpret_cast<float*>(p.y)[off] = v;
         else reinterpret_cast<unsigned short*>(p.y)[off] = f2bf(v);

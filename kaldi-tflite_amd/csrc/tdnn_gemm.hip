@@ -120,11 +120,13 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                     "ktf_tdnn: F16X2 runs on the 256x256 kernel only (units > 128, ldy %% 8 == 0, half or fp32 output)");
     }
     if (y_lo) KTF_REQUIRE(split_in && d->y_dtype == KTF_BF16, "ktf_tdnn_split: a split output needs split input and y_dtype bf16");
-    if (stats_sums) {
+    if (stats_sums && d->gemm == KTF_GEMM_BF16X4) {
+        ldy = d->units;                                  // (any shape: the pair kernel pools the rows it would have written)
+    } else if (stats_sums) {
         KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) || split_in || half2 ||
                      (d->gemm == KTF_GEMM_F16 && d->x_dtype == KTF_F16)) &&
                         d->units > 128 && !d->valid && d->subsampling == 1,
-                    "ktf_tdnn_stats: needs a ring kernel (bf16, f16 or bf16x3 gemm, units > 128, SAME padding, no subsampling)");
+                    "ktf_tdnn_stats: needs a ring kernel (bf16, f16 or bf16x3 gemm, units > 128, SAME padding, no subsampling) or KTF_GEMM_BF16X4");
         ldy = (d->units + 3) / 4 * 4;
     }
     KTF_REQUIRE(B >= 0 && T >= 0, "ktf_tdnn: negative size");
@@ -139,7 +141,10 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     const bool act_pass = d->act > KTF_ACT_TANH;        // not fused by any epilogue: a second launch over the rows written
     if (act_pass) KTF_REQUIRE(d->gemm == KTF_GEMM_F32 && d->y_dtype == KTF_F32 && y && !stats_sums,
                               "ktf_tdnn: activation %d runs with KTF_GEMM_F32 and an fp32 output only (no fused pooling)", d->act);
-    KTF_REQUIRE(d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F16, "ktf_tdnn: bad y_dtype");
+    const bool y_pair = d->y_dtype == KTF_BF16P;        // pairs in fp32-sized slots: the fp32 and the pair kernels write them
+    if (y_pair) KTF_REQUIRE((d->gemm == KTF_GEMM_F32 || d->gemm == KTF_GEMM_BF16X4) && (y || stats_sums) && !act_pass,
+                            "ktf_tdnn: a KTF_BF16P output comes from KTF_GEMM_F32 or KTF_GEMM_BF16X4 (no fused pooling, fused activations only)");
+    KTF_REQUIRE(y_pair || d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F16, "ktf_tdnn: bad y_dtype");
     KTF_REQUIRE(d->y_dtype != KTF_F16 || d->gemm == KTF_GEMM_F16 || half2, "ktf_tdnn: half output needs KTF_GEMM_F16 or KTF_GEMM_F16X2");
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_tdnn: scale and shift go together");
     KTF_REQUIRE(T < (1ll << 30) && B < 65536, "ktf_tdnn: T or B too large");
@@ -155,7 +160,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.x_lo = x_lo; p.y_lo = y_lo;
     p.out_lens = out_lens; p.T = T; p.ldx = ldx; p.ldy = ldy; p.Tout = Tout;
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
-    p.act = act_pass ? KTF_ACT_NONE : d->act; p.y_dtype = d->y_dtype; p.ktot = d->nctx * d->din_pad;
+    p.act = act_pass ? KTF_ACT_NONE : d->act; p.y_dtype = y_pair ? KTF_F32 : d->y_dtype; p.y_pair = y_pair ? 1 : 0; p.ktot = d->nctx * d->din_pad;
     if (act_pass) p.scale = p.shift = nullptr;          // (the BatchNorm affine follows the activation: applied by the pass)
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
     {
@@ -186,6 +191,13 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         if (rc2 != KTF_OK) return rc2;
         KTF_CHECK_LAUNCH("ktf_tdnn (activation pass)");
         return KTF_OK;
+    }
+    if (d->gemm == KTF_GEMM_BF16X4) {
+        KTF_REQUIRE(d->x_dtype == KTF_BF16P && d->w_dtype == KTF_BF16P && !w_lo, "ktf_tdnn: KTF_GEMM_BF16X4 takes x and w of KTF_BF16P (w_lo NULL)");
+        KTF_REQUIRE(stats_sums || y_pair || d->y_dtype == KTF_F32, "ktf_tdnn: KTF_GEMM_BF16X4 writes KTF_F32 or KTF_BF16P rows");
+        KTF_REQUIRE(!(d->flags & ~KTF_TDNN_DET_STATS), "ktf_tdnn: KTF_GEMM_BF16X4 takes no KTF_TDNN_* flag but KTF_TDNN_DET_STATS");
+        p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_tdnn_stats_slots(Tout, d->gemm) : 0;
+        return tdnn_launch_x4(p, d, B, Tout, stats_sums, st);
     }
     if (half2) return tdnn_launch_split(p, d, B, Tout, ldy, false, stats_sums, st);
     if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3 || d->gemm == KTF_GEMM_F16) {
@@ -265,6 +277,12 @@ extern "C" int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t
 
 // 128-row blocks, rounded up to whole 256-row tiles (a 256-row tile always writes both of its blocks)
 extern "C" int64_t ktf_stats_slots(int64_t T) { return T <= 0 ? 2 : 2 * ((T + 255) / 256); }
+// ... of ktf_tdnn_stats by GEMM mode: KTF_GEMM_BF16X4 pools per 64-row tile (csrc/tdnn_pair.hip), the others per 128-row block
+extern "C" int32_t ktf_tdnn_slot_rows(int32_t gemm) { return gemm == KTF_GEMM_BF16X4 ? 64 : 128; }
+extern "C" int64_t ktf_tdnn_stats_slots(int64_t T, int32_t gemm) {
+    if (gemm != KTF_GEMM_BF16X4) return ktf_stats_slots(T);
+    return T <= 0 ? 1 : (T + 63) / 64;
+}
 
 // mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)
 __global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t slots, int slot_rows, const int32_t* __restrict__ lens, int64_t T,

@@ -7,6 +7,7 @@ entry point raises (`KtfBackendError`) instead of silently computing elsewhere.
 """
 
 import ctypes as C
+import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -16,8 +17,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _OVERRIDE = os.environ.get("KTF_LIBRARY") if os.environ.get("KTF_ALLOW_LIBRARY_OVERRIDE") == "1" else None
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, "libktf_hip.so")
 
-KTF_F32, KTF_BF16, KTF_F16 = 0, 1, 2
-GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2, GEMM_F16MX = 0, 1, 2, 3, 4, 5
+KTF_F32, KTF_BF16, KTF_F16, KTF_BF16P = 0, 1, 2, 3
+PAIR = "bf16p"                    # stands for KTF_BF16P where a torch dtype is expected: pairs live in float32 tensors
+GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2, GEMM_F16MX, GEMM_BF16X4 = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 (ACT_ELU, ACT_SELU, ACT_SOFTPLUS, ACT_SOFTSIGN, ACT_SWISH, ACT_GELU, ACT_EXPONENTIAL, ACT_HARD_SIGMOID,
  ACT_SOFTMAX) = range(4, 13)         # run as a pass of their own (ktf_activation_f32)
@@ -41,7 +43,7 @@ class KtfBackendError(RuntimeError):
 def ktf_dtype(t):
     """torch dtype -> KTF_* element type of an activation / weight buffer."""
     import torch
-    return {torch.float32: KTF_F32, torch.bfloat16: KTF_BF16, torch.float16: KTF_F16}[t]
+    return {torch.float32: KTF_F32, torch.bfloat16: KTF_BF16, torch.float16: KTF_F16, PAIR: KTF_BF16P}[t]
 
 
 def act_torch_dtype(gemm):
@@ -112,6 +114,8 @@ PROTOTYPES = {
     "ktf_tdnn_mx_stats": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ktf_stats_finalize": (C.c_int, [_P, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_stats_slots": (_i64, [_i64]),
+    "ktf_tdnn_stats_slots": (_i64, [_i64, _i32]),
+    "ktf_tdnn_slot_rows": (_i32, [_i32]),
     "ktf_mx_stats_slots": (_i64, [_i64, _i32]),
     "ktf_mx_slot_rows": (_i32, [_i32]),
     "ktf_stats_finalize_slots": (C.c_int, [_P, _i64, _i32, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
@@ -175,7 +179,68 @@ def require_gpu():
     load()
 
 
+class _Scope(threading.local):
+    dev = None          # device index the enclosing launch_scope made current
+    stream = None       # ... and its current stream at entry, as a c_void_p
+
+
+_scope = _Scope()
+
+
+class launch_scope:
+    """One extraction = ~10 launches on one device and one stream: looked up once here instead of once per launch (torch's
+    current_stream / device context managers were a quarter of the host time of a batch-1 call). Inside the scope `on_device(d)` is a
+    no-op for the scope's device and `stream_ptr()` returns the stream that was current at entry; nested scopes and other devices
+    fall back to the per-call lookups. Code that switches streams must do so OUTSIDE (as extract_stream does)."""
+
+    def __init__(self, device):
+        import torch
+        self.device = torch.device(device)
+        self.ctx = None
+        self.outer = None
+
+    def __enter__(self):
+        import torch
+        self.outer = (_scope.dev, _scope.stream)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if _scope.dev != idx:
+            self.ctx = torch.cuda.device(idx)
+            self.ctx.__enter__()
+        _scope.dev = idx
+        _scope.stream = C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+        return self
+
+    def __exit__(self, *exc):
+        _scope.dev, _scope.stream = self.outer
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+class _Noop:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOOP = _Noop()
+
+
+def on_device(device):
+    """`with on_device(t.device):` around a library call: makes the device current (torch.cuda.device), unless an enclosing
+    launch_scope already did."""
+    import torch
+    idx = device.index if isinstance(device, torch.device) else device
+    if _scope.dev is not None and (idx is None or idx == _scope.dev):
+        return _NOOP
+    return torch.cuda.device(device)
+
+
 def stream_ptr():
+    if _scope.stream is not None:
+        return _scope.stream
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -853,6 +853,8 @@ class TDNN(Layer):
         w_lo = None
         if gemm == L.GEMM_F32:
             w = W.to(torch.float32)
+        elif gemm == L.GEMM_BF16X4:
+            w = ops.pair_encode(W.to(torch.float32))
         elif gemm == L.GEMM_F16X2:
             w = W.to(torch.float16)
             if opm is None or lo_keep is not None:       # (one pass: no residual plane at all)
@@ -912,7 +914,7 @@ class TDNN(Layer):
         d.act = _ACTS[a.lower() if isinstance(a, str) else a]
         d.gemm = gemm
         d.x_dtype = L.ktf_dtype(x_dtype)
-        d.w_dtype = {L.GEMM_F32: L.KTF_F32, L.GEMM_F16: L.KTF_F16, L.GEMM_F16X2: L.KTF_F16}.get(gemm, L.KTF_BF16)
+        d.w_dtype = {L.GEMM_F32: L.KTF_F32, L.GEMM_F16: L.KTF_F16, L.GEMM_F16X2: L.KTF_F16, L.GEMM_BF16X4: L.KTF_BF16P}.get(gemm, L.KTF_BF16)
         d.y_dtype = L.ktf_dtype(y_dtype)
         return d
 
@@ -941,15 +943,19 @@ class TDNN(Layer):
         return c
 
     def forward(self, x, lens=None, relu=False, bn=None, gemm=None, out_dtype=torch.float32, ldy=None, out=None,
-                out_lens=None, flags=0):
+                out_lens=None, flags=0, pair_in=False, pair_out=False):
         """Low-level launch used by call() and by the fused Sequential runner.
-        x: (B, T, ldx) fp32/bf16 with ldx >= round_up(D,32) (pad columns finite). Returns y (B, Tout, ldy)."""
+        x: (B, T, ldx) fp32/bf16 with ldx >= round_up(D,32) (pad columns finite). Returns y (B, Tout, ldy).
+        `pair_in` (gemm GEMM_BF16X4) / `pair_out` (GEMM_F32 or GEMM_BF16X4): the float32 tensor x / y holds KTF_BF16P pairs."""
         gemm = _GEMM[self.gemm] if gemm is None else gemm
+        if pair_in != (gemm == L.GEMM_BF16X4):
+            raise ValueError("KTF_GEMM_BF16X4 reads pairs, and only it does")
         w, w_lo, bias = self.device_weights(x.device, gemm)
         act = "relu" if relu else None
         if relu and self.activation not in (None, "linear"):
             raise ValueError("cannot fuse a ReLU after a TDNN that already has an activation")
-        d = self.desc(gemm, x.dtype, out_dtype, act=act if relu else None, flags=flags | self.kernelFlags)
+        d = self.desc(gemm, L.PAIR if pair_in else x.dtype, L.PAIR if pair_out else out_dtype, act=act if relu else None,
+                      flags=0 if pair_in else flags | self.kernelFlags)
         B, T = x.shape[0], x.shape[1]
         Tout = self.outputTimesteps(T)
         ldy = self.units if ldy is None else ldy

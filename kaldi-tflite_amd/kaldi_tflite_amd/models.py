@@ -164,6 +164,7 @@ class Sequential:
         self.mx_loader = False       # f16mx: True = the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles on the flat row space, eight
                                      # matrix + four loader waves, plane epilogue from registers); False = the 256 x 256 eight-wave kernel
                                      # (csrc/tdnn_mx.hip), which is 4-6 % faster on the 0008 shapes: the default
+        self.small_tile_pairs = True # batches below `min_tiles` of a reduced-precision model: bf16-pair small tiles instead of fp32 ones
         self.mx_slab = False         # f16mx, 256-row kernel: multi-context layers on activation slabs (csrc/tdnn_mxs.hip, KTF_TDNN_MX_SLAB)
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
@@ -233,14 +234,20 @@ class Sequential:
         256-row tiles (single utterances) cannot fill the chip on the 256-wide ring kernels -- the exact fp32 kernels have
         small-tile forms and are faster there (one 10 s utterance: 0.19 ms against 0.20 bf16 / 0.39 split-bf16); and a batch
         of utterances shorter than `min_frames` frames runs the tighter mode named by SHORT_MODE."""
+        return self._batch_route(B, T, mode)[0]
+
+    def _batch_route(self, B, T, mode=None):
+        """-> (batch_gemm, pairs). `pairs`: a batch of a reduced-precision model that is too small for the 256-row tiles runs its wide
+        layers on the bf16-pair small tiles (KTF_GEMM_BF16X4, csrc/tdnn_pair.hip) instead of the fp32 ones: the first layer (fp32
+        kernel) writes pairs, the layers behind it read and write pairs, the last one in front of the pooling writes fp32."""
         if mode is None:
             mode = self.gemm
             if T < self.min_frames.get(mode, 0):         # short utterances: the tighter mode (MIN_FRAMES)
                 mode = self.SHORT_MODE.get(mode, "f32")
         gemm = _GEMM[mode]
         if gemm != L.GEMM_F32 and B * ((T + 255) // 256) < self.min_tiles.get(mode, 0):
-            gemm = L.GEMM_F32
-        return gemm
+            return L.GEMM_F32, bool(self.small_tile_pairs)
+        return gemm, False
 
     def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0, one_pass_mean=None,
                         in_perm=None, defer_to=None):
@@ -299,7 +306,8 @@ class Sequential:
         self._ws.enter(dev)
         if (self._xbar or self._xvar) and self._calibrating is None and self._cal_sig != self.weights_signature():
             self._xbar, self._xvar = {}, {}      # the weights changed since calibrate(): its statistics describe another network
-        gemm = self.batch_gemm(x.shape[0], x.shape[1], mode=mode)
+        gemm, pairs = self._batch_route(x.shape[0], x.shape[1], mode=mode)
+        x_pair = False                                   # x holds KTF_BF16P pairs (in a float32 tensor)
         act_dtype = L.act_torch_dtype(gemm)
         tail_at = self._tail_step(steps) if defer_tail else -1
         self._deferred = None        # set by a pooling step whose consumer is the deferred tail
@@ -498,6 +506,36 @@ class Sequential:
                     continue
                 g = L.GEMM_F32 if pooled else l.effective_gemm(gemm, relu)
                 ydt = torch.float32 if (pooled or g != gemm) else act_dtype
+                # the pair route (small batches of a reduced-precision model): this layer reads pairs if its producer wrote them,
+                # and writes them if its consumer is a frame-level layer that can read them
+                pair_in, x_pair = x_pair, False
+                pair_ok = lambda t, r: t.activation in (None, "linear") or (t.activation == "relu" and not r)  # noqa: E731
+                pair_out = (pairs and not pooled and g == L.GEMM_F32 and pair_ok(l, relu) and nxt is not None and nxt[0] == "tdnn"
+                            and pair_ok(nxt[1], nxt[2]) and nxt[1].inputDim == l.units)
+                if pair_in:
+                    g = L.GEMM_BF16X4
+                    if can_pool:                         # [affine, relu, batchnorm] -> reducing StatsPooling inside the pair kernel's epilogue
+                        sp = nxt[1]
+                        B, T, _ = x.shape
+                        od = 2 * l.units if sp.includeStd else l.units
+                        slots = ops.tdnn_stats_slots(T, g) if self.deterministic else 0
+                        srows = ops.tdnn_slot_rows(g)
+                        sums = self._ws.get("sums", (B, max(slots, 1), 2, l.units), torch.float64, dev, padded=False)
+                        sbuf = self._ws.get("pooled", (B, ops.round_up(od, 32)), torch.float32, dev)
+                        if x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
+                            x = _padded_copy(x, torch.float32)
+                        w, _, bias = l.device_weights(dev, g)
+                        scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
+                        d = l.desc(g, L.PAIR, torch.float32, act="relu" if relu else None, flags=L.TDNN_DET_STATS if slots else 0)
+                        ops.tdnn_stats(x, lens, d, w, None, bias, scale, shift, sums, zero=not slots)
+                        if si + 2 == tail_at:            # the caller's fused tail finalizes the sums itself
+                            self._deferred = DeferredTail(steps[tail_at][1], B, l.units, sp.includeStd, sp.epsilon, sums=sums, slots=slots,
+                                                          lens=lens, T=T, slot_rows=srows)
+                        else:
+                            ops.stats_finalize(sums, lens, T, l.units, sp.includeStd, sp.epsilon, sbuf, slots=slots, slot_rows=srows)
+                        x = sbuf[:, :od].unsqueeze(0)
+                        lens, pooled, skip = None, True, True
+                        continue
                 if x.dtype != L.act_torch_dtype(g) or x.stride(2) != 1 or \
                         x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
                     x = _padded_copy(x, L.act_torch_dtype(g))
@@ -509,7 +547,9 @@ class Sequential:
                 if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
                     out_lens = torch.empty_like(lens)
                 sc_sh = bn.affine_device(dev) if bn is not None else None
-                l.forward(x, lens=lens, relu=relu, bn=sc_sh, gemm=g, out_dtype=ydt, ldy=ldy, out=ybuf, out_lens=out_lens)
+                l.forward(x, lens=lens, relu=relu, bn=sc_sh, gemm=g, out_dtype=ydt, ldy=ldy, out=ybuf, out_lens=out_lens,
+                          pair_in=pair_in, pair_out=pair_out)
+                x_pair = pair_out
                 if out_lens is not None:
                     lens = out_lens
                 x = ybuf[:, :, : l.units]
@@ -865,9 +905,10 @@ class XvectorExtractor:
                 w6, _, b6 = t.layer.device_weights(dev, L.GEMM_F32)
                 B = t.B
                 # utterances per workgroup: one while 64 workgroups per utterance still fill the chip, then groups (W is read once
-                # per group); a large batch also finalizes the pooled sums once (not once per unit slice): same arithmetic either way
+                # per group); a large batch, or one with many slots per utterance (each of the 64 unit slices would add them up again:
+                # 1.8 us per slot at B = 1), finalizes the pooled sums once in a launch of its own: same arithmetic either way
                 group = max(1, min(32, (B * 64) // 2048))
-                if t.sums is not None and B > 8:
+                if t.sums is not None and (B > 8 or t.slots > 4):
                     sbuf = self.xvec._ws.get("pooled", (B, ops.round_up((2 if t.include_std else 1) * t.D, 32)), torch.float32, dev)
                     ops.stats_finalize(t.sums, t.lens, t.T, t.D, t.include_std, t.eps, sbuf, slots=t.slots, slot_rows=t.slot_rows)
                     t.pooled, t.sums = sbuf, None
@@ -907,7 +948,10 @@ class XvectorExtractor:
         if hasattr(inputs, "shape") and len(inputs.shape) == 2 and inputs.shape[0] == 0:
             L.require_gpu()
             return torch.empty((0, self.ldaMat.shape[1]), dtype=torch.float32, device=ops.default_device())
-        y = self._extract(inputs)
+        L.require_gpu()
+        dev = inputs.device if (isinstance(inputs, torch.Tensor) and inputs.is_cuda) else ops.default_device()
+        with L.launch_scope(dev):                        # device + stream looked up once for the ~10 launches of the call
+            y = self._extract(inputs)
         return y.squeeze(0) if y.shape[0] == 1 else y
 
     call = __call__

@@ -231,7 +231,7 @@ def frontend(x, in_kind, cfg, tables, out_stage, n, B, T, seed=0, want_energy=Fa
     if out is None:
         out = torch.empty((B, T, last), dtype=torch.float32, device=x.device)
     energy = torch.empty((B, T), dtype=torch.float32, device=x.device) if want_energy else None
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = lib.ktf_frontend_f32(L.ptr(x), B, n, in_kind, C.byref(cfg), C.byref(tables.struct), out_stage, L.ptr(out),
                                   L.ptr(energy), C.c_uint64(seed & (2**64 - 1)), L.stream_ptr())
     L.check(rc, "ktf_frontend_f32")
@@ -242,7 +242,7 @@ def dct(x2d, dct_t, lifter_t, out_dim):
     lib = L.load()
     rows, in_dim = x2d.shape
     out = torch.empty((rows, out_dim), dtype=torch.float32, device=x2d.device)
-    with torch.cuda.device(x2d.device):
+    with L.on_device(x2d.device):
         rc = lib.ktf_dct_f32(L.ptr(x2d), rows, in_dim, out_dim, L.ptr(dct_t), L.ptr(lifter_t), L.ptr(out), L.stream_ptr())
     L.check(rc, "ktf_dct_f32")
     return out
@@ -252,7 +252,7 @@ def vad_mask(feats, cfg):
     lib = L.load()
     B, T, D = feats.shape
     mask = torch.empty((B, T), dtype=torch.float32, device=feats.device)
-    with torch.cuda.device(feats.device):
+    with L.on_device(feats.device):
         rc = lib.ktf_vad_mask_f32(L.ptr(feats), B, T, D, C.byref(cfg), L.ptr(mask), L.stream_ptr())
     L.check(rc, "ktf_vad_mask_f32")
     return mask
@@ -263,7 +263,7 @@ def vad_index(feats, cfg):
     B, T, D = feats.shape
     idx = torch.empty((B, T), dtype=torch.int32, device=feats.device)
     lens = torch.empty((B,), dtype=torch.int32, device=feats.device)
-    with torch.cuda.device(feats.device):
+    with L.on_device(feats.device):
         rc = lib.ktf_vad_index(L.ptr(feats), B, T, D, C.byref(cfg), L.ptr(idx), L.ptr(lens), L.stream_ptr())
     L.check(rc, "ktf_vad_index")
     return idx, lens
@@ -276,7 +276,7 @@ def cmvn(x, cfg, lens=None, ldo=None, want_lens=False):
     out = torch.empty((B, T, ldo), dtype=torch.float32, device=x.device)
     work = torch.empty((B * T * 2 * D + 2 * D,), dtype=torch.float32, device=x.device)
     out_lens = torch.empty((B,), dtype=torch.int32, device=x.device) if want_lens else None
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = lib.ktf_cmvn_f32(L.ptr(x), B, T, D, x.stride(1), L.ptr(lens), C.byref(cfg), L.ptr(out), ldo, L.ptr(out_lens),
                               L.ptr(work), L.stream_ptr())
     L.check(rc, "ktf_cmvn_f32")
@@ -287,7 +287,7 @@ def vad_cmvn(feats, vad_cfg, cmvn_cfg, out, lens, idx_work, work):
     lib = L.load()
     B, T, D = feats.shape
     dt = L.ktf_dtype(out.dtype)
-    with torch.cuda.device(feats.device):
+    with L.on_device(feats.device):
         rc = lib.ktf_vad_cmvn(L.ptr(feats), B, T, D, C.byref(vad_cfg), C.byref(cmvn_cfg), L.ptr(out), dt, out.stride(1),
                               L.ptr(lens), L.ptr(idx_work), L.ptr(work), L.stream_ptr())
     L.check(rc, "ktf_vad_cmvn")
@@ -302,7 +302,7 @@ def route_short(lens, min_frames, lens_main, lens_short, host_flag=None, seq=0):
     """lens -> (lens_main, lens_short) by voiced length (ktf_route_short); host_flag: pinned int32[2] CPU tensor that receives the number
     of short utterances and then `seq`."""
     lib = L.load()
-    with torch.cuda.device(lens.device):
+    with L.on_device(lens.device):
         rc = lib.ktf_route_short(L.ptr(lens), lens.shape[0], int(min_frames), L.ptr(lens_main), L.ptr(lens_short),
                                  host_flag.data_ptr() if host_flag is not None else None, int(seq), L.stream_ptr())
     L.check(rc, "ktf_route_short")
@@ -316,7 +316,7 @@ def tdnn(x, lens, desc, w, w_lo, bias, scale, shift, y, out_lens=None):
     """x (B,T,ldx) fp32/bf16, y (B,Tout,ldy) preallocated."""
     lib = L.load()
     B, T = x.shape[0], x.shape[1]
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = lib.ktf_tdnn(L.ptr(x), B, T, x.stride(1), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo), L.ptr(bias),
                           L.ptr(scale), L.ptr(shift), L.ptr(y), y.stride(1), L.ptr(out_lens), L.stream_ptr())
     L.check(rc, "ktf_tdnn")
@@ -331,6 +331,15 @@ def stats_slots(T, mx_flags=None):
     return int(L.load().ktf_mx_stats_slots(int(T), int(mx_flags)))
 
 
+def tdnn_stats_slots(T, gemm):
+    """Slots / rows per slot of ktf_tdnn_stats with KTF_TDNN_DET_STATS for a GEMM mode (KTF_GEMM_BF16X4: one per 64-row tile)."""
+    return int(L.load().ktf_tdnn_stats_slots(int(T), int(gemm)))
+
+
+def tdnn_slot_rows(gemm):
+    return int(L.load().ktf_tdnn_slot_rows(int(gemm)))
+
+
 def mx_slot_rows(mx_flags):
     return int(L.load().ktf_mx_slot_rows(int(mx_flags)))
 
@@ -340,7 +349,7 @@ def tdnn_stats(x, lens, desc, w, w_lo, bias, scale, shift, sums, zero=True):
     stores them per 128-row block into (B,slots,2,units) when desc.flags has TDNN_DET_STATS (zero=False then)."""
     lib = L.load()
     B, T = x.shape[0], x.shape[1]
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         if zero:
             sums.zero_()
         rc = lib.ktf_tdnn_stats(L.ptr(x), B, T, x.stride(1), L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo), L.ptr(bias),
@@ -356,7 +365,7 @@ def plda_score(test_tr, enroll_tr, psi):
     M = enroll_tr.shape[0]
     scores = torch.empty((N, M), dtype=test_tr.dtype, device=test_tr.device)
     fn = lib.ktf_plda_score_f64 if test_tr.dtype == torch.float64 else lib.ktf_plda_score_f32
-    with torch.cuda.device(test_tr.device):
+    with L.on_device(test_tr.device):
         rc = fn(L.ptr(test_tr), N, L.ptr(enroll_tr), M, dim, L.ptr(psi), L.ptr(scores), L.stream_ptr())
     L.check(rc, "ktf_plda_score")
     return scores
@@ -366,7 +375,7 @@ def split_bf16(src, D, planes):
     """fp32 (B,T,ld_src) rows -> planes (2,B,T,ld) bf16: hi = bf16(v), lo = bf16(v - hi); pad columns zero."""
     lib = L.load()
     rows = src.shape[0] * src.shape[1]
-    with torch.cuda.device(src.device):
+    with L.on_device(src.device):
         rc = lib.ktf_split_bf16(L.ptr(src), rows, D, src.stride(1), L.ptr(planes[0]), L.ptr(planes[1]), planes.shape[-1],
                                 L.stream_ptr())
     L.check(rc, "ktf_split_bf16")
@@ -384,7 +393,7 @@ def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_le
     """xp: (2,B,T,ldx) bf16 hi/lo planes, or one (B,T,ldx) half plane (F16X2). y: (B,Tout,ldy) 16-bit plane (+ y_lo) or fp32."""
     lib = L.load()
     hi, lo, B, T, ldx = _planes(xp)
-    with torch.cuda.device(xp.device):
+    with L.on_device(xp.device):
         rc = lib.ktf_tdnn_split(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(lens), C.byref(desc), L.ptr(w), L.ptr(w_lo),
                                 L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(y_lo), y.stride(1), L.ptr(out_lens),
                                 L.stream_ptr())
@@ -395,7 +404,7 @@ def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_le
 def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums, zero=True):
     lib = L.load()
     hi, lo, B, T, ldx = _planes(xp)
-    with torch.cuda.device(xp.device):
+    with L.on_device(xp.device):
         if zero:
             sums.zero_()
         rc = lib.ktf_tdnn_split_stats(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(lens), C.byref(desc), L.ptr(w),
@@ -408,7 +417,7 @@ def mx_planes(src, D, lens, planes):
     """fp32 (B,T,ld) rows -> the four KTF_GEMM_F16MX planes (mx.Planes); rows >= lens[b] are left unwritten."""
     lib = L.load()
     B, T = src.shape[0], src.shape[1]
-    with torch.cuda.device(src.device):
+    with L.on_device(src.device):
         rc = lib.ktf_mx_planes(L.ptr(src), B, T, D, src.stride(1), L.ptr(lens), L.ptr(planes.xh), L.ptr(planes.xl4), L.ptr(planes.x4),
                                L.ptr(planes.xs), L.stream_ptr())
     L.check(rc, "ktf_mx_planes")
@@ -420,7 +429,7 @@ def tdnn_mx(xp, lens, desc, wh, wq, bias, scale, shift, y):
     lib = L.load()
     B, T, _ = xp.shape
     planes = not isinstance(y, torch.Tensor)
-    with torch.cuda.device(xp.device):
+    with L.on_device(xp.device):
         rc = lib.ktf_tdnn_mx(L.ptr(xp.xh), L.ptr(xp.xl4), L.ptr(xp.x4), L.ptr(xp.xs), B, T, L.ptr(lens), C.byref(desc), L.ptr(wh),
                              L.ptr(wq), L.ptr(bias), L.ptr(scale), L.ptr(shift),
                              L.ptr(y.xh) if planes else None, L.ptr(y.xl4) if planes else None, L.ptr(y.x4) if planes else None,
@@ -432,7 +441,7 @@ def tdnn_mx(xp, lens, desc, wh, wq, bias, scale, shift, y):
 def tdnn_mx_stats(xp, lens, desc, wh, wq, bias, scale, shift, sums, zero=True):
     lib = L.load()
     B, T, _ = xp.shape
-    with torch.cuda.device(xp.device):
+    with L.on_device(xp.device):
         if zero:
             sums.zero_()
         rc = lib.ktf_tdnn_mx_stats(L.ptr(xp.xh), L.ptr(xp.xl4), L.ptr(xp.x4), L.ptr(xp.xs), B, T, L.ptr(lens), C.byref(desc),
@@ -445,7 +454,7 @@ def stats_finalize(sums, lens, T, D, include_std, eps, out, slots=0, slot_rows=1
     """sums (B,2,D) [slots == 0] or (B,slots,2,D) fp64 (one slot per `slot_rows` rows) -> out (B, ld) mean | std."""
     lib = L.load()
     B = sums.shape[0]
-    with torch.cuda.device(sums.device):
+    with L.on_device(sums.device):
         if slots:
             rc = lib.ktf_stats_finalize_slots(L.ptr(sums), slots, int(slot_rows), L.ptr(lens), T, B, D, int(include_std), eps, L.ptr(out),
                                               out.stride(0), L.stream_ptr())
@@ -461,7 +470,7 @@ def affine_act(x, act, scale=None, shift=None):
     D = x.shape[-1]
     rows = x.numel() // D
     y = torch.empty_like(x)
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = lib.ktf_affine_act_f32(L.ptr(x), rows, D, act, L.ptr(scale), L.ptr(shift), L.ptr(y), L.stream_ptr())
     L.check(rc, "ktf_affine_act_f32")
     return y
@@ -472,10 +481,28 @@ def activation_(y, lens, act, scale=None, shift=None):
     lib = L.load()
     B, T, D = y.shape
     assert y.dtype == torch.float32 and y.stride(2) == 1 and y.stride(0) == T * y.stride(1)
-    with torch.cuda.device(y.device):
+    with L.on_device(y.device):
         rc = lib.ktf_activation_f32(L.ptr(y), B, T, D, y.stride(1), L.ptr(lens), act, L.ptr(scale), L.ptr(shift), L.stream_ptr())
     L.check(rc, "ktf_activation_f32")
     return y
+
+
+def pair_encode(t):
+    """fp32 tensor -> the KTF_BF16P pairs of its values, as a float32 tensor of the same shape (raw bits: bits 0-15 = bf16(v), round
+    to nearest even, bits 16-31 = bf16(v - bf16(v)))."""
+    t = t.to(torch.float32).contiguous()
+    hi = t.to(torch.bfloat16)
+    lo = (t - hi.to(torch.float32)).to(torch.bfloat16)
+    bits = (hi.view(torch.int16).to(torch.int32) & 0xFFFF) | (lo.view(torch.int16).to(torch.int32) << 16)
+    return bits.view(torch.float32)
+
+
+def pair_decode(t):
+    """The values a KTF_BF16P tensor holds (hi + lo), fp32."""
+    bits = t.contiguous().view(torch.int32)
+    hi = (bits << 16).view(torch.float32)
+    lo = (bits & ~0xFFFF).view(torch.float32)
+    return hi + lo
 
 
 def convert_pad(src, D, dst):
@@ -483,7 +510,7 @@ def convert_pad(src, D, dst):
     lib = L.load()
     rows = src.numel() // src.shape[-1]
     sd, dd = L.ktf_dtype(src.dtype), L.ktf_dtype(dst.dtype)
-    with torch.cuda.device(src.device):
+    with L.on_device(src.device):
         rc = lib.ktf_convert_pad(L.ptr(src), sd, rows, D, src.shape[-1], L.ptr(dst), dd, dst.shape[-1], L.stream_ptr())
     L.check(rc, "ktf_convert_pad")
     return dst
@@ -494,7 +521,7 @@ def stats_pool(x, D, lens, input_period, include_std, eps, out):
     lib = L.load()
     B, T = x.shape[0], x.shape[1]
     dt = L.ktf_dtype(x.dtype)
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = lib.ktf_stats_pool(L.ptr(x), dt, B, T, D, x.stride(1), L.ptr(lens), input_period, int(include_std), eps,
                                 L.ptr(out), out.stride(0), L.stream_ptr())
     L.check(rc, "ktf_stats_pool")
@@ -505,7 +532,7 @@ def stats_pool_windowed(x, left, right, input_period, output_period, start, T_ou
     lib = L.load()
     B, T, D = x.shape
     out = torch.empty((B, T_out, 2 * D if include_std else D), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = lib.ktf_stats_pool_windowed_f32(L.ptr(x), B, T, D, left, right, input_period, output_period, start, T_out,
                                              int(include_std), eps, L.ptr(out), L.stream_ptr())
     L.check(rc, "ktf_stats_pool_windowed_f32")
@@ -518,7 +545,7 @@ def xvec_post(x, mean, A, off, out=None):
     out_dim = A.shape[1]
     if out is None:
         out = torch.empty((B, out_dim), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = lib.ktf_xvec_post_f32(L.ptr(x), B, in_dim, out_dim, L.ptr(mean), L.ptr(A), L.ptr(off), L.ptr(out), L.stream_ptr())
     L.check(rc, "ktf_xvec_post_f32")
     return out
@@ -530,7 +557,7 @@ def xvec_tail(pooled, sums, slots, lens, T, D, include_std, eps, W, bias, units,
     lib = L.load()
     B = out.shape[0]
     src = pooled if pooled is not None else sums
-    with torch.cuda.device(src.device):
+    with L.on_device(src.device):
         rc = lib.ktf_xvec_tail_f32(L.ptr(pooled), pooled.stride(0) if pooled is not None else 0, L.ptr(sums), int(slots), int(slot_rows), L.ptr(lens), int(T), B,
                                    int(D), int(include_std), float(eps), L.ptr(W), W.stride(0), L.ptr(bias), int(units), L.ptr(mean), L.ptr(A),
                                    L.ptr(off), A.shape[1], L.ptr(partial), L.ptr(counters), L.ptr(out), L.ptr(h_out), int(group),
@@ -545,7 +572,7 @@ def plda(x, A, offset, psi, normalize_length, simple_length_norm, want_scores=Tr
     tr = torch.empty_like(x)
     scores = torch.empty((B, B), dtype=x.dtype, device=x.device) if want_scores else None
     fn = lib.ktf_plda_f64 if x.dtype == torch.float64 else lib.ktf_plda_f32
-    with torch.cuda.device(x.device):
+    with L.on_device(x.device):
         rc = fn(L.ptr(x), B, dim, L.ptr(A), L.ptr(offset), L.ptr(psi), int(normalize_length), int(simple_length_norm),
                 L.ptr(tr), L.ptr(scores), L.stream_ptr())
     L.check(rc, "ktf_plda")

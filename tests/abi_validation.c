@@ -39,6 +39,16 @@ int main(void) {
     t.gemm = KTF_GEMM_F32; t.act = KTF_ACT_SOFTMAX + 1; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32;
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
     t.act = KTF_ACT_NONE;
+    t.gemm = KTF_GEMM_BF16X4;                                                                          /* pairs in, pairs or fp32 out */
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));       /* fp32 operands */
+    t.x_dtype = t.w_dtype = KTF_BF16P; t.y_dtype = KTF_BF16;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));       /* 16-bit output */
+    t.y_dtype = KTF_F32;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, f, 8, NULL, NULL));          /* a residual plane */
+    EXPECT_EINVAL(ktf_tdnn_stats(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, d, NULL));          /* no fused pooling */
+    t.gemm = KTF_GEMM_BF16; t.x_dtype = t.w_dtype = KTF_BF16; t.y_dtype = KTF_BF16P;
+    EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));       /* pairs from a 16-bit kernel */
+    t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32;
     t.gemm = KTF_GEMM_F16MX;
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, NULL, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 8, NULL));     /* no output */

@@ -91,24 +91,25 @@ def test_calibrated_f16x2_runs_one_pass_in_front_of_the_pooling():
 
 
 def test_single_utterance_dispatch():
-    """One 10 s utterance: every reduced mode hands it to the exact fp32 small-tile kernels (Sequential.min_tiles)."""
+    """One 10 s utterance: the 256-row tiles cannot fill the chip (Sequential.min_tiles). "f32" runs the exact fp32 small-tile kernels;
+    the reduced modes run the bf16-pair small tiles (KTF_GEMM_BF16X4) behind an fp32 first layer that writes pairs, or -- with
+    `small_tile_pairs` off -- the fp32 kernels throughout."""
     S = ktf.models.Sequential
     old = S.MIN_TILES
     S.MIN_TILES = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
     try:
         w = synth.make_weights(seed=4321)
         wav = synth.make_wav(1, 160000, seed=3)
-        want = None
-        for gemm in ("f32", "bf16x3", "f16mx"):
+        for gemm, pairs in (("f32", True), ("bf16x3", True), ("f16mx", True), ("f16mx", False)):
             m1 = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm=gemm)
             m1.fuse_tail = False
+            m1.xvec.small_tile_pairs = pairs
             got = trace(m1, wav)
             kernels = [k for _, k in got]
             assert kernels[0] == "tdnn_f32s_kernel<32, 64>"                     # 30 -> 32 input columns: K-step 32
-            assert all(k.startswith("tdnn_f32s_kernel<64, ") for k in kernels[1:5]), got
+            family = "tdnn_x4s_kernel<64, " if (pairs and gemm != "f32") else "tdnn_f32s_kernel<64, "
+            assert all(k.startswith(family) for k in kernels[1:5]), got
             assert kernels[5] == "tdnn_f32_rowvec_kernel"
-            want = want or kernels
-            assert kernels == want
     finally:
         S.MIN_TILES = old
 

@@ -750,8 +750,9 @@ def test_bf16x3_split_planes_equal_fp32_activation_path():
         assert np.abs(a[i, :n] - want).max() < 2e-5, np.abs(a[i, :n] - want).max()
 
 
-def test_bf16x3_tiny_batches_run_on_the_fp32_kernels():
-    # a single utterance is a handful of 256-row tiles: the split-bf16 model hands it to the exact fp32 kernels
+def test_bf16x3_tiny_batches_run_on_small_tiles():
+    # a single utterance is a handful of 256-row tiles: the split-bf16 model hands it to the small-tile kernels -- the bf16-pair
+    # ones (fp32-grade, not bitwise fp32), or with `small_tile_pairs` off the exact fp32 ones
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
     wav = synth.make_wav(1, 16000 * 3, seed=8)
@@ -759,9 +760,12 @@ def test_bf16x3_tiny_batches_run_on_the_fp32_kernels():
     f32 = synth.build_extractor(ktf, cfg, w, gemm="f32")
     forced = host(x3(dev(wav)))
     x3.xvec.min_tiles = {"bf16x3": 32}
+    pairs = host(x3(dev(wav)))
+    x3.xvec.small_tile_pairs = False
     routed = host(x3(dev(wav)))
     exact = host(f32(dev(wav)))
     assert np.array_equal(routed, exact)
+    assert not np.array_equal(pairs, exact) and np.abs(pairs - exact).max() < 2e-5
     assert not np.array_equal(forced, exact) and np.abs(forced - exact).max() < 1e-4
 
 

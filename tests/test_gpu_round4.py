@@ -70,3 +70,131 @@ def test_wide_lda_takes_the_three_launch_tail():
         assert np.abs(got.cpu().numpy() - want).max() <= 1e-4
     narrow = synth.build_extractor(ktf, cfg, synth.make_weights(seed=5), gemm="f32")
     assert narrow._tail_fusable()
+
+
+# ----------------------------------------------------------------------------- bf16-pair small tiles (KTF_GEMM_BF16X4)
+def _pair_case(rng, B, T, D, U, ctx, sub, pad, relu, lens=None):
+    from kaldi_tflite_amd import ops
+    x = rng.standard_normal((B, T, D)).astype(np.float32) * 3.0
+    W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+    b = rng.standard_normal(U).astype(np.float32)
+    t = ktf.layers.TDNN(U, context=list(ctx), subsampling_factor=sub, padding=pad, name="p")
+    t.build(x.shape)
+    t.set_weights([W, b])
+    Dp = ops.round_up(D, 32)
+    xp = torch.zeros((B, T, Dp), device="cuda")
+    xp[:, :, :D] = torch.as_tensor(x, device="cuda")
+    return t, x, W, b, xp
+
+
+@pytest.mark.parametrize("case", [
+    (1, 998, 512, 512, [-2, 0, 2], 1, "SAME", True),          # tdnn2 of one utterance: 64 x 32 tiles
+    (1, 998, 512, 1500, [0], 1, "SAME", True),                # tdnn5: 64 x 96 tiles
+    (3, 200, 512, 512, [0], 1, "SAME", False),                # 64 x 64 tiles
+    (2, 141, 40, 33, [-3, 1], 2, "VALID", True),              # din_pad 64; VALID + subsampling; pad units
+    (2, 90, 96, 200, [-1, 0, 1], 1, "SAME", False),           # din_pad 96: K-step 32
+])
+def test_pair_kernel_vs_oracle(case):
+    """ktf_tdnn with KTF_GEMM_BF16X4: operands as bf16 pairs (16 mantissa bits), all four partial products, fp32 accumulation:
+    against the fp64 oracle ON THE SAME pair-rounded operands the error is fp32 summation noise; against the exact operands it is
+    the 2^-17 of the split. Ragged lengths, VALID padding, subsampling; rows beyond an utterance's output stay untouched; a pair
+    output decodes to the fp32 output within 2^-17."""
+    from kaldi_tflite_amd import ops, _lib as L
+    from oracle import ktf_oracle as O
+    rng = np.random.default_rng(77)
+    B, T, D, U, ctx, sub, pad, relu = case
+    t, x, W, b, xp = _pair_case(rng, *case)
+    lens = [T] + [max(1, T // 3)] * (B - 1)
+    dl = torch.as_tensor(np.array(lens, np.int32), device="cuda")
+    Tout = t.outputTimesteps(T)
+    sc = rng.uniform(0.5, 2.0, U).astype(np.float32)
+    sh = rng.uniform(-1.0, 1.0, U).astype(np.float32)
+    bn = (torch.as_tensor(sc, device="cuda"), torch.as_tensor(sh, device="cuda"))
+    pairs = ops.pair_encode(xp)
+    out = torch.full((B, Tout, U), 7.0, device="cuda")
+    out_lens = torch.zeros(B, dtype=torch.int32, device="cuda")
+    t.forward(pairs, lens=dl, relu=relu, bn=bn, gemm=L.GEMM_BF16X4, out=out, out_lens=out_lens, pair_in=True)
+    assert ops.last_kernel().startswith("tdnn_x4s_kernel")
+    got = out.cpu().numpy()
+    xr = ops.pair_decode(pairs).cpu().numpy()[:, :, :D].astype(np.float64)
+    Wr = ops.pair_decode(ops.pair_encode(torch.as_tensor(W))).numpy().astype(np.float64)
+    for bi in range(B):
+        want_r = O.tdnn(xr[bi:bi + 1, : lens[bi]], Wr, b, ctx, sub, pad, "relu" if relu else None, dtype=np.float64)[0] * sc + sh
+        want_x = O.tdnn(x[bi:bi + 1, : lens[bi]], W, b, ctx, sub, pad, "relu" if relu else None, dtype=np.float64)[0] * sc + sh
+        n = want_r.shape[0]
+        assert int(out_lens[bi]) == n
+        scale = max(1.0, np.abs(want_x).max(initial=0.0))
+        assert np.abs(got[bi, :n] - want_r).max(initial=0.0) <= 3e-6 * scale, "kernel != its own arithmetic"
+        assert np.abs(got[bi, :n] - want_x).max(initial=0.0) <= 4e-5 * scale
+        assert (got[bi, n:] == 7.0).all()
+    # pair output of the pair kernel and of the fp32 kernel
+    outp = torch.zeros((B, Tout, U), device="cuda")
+    t.forward(pairs, lens=dl, relu=relu, bn=bn, gemm=L.GEMM_BF16X4, out=outp, pair_in=True, pair_out=True)
+    dec = ops.pair_decode(outp).cpu().numpy()
+    out32 = torch.zeros((B, Tout, U), device="cuda")
+    t.forward(xp, lens=dl, relu=relu, bn=bn, gemm=L.GEMM_F32, out=out32)
+    outp32 = torch.zeros((B, Tout, U), device="cuda")
+    t.forward(xp, lens=dl, relu=relu, bn=bn, gemm=L.GEMM_F32, out=outp32, pair_out=True)
+    dec32 = ops.pair_decode(outp32).cpu().numpy()
+    ref32 = out32.cpu().numpy()
+    for bi in range(B):
+        n = int(out_lens[bi])
+        assert np.abs(dec[bi, :n] - got[bi, :n]).max(initial=0.0) <= 2.0 ** -16 * max(1.0, np.abs(got[bi, :n]).max(initial=0.0))
+        assert np.abs(dec32[bi, :n] - ref32[bi, :n]).max(initial=0.0) <= 2.0 ** -16 * max(1.0, np.abs(ref32[bi, :n]).max(initial=0.0))
+
+
+@pytest.mark.parametrize("units,ctx", [(1500, [0]), (512, [-2, 0, 2]), (200, [0])])
+def test_pair_kernel_fused_pooling(units, ctx):
+    """ktf_tdnn_stats with KTF_GEMM_BF16X4: fp64 column sums per 64-row tile (KTF_TDNN_DET_STATS: ktf_tdnn_stats_slots slots of
+    ktf_tdnn_slot_rows rows) or by atomics, finalized to mean | std; against the same layer written out and pooled on the host."""
+    from kaldi_tflite_amd import ops, _lib as L
+    rng = np.random.default_rng(78)
+    B, T, D = 3, 300, 512
+    t, x, W, b, xp = _pair_case(rng, B, T, D, units, ctx, 1, "SAME", True)
+    lens = [300, 129, 64]
+    dl = torch.as_tensor(np.array(lens, np.int32), device="cuda")
+    sc = rng.uniform(0.5, 2.0, units).astype(np.float32)
+    sh = rng.uniform(-1.0, 1.0, units).astype(np.float32)
+    bn = (torch.as_tensor(sc, device="cuda"), torch.as_tensor(sh, device="cuda"))
+    pairs = ops.pair_encode(xp)
+    rows = torch.zeros((B, T, units), device="cuda")
+    t.forward(pairs, lens=dl, relu=True, bn=bn, gemm=L.GEMM_BF16X4, out=rows, pair_in=True)
+    y = rows.cpu().numpy().astype(np.float64)
+    w, _, bias = t.device_weights(torch.device("cuda"), L.GEMM_BF16X4)
+    assert ops.tdnn_slot_rows(L.GEMM_BF16X4) == 64 and ops.tdnn_stats_slots(T, L.GEMM_BF16X4) == 5
+    for det in (True, False):
+        slots = ops.tdnn_stats_slots(T, L.GEMM_BF16X4) if det else 0
+        d = t.desc(L.GEMM_BF16X4, L.PAIR, torch.float32, act="relu", flags=L.TDNN_DET_STATS if det else 0)
+        sums = torch.full((B, max(slots, 1), 2, units), 3.0, dtype=torch.float64, device="cuda")
+        ops.tdnn_stats(pairs, dl, d, w, None, bias, bn[0], bn[1], sums, zero=not det)
+        assert ops.last_kernel().startswith("tdnn_x4s_kernel")
+        out = torch.zeros((B, 2 * units), device="cuda")
+        ops.stats_finalize(sums, dl, T, units, True, 1e-10, out, slots=slots, slot_rows=64)
+        got = out.cpu().numpy()
+        for bi in range(B):
+            v = y[bi, : lens[bi]]
+            want = np.concatenate([v.mean(0), np.sqrt(np.maximum((v * v).mean(0) - v.mean(0) ** 2, 0) + 1e-10)])
+            assert np.abs(got[bi] - want).max() <= 2e-6 * max(1.0, np.abs(want).max()), (det, bi)
+
+
+@pytest.mark.parametrize("gemm", ["f16mx", "bf16x3", "bf16"])
+def test_small_batches_on_the_pair_route_vs_oracle(gemm):
+    """Batches below Sequential.min_tiles of every reduced mode: x-vectors through the pair route against the fp64 oracle (the bar
+    of the compliant modes: 1e-4; measured ~1e-5), for one utterance and for a ragged handful, and the route switched off."""
+    from oracle import ktf_oracle as O
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321)
+    wav = np.concatenate([synth.make_wav(1, 160000, seed=3), synth.make_wav(2, 160000, seed=5, ragged=True)], 0)
+    want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
+    assert mdl.xvec.min_tiles.get(gemm, 0) > 3
+    for sl in (slice(0, 1), slice(0, 3)):
+        if sl.stop * 4 >= mdl.xvec.min_tiles[gemm]:        # (10 s = four 256-row tiles per utterance: "bf16" fills the chip from 6 tiles on)
+            continue
+        got = mdl(torch.as_tensor(wav[sl], device="cuda")).cpu().numpy()
+        err = np.abs(got - want[sl]).max()
+        print(f"pair route, {gemm}, batch {sl.stop}: max-abs dev vs fp64 oracle {err:.2e}")
+        assert err <= 3e-5
+    mdl.xvec.small_tile_pairs = False
+    got = mdl(torch.as_tensor(wav[:1], device="cuda")).cpu().numpy()
+    assert np.abs(got - want[:1]).max() <= 2e-5
