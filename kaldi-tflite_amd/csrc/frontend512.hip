@@ -126,10 +126,14 @@ __device__ __forceinline__ void transpose4(float2 (&r)[4], int lane) {
     swap_step<BL>(r[2].x, r[3].x, lane); swap_step<BL>(r[2].y, r[3].y, lane);
 }
 
-// Dither (windowing.py:182-183: x += N(0,1) * dither): counter-based Philox4x32-10 keyed by `seed`, counter (frame, lane group);
-// ONE Philox call gives four uniform words = two Box-Muller pairs = FOUR Gaussians (the generic kernel in frontend.hip spends one
-// call and one log / sqrt / cos per sample: 1024 x 998 frames x 400 samples of that cost 3.5 ms per step, four times this).
-__device__ __forceinline__ void gauss_noise5x4(uint64_t seed, uint64_t row, uint32_t i, float (&g)[4]) {
+// Dither (windowing.py:182-183: x += N(0,1) * dither): counter-based Philox4x32-10 keyed by `seed`, counter (frame, lane). ONE call
+// per lane and frame: its four 32-bit words are eight 16-bit uniforms = four Box-Muller pairs = the EIGHT Gaussians of the lane's eight
+// samples (radius from v_log_f32 / v_sqrt_f32, angle straight into v_sin_f32 / v_cos_f32, whose argument is in revolutions). 16-bit
+// uniforms bound the noise at 4.85 sigma in steps of <= 3e-5 sigma -- dither, not a Monte-Carlo source (Kaldi's own RandGauss draws from
+// rand()). The 32-bit multiplies of Philox run at a quarter of the vector rate, so halving the calls is what counts: two calls and the
+// exact sinpif / cospif took 1.2 ms per 1024 x 998 frames, this form takes half (the generic kernel in frontend.hip still spends one
+// call and one log / sqrt / cos per sample).
+__device__ __forceinline__ void gauss_noise8(uint64_t seed, uint64_t row, uint32_t i, float (&g)[8]) {
     uint32_t c0 = (uint32_t)row, c1 = (uint32_t)(row >> 32), c2 = i, c3 = 0x9E3779B9u;
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -140,15 +144,15 @@ __device__ __forceinline__ void gauss_noise5x4(uint64_t seed, uint64_t row, uint
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    const float u1 = ((float)(c0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u3 = ((float)(c2 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u4 = ((float)(c3 >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float ra = sqrtf(-2.0f * __logf(u1)), rb = sqrtf(-2.0f * __logf(u3));
-    g[0] = ra * cospif(2.0f * u2);
-    g[1] = ra * sinpif(2.0f * u2);
-    g[2] = rb * cospif(2.0f * u4);
-    g[3] = rb * sinpif(2.0f * u4);
+    const uint32_t c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float u1 = fmaf((float)(c[k] & 0xffffu), 1.0f / 65536.0f, 0.5f / 65536.0f);
+        const float u2 = fmaf((float)(c[k] >> 16), 1.0f / 65536.0f, 0.5f / 65536.0f);
+        const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));      // sqrt(-2 ln u1), v_log_f32 = log2
+        g[2 * k] = ra * __builtin_amdgcn_cosf(u2);                                                        // cos(2 pi u2)
+        g[2 * k + 1] = ra * __builtin_amdgcn_sinf(u2);
+    }
 }
 
 #define F5_WAVE_SYNC()                           \
@@ -316,16 +320,11 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         // ---- Windowing.call (windowing.py:180-209)
         if (in_kind != KTF_IN_WINDOWED) {
             if (DITHER) {
+                float g[NV];                                          // the eight samples of this lane from one Philox call
+                gauss_noise8(seed, (uint64_t)row, (uint32_t)lane, g);
 #pragma unroll
-                for (int q = 0; q < (NV + 3) / 4; ++q) {              // four samples of this lane per Philox call
-                    float g[4];
-                    gauss_noise5x4(seed, (uint64_t)row, (uint32_t)(lane + KTF_WAVE * q), g);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int j = 4 * q + e;
-                        if (j < NV && lane + KTF_WAVE * j < M) v[j] += g[e] * cfg.dither;
-                    }
-                }
+                for (int j = 0; j < NV; ++j)
+                    if (lane + KTF_WAVE * j < M) v[j] += g[j] * cfg.dither;
             }
             if (cfg.remove_dc) {
                 float s = 0.0f;

@@ -407,7 +407,7 @@ class MFCC(Layer):
             raise ValueError("num_mfccs must be <= num_mels")
         self.eps = float(epsilon)
         self.batchAxis, self.frameAxis, self.sampleAxis = 0, -2, -1
-        self.lifters = ops.lifter_coeffs(self.numMfccs, self.cepstralLifter) if self.numMfccs > 1 else None
+        self.lifters = ops.lifter_coeffs(self.numMfccs, self.cepstralLifter) if (self.numMfccs > 1 and self.cepstralLifter > 1) else None
         self.windowing = Windowing(window_type=window_type, dither=dither, remove_dc_offset=remove_dc_offset,
                                    preemphasis_coefficient=preemphasis_coefficient, raw_energy=raw_energy,
                                    return_energy=use_energy, energy_floor=energy_floor, epsilon=epsilon)

@@ -143,7 +143,8 @@ class Sequential:
     # the utterance shrinks (measured on speech windows with BatchNorm statistics that are the network's own, tests/test_gpu_margin.py:
     # 10 s 2-5e-5, 5 s 5-6.5e-5, 3 s 6-7.5e-5, 1.5 s up to 1.2e-4 -- outside the 1e-4 tolerance); below 4 s the split-bf16 kernels
     # (1.5e-5) take the batch, and XvectorExtractor applies the same rule per utterance on the device (route_short_utterances).
-    MIN_TILES = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
+    MIN_TILES = {"bf16": 12, "f16": 12, "bf16x3": 32, "f16x2": 20, "f16mx": 20}      # (tools/small_batch_crossover.py, 10 s utterances =
+                                                                                     # 4 tiles each: bf16 from 3, f16mx from 5, bf16x3 from 8)
     MIN_FRAMES = {"f16mx": 400}
     SHORT_MODE = {"f16mx": "bf16x3"}
 

@@ -146,6 +146,31 @@ def test_windowing_dither_statistics():
     assert not np.array_equal(b, c)         # fresh noise on every call
 
 
+def test_dither_of_the_fused_front_end_is_white_gaussian_noise():
+    """The register-resident front-end (nfft 512: the shipped 25 ms / 16 kHz frames) draws its dither from ONE Philox call per lane and
+    frame (eight 16-bit uniforms -> four Box-Muller pairs). Checked through what the fused kernel returns, on silence + N(0, 1) dither
+    with a rectangular window: the frame energy sum g^2 over 400 samples has mean 400 and variance 800 (second and fourth moments of
+    the samples), and the mel energies of the power spectrum are 400 x the filter's weight sum (white: no correlation between samples)."""
+    wav = np.zeros((8, 160000), np.float32)
+    base = dict(num_mfccs=23, num_mels=23, cepstral_lifter=0, sample_frequency=16000.0, window_type="rectangular", dither=1.0,
+                remove_dc_offset=False, preemphasis_coefficient=0.0, raw_energy=True, energy_floor=0.0, epsilon=1e-10)
+    frames = Ls.Framing()(dev(wav))
+    assert frames.shape[-1] == 400
+    e = np.exp(host(Ls.MFCC(use_energy=True, use_log_fbank=True, **base)(frames))[..., 0].astype(np.float64)).reshape(-1)
+    n = e.size
+    assert abs(e.mean() - 400.0) < 5 * np.sqrt(800.0 / n), e.mean()
+    assert abs(e.var() - 800.0) < 60.0, e.var()
+    c = host(Ls.MFCC(use_energy=False, use_log_fbank=False, **base)(frames)).astype(np.float64).reshape(-1, 23)
+    mel = c @ np.linalg.inv(O.dct_matrix(23, 23))
+    _, bank = O.mel_bank(400, 23, 16000.0, 0.0, 20.0)
+    bank = np.asarray(bank, np.float64)
+    wsum = bank.sum(axis=0 if bank.shape[0] != 23 else 1)
+    got = mel.mean(0) / (400.0 * wsum)
+    assert np.abs(got - 1.0).max() < 0.02, got
+    # adjacent frames and adjacent lanes are independent: the energies of consecutive frames do not correlate
+    assert abs(np.corrcoef(e[:-1], e[1:])[0, 1]) < 0.05
+
+
 # ----------------------------------------------------------------------------- a3-a5 FilterBank / MFCC vs Kaldi goldens
 def test_fbank_goldens():
     for name in G.fbank_case_names():
