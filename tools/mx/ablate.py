@@ -8,6 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CS = os.path.join(ROOT, "kaldi-tflite_amd", "csrc")
 src = open(os.path.join(CS, "tdnn_mx.hip")).read()
 
+
+def _product_objects():
+    """The object files of libktf_hip.so (csrc/Makefile: SRCS), built by `make` beforehand."""
+    import re
+    srcs = re.search(r"^SRCS := (.*)$", open(os.path.join(CS, "Makefile")).read(), re.M).group(1).split()
+    return [f[:-4] + ".o" for f in srcs]
+
 def rep(s, a, b, count=1):
     assert s.count(a) >= 1, a
     return s.replace(a, b) if count == 0 else s.replace(a, b, count)
@@ -105,8 +112,62 @@ V["dma_only_stage"] = lambda s: V["no_side_dma"](V["no_mfma"](s))
 V["dma_only_sides"] = lambda s: V["no_f16_dma"](V["no_mfma"](s))
 V["dma_only_none"] = lambda s: V["no_dma"](V["no_mfma"](s))
 
+
+
+# A/B (correct results): the half-stage DMAs of K-step ks + 1 are all issued by ONE wave of each SIMD pair (waves w, w ^ 4) -- the pair
+# takes turns K-step by K-step -- so that while one wave sits in vector-memory issue its partner has the matrix pipe to itself
+def _alt_stage(s, sides=False):
+    s = rep(s, "    MX_DMA_F16(0, 2) MX_DMA_F16(0, 3) MX_DMA_F16(0, 0) MX_DMA_F16(0, 1)",
+            """#define MX_DMA_F16P(ks_, n_)                                                                                           \
+    {                                                                                                                  \
+        unsigned char* st_ = rsm + ((ks_) & 1) * MX_STAGE + (wave ^ 4) * 1024;                                         \
+        if ((n_) < 2) {                                                                                                \
+            int r_ = a_row[(n_) & 1] + ((wave & 4) ? -64 : 64) + f_off;                                                \
+            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
+            const unsigned vo_ = (f_base + (unsigned)r_) * 64u + a_cb[(n_) & 1];                                       \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + ((n_) & 1) * 8192), 16, 0, 0); \
+        } else {                                                                                                       \
+            const unsigned vo_ = (unsigned)(ks_) * (unsigned)MX_TILE + (unsigned)(((n_) & 1) * 512 + (tid ^ 256)) * 16u; \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + MX_TILE + ((n_) & 1) * 8192), 16, 0, 0); \
+        }                                                                                                              \
+    }
+    MX_DMA_F16(0, 2) MX_DMA_F16(0, 3) MX_DMA_F16(0, 0) MX_DMA_F16(0, 1)""")
+    s = rep(s, """                if (next) {
+                    if (i == 0) MX_DMA_F16(ks + 1, 0)
+                    if (i == 1) { MX_DMA_F16(ks + 1, 1) MX_F_ADV(ks + 2) }
+                    if (i == 2) MX_DMA_F16(ks + 1, 2)
+                    if (i == 3) MX_DMA_F16(ks + 1, 3)
+                }""", """                if (next) {
+                    const bool mine = ((wave >> 2) & 1) == (j & 1);
+                    if (mine) {
+                        if (i == 0) { MX_DMA_F16(ks + 1, 0) MX_DMA_F16P(ks + 1, 0) }
+                        if (i == 1) { MX_DMA_F16(ks + 1, 1) MX_DMA_F16P(ks + 1, 1) }
+                        if (i == 2) { MX_DMA_F16(ks + 1, 2) MX_DMA_F16P(ks + 1, 2) }
+                        if (i == 3) { MX_DMA_F16(ks + 1, 3) MX_DMA_F16P(ks + 1, 3) }
+                    }
+                    if (i == 1) MX_F_ADV(ks + 2)
+                }""")
+    # the counted waits assumed every wave has the same DMAs in flight: wait for everything but this super-step's sides as before
+    # (a wave that issued no stage has only side DMAs outstanding; vmcnt(6) / vmcnt(0) still cover what it must wait for)
+    return s
+
+
+V["alt_stage"] = _alt_stage
+# ... spread over the whole K-step of the issuing wave (eight DMAs, one per row block) instead of two per row block in its first half
+V["alt_stage_spread"] = lambda s: rep(_alt_stage(s), """                        if (i == 0) { MX_DMA_F16(ks + 1, 0) MX_DMA_F16P(ks + 1, 0) }
+                        if (i == 1) { MX_DMA_F16(ks + 1, 1) MX_DMA_F16P(ks + 1, 1) }
+                        if (i == 2) { MX_DMA_F16(ks + 1, 2) MX_DMA_F16P(ks + 1, 2) }
+                        if (i == 3) { MX_DMA_F16(ks + 1, 3) MX_DMA_F16P(ks + 1, 3) }""", """                        if (i == 0) MX_DMA_F16(ks + 1, 0)
+                        if (i == 1) MX_DMA_F16P(ks + 1, 0)
+                        if (i == 2) MX_DMA_F16(ks + 1, 1)
+                        if (i == 3) MX_DMA_F16P(ks + 1, 1)
+                        if (i == 4) MX_DMA_F16(ks + 1, 2)
+                        if (i == 5) MX_DMA_F16P(ks + 1, 2)
+                        if (i == 6) MX_DMA_F16(ks + 1, 3)
+                        if (i == 7) MX_DMA_F16P(ks + 1, 3)""")
+
 names = sys.argv[1:] or list(V)
-objs = [o for o in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "tdnn_mxl.o", "tdnn_mxs.o", "pool_post.o")]
+objs = [o for o in _product_objects() if o != "tdnn_mx.o"]
 FLAGS = {
     "flags_O2": ["-O2"],
     "flags_maxilp": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],

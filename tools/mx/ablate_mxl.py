@@ -11,6 +11,13 @@ CS = os.path.join(ROOT, "kaldi-tflite_amd", "csrc")
 src = open(os.path.join(CS, "tdnn_mxl.hip")).read()
 
 
+
+def _product_objects():
+    """The object files of libktf_hip.so (csrc/Makefile: SRCS), built by `make` beforehand."""
+    import re
+    srcs = re.search(r"^SRCS := (.*)$", open(os.path.join(CS, "Makefile")).read(), re.M).group(1).split()
+    return [f[:-4] + ".o" for f in srcs]
+
 def rep(s, a, b, count=1):
     assert s.count(a) >= 1, a
     return s.replace(a, b) if count == 0 else s.replace(a, b, count)
@@ -104,7 +111,7 @@ for _n, _c in ():
 if __name__ == "__main__":
     names = sys.argv[1:] or list(V)
     flags = "-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wno-unused-function -Wno-unused-result -Wno-unused-value".split()
-    objs = [os.path.join(CS, f) for f in ("api.o", "frontend.o", "frontend512.o", "vad_cmvn.o", "tdnn_gemm.o", "tdnn_f32.o", "tdnn_bf16.o", "tdnn_split.o", "tdnn_mx.o", "tdnn_mxs.o", "pool_post.o")]
+    objs = [os.path.join(CS, o) for o in _product_objects() if o != "tdnn_mxl.o"]
     for n in names:
         scratch = os.path.join(CS, f"_abl_{n}.hip")
         open(scratch, "w").write(V[n](src))
