@@ -166,6 +166,25 @@ V["alt_stage_spread"] = lambda s: rep(_alt_stage(s), """                        
                         if (i == 6) MX_DMA_F16(ks + 1, 3)
                         if (i == 7) MX_DMA_F16P(ks + 1, 3)""")
 
+# timing only (transposed results): every MFMA with its two operands exchanged -- what the register plane epilogue needs (a lane then
+# holds four consecutive UNITS of one row). Is the exchange itself what cost the ported kernel 3 %?
+V["swap_ops"] = lambda s: rep(rep(rep(s,
+    "acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);",
+    "acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[jj], a_cur, acc[i][jj], 0, 0, 0);"),
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, bw, acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);",
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bw, al, acc[i][jj], 4, 4, 0, wsc[jj], 0, asc);"),
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, bw, acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);",
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bw, ah, acc[i][jj], 2, 4, 1, wsc[jj], 1, asc);")
+# ... only the half-precision MFMAs / only the block-scaled ones
+V["swap_ops_f16"] = lambda s: rep(s,
+    "acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);",
+    "acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[jj], a_cur, acc[i][jj], 0, 0, 0);")
+V["swap_ops_mx"] = lambda s: rep(rep(s,
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, bw, acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);",
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bw, al, acc[i][jj], 4, 4, 0, wsc[jj], 0, asc);"),
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, bw, acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);",
+    "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bw, ah, acc[i][jj], 2, 4, 1, wsc[jj], 1, asc);")
+
 names = sys.argv[1:] or list(V)
 objs = [o for o in _product_objects() if o != "tdnn_mx.o"]
 FLAGS = {
