@@ -412,7 +412,8 @@ def _roofline(gemm, gemm_stats, steps, B, T, passes):
 def _attach_traffic(roof, gemm):
     """HBM traffic of the GEMM launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x 2 on gfx950, WRITE_SIZE) committed
     under profiles/: it cannot be collected from inside this process."""
-    for tpath in (os.path.join(ROOT, "profiles", "r3", f"traffic_{gemm}.json"), os.path.join(ROOT, "profiles", f"r2_traffic_{gemm}.json")):
+    for tpath in (os.path.join(ROOT, "profiles", "r4", f"traffic_{gemm}.json"), os.path.join(ROOT, "profiles", "r3", f"traffic_{gemm}.json"),
+                  os.path.join(ROOT, "profiles", f"r2_traffic_{gemm}.json")):
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
