@@ -45,7 +45,9 @@ int main(void) {
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));       /* 16-bit output */
     t.y_dtype = KTF_F32;
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, f, 8, NULL, NULL));          /* a residual plane */
-    EXPECT_EINVAL(ktf_tdnn_stats(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, d, NULL));          /* no fused pooling */
+    t.flags = KTF_TDNN_W_TILED;
+    EXPECT_EINVAL(ktf_tdnn_stats(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, d, NULL));          /* no flag but KTF_TDNN_DET_STATS */
+    t.flags = 0;
     t.gemm = KTF_GEMM_BF16; t.x_dtype = t.w_dtype = KTF_BF16; t.y_dtype = KTF_BF16P;
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));       /* pairs from a 16-bit kernel */
     t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32;

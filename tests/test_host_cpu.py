@@ -110,15 +110,33 @@ def test_gemm_mode_selection_host_logic():
     assert (d.x_dtype, d.w_dtype, d.y_dtype, d.gemm) == (L.KTF_F16, L.KTF_F16, L.KTF_F16, L.GEMM_F16)
     with pytest.raises(ValueError):
         ktf.layers.TDNN(8, context=[0], gemm="fp8")
-    # batches of only a few 256-row tiles run on the exact fp32 kernels in every reduced mode (Sequential.batch_gemm)
+    # batches of only a few 256-row tiles leave the 256-row kernels in every reduced mode (Sequential.batch_gemm: the crossovers of
+    # tools/small_batch_crossover.py) -- for the bf16-pair small tiles (`small_tile_pairs`, the default) or the exact fp32 ones
     S = ktf.models.Sequential
-    assert S([], gemm="bf16").batch_gemm(1, 998) == L.GEMM_F32 and S([], gemm="bf16").batch_gemm(2, 998) == L.GEMM_BF16
-    assert S([], gemm="f16").batch_gemm(5, 200) == L.GEMM_F32 and S([], gemm="f16").batch_gemm(6, 200) == L.GEMM_F16
+    assert S([], gemm="bf16").batch_gemm(2, 998) == L.GEMM_F32 and S([], gemm="bf16").batch_gemm(3, 998) == L.GEMM_BF16
+    assert S([], gemm="f16").batch_gemm(11, 200) == L.GEMM_F32 and S([], gemm="f16").batch_gemm(12, 200) == L.GEMM_F16
     assert S([], gemm="bf16x3").batch_gemm(7, 998) == L.GEMM_F32 and S([], gemm="bf16x3").batch_gemm(8, 998) == L.GEMM_BF16X3
+    assert S([], gemm="f16mx").batch_gemm(4, 998) == L.GEMM_F32 and S([], gemm="f16mx").batch_gemm(5, 998) == L.GEMM_F16MX
     assert S([], gemm="f32").batch_gemm(1024, 998) == L.GEMM_F32
+    assert S([], gemm="f16mx")._batch_route(1, 998) == (L.GEMM_F32, True)          # small tiles, pairs behind the first layer
+    assert S([], gemm="f16mx")._batch_route(1024, 998) == (L.GEMM_F16MX, False)
+    assert S([], gemm="f16mx")._batch_route(1024, 300) == (L.GEMM_BF16X3, False)    # short utterances: the tighter mode, its own kernels
+    assert S([], gemm="f16mx")._batch_route(2, 300) == (L.GEMM_F32, True)
+    assert S([], gemm="f32")._batch_route(1, 998) == (L.GEMM_F32, False)            # the exact mode never leaves the fp32 kernels
     m = S([], gemm="bf16")
     m.min_tiles = {}
     assert m.batch_gemm(1, 10) == L.GEMM_BF16
+    m = S([], gemm="f16mx")
+    m.small_tile_pairs = False
+    assert m._batch_route(1, 998) == (L.GEMM_F32, False)
+    # KTF_BF16P: operands of KTF_GEMM_BF16X4, in float32 tensors
+    assert L.ktf_dtype(L.PAIR) == L.KTF_BF16P and L.act_torch_dtype(L.GEMM_BF16X4) == torch.float32
+    from kaldi_tflite_amd import ops
+    v = torch.tensor([0.0, 1.0, -3.14159265, 1e-3, 65504.0, 1e-30])
+    p = ops.pair_encode(v)
+    bits = p.view(torch.int32)
+    assert p.dtype == torch.float32 and int(bits[0]) == 0 and (int(bits[1]) & 0xFFFF) == 0x3F80 and (int(bits[1]) >> 16) == 0
+    assert torch.all((ops.pair_decode(p) - v).abs() <= v.abs() * 2.0 ** -16)
 
 
 def test_no_cpu_fallback():
