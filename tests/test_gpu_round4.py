@@ -143,6 +143,50 @@ def test_pair_kernel_vs_oracle(case):
         assert np.abs(dec32[bi, :n] - ref32[bi, :n]).max(initial=0.0) <= 2.0 ** -16 * max(1.0, np.abs(ref32[bi, :n]).max(initial=0.0))
 
 
+def test_pair_kernel_random_shapes_against_the_fp32_kernels():
+    """Forty random layers (units 1 ... 700, input width 1 ... 300, 1-5 context offsets within +-6, SAME / VALID, subsampling 1-3, ragged
+    batches with empty and one-frame utterances, fused ReLU and BatchNorm affine on or off): the pair kernel against the exact fp32
+    kernels on the same fp32 inputs -- the 2^-17 operand split is the only difference -- and the same out_lens."""
+    from kaldi_tflite_amd import ops, _lib as L
+    rng = np.random.default_rng(2024)
+    for trial in range(40):
+        B = int(rng.integers(1, 5))
+        T = int(rng.integers(1, 400))
+        D = int(rng.integers(1, 301))
+        U = int(rng.integers(1, 701))
+        K = int(rng.integers(1, 6))
+        ctx = sorted(rng.choice(np.arange(-6, 7), size=K, replace=False).tolist())
+        sub = int(rng.integers(1, 4))
+        pad = "VALID" if rng.random() < 0.4 else "SAME"
+        relu = bool(rng.random() < 0.5)
+        t, x, W, b, xp = _pair_case(rng, B, T, D, U, ctx, sub, pad, relu)
+        lens = rng.integers(0, T + 1, size=B)
+        lens[0] = T
+        if B > 1:
+            lens[1] = min(T, 1)
+        dl = torch.as_tensor(lens.astype(np.int32), device="cuda")
+        bn = None
+        if rng.random() < 0.5:
+            bn = (torch.as_tensor(rng.uniform(0.5, 2.0, U).astype(np.float32), device="cuda"),
+                  torch.as_tensor(rng.uniform(-1.0, 1.0, U).astype(np.float32), device="cuda"))
+        Tout = t.outputTimesteps(T)
+        if Tout == 0:
+            continue
+        got = torch.full((B, Tout, U), 7.0, device="cuda")
+        ref = torch.full((B, Tout, U), 7.0, device="cuda")
+        gl = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        rl = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        t.forward(ops.pair_encode(xp), lens=dl, relu=relu, bn=bn, gemm=L.GEMM_BF16X4, out=got, out_lens=gl, pair_in=True)
+        t.forward(xp, lens=dl, relu=relu, bn=bn, gemm=L.GEMM_F32, out=ref, out_lens=rl)
+        assert torch.equal(gl, rl), (trial, gl, rl)
+        g, r = got.cpu().numpy(), ref.cpu().numpy()
+        for bi in range(B):
+            n = int(rl[bi])
+            scale = max(1.0, float(np.abs(r[bi, :n]).max(initial=0.0)))
+            assert np.abs(g[bi, :n] - r[bi, :n]).max(initial=0.0) <= 5e-5 * scale, (trial, B, T, D, U, ctx, sub, pad, relu)
+            assert (g[bi, n:] == 7.0).all(), (trial, "rows beyond the utterance")
+
+
 @pytest.mark.parametrize("units,ctx", [(1500, [0]), (512, [-2, 0, 2]), (200, [0])])
 def test_pair_kernel_fused_pooling(units, ctx):
     """ktf_tdnn_stats with KTF_GEMM_BF16X4: fp64 column sums per 64-row tile (KTF_TDNN_DET_STATS: ktf_tdnn_stats_slots slots of
