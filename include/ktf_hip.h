@@ -309,9 +309,10 @@ int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* le
  * output is never written; instead sums[b, 0, u] += sum_t y[b,t,u] and sums[b, 1, u] += sum_t y[b,t,u]^2 (fp64, over
  * the valid rows). `sums` (B, 2, units) must be zeroed by the caller before the call (the order of the fp64 atomic adds
  * of an utterance's row blocks is not fixed: results can differ in the last fp64 bits from run to run; see
- * KTF_TDNN_DET_STATS for the reproducible form). Implemented by the bf16 ring
- * kernels only: KTF_GEMM_BF16 (bf16 x) or KTF_GEMM_BF16X3 (fp32 x, w_lo given), units > 128, SAME padding,
- * subsampling 1. */
+ * KTF_TDNN_DET_STATS for the reproducible form). Implemented by the 16-bit ring kernels -- KTF_GEMM_BF16 (bf16 x), KTF_GEMM_F16,
+ * KTF_GEMM_BF16X3 (fp32 x, w_lo given), KTF_GEMM_F16X2: units > 128, SAME padding, subsampling 1 -- and by the bf16-pair small
+ * tiles (KTF_GEMM_BF16X4: any layer shape; its KTF_TDNN_DET_STATS slots are ktf_tdnn_stats_slots(T, gemm) of
+ * ktf_tdnn_slot_rows(gemm) = 64 rows). */
 int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                    const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift, double* sums,
                    void* stream);
