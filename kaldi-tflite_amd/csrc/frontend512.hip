@@ -46,6 +46,7 @@
 #define DPP_ROW_ROR4 0x124
 #define DPP_ROW_ROR8 0x128
 #define DPP_WAVE_SHR1 0x138
+#define DPP_WAVE_ROR1 0x13C
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -72,7 +73,17 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// Complex product on the packed fp32 pipe: two instructions, the operand swizzles and the sign in the op_sel / neg modifiers (from C
+// the compiler builds the same product from v_pk_mul + scalar v_mul / v_sub / v_add and two to four register moves).
+//   t = (a.x b.x, a.y b.x);   r = (-a.y b.y + t.x, a.x b.y + t.y)
+typedef float f5v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
+    const f5v2 av = {a.x, a.y}, bv = {b.x, b.y};
+    f5v2 t, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[0,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+    return make_float2(r.x, r.y);
+}
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
@@ -109,21 +120,57 @@ __device__ __forceinline__ void swap_step(float& a, float& b, int lane) {
         const float nb = dpp_merge<DPP_ROW_SHL4, 0x5>(b, a);     // lanes 0-3,8-11:  b <- a of lane+4
         a = na; b = nb;
     } else {
-        const bool hi = (lane >> BIT) & 1;
-        const float s = hi ? a : b;
-        const float g = (BIT == 0) ? dpp_mov<DPP_QUAD_XOR1>(s) : dpp_mov<DPP_QUAD_XOR2>(s);
-        if (hi) a = g; else b = g;
+        static_assert(BIT >= 2, "lane bits 0 and 1 go through swap4_quad");
     }
+}
+
+// swap_step<BIT> for BIT = 0, 1 on four register pairs at once. Inside a quad a DPP move cannot address single lanes (bank masks
+// select groups of four), so the step is a select -- but v_cndmask_b32 takes its first operand THROUGH the DPP crossbar:
+//   a' = (lane bit set) ? quad_perm(b) : a        b' = (lane bit set) ? b : quad_perm(a)
+// is two instructions per pair (select-move-select-select was four). VOP2 + DPP reads its condition from VCC only, hence the
+// assembly block: VCC = lanes with the bit clear, four selects, VCC = lanes with the bit set, four selects. The s_nop covers the
+// DPP hazard (a VGPR written by the previous vector instruction is not readable through DPP for two cycles), which the compiler
+// cannot see inside an asm statement.
+template <int BIT>
+__device__ __forceinline__ void swap4_quad(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2, float& a3, float& b3) {
+    static_assert(BIT == 0 || BIT == 1, "quad-local lane bits");
+    float na0, na1, na2, na3;                     // (the b' are written in place: the second group reads a and b before it writes b)
+#define F5_SWAP4(LO_, HI_, QP_)                                                                                        \
+    asm("s_mov_b32 vcc_lo, " LO_ "\n\ts_mov_b32 vcc_hi, " LO_ "\n\ts_nop 1\n\t"                                        \
+        "v_cndmask_b32_dpp %0, %4, %8, vcc " QP_ " row_mask:0xf bank_mask:0xf\n\t"                                     \
+        "v_cndmask_b32_dpp %1, %5, %9, vcc " QP_ " row_mask:0xf bank_mask:0xf\n\t"                                     \
+        "v_cndmask_b32_dpp %2, %6, %10, vcc " QP_ " row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_cndmask_b32_dpp %3, %7, %11, vcc " QP_ " row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "s_mov_b32 vcc_lo, " HI_ "\n\ts_mov_b32 vcc_hi, " HI_ "\n\t"                                                   \
+        "v_cndmask_b32_dpp %4, %8, %4, vcc " QP_ " row_mask:0xf bank_mask:0xf\n\t"                                     \
+        "v_cndmask_b32_dpp %5, %9, %5, vcc " QP_ " row_mask:0xf bank_mask:0xf\n\t"                                     \
+        "v_cndmask_b32_dpp %6, %10, %6, vcc " QP_ " row_mask:0xf bank_mask:0xf\n\t"                                    \
+        "v_cndmask_b32_dpp %7, %11, %7, vcc " QP_ " row_mask:0xf bank_mask:0xf"                                         \
+        : "=&v"(na0), "=&v"(na1), "=&v"(na2), "=&v"(na3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3)                       \
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3)                                                                           \
+        : "vcc")
+    if constexpr (BIT == 0) F5_SWAP4("0x55555555", "0xaaaaaaaa", "quad_perm:[1,0,3,2]");
+    else F5_SWAP4("0x33333333", "0xcccccccc", "quad_perm:[2,3,0,1]");
+#undef F5_SWAP4
+    a0 = na0; a1 = na1; a2 = na2; a3 = na3;
 }
 
 // 4x4 transpose between the 4 registers of a lane and the 4 lanes that differ only in lane bits (BH, BL):
 // afterwards the lane at group position p = 2*bit(BH) + bit(BL) holds in register q what position q held in register p.
 template <int BH, int BL>
 __device__ __forceinline__ void transpose4(float2 (&r)[4], int lane) {
-    swap_step<BH>(r[0].x, r[2].x, lane); swap_step<BH>(r[0].y, r[2].y, lane);
-    swap_step<BH>(r[1].x, r[3].x, lane); swap_step<BH>(r[1].y, r[3].y, lane);
-    swap_step<BL>(r[0].x, r[1].x, lane); swap_step<BL>(r[0].y, r[1].y, lane);
-    swap_step<BL>(r[2].x, r[3].x, lane); swap_step<BL>(r[2].y, r[3].y, lane);
+    if constexpr (BH <= 1) {
+        swap4_quad<BH>(r[0].x, r[2].x, r[0].y, r[2].y, r[1].x, r[3].x, r[1].y, r[3].y);
+    } else {
+        swap_step<BH>(r[0].x, r[2].x, lane); swap_step<BH>(r[0].y, r[2].y, lane);
+        swap_step<BH>(r[1].x, r[3].x, lane); swap_step<BH>(r[1].y, r[3].y, lane);
+    }
+    if constexpr (BL <= 1) {
+        swap4_quad<BL>(r[0].x, r[1].x, r[0].y, r[1].y, r[2].x, r[3].x, r[2].y, r[3].y);
+    } else {
+        swap_step<BL>(r[0].x, r[1].x, lane); swap_step<BL>(r[0].y, r[1].y, lane);
+        swap_step<BL>(r[2].x, r[3].x, lane); swap_step<BL>(r[2].y, r[3].y, lane);
+    }
 }
 
 // Dither (windowing.py:182-183: x += N(0,1) * dither): counter-based Philox4x32-10 keyed by `seed`, counter (frame, lane). ONE call
@@ -239,7 +286,6 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     }
     // output index of this lane's FFT results: X[mo + 64*r4]
     const int mo = (2 * (lane & 1) + ((lane >> 5) & 1)) + 4 * ((lane >> 3) & 3) + 16 * ((lane >> 1) & 3);
-    const bool even = (lane & 1) == 0;
     const float invM = 1.0f / (float)M;
     __syncthreads();
 
@@ -345,13 +391,15 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                 logE = fmaxf(e, cfg.energy_floor);
             }
             if (cfg.preemph > 0.0f) {
+                // y[i] = x[i] - c x[i-1] (x[-1] := x[0]). Sample i - 1 lives in lane l - 1 of the same register, for lane 0 in lane 63
+                // of the previous one: a whole-wave rotate of v[j-1] puts that value into lane 0, where the whole-wave shift of v[j]
+                // (which has no source for lane 0) leaves it -- two DPP moves per register, no readlane / select
                 float y[NV];
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
-                    const float up = dpp_mov<DPP_WAVE_SHR1>(v[j]);                 // lane l gets lane l-1 (lane 0: 0)
-                    const float wrap = (j > 0) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[j > 0 ? j - 1 : 0]), 63))
-                                               : v[0];      // lane 0: sample i-1 lives in lane 63 of the previous register
-                    const float prev = (lane == 0) ? wrap : up;
+                    const int wrap = (j > 0) ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[j > 0 ? j - 1 : 0]), DPP_WAVE_ROR1, 0xF, 0xF, true)
+                                             : __float_as_int(v[0]);
+                    const float prev = __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(v[j]), DPP_WAVE_SHR1, 0xF, 0xF, false));
                     y[j] = v[j] - cfg.preemph * prev;
                 }
 #pragma unroll
@@ -371,12 +419,9 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         // ---- 256-point complex FFT of z[n] = x[2n] + i x[2n+1], in registers.
         // lane l holds samples l + 64 j; after one lane^1 exchange it holds z[n0 + 64 k], n0 = (l>>1) + 32 (l&1)
         float2 z[4];
+        swap4_quad<0>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);    // even lanes: (own, partner's) v[2k]; odd: (partner's, own) v[2k+1]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float s = even ? v[2 * k + 1] : v[2 * k];          // what the partner needs from this lane
-            const float g = dpp_mov<DPP_QUAD_XOR1>(s);
-            z[k] = even ? make_float2(v[2 * k], g) : make_float2(g, v[2 * k + 1]);
-        }
+        for (int k = 0; k < 4; ++k) z[k] = make_float2(v[2 * k], v[2 * k + 1]);
 #if F5_TW_LDS
         // record floats: tw1 = 0..5, tw2 = 6..11, tw3 = 12..17, rw = 18..25
         const f32x4 q0 = F5_TWQ(0), q1 = F5_TWQ(1), q2 = F5_TWQ(2), q3 = F5_TWQ(3), q4 = F5_TWQ(4);
@@ -411,12 +456,16 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         for (int j = 0; j < 4; ++j) {
             const int k = lane + 64 * j;
             const float2 zk = Zb[k], zm = Zb[(N2 - k) & (N2 - 1)];
-            const float er = 0.5f * (zk.x + zm.x), ei = 0.5f * (zk.y - zm.y);
-            const float orr = 0.5f * (zk.y + zm.y), oi = -0.5f * (zk.x - zm.x);
-            const float xr = er + rw[j].x * orr - rw[j].y * oi;
-            const float xi = ei + rw[j].x * oi + rw[j].y * orr;
+            // X[k] = E + rw O with E = (zk + conj zm) / 2, O = -i (zk - conj zm) / 2 = ((zk.y + zm.y), (zm.x - zk.x)) / 2. The halves are
+            // factored out (powers of two: exact): |X|^2 = |2 E + rw 2 O|^2 / 4, each step one packed instruction
+            const f5v2 kv = {zk.x, zk.y}, mv = {zm.x, zm.y}, rv = {rw[j].x, rw[j].y};
+            f5v2 e2, o2, u, x2;
+            asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,0] neg_hi:[0,1]" : "=v"(e2) : "v"(kv), "v"(mv));                                   // (zk.x + zm.x, zk.y - zm.y)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_lo:[0,0] neg_hi:[1,0]" : "=v"(o2) : "v"(kv), "v"(mv));      // (zk.y + zm.y, zm.x - zk.x)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(u) : "v"(o2), "v"(rv), "v"(e2));               // e2 + o2 * rw.x
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[0,0,0]" : "=v"(x2) : "v"(o2), "v"(rv), "v"(u));   // (-o2.y rw.y, o2.x rw.y) + u
             // |X|^2 directly (what Kaldi's ComputePowerSpectrum does; the reference's abs-then-square differs by an ulp)
-            pw[j] = xr * xr + xi * xi;
+            pw[j] = 0.25f * fmaf(x2.x, x2.x, x2.y * x2.y);
         }
         if (!cfg.use_power) {                        // wave-uniform branch: the magnitude spectrum pays for its sqrt only when asked
 #pragma unroll
@@ -445,7 +494,8 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
             const float t2 = __shfl_down(acc, 2, 64);
             if (mel_flags & 2) acc += t2;
         }
-        if (cfg.use_log) acc = logf(fmaxf(acc, 0.0f) + cfg.eps);
+        // (v_log_f32 is log2 to 1 ulp; its argument here is >= eps, a normal number: none of logf's denormal handling is needed)
+        if (cfg.use_log) acc = 0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(acc, 0.0f) + cfg.eps);
         if (mel_flags & 4) {
             if (out_stage == KTF_OUT_FBANK) {
                 if (valid) out[row * (int64_t)nm + mel_filter] = acc;
