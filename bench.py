@@ -131,7 +131,7 @@ def main(argv=None):
     if args.full_residual:
         mdl.xvec.lo_fraction = 0.0
     mdl.xvec.deterministic = not args.atomic_pooling
-    mdl.xvec.mx_loader = args.mx_loader
+    mdl.xvec.mx_loader = True if args.mx_loader else None          # (None: the model picks per batch; 1024 x 10 s takes the 256-row kernel)
     mdl.xvec.mx_slab = args.mx_slab
     mdl.route_short_utterances = not args.no_short_routing
     mdl.xvec.k_interleaved = not args.ctx_major_k

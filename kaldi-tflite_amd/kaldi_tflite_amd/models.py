@@ -162,9 +162,12 @@ class Sequential:
         self.gemm = gemm
         self.min_tiles = dict(self.MIN_TILES)
         self.min_frames = dict(self.MIN_FRAMES)
-        self.mx_loader = False       # f16mx: True = the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles on the flat row space, eight
-                                     # matrix + four loader waves, plane epilogue from registers); False = the 256 x 256 eight-wave kernel
-                                     # (csrc/tdnn_mx.hip), which is 4-6 % faster on the 0008 shapes: the default
+        self.mx_loader = None        # f16mx: which kernel runs the frame-level layers. False = the 256 x 256 eight-wave kernel (csrc/tdnn_mx.hip),
+                                     # True = the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles on the flat row space, eight matrix +
+                                     # four loader waves), None = per call, whichever needs less time by rounds of 256 workgroups x rows
+                                     # per tile (_mx_use_loader): the 256-row kernel is 4-6 % faster per unit of work
+                                     # and takes every batch that fills the chip; 5 ... 24 and ~48 utterances of 10 s leave it
+                                     # partly empty and run 8-16 % faster on the smaller flat tiles (tools/mid_batch.py)
         self.small_tile_pairs = True # batches below `min_tiles` of a reduced-precision model: bf16-pair small tiles instead of fp32 ones
         self.mx_slab = False         # f16mx, 256-row kernel: multi-context layers on activation slabs (csrc/tdnn_mxs.hip, KTF_TDNN_MX_SLAB)
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
@@ -249,6 +252,15 @@ class Sequential:
         if gemm != L.GEMM_F32 and B * ((T + 255) // 256) < self.min_tiles.get(mode, 0):
             return L.GEMM_F32, bool(self.small_tile_pairs)
         return gemm, False
+
+    def _mx_use_loader(self, B, T):
+        """f16mx: the loader-wave kernel for this batch? (`mx_loader` None: rounds of 256 workgroups x rows per tile, two N-tiles)"""
+        if self.mx_loader is not None:
+            return bool(self.mx_loader)
+        rounds = lambda wgs: -(-wgs // 256)  # noqa: E731
+        cost_256 = rounds(2 * B * ((T + 255) // 256)) * 256
+        cost_loader = rounds(2 * ((B * T + 191) // 192)) * 192 * 1.05
+        return cost_loader < cost_256
 
     def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0, one_pass_mean=None,
                         in_perm=None, defer_to=None):
@@ -353,8 +365,9 @@ class Sequential:
                     ops.mx_planes(src, D, lens, mxp)
                 B, T, _ = mxp.shape
                 fold, pending_bn = pending_bn, None
-                wh, wq, bias = l.device_weights_mx(dev, fold=fold, loader=self.mx_loader)
-                mxf = L.TDNN_MX_LOADER if self.mx_loader else (L.TDNN_MX_SLAB if self.mx_slab else 0)
+                use_loader = self._mx_use_loader(B, T)
+                wh, wq, bias = l.device_weights_mx(dev, fold=fold, loader=use_loader)
+                mxf = L.TDNN_MX_LOADER if use_loader else (L.TDNN_MX_SLAB if self.mx_slab else 0)
                 d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None, flags=mxf)
                 if can_pool:                             # ... -> reducing StatsPooling inside the epilogue (BatchNorm applied there)
                     sp = nxt[1]
@@ -762,6 +775,7 @@ class XvectorExtractor:
         self._short_flag = None               # pinned int32[2]: short utterances of the batch in flight, call sequence number
         self._short_seq = 0
         self.last_short_count = 0             # short utterances of the last call
+        self._warming_for_capture = False     # compile(): the warm-up calls run the short-utterance pass unconditionally
         self.last_lens = None
 
     @property
@@ -861,7 +875,7 @@ class XvectorExtractor:
         y = self._xvectors(feats, lens_main, out)
         if not capturing:
             self.last_short_count = self._await_short_count(feats.device)
-            if self.last_short_count == 0:
+            if self.last_short_count == 0 and not self._warming_for_capture:
                 return y
         short_mode = seq.SHORT_MODE[seq.gemm]
         if self._tail_fusable() and self.fuse_tail:
@@ -979,9 +993,13 @@ class XvectorExtractor:
         cap_ws, cap_xws = _Workspace(), _Workspace()
         self._ws, self.xvec._ws = cap_ws, cap_xws
         try:
-            with torch.cuda.stream(side):                # warm-up on the capture stream: workspaces, tables, LDS opt-ins
-                for _ in range(2):
-                    self._extract(static_in)
+            with torch.cuda.stream(side):                # warm-up on the capture stream: workspaces, tables, LDS opt-ins -- of BOTH
+                self._warming_for_capture = True         # passes of a routed batch (the capture contains the short-utterance pass
+                try:                                     # whether or not the example has a short utterance; its weights cannot be
+                    for _ in range(2):                   # uploaded while the stream is capturing)
+                        self._extract(static_in)
+                finally:
+                    self._warming_for_capture = False
                 static_out = torch.empty((static_in.shape[0], self.ldaMat.shape[1]), dtype=torch.float32, device=dev)
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph, stream=side):

@@ -74,6 +74,22 @@ def test_batch_dispatch(gemm):
     assert len(tail) == 1 and tail[0].startswith("tdnn_f32"), tail
 
 
+def test_f16mx_kernel_by_batch_size():
+    """An f16mx model as shipped: 6 x 10 s leave the chip three quarters empty on 256-row tiles and run on the loader-wave kernel's
+    smaller flat tiles, 32 x 10 s fill it with 256-row tiles (Sequential._mx_use_loader; tools/mid_batch.py)."""
+    S = ktf.models.Sequential
+    old = (S.MIN_TILES, S.MIN_FRAMES)
+    S.MIN_TILES, S.MIN_FRAMES = {"f16mx": 20}, {"f16mx": 400}
+    try:
+        mdl = synth.build_extractor(ktf, synth.extractor_cfg(), synth.make_weights(seed=4321), gemm="f16mx")
+        wav = synth.make_wav(32, 160000, seed=3)
+        for B, family in ((6, "tdnn_mxl_kernel"), (32, "tdnn_mx_kernel")):
+            got = [k for _, k in trace(mdl, wav[:B])]
+            assert got[:5] == [family] * 5, (B, got)
+    finally:
+        S.MIN_TILES, S.MIN_FRAMES = old
+
+
 def test_f16mx_loader_kernel_dispatch():
     """`Sequential.mx_loader`: every frame-level layer of an f16mx model on the loader-wave kernel (csrc/tdnn_mxl.hip)."""
     w = synth.make_weights(seed=4321)

@@ -278,6 +278,7 @@ def test_slab_kernel_is_bit_identical_to_the_gathering_kernel():
     for slab in (False, True):
         mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
         mdl.xvec.mx_slab = slab
+        mdl.xvec.mx_loader = False              # (a batch this small would otherwise take the loader-wave kernel: Sequential._mx_use_loader)
         seen = []
         real = ops.tdnn_mx
 

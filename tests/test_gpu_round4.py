@@ -242,3 +242,26 @@ def test_small_batches_on_the_pair_route_vs_oracle(gemm):
     mdl.xvec.small_tile_pairs = False
     got = mdl(torch.as_tensor(wav[:1], device="cuda")).cpu().numpy()
     assert np.abs(got - want[:1]).max() <= 2e-5
+
+
+def test_captured_graph_of_a_routed_batch():
+    """XvectorExtractor.compile on a batch the per-utterance routing applies to (f16mx, 256-row kernels): the capture holds BOTH passes --
+    the second one's weights and workspaces exist before the capture starts (they used to be uploaded on first use, i.e. inside the
+    capture: hipErrorStreamCaptureUnsupported) -- and a replay equals the eager call bit for bit, with and without a short utterance."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321)
+    wav = synth.make_wav(6, 160000, seed=11)
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+    assert mdl.xvec.batch_gemm(6, 998) == ktf._lib.GEMM_F16MX and mdl.route_short_utterances
+    x = torch.as_tensor(wav, device="cuda")
+    run = mdl.compile(x)
+    y = mdl(x)
+    assert mdl.last_short_count == 0
+    assert torch.equal(run(x), y)
+    quiet = wav.copy()
+    quiet[2, 30000:] = 0.0                              # utterance 2: < 400 voiced frames -> the split-bf16 pass
+    xq = torch.as_tensor(quiet, device="cuda")
+    yq = mdl(xq)
+    assert mdl.last_short_count == 1
+    assert torch.equal(run(xq), yq)
+    assert not torch.equal(yq[2], y[2]) and torch.equal(yq[0], y[0])

@@ -126,6 +126,13 @@ def test_gemm_mode_selection_host_logic():
     m = S([], gemm="bf16")
     m.min_tiles = {}
     assert m.batch_gemm(1, 10) == L.GEMM_BF16
+    # f16mx: which kernel takes a batch of B x 998 frames (tools/mid_batch.py measured the loader-wave kernel faster exactly there)
+    mm = S([], gemm="f16mx")
+    assert [b for b in (5, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128, 256, 1024) if mm._mx_use_loader(b, 998)] == [5, 6, 8, 12, 16, 24, 48]
+    mm.mx_loader = True
+    assert mm._mx_use_loader(1024, 998)
+    mm.mx_loader = False
+    assert not mm._mx_use_loader(6, 998)
     m = S([], gemm="f16mx")
     m.small_tile_pairs = False
     assert m._batch_route(1, 998) == (L.GEMM_F32, False)
