@@ -169,7 +169,10 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // of row group g+1 are read while the MFMAs of group g run (two fragment register sets).
 #define XS_STAGE_BYTES (4 * R_TILE_BYTES)                // 64 KiB
 #define XS_LDS_BYTES (2 * XS_STAGE_BYTES)                // 128 KiB
-template <int ACT, bool STATS, bool F16 = false, int TERMS = 3>
+// SKIP: row groups (two 16-row blocks) of the wave's 128 rows that hold no valid output row issue no MFMAs -- for launches whose
+// tiles are mostly padding (1.5 s windows: 148 rows of a 256-row tile, -17 % per step; the launcher decides from T). On full tiles the
+// test costs 1.7 % (it splits the scheduler's K-step into regions), so the plain instantiation keeps them.
+template <int ACT, bool STATS, bool F16 = false, int TERMS = 3, bool SKIP = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
     // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused
@@ -292,6 +295,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int coff = (((lane >> 4) ^ fr) << 4);
     const int a_row_off = (wm * 128 + (lane & 15)) * 64 + coff;
     const int b_row_off = (wn * 64 + (lane & 15)) * 64 + coff;
+    // 16-row blocks of this wave's 128 rows that hold a valid output row (wave-uniform)
+    const int nblk = SKIP ? __builtin_amdgcn_readfirstlane(min(8, max(0, (out_len - t0 - wm * 128 + 15) >> 4))) : 8;
     {
         for (int ks = 0; ks < nk; ++ks) {
             // stage ks landed: nothing else is in flight (two stages), or only the DMAs of stage ks+1 are (three stages)
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                 for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24 (4c .. 4c+3 of 16)
                     // 2-pass form: the odd chunks are the residual passes of the group's two rows; a step behind the residual
                     // prefix skips them (wave-uniform)
-                    if (TERMS != 2 || !(c & 1) || two)
+                    if ((TERMS != 2 || !(c & 1) || two) && (!SKIP || 2 * g < nblk))
 #pragma unroll
                     for (int m = PER_CHUNK * c; m < PER_CHUNK * c + PER_CHUNK; ++m) {
                         const int r = m / PER_ROW, j = m & 3;                  // row, column block
@@ -455,11 +460,18 @@ int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int6
             hipLaunchKernelGGL((tdnn_x3r_kernel<A, false>), dim3((unsigned)nblocks), dim3(512), X_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
         }                                                                                                              \
     } while (0)
+            // mostly-padding tiles (fewer than 80 % of the 16-row blocks computed hold a row of a full-length utterance): the SKIP form
+            const bool skip = 5 * (int64_t)ktf_cdiv(Tout, 16) < 4 * (int64_t)mtiles * 16;
 #define XS_LAUNCH1(A, ST)                                                                                              \
     do {                                                                                                               \
         KTF_NOTE_KERNEL("tdnn_x3s_kernel<bf16, 3>");                                                                   \
-        KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST>); \
-        hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        if (skip) {                                                                                                    \
+            KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST, false, 3, true>);                                        \
+            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, false, 3, true>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        } else {                                                                                                       \
+            KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST>);                                                        \
+            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+        }                                                                                                              \
     } while (0)
 #define XS_LAUNCH(A)                                                                                                   \
     do {                                                                                                               \
