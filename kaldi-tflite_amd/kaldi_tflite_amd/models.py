@@ -249,7 +249,9 @@ class Sequential:
             if T < self.min_frames.get(mode, 0):         # short utterances: the tighter mode (MIN_FRAMES)
                 mode = self.SHORT_MODE.get(mode, "f32")
         gemm = _GEMM[mode]
-        if gemm != L.GEMM_F32 and B * ((T + 255) // 256) < self.min_tiles.get(mode, 0):
+        # (the batch's rows in units of 256: what the small tiles' time follows -- a 3 s utterance is 1.2 of them, not two tiles;
+        # measured crossovers at 1.5 / 3 / 10 s: 28-32 / 24-28 / 7 utterances for "bf16x3", tools/small_batch_crossover.py)
+        if gemm != L.GEMM_F32 and -(-(B * T) // 256) < self.min_tiles.get(mode, 0):
             return L.GEMM_F32, bool(self.small_tile_pairs)
         return gemm, False
 

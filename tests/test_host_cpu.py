@@ -114,7 +114,7 @@ def test_gemm_mode_selection_host_logic():
     # tools/small_batch_crossover.py) -- for the bf16-pair small tiles (`small_tile_pairs`, the default) or the exact fp32 ones
     S = ktf.models.Sequential
     assert S([], gemm="bf16").batch_gemm(2, 998) == L.GEMM_F32 and S([], gemm="bf16").batch_gemm(3, 998) == L.GEMM_BF16
-    assert S([], gemm="f16").batch_gemm(11, 200) == L.GEMM_F32 and S([], gemm="f16").batch_gemm(12, 200) == L.GEMM_F16
+    assert S([], gemm="f16").batch_gemm(14, 200) == L.GEMM_F32 and S([], gemm="f16").batch_gemm(15, 200) == L.GEMM_F16    # (rows / 256, rounded up)
     assert S([], gemm="bf16x3").batch_gemm(7, 998) == L.GEMM_F32 and S([], gemm="bf16x3").batch_gemm(8, 998) == L.GEMM_BF16X3
     assert S([], gemm="f16mx").batch_gemm(4, 998) == L.GEMM_F32 and S([], gemm="f16mx").batch_gemm(5, 998) == L.GEMM_F16MX
     assert S([], gemm="f32").batch_gemm(1024, 998) == L.GEMM_F32
