@@ -317,8 +317,11 @@ def _bench_mfcc(torch, mdl, wav, ops, iters=20, warm=5):
     cfg.frame_size, cfg.frame_shift = fr.frameWidth, fr.frameShift
     out = torch.empty((B, T, mf.numMfccs), dtype=torch.float32, device=wav.device)
     tabs = mf.tables(wav.device)
-    for _ in range(warm):          # (the clock ramps up over the first launches after an idle gap: 0.92 ms cold against 0.77 sustained)
+    t0 = time.perf_counter()       # (the clock takes ~50 ms of launches to settle after an idle gap: 0.75 ms for the first 25 launches,
+    while time.perf_counter() - t0 < 0.12 or warm > 0:                  # 0.65 ms from the 50th on -- what the launch takes inside the step)
         ops.frontend(wav, L.IN_WAV, cfg, tabs, L.OUT_MFCC, N, B, T, out=out)
+        warm -= 1
+    torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -434,14 +437,25 @@ def _layer_flops(key, B, T):
     return 2.0 * B * T * int(k) * int(d) * int(u.replace("+stats", "")) * n
 
 
-def _time_ms(torch, fn, iters):
+def _time_ms(torch, fn, iters, warm_s=0.15, min_s=0.05):
+    """ms per call of fn in steady state: the GPU's clocks take ~0.1 s of load to settle after an idle gap (the first 20 steps of a
+    256-utterance batch ran 7 % slower than the next 100: 2.63 against 2.45 ms), so the timed region starts after `warm_s` seconds of
+    calls and lasts at least `iters` calls and `min_s` seconds."""
     fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(iters):
+    while time.perf_counter() - t0 < warm_s:
         fn()
     torch.cuda.synchronize()
-    return 1e3 * (time.perf_counter() - t0) / iters
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(iters):
+            fn()
+        n += iters
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= min_s:
+            return 1e3 * dt / n
 
 
 def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
