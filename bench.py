@@ -318,10 +318,10 @@ def _bench_mfcc(torch, mdl, wav, ops, iters=20, warm=5):
     out = torch.empty((B, T, mf.numMfccs), dtype=torch.float32, device=wav.device)
     tabs = mf.tables(wav.device)
     t0 = time.perf_counter()       # (the clock takes ~50 ms of launches to settle after an idle gap: 0.75 ms for the first 25 launches,
-    while time.perf_counter() - t0 < 0.12 or warm > 0:                  # 0.65 ms from the 50th on -- what the launch takes inside the step)
-        ops.frontend(wav, L.IN_WAV, cfg, tabs, L.OUT_MFCC, N, B, T, out=out)
-        warm -= 1
-    torch.cuda.synchronize()
+    while time.perf_counter() - t0 < 0.12:                              # 0.65 ms from the 50th on -- what the launch takes inside the step)
+        for _ in range(max(warm, 1)):
+            ops.frontend(wav, L.IN_WAV, cfg, tabs, L.OUT_MFCC, N, B, T, out=out)
+        torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -446,7 +446,7 @@ def _time_ms(torch, fn, iters, warm_s=0.15, min_s=0.05):
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < warm_s:
         fn()
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()         # (per call: a host that runs ahead would queue seconds of work in `warm_s` of wall time)
     n, t0 = 0, time.perf_counter()
     while True:
         for _ in range(iters):
