@@ -37,6 +37,11 @@ V["no_epilogue"] = lambda s: rep(s, "        for (int pass = 0; pass < 2; ++pass
 V["hot_a"] = lambda s: rep(rep(rep(s, "const int64_t ub = (int64_t)b * p.nch_in * p.T;", "const int64_t ub = 0;"),
                                 "        a_row[i] = t0 + row;", "        a_row[i] = row;"),
                             "        int r_ = t0 + rg_ * 64 + lane + off__;", "        int r_ = rg_ * 64 + lane + off__;")
+# ... only the workgroups of the N-tiles behind the first read the hot region (the first N-tile of every M-tile still touches its own
+# rows): how much of the cold-fetch cost do the OTHER N-tiles of an M-tile pay today? (they start together with the first one)
+V["hot_a_nt"] = lambda s: rep(rep(rep(s, "const int64_t ub = (int64_t)b * p.nch_in * p.T;", "const int64_t ub = nt ? 0 : (int64_t)b * p.nch_in * p.T;"),
+                                   "        a_row[i] = t0 + row;", "        a_row[i] = (nt ? 0 : t0) + row;"),
+                               "        int r_ = t0 + rg_ * 64 + lane + off__;", "        int r_ = (nt ? 0 : t0) + rg_ * 64 + lane + off__;")
 def _no_stores(s):
     import re
     s = re.sub(r"__builtin_nontemporal_store\(([^,]+), (reinterpret_cast<[^;]+)\);", r"if (abl_word(\1) == 0x12345678u) __builtin_nontemporal_store(\1, \2);", s)
