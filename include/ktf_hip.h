@@ -324,6 +324,15 @@ int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32
 int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* lens,
                    const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                    const float* shift, void* y, void* y_lo, int64_t ldy, int32_t* out_lens, void* stream);
+/* ktf_tdnn_split with the M-tiles laid over the batch's VALID rows end to end instead of 256-row tiles per utterance (short
+ * utterances: a 1.5 s window is 148 rows, 0.58 of a tile). row_starts: (B + 1) int32 on the device, the exclusive prefix sums of the
+ * utterance lengths (row_starts[0] = 0, row_starts[B] = the number of valid rows); a row's context offsets clamp against its own
+ * utterance as in ktf_tdnn_split, and rows at or beyond an utterance's length are not written. KTF_GEMM_BF16X3 on row-major hi / lo
+ * planes, SAME padding, no subsampling, ReLU or no activation, y as for ktf_tdnn_split (planes or fp32); B <= 4095 and
+ * B * T * ldx * 2 < 2^32. Results equal ktf_tdnn_split's bit for bit (same operands into the same MFMAs in the same order). */
+int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
+                        const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                        const float* shift, void* y, void* y_lo, int64_t ldy, void* stream);
 int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* lens,
                          const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                          const float* shift, double* sums, void* stream);

@@ -47,6 +47,7 @@ struct TdnnParams {
     int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
     int32_t lo_steps;       // F16X2: K-steps [0, lo_steps) run two passes, the rest one (KTF_TDNN_LO_PREFIX); >= ktot / 32: all of them
     int32_t y_pair;         // fp32-sized output slots hold the KTF_BF16P pair of the value (y_dtype is KTF_F32 to the store paths)
+    const int32_t* row_starts;  // ktf_tdnn_split_flat: (B + 1) exclusive prefix sums of lens (flat row tiling of tdnn_x3s_kernel), else NULL
 };
 
 // KTF_BF16P: bf16(v) in the low half, bf16(v - bf16(v)) in the high half of a 32-bit slot (tdnn_pair.hip), returned as the float

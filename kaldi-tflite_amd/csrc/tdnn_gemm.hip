@@ -108,7 +108,7 @@ extern "C" int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d) {
 static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,
-                       const void* x_lo = nullptr, void* y_lo = nullptr) {
+                       const void* x_lo = nullptr, void* y_lo = nullptr, const int32_t* row_starts = nullptr) {
     KTF_REQUIRE(x && d && w && (y || stats_sums), "ktf_tdnn: null argument");
     const bool split_in = d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16;     // activations as hi/lo bf16 planes
     const bool half2 = d->gemm == KTF_GEMM_F16X2;                                    // one half plane in, hi + lo half weights
@@ -157,7 +157,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     TdnnParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.lens = lens; p.w = w; p.w_lo = w_lo; p.bias = bias; p.scale = scale; p.shift = shift; p.y = y;
-    p.x_lo = x_lo; p.y_lo = y_lo;
+    p.x_lo = x_lo; p.y_lo = y_lo; p.row_starts = row_starts;
     p.out_lens = out_lens; p.T = T; p.ldx = ldx; p.ldy = ldy; p.Tout = Tout;
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
     p.act = act_pass ? KTF_ACT_NONE : d->act; p.y_dtype = y_pair ? KTF_F32 : d->y_dtype; p.y_pair = y_pair ? 1 : 0; p.ktot = d->nctx * d->din_pad;
@@ -236,6 +236,15 @@ extern "C" int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int
     KTF_REQUIRE((d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16) || d->gemm == KTF_GEMM_F16X2,
                 "ktf_tdnn_split: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes) or KTF_GEMM_F16X2 (one half plane)");
     return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, y, ldy, out_lens, nullptr, stream, x_lo, y_lo);
+}
+
+// ktf_tdnn_split over the batch's valid rows laid end to end (short utterances: a 1.5 s window fills 0.58 of a 256-row tile)
+extern "C" int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
+                                   const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                                   const float* shift, void* y, void* y_lo, int64_t ldy, void* stream) {
+    KTF_REQUIRE(x_hi && x_lo && row_starts && d && w && w_lo && y, "ktf_tdnn_split_flat: null argument");
+    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_flat: needs KTF_GEMM_BF16X3 on bf16 hi / lo planes");
+    return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, y, ldy, nullptr, nullptr, stream, x_lo, y_lo, row_starts);
 }
 
 extern "C" int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx,

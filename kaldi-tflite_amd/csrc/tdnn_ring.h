@@ -160,10 +160,12 @@ __device__ __forceinline__ void st16(u32x4* dst, const u32x4& v) {
     else *dst = v;
 }
 
-template <int ACT, bool STATS, bool F16 = false>
+// FLAT (tdnn_x3s_kernel's flat row tiling; row-major outputs only): tile row m is output row rowmap[m] of the (B * Tout)-row output
+// (an LDS table behind the staging image), t0 = 0 and out_len = the tile's valid rows.
+template <int ACT, bool STATS, bool F16 = false, bool FLAT = false>
 __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats,
                                                 unsigned char* rsm, int b, int t0, int n0, int out_len, int wm, int wn,
-                                                int wave, int lane, const Epi16Prm& prm) {
+                                                int wave, int lane, const Epi16Prm& prm, const int* rowmap = nullptr) {
     float* et = reinterpret_cast<float*>(rsm);
     const float (&bias)[4] = prm.bias;
     const float (&sc)[4] = prm.sc;
@@ -280,7 +282,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                 if (m < rows_valid) {
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + (lane & 31) * 8);
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + (lane & 31) * 8 + 4);
-                    const int64_t off = (out_row0 + m) * p.ldy + n8;
+                    const int64_t off = (FLAT ? (int64_t)rowmap[m] : out_row0 + m) * p.ldy + n8;
                     unsigned short* yp = reinterpret_cast<unsigned short*>(p.y) + off;
                     const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     unsigned short hh[8];
@@ -318,7 +320,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
             const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
             if (m < rows_valid) {
                 const f32x4 v = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + nl);
-                const int64_t off = (out_row0 + m) * p.ldy + n;
+                const int64_t off = (FLAT ? (int64_t)rowmap[m] : out_row0 + m) * p.ldy + n;
                 if (n + 4 <= p.units) {
                     if (p.y_dtype == KTF_F32) {
                         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y) + off) = v;

@@ -172,9 +172,17 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // SKIP: row groups (two 16-row blocks) of the wave's 128 rows that hold no valid output row issue no MFMAs -- for launches whose
 // tiles are mostly padding (1.5 s windows: 148 rows of a 256-row tile, -17 % per step; the launcher decides from T). On full tiles the
 // test costs 1.7 % (it splits the scheduler's K-step into regions), so the plain instantiation keeps them.
-template <int ACT, bool STATS, bool F16 = false, int TERMS = 3, bool SKIP = false>
+// FLAT (with SKIP; SAME padding, no subsampling, row-major planes, no fused pooling): the M-tiles cover the batch's VALID rows laid end
+// to end (p.row_starts: exclusive prefix sums of lens) instead of 256-row tiles per utterance -- a 1.5 s window is 148 rows, 0.58 of a
+// tile. A tile's rows belong to several utterances: each row's (utterance, frame, length) comes from an LDS table built at entry
+// (two 64-way steps over p.row_starts find the tile's first utterance, a search in the 258 staged prefix sums each row's own), the
+// context offsets clamp against the row's own utterance, and the epilogue scatters rows through the same table. `mtiles` carries B.
+#define XS_FLAT_OFF XS_LDS_BYTES                        // rs[260] | out_row[256] | t[256] | len[256]
+#define XS_FLAT_BYTES (260 * 4 + 3 * 256 * 4)
+template <int ACT, bool STATS, bool F16 = false, int TERMS = 3, bool SKIP = false, bool FLAT = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
+    static_assert(!FLAT || (SKIP && !STATS && TERMS == 3 && !F16), "flat row tiling: the split-bf16 plane kernel, rows out");
     // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused
     constexpr int NST = (TERMS == 1) ? KTF_X1_STAGES : 2;
     constexpr int STG = (TERMS == 1) ? 2 * R_TILE_BYTES : (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;      // one pass: A | W
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int g = (slot / ntiles) * 8 + xcd;
     const int nt = slot - (slot / ntiles) * ntiles;
     if (g >= gtiles) return;
-    const int b = g / mtiles, mt = g - b * mtiles;
+    const int b = FLAT ? 0 : g / mtiles, mt = FLAT ? g : g - b * mtiles;
     const int n0 = nt * R_BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -218,21 +226,89 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     // (Tried on top: the A half too, clamped to the buffer instead of the utterance -- valid while ctx[0] <= 0 -- and the
     // epilogue constants before everything: 0.7 % and 1.5 % slower.)
     if (KTF_X3_WFIRST) asm volatile("" ::: "memory");
-    const int len = p.lens ? p.lens[b] : (int)p.T;
-    int start;
-    const int out_len = tdnn_out_len(len, p, start);
-    if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
-    const int t0 = mt * R_BM;
-    if (t0 >= out_len || len <= 0) {
-        if (KTF_X3_WFIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing lands in the LDS of a finished workgroup
-        return;
-    }
-    const char* xh = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 2;      // (re-pointed by a timing ablation)
-    const char* xl = reinterpret_cast<const char*>(p.x_lo) + ((int64_t)b * p.T * p.ldx) * 2;
+    int len, start = 0, out_len, t0;
     const unsigned ldxb = (unsigned)p.ldx * 2u;
-    int a_t[2];
+    int a_t[2], a_len1[2];
+    unsigned a_base[2];
+    if constexpr (FLAT) {
+        const int B = mtiles;
+        const int32_t* rs_g = p.row_starts;
+        const int total = rs_g[B];
+        const int R0 = mt * R_BM;
+        if (R0 >= total) {
+            if (KTF_X3_WFIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        int* rs = reinterpret_cast<int*>(rsm + XS_FLAT_OFF);           // prefix sums of utterances b0 .. b0 + 259
+        int* trow = rs + 260;                                           // output row (b * T + t) of tile row m
+        int* tt = trow + 256;                                           // its frame
+        int* tlen = tt + 256;                                           // its utterance's length
+        // first utterance of the tile: the last b with row_starts[b] <= R0, by two 64-way steps (every wave, same result)
+        const int S = (B + 64) >> 6;                                    // ceil((B + 1) / 64) entries per lane of the first step
+        int cnt = __popcll(__ballot(lane * S <= B && rs_g[min(lane * S, B)] <= R0));
+        const int k0 = (cnt - 1) * S;
+        cnt = __popcll(__ballot(lane < S && k0 + lane <= B && rs_g[min(k0 + lane, B)] <= R0));
+        const int b0 = __builtin_amdgcn_readfirstlane(k0 + cnt - 1);
+        if (tid < 260) rs[tid] = rs_g[min(b0 + tid, B)];
+        __syncthreads();
+        if (tid < 256) {
+            const int R = R0 + tid;
+            int orow = -1, t = 0, ln = 1;
+            if (R < total) {
+                int lo = 0, hi = 259;                                   // last j with rs[j] <= R (empty utterances repeat a start: the last one wins)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (rs[mid] <= R) lo = mid; else hi = mid - 1;
+                }
+                int bb = b0 + lo;
+                if (lo == 259) {                                        // (more than 259 utterance starts inside one tile: finish in global memory)
+                    int l2 = bb, h2 = B - 1;
+                    while (l2 < h2) {
+                        const int mid = (l2 + h2 + 1) >> 1;
+                        if (rs_g[mid] <= R) l2 = mid; else h2 = mid - 1;
+                    }
+                    bb = l2;
+                }
+                bb = min(bb, B - 1);
+                const int s0 = rs_g[bb];
+                t = R - s0;
+                ln = rs_g[bb + 1] - s0;
+                orow = bb * (int)p.T + t;
+            }
+            trow[tid] = orow;
+            tt[tid] = t;
+            tlen[tid] = ln;
+        }
+        __syncthreads();
+        len = (int)p.T;
+        t0 = 0;
+        out_len = min(R_BM, total - R0);                                // valid rows of the tile
 #pragma unroll
-    for (int i = 0; i < 2; ++i) a_t[i] = start + (t0 + ((i * 512 + tid) >> 2)) * p.sub;
+        for (int i = 0; i < 2; ++i) {
+            const int row = (i * 512 + tid) >> 2;
+            a_t[i] = tt[row];
+            a_len1[i] = tlen[row] - 1;
+            const int orow = trow[row];
+            a_base[i] = orow < 0 ? 0u : (unsigned)(orow - a_t[i]) * ldxb;     // first row of the utterance, in bytes (B * T * ldx * 2 < 2^32)
+        }
+    } else {
+        len = p.lens ? p.lens[b] : (int)p.T;
+        out_len = tdnn_out_len(len, p, start);
+        if (p.out_lens && nt == 0 && mt == 0 && threadIdx.x == 0) p.out_lens[b] = out_len;
+        t0 = mt * R_BM;
+        if (t0 >= out_len || len <= 0) {
+            if (KTF_X3_WFIRST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing lands in the LDS of a finished workgroup
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a_t[i] = start + (t0 + ((i * 512 + tid) >> 2)) * p.sub;
+            a_len1[i] = len - 1;
+            a_base[i] = 0;
+        }
+    }
+    const char* xh = reinterpret_cast<const char*>(p.x) + (FLAT ? 0 : ((int64_t)b * p.T * p.ldx) * 2);      // (re-pointed by a timing ablation)
+    const char* xl = reinterpret_cast<const char*>(p.x_lo) + (FLAT ? 0 : ((int64_t)b * p.T * p.ldx) * 2);
 
     f32x4v acc[8][4];
 #pragma unroll
@@ -243,7 +319,6 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.0f;
 
     const int nk = p.ktot / R_BK;
-    const int lenm1 = len - 1;
     int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
     const int dpad_b = p.din_pad * 2;
     // A-piece address = row * x_rm + is_xb + chunk: row-major planes x_rm = row pitch, is_xb = byte offset of the 32-feature chunk in
@@ -256,8 +331,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         unsigned char* st_ = rsm + fill_slot * STG + wave * 1024;                                                      \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             int r_ = a_t[i] + is_off;                                                                                  \
-            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = (unsigned)r_ * x_rm + a_cb[i] + is_xb;                                                \
+            r_ = r_ < 0 ? 0 : (r_ > a_len1[i] ? a_len1[i] : r_);                                                       \
+            const unsigned vo_ = a_base[i] + (unsigned)r_ * x_rm + a_cb[i] + is_xb;                                    \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
             if (TERMS == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
@@ -343,8 +418,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 int r_ = a_t[i] + is_off;
-                r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);
-                va[i] = (unsigned)r_ * x_rm + a_cb[i] + is_xb;
+                r_ = r_ < 0 ? 0 : (r_ > a_len1[i] ? a_len1[i] : r_);
+                va[i] = a_base[i] + (unsigned)r_ * x_rm + a_cb[i] + is_xb;
                 vw[i] = w_ob[i] + (unsigned)is_ks * w_step;
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -413,7 +488,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     }
 #undef XS_STAGE
     if (!STATS) __syncthreads();      // all fragment reads done before the LDS is reused as the store staging area
-    ring_epilogue16<ACT, STATS, F16>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm);
+    ring_epilogue16<ACT, STATS, F16, FLAT>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm,
+                                           FLAT ? reinterpret_cast<const int*>(rsm + XS_FLAT_OFF) + 260 : nullptr);
 }
 
 
@@ -478,6 +554,24 @@ int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int6
         if (stats_sums) XS_LAUNCH1(A, true); else XS_LAUNCH1(A, false);                                                \
     } while (0)
             // hi / lo planes in: the 16x16x32 plane kernel; fp32 activations in: the kernel that splits them in registers
+            if (split_in && p.row_starts) {              // ktf_tdnn_split_flat: M-tiles over the batch's valid rows laid end to end
+                KTF_REQUIRE(!stats_sums && !d->valid && d->subsampling == 1 && !p.xchunk && !p.ychunk,
+                            "ktf_tdnn_split_flat: SAME padding, no subsampling, row-major planes, rows out");
+                KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn_split_flat: fuses ReLU or no activation");
+                KTF_REQUIRE(B <= 4095 && B * p.T * p.ldx * 2 < (1ll << 32), "ktf_tdnn_split_flat: B <= 4095 and B * T * ldx * 2 < 2^32");
+                const int64_t ftiles = ktf_cdiv(B * p.T, R_BM);
+                const int64_t fblocks = ((ftiles + 7) / 8) * 8 * ntiles_r;
+                KTF_REQUIRE(fblocks < (1ll << 31), "ktf_tdnn: grid too large");
+                constexpr int lds_ = XS_LDS_BYTES + XS_FLAT_BYTES;
+                KTF_NOTE_KERNEL("tdnn_x3s_kernel<bf16, 3, flat>");
+                if (d->act == KTF_ACT_RELU) {
+                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, false, false, 3, true, true>);
+                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, false, false, 3, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
+                } else {
+                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, false, false, 3, true, true>);
+                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, false, false, 3, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
+                }
+            } else
             if (split_in) {
                 if (d->act == KTF_ACT_NONE) XS_LAUNCH(KTF_ACT_NONE);
                 else if (d->act == KTF_ACT_RELU) XS_LAUNCH(KTF_ACT_RELU);

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "ktf_tdnn": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
     "ktf_tdnn_stats": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ktf_tdnn_split": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
+    "ktf_tdnn_split_flat": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "ktf_tdnn_split_stats": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ktf_split_bf16": (C.c_int, [_P, _i64, _i32, _i64, _P, _P, _i64, _P]),
     "ktf_mx_planes": (C.c_int, [_P, _i64, _i64, _i32, _i64, _P, _P, _P, _P, _P, _P]),

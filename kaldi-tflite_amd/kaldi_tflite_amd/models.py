@@ -168,6 +168,7 @@ class Sequential:
                                      # per tile (_mx_use_loader): the 256-row kernel is 4-6 % faster per unit of work
                                      # and takes every batch that fills the chip; 5 ... 24 and ~48 utterances of 10 s leave it
                                      # partly empty and run 8-16 % faster on the smaller flat tiles (tools/mid_batch.py)
+        self.flat_rows = True        # bf16x3 plane layers of short utterances: M-tiles over the valid rows laid end to end (ktf_tdnn_split_flat)
         self.small_tile_pairs = True # batches below `min_tiles` of a reduced-precision model: bf16-pair small tiles instead of fp32 ones
         self.mx_slab = False         # f16mx, 256-row kernel: multi-context layers on activation slabs (csrc/tdnn_mxs.hip, KTF_TDNN_MX_SLAB)
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
@@ -323,6 +324,7 @@ class Sequential:
             self._xbar, self._xvar = {}, {}      # the weights changed since calibrate(): its statistics describe another network
         gemm, pairs = self._batch_route(x.shape[0], x.shape[1], mode=mode)
         x_pair = False                                   # x holds KTF_BF16P pairs (in a float32 tensor)
+        row_starts = None                                # prefix sums of lens, made once per call when a layer runs flat row tiles
         act_dtype = L.act_torch_dtype(gemm)
         tail_at = self._tail_step(steps) if defer_tail else -1
         self._deferred = None        # set by a pooling step whose consumer is the deferred tail
@@ -494,16 +496,23 @@ class Sequential:
                     out_lens = torch.empty_like(lens)
                 keep = (nxt is not None and nxt[0] == "tdnn" and nxt[1].units > 128 and         # the consumer reads planes too
                         nxt[1].effective_gemm(gemm, nxt[2]) == gemm)
+                # utterances that fill their 256-row tiles badly (a 1.5 s window: 148 rows): M-tiles over the batch's valid rows laid
+                # end to end (ktf_tdnn_split_flat), same bits
+                flat = (self.flat_rows and gemm == L.GEMM_BF16X3 and l.padding == "SAME" and l.subsamplingFactor == 1
+                        and l.activation in (None, "linear", "relu") and B <= 4095 and B * T * planes.shape[3] * 2 < 2 ** 32
+                        and 5 * (-(-T // 16)) < 4 * (-(-T // 256)) * 16)
+                if flat and row_starts is None:
+                    row_starts = ops.row_starts(lens, B, T, self._ws.get("row_starts", (B + 1,), torch.int32, dev, padded=False))
+                split = (lambda d_, y_, ylo_: ops.tdnn_split_flat(planes, row_starts, d_, w, w_lo, bias, scale, shift, y_, ylo_)) if flat else \
+                        (lambda d_, y_, ylo_: ops.tdnn_split(planes, lens, d_, w, w_lo, bias, scale, shift, y_, ylo_, out_lens))
                 if keep:
                     ybuf = self._ws.get(out_role, (2, B, Tout, ldy), torch.bfloat16, dev, padded=ldy != l.units)
-                    d = l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None, flags=kflag)
-                    ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf[0], ybuf[1], out_lens)
+                    split(l.desc(gemm, torch.bfloat16, torch.bfloat16, act="relu" if relu else None, flags=kflag), ybuf[0], ybuf[1])
                     planes = ybuf
                     x = ybuf[0][:, :, : l.units]                     # shape carrier only (the values live in `planes`)
                 else:
                     ybuf = self._ws.get(out_role, (B, Tout, ldy), torch.float32, dev, padded=ldy != l.units)
-                    d = l.desc(gemm, torch.bfloat16, torch.float32, act="relu" if relu else None, flags=kflag)
-                    ops.tdnn_split(planes, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
+                    split(l.desc(gemm, torch.bfloat16, torch.float32, act="relu" if relu else None, flags=kflag), ybuf, None)
                     planes = None
                     x = ybuf[:, :, : l.units]
                 if out_lens is not None:

@@ -401,6 +401,27 @@ def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_le
     return y
 
 
+def row_starts(lens, B, T, out):
+    """out (B + 1,) int32, out[0] == 0 -> the exclusive prefix sums of the utterance lengths (all T when lens is None):
+    ktf_tdnn_split_flat's row map."""
+    if lens is None:
+        out[1:] = torch.arange(1, B + 1, dtype=torch.int32, device=out.device) * int(T)
+    else:
+        torch.cumsum(lens, 0, dtype=torch.int32, out=out[1:])
+    return out
+
+
+def tdnn_split_flat(xp, starts, desc, w, w_lo, bias, scale, shift, y, y_lo=None):
+    """tdnn_split with M-tiles over the batch's valid rows laid end to end (`starts` = row_starts(lens, ...)): short utterances."""
+    lib = L.load()
+    hi, lo, B, T, ldx = _planes(xp)
+    with L.on_device(xp.device):
+        rc = lib.ktf_tdnn_split_flat(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(starts), C.byref(desc), L.ptr(w), L.ptr(w_lo),
+                                     L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(y_lo), y.stride(1), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_split_flat")
+    return y
+
+
 def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums, zero=True):
     lib = L.load()
     hi, lo, B, T, ldx = _planes(xp)

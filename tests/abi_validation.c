@@ -76,6 +76,15 @@ int main(void) {
     EXPECT_EINVAL(ktf_stats_finalize(NULL, NULL, 1, 1, 4, 1, 1e-10f, f, 8, NULL));
     EXPECT_EINVAL(ktf_stats_finalize_slots(d, 1, 128, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));       /* too few slots */
     EXPECT_EINVAL(ktf_route_short(NULL, 1, 400, l, l, NULL, 0, NULL));
+    t.gemm = KTF_GEMM_BF16X3; t.x_dtype = KTF_BF16; t.w_dtype = KTF_BF16; t.y_dtype = KTF_F32; t.units = 256;
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));        /* no row map */
+    t.valid = 1;
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));           /* VALID padding */
+    t.valid = 0; t.act = KTF_ACT_TANH;
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));           /* fuses ReLU / none */
+    t.act = KTF_ACT_NONE;
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 5000, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));        /* B > 4095 */
+    t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32; t.units = 8;
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));
     EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, 99, NULL, NULL, f, NULL));

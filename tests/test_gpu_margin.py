@@ -69,7 +69,7 @@ def deviations(gemm, kind, seed, routed):
     if not routed:
         mdl.xvec.min_frames = {}
     out = {}
-    names = ("tdnn", "tdnn_split", "tdnn_mx")
+    names = ("tdnn", "tdnn_split", "tdnn_split_flat", "tdnn_mx")
     orig = {n: getattr(ops, n) for n in names}
     for sec in WINDOWS_S:
         wav = windows(sec)

@@ -265,3 +265,93 @@ def test_captured_graph_of_a_routed_batch():
     assert mdl.last_short_count == 1
     assert torch.equal(run(xq), yq)
     assert not torch.equal(yq[2], y[2]) and torch.equal(yq[0], y[0])
+
+
+# ----------------------------------------------------------------------------- flat row tiles of the split-bf16 plane kernel
+@pytest.mark.parametrize("case", [
+    (40, 148, 512, 512, [-2, 0, 2], "1.5 s windows"),
+    (7, 300, 512, 1500, [0], "3 s, an N-tile with pad units"),
+    (700, 5, 512, 256, [-1, 0, 1], "hundreds of utterances inside one tile, empty ones among them"),
+])
+def test_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case):
+    """ktf_tdnn_split_flat lays the M-tiles over the batch's valid rows end to end; every row still clamps its context offsets against
+    its own utterance and goes through the same MFMAs in the same order: planes and fp32 rows equal ktf_tdnn_split's bit for bit on
+    every valid row, and rows beyond an utterance's length are not written."""
+    from kaldi_tflite_amd import _lib as L
+    B, T, D, U, ctx, _ = case
+    rng = np.random.default_rng(123)
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+    b = rng.standard_normal(U).astype(np.float32)
+    t = ktf.layers.TDNN(U, context=list(ctx), name="f")
+    t.build(x.shape)
+    t.set_weights([W, b])
+    lens = rng.integers(0, T + 1, size=B).astype(np.int32)
+    lens[0] = T
+    lens[B // 2] = 0
+    dl = torch.as_tensor(lens, device="cuda")
+    planes = torch.zeros((2, B, T, D), dtype=torch.bfloat16, device="cuda")
+    ops.split_bf16(torch.as_tensor(x, device="cuda"), D, planes)
+    dev = torch.device("cuda")
+    w, w_lo, bias = t.device_weights(dev, L.GEMM_BF16X3, k_interleaved=len(ctx) > 1, w_tiled=True)
+    kflag = (L.TDNN_K_INTERLEAVED if len(ctx) > 1 else 0) | L.TDNN_W_TILED
+    sc = torch.as_tensor(rng.uniform(0.5, 2.0, U).astype(np.float32), device="cuda")
+    sh = torch.as_tensor(rng.uniform(-1.0, 1.0, U).astype(np.float32), device="cuda")
+    starts = ops.row_starts(dl, B, T, torch.zeros(B + 1, dtype=torch.int32, device="cuda"))
+    assert starts.tolist() == [0] + np.cumsum(lens).tolist()
+    ldy = ops.round_up(U, 32)
+    for out_planes in (True, False):
+        ydt = torch.bfloat16 if out_planes else torch.float32
+        d = t.desc(L.GEMM_BF16X3, torch.bfloat16, ydt, act="relu", flags=kflag)
+        shape = (2, B, T, ldy) if out_planes else (B, T, ldy)
+        ref = torch.full(shape, 7.0, dtype=ydt, device="cuda")
+        got = torch.full(shape, 7.0, dtype=ydt, device="cuda")
+        if out_planes:
+            ops.tdnn_split(planes, dl, d, w, w_lo, bias, sc, sh, ref[0], ref[1])
+            assert ops.last_kernel() == "tdnn_x3s_kernel<bf16, 3>"
+            ops.tdnn_split_flat(planes, starts, d, w, w_lo, bias, sc, sh, got[0], got[1])
+        else:
+            ops.tdnn_split(planes, dl, d, w, w_lo, bias, sc, sh, ref, None)
+            ops.tdnn_split_flat(planes, starts, d, w, w_lo, bias, sc, sh, got, None)
+        assert ops.last_kernel() == "tdnn_x3s_kernel<bf16, 3, flat>"
+        assert torch.equal(got, ref), case[-1]
+        g = got.float().cpu().numpy()
+        g = g if out_planes else g[None]
+        for bi in (0, B // 2, B - 1):
+            assert (g[:, bi, lens[bi]:, :U] == 7.0).all()
+
+
+def test_short_windows_run_flat_rows_and_equal_the_tiled_route():
+    """A split-bf16 model on 1.5 s windows (what an f16mx model routes its short utterances to): the plane layers run on flat row
+    tiles (Sequential.flat_rows) and the x-vectors equal the per-utterance tiles' bit for bit; 10 s utterances keep the tiles."""
+    cfg = synth.extractor_cfg()
+    w = synth.make_weights(seed=4321)
+    wav = synth.make_wav(48, 24000, seed=21, ragged=True)
+    got = {}
+    for flat in (True, False):
+        mdl = synth.build_extractor(ktf, cfg, w, gemm="bf16x3")
+        mdl.xvec.min_tiles = {}
+        mdl.xvec.flat_rows = flat
+        seen = []
+        real = ops.tdnn_split_flat
+
+        def spy(*a, **k):
+            seen.append(1)
+            return real(*a, **k)
+        ops.tdnn_split_flat = spy
+        try:
+            got[flat] = mdl(torch.as_tensor(wav, device="cuda"))
+        finally:
+            ops.tdnn_split_flat = real
+        assert len(seen) == (4 if flat else 0)             # tdnn1-4 (tdnn5 pools: per-utterance tiles)
+    assert torch.equal(got[True], got[False])
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="bf16x3")
+    mdl.xvec.min_tiles = {}
+    calls = []
+    real = ops.tdnn_split_flat
+    ops.tdnn_split_flat = lambda *a, **k: calls.append(1) or real(*a, **k)
+    try:
+        mdl(torch.as_tensor(synth.make_wav(16, 160000, seed=22), device="cuda"))
+    finally:
+        ops.tdnn_split_flat = real
+    assert not calls

@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ktf_version() == 112
+    assert lib.ktf_version() == 113
 
 
 def test_abi_argument_validation_without_gpu():
@@ -534,7 +534,7 @@ def test_library_kernel_families():
                         "tdnn_bf16g_kernel", "tdnn_bf16r_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16h_kernel", "tdnn_x3r_kernel",
                         "tdnn_x3s_kernel", "tdnn_x4s_kernel", "tdnn_mx_kernel", "tdnn_mxl_kernel", "tdnn_mxs_kernel"}, fam
     assert fam["tdnn_x3r_kernel"] == 8                  # 4 activations x {store, pooled}: fp32 activations only
-    assert fam["tdnn_x3s_kernel"] == 8 + 8 + 4 + 4      # split-bf16 (4 activations x 2, plain and row-group-skipping), half two-pass and one-pass (2 x 2 each)
+    assert fam["tdnn_x3s_kernel"] == 8 + 8 + 2 + 4 + 4  # split-bf16 (4 activations x 2, plain and row-group-skipping; flat rows: ReLU / none), half two-pass and one-pass (2 x 2 each)
     assert fam["tdnn_x4s_kernel"] == 8                  # bf16-pair small tiles: 64 x 32 / 64 / 96 and the K-step-32 form, x {rows, pooled}
     assert fam["tdnn_mx_kernel"] == 6                   # {ReLU, none} x {planes, fp32, pooled}
     assert fam["tdnn_mxl_kernel"] == 6                  # the same on the loader-wave kernel (KTF_TDNN_MX_LOADER)
