@@ -511,6 +511,12 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     res[f"{gemm}_ragged"] = {"x_vectors_per_s": B / (ms * 1e-3), "ms_per_step": ms, "mean_voiced_frames": float(lens.mean()),
                              "min_voiced_frames": int(lens.min()), "note": "30 % of the 0.5 s blocks at 1e-3 gain: lens < T, compaction exercised"}
     del wav_r, gain, quiet
+    # diarization-sized windows: 1024 x 1.5 s per step. The timed mode routes utterances under 400 frames to the split-bf16
+    # kernels, which run such batches on flat row tiles (ktf_tdnn_split_flat)
+    short = torch.clamp(torch.round(1000.0 * torch.randn((B, 24000), generator=torch.Generator(device=dev).manual_seed(77), device=dev)), -32767, 32767)
+    ms = _time_ms(torch, lambda: mdl(short), 5)
+    res[f"{gemm}_1.5s_windows"] = {"x_vectors_per_s": B / (ms * 1e-3), "ms_per_step": ms, "note": "1024 windows of 1.5 s (148 frames) per step"}
+    del short
     # int16 PCM input: same step, half the input bytes; and the PCIe-inclusive rate of a host-fed step
     wav16 = wav.to(torch.int16)
     res[f"{gemm}_int16_input"] = {"x_vectors_per_s": B / (_time_ms(torch, lambda: mdl(wav16), 5) * 1e-3)}
