@@ -321,6 +321,46 @@ def test_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case):
             assert (g[:, bi, lens[bi]:, :U] == 7.0).all()
 
 
+def test_flat_row_tiles_random_batches():
+    """Twenty-five random ragged batches (1 ... 300 utterances of up to 20 ... 400 frames, empty ones and one-frame ones among them,
+    1-5 context offsets within +-9, input widths 40 ... 512, 129 ... 700 units): flat row tiles == per-utterance tiles, bit for bit,
+    and nothing is written beyond an utterance's length."""
+    from kaldi_tflite_amd import _lib as L
+    rng = np.random.default_rng(4242)
+    dev = torch.device("cuda")
+    for trial in range(25):
+        B = int(rng.integers(1, 301))
+        T = int(rng.integers(20, 401))
+        D = int(rng.choice([40, 64, 96, 200, 512]))
+        U = int(rng.integers(129, 701))
+        K = int(rng.integers(1, 6))
+        ctx = sorted(rng.choice(np.arange(-9, 10), size=K, replace=False).tolist())
+        relu = bool(rng.random() < 0.5)
+        x = rng.standard_normal((B, T, D)).astype(np.float32)
+        W = (rng.standard_normal((U, K * D)) / np.sqrt(K * D)).astype(np.float32)
+        t = ktf.layers.TDNN(U, context=ctx, name="r")
+        t.build(x.shape)
+        t.set_weights([W, rng.standard_normal(U).astype(np.float32)])
+        lens = rng.integers(0, T + 1, size=B).astype(np.int32)
+        lens[rng.integers(0, B)] = T
+        lens[rng.integers(0, B)] = min(T, 1)
+        dl = torch.as_tensor(lens, device="cuda")
+        Dp = ops.round_up(D, 32)
+        planes = torch.zeros((2, B, T, Dp), dtype=torch.bfloat16, device="cuda")
+        ops.split_bf16(torch.as_tensor(x, device="cuda"), D, planes)
+        kint = K > 1
+        w, w_lo, bias = t.device_weights(dev, L.GEMM_BF16X3, k_interleaved=kint, w_tiled=True)
+        kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | L.TDNN_W_TILED
+        starts = ops.row_starts(dl, B, T, torch.zeros(B + 1, dtype=torch.int32, device="cuda"))
+        ldy = ops.round_up(U, 32)
+        d = t.desc(L.GEMM_BF16X3, torch.bfloat16, torch.bfloat16, act="relu" if relu else None, flags=kflag)
+        ref = torch.full((2, B, T, ldy), 7.0, dtype=torch.bfloat16, device="cuda")
+        got = torch.full((2, B, T, ldy), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.tdnn_split(planes, dl, d, w, w_lo, bias, None, None, ref[0], ref[1])
+        ops.tdnn_split_flat(planes, starts, d, w, w_lo, bias, None, None, got[0], got[1])
+        assert torch.equal(got, ref), (trial, B, T, D, U, ctx)
+
+
 def test_short_windows_run_flat_rows_and_equal_the_tiled_route():
     """A split-bf16 model on 1.5 s windows (what an f16mx model routes its short utterances to): the plane layers run on flat row
     tiles (Sequential.flat_rows) and the x-vectors equal the per-utterance tiles' bit for bit; 10 s utterances keep the tiles."""
