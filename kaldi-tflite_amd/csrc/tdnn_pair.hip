@@ -52,77 +52,7 @@ __global__ __launch_bounds__(64 * 4 * (BN / 16 / NB)) void tdnn_x4s_kernel(TdnnP
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
 
-    // staging, exactly as tdnn_f32s_kernel (a pair row IS an fp32 row to the DMA): chunk q of a tile -> row q / CH, LDS position
-    // q % CH holds global chunk (q % CH) ^ (row & (CH-1))
-    const bool isw = HALVES && tid >= NT / 2;
-    constexpr int NAq = NA > 0 ? NA : 1, NWq = NW > 0 ? NW : 1;
-    int a_t[NAq];
-    unsigned a_cb[NAq], w_ob[NWq];
-#pragma unroll
-    for (int i = 0; i < NAq; ++i) {
-        const int q = HALVES ? (tid & (NT / 2 - 1)) : i * NT + tid;
-        const int row = q / CH;
-        a_cb[i] = (unsigned)(((q % CH) ^ (row & (CH - 1))) * 16);
-        a_t[i] = start + (t0 + row) * p.sub;
-    }
-#pragma unroll
-    for (int i = 0; i < NWq; ++i) {
-        const int q = HALVES ? (tid & (NT / 2 - 1)) : i * NT + tid;
-        const int row = q / CH;
-        w_ob[i] = (unsigned)(n0 + row) * (unsigned)p.ktot * 4u + (unsigned)(((q % CH) ^ (row & (CH - 1))) * 16);
-    }
-    const char* xb = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.T * p.ldx) * 4;
-    const char* wb = reinterpret_cast<const char*>(p.w);
-    const unsigned ldxb = (unsigned)p.ldx * 4u;
-    const int nk = p.ktot / BK;
-    const int lenm1 = len - 1;
-    int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
-    const int dpad_b = p.din_pad * 4;
-    unsigned soff[NDMA];
-    unsigned char* st_d;
-#define FS_SRC()                                                                                                       \
-    {                                                                                                                  \
-        st_d = fsm + (is_ks & (FS_NSTAGE - 1)) * STAGE_BYTES + wave * 1024;                                            \
-        if (HALVES) {                                                                                                  \
-            int r_ = a_t[0] + is_off;                                                                                  \
-            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            soff[0] = isw ? w_ob[0] + (unsigned)(is_ks * ROWB) : (unsigned)r_ * ldxb + a_cb[0] + (unsigned)is_db;      \
-        } else {                                                                                                       \
-            _Pragma("unroll") for (int i = 0; i < NA; ++i) {                                                           \
-                int r_ = a_t[i] + is_off;                                                                              \
-                r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                           \
-                soff[i] = (unsigned)r_ * ldxb + a_cb[i] + (unsigned)is_db;                                             \
-            }                                                                                                          \
-            _Pragma("unroll") for (int i = 0; i < NW; ++i) soff[NA + i] = w_ob[i] + (unsigned)(is_ks * ROWB);          \
-        }                                                                                                              \
-    }
-#define FS_DMA(i_)                                                                                                     \
-    {                                                                                                                  \
-        if (HALVES)                                                                                                    \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)((isw ? wb : xb) + soff[0]), (lds_ptr_t*)st_d, 16, 0, 0);     \
-        else if ((i_) < NA)                                                                                            \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xb + soff[i_]), (lds_ptr_t*)(st_d + (i_) * (NT * 16)), 16, 0, 0); \
-        else                                                                                                           \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wb + soff[i_]),                                              \
-                                             (lds_ptr_t*)(st_d + TILE_BYTES + ((i_) - NA) * (NT * 16)), 16, 0, 0);     \
-    }
-#define FS_ADV()                                                                                                       \
-    {                                                                                                                  \
-        ++is_ks;                                                                                                       \
-        is_db += ROWB;                                                                                                 \
-        if (is_db == dpad_b) {                                                                                         \
-            is_db = 0;                                                                                                 \
-            ++is_c;                                                                                                    \
-            is_off = (is_c < p.nctx) ? p.ctx[is_c] : 0;                                                                \
-        }                                                                                                              \
-    }
-#define FS_STAGE()                                                                                                     \
-    {                                                                                                                  \
-        FS_SRC()                                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < NDMA; ++i) FS_DMA(i)                                                     \
-        FS_ADV()                                                                                                       \
-    }
-    for (int s_ = 0; s_ < FS_NSTAGE && s_ < nk; ++s_) FS_STAGE()
+#include "tdnn_small_ring.inc"
 
     // two accumulators per block -- the (A, B) and the (A', B) products -- so that consecutive MFMAs never depend on each other
     f32x4v acc[NB][2];
