@@ -190,6 +190,70 @@ V["swap_ops_mx"] = lambda s: rep(rep(s,
     "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, bw, acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);",
     "acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bw, ah, acc[i][jj], 2, 4, 1, wsc[jj], 1, asc);")
 
+# timing only (WRONG results: the operand registers of the 16 x 16 tiles are fed to 32 x 32 instructions as they are): every MFMA in its
+# 32 x 32 form -- v_mfma_f32_32x32x16_f16 and v_mfma_scale_f32_32x32x64_f8f6f4: the same operand bytes per lane, the same fragment reads,
+# the same 128 accumulator registers, half as many matrix instructions of twice the length. Does the matrix SHAPE change what the DMA
+# stream costs beside it (a 16 x 16 instruction holds the SIMD's vector issue for 8 of its 16 cycles, a 32 x 32 one for 8 of its 32)?
+def _mfma32(s, f16=True, mx=True):
+    s = rep(s, "    f32x4 acc[8][4];\n", "    typedef float f32x16_abl __attribute__((ext_vector_type(16)));\n    f32x16_abl accw[4][2];\n    f32x4 acc[8][4];\n")
+    s = rep(s, "        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};",
+            "        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};\n"
+            "    for (int i = 0; i < 4; ++i) for (int j = 0; j < 2; ++j) for (int e = 0; e < 16; ++e) accw[i][j][e] = 0.0f;")
+    if f16:
+        s = rep(s, "                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);",
+                "                    for (int jj = 0; jj < 2; ++jj) accw[i >> 1][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_cur, bh[(i & 1) * 2 + jj], accw[i >> 1][jj], 0, 0, 0);")
+    if mx:
+        s = rep(s, """                for (int jj = 0; jj < 4; ++jj) {     // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
+                    const i32x8 bw = i32x8{(int)w4[jj].x, (int)w4[jj].y, (int)w4[jj].z, (int)w4[jj].w, 0, 0, 0, 0};
+                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, bw, acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);
+                }""", """                for (int jj = 0; jj < 2; ++jj) {
+                    const int jw = (i & 1) * 2 + jj;
+                    const i32x8 bw = i32x8{(int)w4[jw].x, (int)w4[jw].y, (int)w4[jw].z, (int)w4[jw].w, 0, 0, 0, 0};
+                    accw[i >> 1][jj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(al, bw, accw[i >> 1][jj], 4, 4, 0, asc, 0, wsc[jw]);
+                }""")
+        s = rep(s, """                for (int jj = 0; jj < 4; ++jj) {     // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
+                    const i32x8 bw = i32x8{(int)wl6a[jj].x, (int)wl6a[jj].y, (int)wl6a[jj].z, (int)wl6a[jj].w, (int)wl6b[jj].x, (int)wl6b[jj].y, 0, 0};
+                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, bw, acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);
+                }""", """                for (int jj = 0; jj < 2; ++jj) {
+                    const int jw = (i & 1) * 2 + jj;
+                    const i32x8 bw = i32x8{(int)wl6a[jw].x, (int)wl6a[jw].y, (int)wl6a[jw].z, (int)wl6a[jw].w, (int)wl6b[jw].x, (int)wl6b[jw].y, 0, 0};
+                    accw[i >> 1][jj] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(ah, bw, accw[i >> 1][jj], 4, 2, 1, asc, 1, wsc[jw]);
+                }""")
+    # the epilogue reads acc[8][4]: the 32 x 32 accumulators are added to it in place (sub-registers of the wide accumulators)
+    s = rep(s, '#include "tdnn_mx_epilogue.inc"', """#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][jj][e] += accw[i >> 1][jj >> 1][((i & 1) * 2 + (jj & 1)) * 4 + e];
+#include "tdnn_mx_epilogue.inc"
+""")
+    return s
+
+
+V["mfma32"] = _mfma32
+V["mfma32_no_dma"] = lambda s: V["no_dma"](_mfma32(s))      # (one shape at a time keeps both accumulator sets live: 190 spills)
+
+# A/B (correct results): waves 4-7 (the SIMD partners of waves 0-3) issue their DMAs half a K-step away from their partners' -- the half
+# stage between row blocks 4-7 instead of 0-3, the side pieces between row blocks 0-3 instead of 4-7 -- so that the two waves of a SIMD
+# are never both in vector-memory issue (the K-loop exists twice, one copy per half of the workgroup)
+def _stagger_dma(s):
+    a = s.index("    for (int ss = 0; ss < p.nss; ++ss) {")
+    b = s.index("#undef MX_DMA_F16")
+    loop = s[a:b]
+    sh = loop
+    for k in range(8):
+        sh = sh.replace(f"if (i == {k}) MX_DMA_F16", f"if (i == @{(k + 4) & 7}) MX_DMA_F16").replace(f"if (i == {k}) {{ MX_DMA_F16", f"if (i == @{(k + 4) & 7}) {{ MX_DMA_F16")
+        sh = sh.replace(f"if (i == {k}) MX_DMA_S", f"if (i == @{(k + 4) & 7}) MX_DMA_S").replace(f"if (i == {k}) {{ MX_DMA_S", f"if (i == @{(k + 4) & 7}) {{ MX_DMA_S")
+    sh = sh.replace("@", "").replace("if (i == 3) MX_SA_SETUP(ss)", "if (i == 0) MX_SA_SETUP(ss)")
+    # (these waves issue a K-step's side pieces BEFORE its half stage: the stage is the youngest DMA at every barrier)
+    sh = rep(sh, 'if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");\n            else asm volatile', 'asm volatile')
+    assert sh != loop
+    return s[:a] + "    if (wave < 4) {\n" + loop + "    } else {\n" + sh + "    }\n" + s[b:]
+
+
+V["stagger_dma"] = _stagger_dma
+
 names = sys.argv[1:] or list(V)
 objs = [o for o in _product_objects() if o != "tdnn_mx.o"]
 FLAGS = {
