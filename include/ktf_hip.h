@@ -212,9 +212,9 @@ int ktf_vad_index(const float* feats, int64_t B, int64_t T, int32_t D, const Ktf
 int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int64_t ldx, const int32_t* lens,
                  const KtfCmvnCfg* cfg, float* out, int64_t ldo, int32_t* out_lens, float* work, void* stream);
 /* Fused hot path: VAD -> per-utterance compaction -> CMVN (xvector_extractor.py:162-166).
- * out_dtype KTF_F32, KTF_BF16 or KTF_F16. idx_work = B*T int32 (on return: the kept frame numbers of each utterance;
- * for recordings of more than 38,400 frames, whose frame -> row map no longer fits in LDS beside the kernel's scratch, the
- * map itself: row of frame t, or -1), work = B*T*2*D floats. Any T < 2^31 / ldo. */
+ * out_dtype KTF_F32, KTF_BF16 or KTF_F16. idx_work = B*T int32 (on return: the kept frame numbers of each utterance),
+ * work = B*T*2*D floats (touched only by recordings too long for the LDS: more than ~38,000 frames). Any T < 2^31 / ldo.
+ * Batches of fewer than 256 utterances spread each utterance over up to eight workgroups (same values, bit for bit). */
 int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* vad, const KtfCmvnCfg* cmvn,
                  void* out, int32_t out_dtype, int64_t ldo, int32_t* lens, int32_t* idx_work, float* work,
                  void* stream);

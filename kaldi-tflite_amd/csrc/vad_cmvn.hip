@@ -12,6 +12,7 @@
 // Replaces: layers/dsp/vad.py:156-203, models/kaldi/xvector_extractor.py:163-165,
 //           layers/normalization/cmvn.py:186-250 of the reference.
 #include "common.h"
+#include <type_traits>
 
 #define VC_THREADS 1024
 #define VC_RG (VC_THREADS / 32)      // row groups of the (row group, 32 columns) thread map
@@ -34,15 +35,16 @@ __device__ __forceinline__ float block_sum(float v, float* red /* VC_WAVES float
     return t;
 }
 
-// keep[t] of VAD.call for one utterance; feats rows of stride D.
-__device__ __forceinline__ bool vad_keep(const float* __restrict__ f, int64_t T, int D, const KtfVadCfg& c, float thr,
+// keep[t] of VAD.call for one utterance; e[u * es] = the energy coefficient of frame u (the feature rows themselves: e = feats +
+// energy_coeff, es = D; or a copy of that column: es = 1).
+__device__ __forceinline__ bool vad_keep(const float* __restrict__ e, int64_t es, int64_t T, const KtfVadCfg& c, float thr,
                                          int64_t t) {
     const int ctx = c.frames_context;
-    if (ctx == 0) return f[t * D + c.energy_coeff] > thr;
+    if (ctx == 0) return e[t * es] > thr;
     int cnt = 0;
     for (int k = -ctx; k <= ctx; ++k) {
         const int64_t u = t + k;
-        if (u >= 0 && u < T) cnt += (f[u * D + c.energy_coeff] > thr) ? 1 : 0;
+        if (u >= 0 && u < T) cnt += (e[u * es] > thr) ? 1 : 0;
     }
     // vad.py:124-135,187-193: denominators at the edges = number of taps inside the sequence
     int den = 2 * ctx + 1;
@@ -64,27 +66,35 @@ __device__ __forceinline__ bool vad_keep(const float* __restrict__ f, int64_t T,
     return ((float)cnt / (float)den) >= c.proportion_threshold;
 }
 
+// (col: when given, the energy column is also copied there -- T floats of LDS the vote then reads instead of the feature rows)
 __device__ __forceinline__ float vad_threshold(const float* __restrict__ f, int64_t T, int D, const KtfVadCfg& c,
-                                               float* red) {
+                                               float* red, float* __restrict__ col = nullptr) {
     float thr = c.energy_threshold;
-    if (c.energy_mean_scale > 0.0f) {
+    if (c.energy_mean_scale > 0.0f || col) {
         float s = 0.0f;
-        for (int64_t t = threadIdx.x; t < T; t += VC_THREADS) s += f[t * D + c.energy_coeff];
-        const float mean = block_sum(s, red) / (float)T;
-        thr += c.energy_mean_scale * mean;
+        for (int64_t t = threadIdx.x; t < T; t += VC_THREADS) {
+            const float v = f[t * D + c.energy_coeff];
+            if (col) col[t] = v;
+            s += v;
+        }
+        if (c.energy_mean_scale > 0.0f) {
+            const float mean = block_sum(s, red) / (float)T;
+            thr += c.energy_mean_scale * mean;
+        } else {
+            __syncthreads();
+        }
     }
     return thr;
 }
 
-// Compacts kept frame numbers of one utterance into idx[0..count) (if idx != NULL) and/or records each frame's position
-// in the compacted sequence in pos[t] (-1 = dropped; if pos != NULL); returns count (block-uniform).
-__device__ int vad_compact(const float* __restrict__ f, int64_t T, int D, const KtfVadCfg& c, float thr,
-                           int32_t* __restrict__ idx, int* __restrict__ pos, int* scan /* VC_WAVES+1 ints in LDS */) {
+// Compacts kept frame numbers of one utterance into idx[0..count) (and into idx2, if given); returns count (block-uniform).
+__device__ int vad_compact(const float* __restrict__ e, int64_t es, int64_t T, const KtfVadCfg& c, float thr,
+                           int32_t* __restrict__ idx, int32_t* __restrict__ idx2, int* scan /* VC_WAVES+1 ints in LDS */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int base = 0;
     for (int64_t t0 = 0; t0 < T; t0 += VC_THREADS) {
         const int64_t t = t0 + threadIdx.x;
-        const bool keep = (t < T) && vad_keep(f, T, D, c, thr, t);
+        const bool keep = (t < T) && vad_keep(e, es, T, c, thr, t);
         const unsigned long long m = __ballot(keep);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         __syncthreads();
@@ -97,8 +107,10 @@ __device__ int vad_compact(const float* __restrict__ f, int64_t T, int D, const 
             if (w < wave) woff += cw;
             tot += cw;
         }
-        if (keep && idx) idx[base + woff + before] = (int32_t)t;
-        if (pos && t < T) pos[t] = keep ? base + woff + before : -1;
+        if (keep) {
+            idx[base + woff + before] = (int32_t)t;
+            if (idx2) idx2[base + woff + before] = (int32_t)t;
+        }
         base += tot;
     }
     return base;
@@ -113,40 +125,54 @@ __device__ __forceinline__ void store_out<unsigned short>(unsigned short* p, flo
 template <>
 __device__ __forceinline__ void store_out<_Float16>(_Float16* p, float v) { *p = (_Float16)v; }
 
-// CMVN of one utterance: rows r < len, row r read at x[(idx ? idx[r] : r) * ldx + d].
+// CMVN of one utterance: rows r < len, row r read at x[(inv ? inv[r] : r) * ldx + d].
 // The (compacted) rows are first staged contiguously into `xs` (len*D floats: LDS when the utterance fits, else the
 // caller's global workspace), which removes the idx indirection and the global-memory latency from the sliding loops.
 // Then every (chunk of CMVN_CHUNK window starts, column) item computes its first window sum directly, slides it, and
 // writes the normalised frames itself — no window-sum array, no second pass. Pad columns [D, ldo) are written as zeros.
 // gm: VC_GM floats of LDS scratch for the whole-utterance branch.
+// split / nsplit: the workgroup is one of nsplit that share the utterance (small batches: one workgroup per utterance leaves 255 CUs
+// idle and its window phase is bound by ONE CU's vector issue). A split owns a contiguous range of the window-start chunks; it stages
+// only the rows its windows read and writes only its frames -- every value is computed exactly as the unsplit workgroup computes it.
 template <typename OutT>
-__device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* __restrict__ pos, int Tsrc, int len, int D,
+__device__ __forceinline__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int32_t* __restrict__ inv, int len, int D,
                            const KtfCmvnCfg& c, OutT* __restrict__ out, int64_t ldo, float* __restrict__ xs, float* gm,
-                           int* out_len, float* __restrict__ bs = nullptr) {
+                           int* out_len, float* __restrict__ bs = nullptr, int split = 0, int nsplit = 1) {
     const int N = c.window;
     const int tid = threadIdx.x;
     const int ldo_i = (int)ldo;
-    // staging walks the SOURCE rows (coalesced, no dependent loads): row t goes to compacted row pos[t] (or t itself)
+    if (len <= N && split) return;                         // whole-utterance statistics: the first split does all of it
+    // this split's chunks [cA, cB) of window starts and the rows [r_lo, r_hi) they read
+    int cA = 0, cB = 0, r_lo = 0, r_hi = len;
+    if (len > N) {
+        const int nstart_ = len - N + 1, nchunk_ = (nstart_ + CMVN_CHUNK - 1) / CMVN_CHUNK;
+        cA = (int)((int64_t)nchunk_ * split / nsplit);
+        cB = (int)((int64_t)nchunk_ * (split + 1) / nsplit);
+        if (cB <= cA) return;
+        r_lo = cA * CMVN_CHUNK;
+        r_hi = min(cB * CMVN_CHUNK, nstart_) + N - 1;
+    }
+    // staging: the rows this split reads, up to 32 independent global loads in flight per thread (one load behind each store
+    // would serialise the ~1 us latencies); kept frames are mostly consecutive, so a row group's loads stay coalesced
     {
         const int rs = tid >> 5, dl = tid & 31;
         for (int d0 = 0; d0 < D; d0 += 32) {
             const int d = d0 + dl;
             if (d < D)
-                for (int t = rs; t < Tsrc; t += VC_RG * 8) {
-                    // eight independent global loads in flight per thread (a load behind each conditional store would
-                    // serialise the ~1 us latencies: 31 of them per thread at T = 998)
-                    float v[8];
-                    int pr[8];
+                for (int r = r_lo + rs; r < r_hi; r += VC_RG * 16) {
+                    float v[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const int tt = t + u * VC_RG;
-                        const bool ok = tt < Tsrc;
-                        pr[u] = ok ? (pos ? pos[tt] : (tt < len ? tt : -1)) : -1;
-                        v[u] = ok ? x[(int64_t)tt * ldx + d] : 0.0f;
+                    for (int u = 0; u < 16; ++u) {
+                        const int rr = r + u * VC_RG;
+                        const bool ok = rr < r_hi;
+                        const int t = ok ? (inv ? inv[rr] : rr) : 0;
+                        v[u] = ok ? x[(int64_t)t * ldx + d] : 0.0f;
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        if (pr[u] >= 0) xs[pr[u] * D + d] = v[u];
+                    for (int u = 0; u < 16; ++u) {
+                        const int rr = r + u * VC_RG;
+                        if (rr < r_hi) xs[rr * D + d] = v[u];
+                    }
                 }
         }
     }
@@ -204,7 +230,8 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
     const int nblk = len / CMVN_CHUNK;                 // complete blocks
     if (bs) {
         float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo_i;
-        for (int item = tid; item < nblk * ldo_i; item += VC_THREADS) {
+        const int kB = min(nblk, cB - 1 + N / CMVN_CHUNK);         // the blocks this split's first windows are made of
+        for (int item = cA * ldo_i + tid; item < kB * ldo_i; item += VC_THREADS) {
             const int k = item / ldo_i, d = item - k * ldo_i;
             float a = 0.0f, a2 = 0.0f;
             if (d < D) {
@@ -222,7 +249,8 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         __syncthreads();
     }
     VC_PROBE(4)
-    for (int item = tid; item < nchunk * ldo_i; item += VC_THREADS) {
+    (void)nchunk;
+    for (int item = cA * ldo_i + tid; item < cB * ldo_i; item += VC_THREADS) {
         const int ch = item / ldo_i, d = item - ch * ldo_i;
         const int s0 = ch * CMVN_CHUNK;
         const int s1 = min(s0 + CMVN_CHUNK, nstart);
@@ -233,6 +261,7 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
             if (bs) {
                 const float* bs2 = bs + (size_t)((len + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo_i;
                 const int nb = N / CMVN_CHUNK;       // whole blocks inside the window (all complete: s0 + N <= len)
+#pragma unroll 4
                 for (int k = 0; k < nb; ++k) {
                     a += bs[(ch + k) * ldo_i + d];
                     a2 += bs2[(ch + k) * ldo_i + d];
@@ -247,32 +276,58 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
                 a2 += v * v;
             }
         }
-        for (int s = s0; s < s1; ++s) {
-            if (s > s0 && real) {
-                const float vn = xs[(s + N - 1) * D + d], vo = xs[(s - 1) * D + d];
-                a += vn - vo;
-                if (c.norm_vars) a2 += vn * vn - vo * vo;        // wave-uniform: the variance path costs nothing when off
-            }
-            const float mean = a / fN;
-            float sd = 1.0f;
-            if (c.norm_vars && real) sd = sqrtf(a2 / fN - mean * mean);
-            // the frame centred on this window; the first / last window also serve the N/2 edge frames before / after
-            // it (SAME): their statistics are parked in LDS and those ~N frames are written by the whole workgroup below
-            // (one thread per column walking 150 frames was the critical path of the kernel)
-            if (!c.valid) {
-                if (s == 0) { gm[d] = mean; gm[ldo_i + d] = sd; }
-                if (s == nstart - 1) { gm[2 * ldo_i + d] = mean; gm[3 * ldo_i + d] = sd; }
-            }
-            {
-                const int t = s + half;
-                float v = 0.0f;
-                if (real) {
-                    v = xs[t * D + d] - mean;
-                    if (c.norm_vars) v = v / sd;
+        // the slide, fully unrolled and branch-free but for the store: eight starts' operands are read ahead of their arithmetic,
+        // ~28 instructions per start. (A loop over the starts with its conditions inside compiles to ~100 per start, most of them
+        // branches, and with one or two waves of items per SIMD the instruction count IS the time: 7.5 of the kernel's 20 us.)
+        // Pad columns run the arithmetic on column 0 and store zeros; an utterance's last chunk may be short: the starts behind
+        // its end repeat the last one's operands and store nothing.
+        {
+            const int cnt = s1 - s0;
+            const int dd = real ? d : 0;
+            const float* pn = xs + (s0 + N - 1) * D + dd;          // frame entering the window of start s0 + i: pn[i * D]
+            const float* po = xs + (s0 - 1) * D + dd;              // frame leaving it: po[i * D] (i >= 1)
+            const float* pc = xs + (s0 + half) * D + dd;           // the frame the window is centred on
+            OutT* op = out + (s0 + (c.valid ? 0 : half)) * ldo_i + d;      // (T * ldo < 2^31: the launcher checks)
+            const int last = (cnt - 1) * D;
+            auto chunk = [&](auto nv_tag) {
+                constexpr bool NV = decltype(nv_tag)::value;
+                float mean = 0.0f, sd = 1.0f, mean0 = 0.0f, sd0 = 1.0f, meanl = 0.0f, sdl = 1.0f;
+#pragma unroll
+                for (int q = 0; q < CMVN_CHUNK / 8; ++q) {
+                    float vn[8], vo[8], xc[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = q * 8 + k;
+                        const int o = min(i * D, last);
+                        vn[k] = i ? pn[o] : 0.0f;
+                        vo[k] = i ? po[o] : 0.0f;
+                        xc[k] = pc[o];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = q * 8 + k;
+                        if (i) {
+                            a += vn[k] - vo[k];
+                            if (NV) a2 += vn[k] * vn[k] - vo[k] * vo[k];
+                        }
+                        mean = a / fN;
+                        if (NV) sd = sqrtf(a2 / fN - mean * mean);
+                        if (i == 0) { mean0 = mean; sd0 = sd; }
+                        if (i == cnt - 1) { meanl = mean; sdl = sd; }
+                        float v = xc[k] - mean;
+                        if (NV) v = v / sd;
+                        if (i < cnt) store_out<OutT>(op + i * ldo_i, real ? v : 0.0f);
+                    }
                 }
-                const int j = c.valid ? t - half : t;
-                store_out<OutT>(out + (int64_t)j * ldo + d, v);
-            }
+                // the first / last window also serve the N/2 edge frames before / after it (SAME): their statistics are parked
+                // in LDS and those ~N frames are written by the whole workgroup below
+                if (!c.valid) {
+                    if (s0 == 0) { gm[d] = real ? mean0 : 0.0f; gm[ldo_i + d] = real ? sd0 : 1.0f; }
+                    if (s1 == nstart) { gm[2 * ldo_i + d] = real ? meanl : 0.0f; gm[3 * ldo_i + d] = real ? sdl : 1.0f; }
+                }
+            };
+            if (c.norm_vars) chunk(std::true_type{});
+            else chunk(std::false_type{});
         }
     }
     VC_PROBE(5)
@@ -280,8 +335,9 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         __syncthreads();
         const int n_head = half;                              // frames [0, half) use the first window
         const int t_tail = nstart + half;                     // frames [t_tail, len) use the last window
-        const int n_edge = n_head + (len - t_tail);
-        for (int e = tid; e < n_edge * ldo_i; e += VC_THREADS) {
+        const int e_lo = cA == 0 ? 0 : n_head;                // (the split that owns the first / last chunk holds its statistics)
+        const int e_hi = cB == nchunk ? n_head + (len - t_tail) : n_head;
+        for (int e = e_lo * ldo_i + tid; e < e_hi * ldo_i; e += VC_THREADS) {
             const int k = e / ldo_i, d = e - k * ldo_i;
             const bool tail = k >= n_head;
             const int t = tail ? t_tail + (k - n_head) : k;
@@ -294,7 +350,7 @@ __device__ void cmvn_block(const float* __restrict__ x, int64_t ldx, const int* 
         }
     }
     VC_PROBE(6)
-    if (out_len && tid == 0) *out_len = c.valid ? nstart : len;
+    if (out_len && tid == 0 && cA == 0) *out_len = c.valid ? nstart : len;     // (the split that owns the first chunk)
 }
 
 __global__ __launch_bounds__(VC_THREADS) void vad_mask_kernel(const float* __restrict__ feats, int64_t T, int D,
@@ -303,7 +359,7 @@ __global__ __launch_bounds__(VC_THREADS) void vad_mask_kernel(const float* __res
     const float* f = feats + (int64_t)blockIdx.x * T * D;
     const float thr = vad_threshold(f, T, D, c, red);
     for (int64_t t = threadIdx.x; t < T; t += VC_THREADS)
-        mask[(int64_t)blockIdx.x * T + t] = vad_keep(f, T, D, c, thr, t) ? 1.0f : 0.0f;
+        mask[(int64_t)blockIdx.x * T + t] = vad_keep(f + c.energy_coeff, D, T, c, thr, t) ? 1.0f : 0.0f;
 }
 
 __global__ __launch_bounds__(VC_THREADS) void vad_index_kernel(const float* __restrict__ feats, int64_t T, int D,
@@ -313,10 +369,13 @@ __global__ __launch_bounds__(VC_THREADS) void vad_index_kernel(const float* __re
     __shared__ int scan[VC_WAVES + 1];
     const float* f = feats + (int64_t)blockIdx.x * T * D;
     const float thr = vad_threshold(f, T, D, c, red);
-    const int n = vad_compact(f, T, D, c, thr, idx + (int64_t)blockIdx.x * T, nullptr, scan);
+    const int n = vad_compact(f + c.energy_coeff, D, T, c, thr, idx + (int64_t)blockIdx.x * T, nullptr, scan);
     if (threadIdx.x == 0) lens[blockIdx.x] = n;
 }
 
+// LDSF: the utterance is staged in LDS -- a pointer that is LDS in one launch and the global workspace in another compiles to flat
+// loads (80 of them in the window phase, ~300 ns per dependent access); the two forms are two instantiations instead.
+template <bool LDSF>
 __global__ __launch_bounds__(VC_THREADS) void cmvn_kernel(const float* __restrict__ x, int64_t T, int D, int64_t ldx,
                                                           const int32_t* __restrict__ lens, KtfCmvnCfg c,
                                                           float* __restrict__ out, int64_t ldo,
@@ -329,38 +388,41 @@ __global__ __launch_bounds__(VC_THREADS) void cmvn_kernel(const float* __restric
     const int b = blockIdx.x;
     const int len = lens ? lens[b] : (int)T;
     int* ol = out_lens ? out_lens + b : nullptr;
-    float* xs = ((int64_t)len * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
-    cmvn_block<float>(x + (int64_t)b * T * ldx, ldx, nullptr, len, len, D, c, out + (int64_t)b * T * ldo, ldo, xs, gm, ol, bsp);
+    float* xs = LDSF ? stage : work + (int64_t)b * T * 2 * D;
+    cmvn_block<float>(x + (int64_t)b * T * ldx, ldx, nullptr, len, D, c, out + (int64_t)b * T * ldo, ldo, xs, gm, ol, bsp);
 }
 
-template <typename OutT>
+template <typename OutT, bool LDSF>
 __global__ __launch_bounds__(VC_THREADS) void vad_cmvn_kernel(const float* __restrict__ feats, int64_t T, int D,
                                                               KtfVadCfg vc, KtfCmvnCfg cc, OutT* __restrict__ out,
                                                               int64_t ldo, int32_t* __restrict__ lens,
                                                               int32_t* __restrict__ idx_work,
                                                               float* __restrict__ work, int64_t stage_floats,
-                                                              int64_t bs_floats, int64_t pos_ints) {
+                                                              int64_t bs_floats, int64_t pos_ints, int64_t col_floats) {
     extern __shared__ __attribute__((aligned(16))) float vc_lds[];
     float* gm = vc_lds;                      // VC_GM floats (also the reduction scratch of the VAD phase)
     const int b = blockIdx.x;
+    const int split = blockIdx.y, nsplit = gridDim.y;     // (every split repeats the VAD: it needs the whole frame -> row map)
     int32_t* idx = idx_work + (int64_t)b * T;
-    // frame -> compacted row (-1 = dropped): T ints of LDS; a recording too long for that (pos_ints == 0, > 38,400 frames)
-    // keeps the map in the caller's idx_work instead (written and read by this workgroup only: same CU, same L1)
-    int* pos = pos_ints ? reinterpret_cast<int*>(vc_lds + VC_GM) : reinterpret_cast<int*>(idx);
+    // compacted row -> frame: T ints of LDS (and, from the first split, a copy in the caller's idx_work); a recording too long for
+    // that (pos_ints == 0, > 38,400 frames) keeps only the copy in idx_work (written and read by this workgroup: same CU, same L1)
+    int32_t* inv = (LDSF || pos_ints) ? reinterpret_cast<int32_t*>(vc_lds + VC_GM) : idx;
     float* bsp = bs_floats ? vc_lds + VC_GM + pos_ints : nullptr;
-    float* stage = vc_lds + VC_GM + pos_ints + bs_floats;
+    float* col = col_floats ? vc_lds + VC_GM + pos_ints + bs_floats : nullptr;       // the energy column (vote input)
+    float* stage = vc_lds + VC_GM + pos_ints + bs_floats + col_floats;
     float* red = gm;
     int* scan = reinterpret_cast<int*>(gm + 64);
     const float* f = feats + (int64_t)b * T * D;
     VC_PROBE(0)
-    const float thr = vad_threshold(f, T, D, vc, red);
+    const float thr = vad_threshold(f, T, D, vc, red, col);
     VC_PROBE(1)
-    const int n = vad_compact(f, T, D, vc, thr, pos_ints ? idx : nullptr, pos, scan);
-    __syncthreads();  // pos[] written by this workgroup is read below by other threads of it
+    const int n = LDSF ? vad_compact(col, 1, T, vc, thr, inv, split == 0 ? idx : nullptr, scan)
+                       : vad_compact(col ? col : f + vc.energy_coeff, col ? 1 : D, T, vc, thr, inv, (pos_ints && split == 0) ? idx : nullptr, scan);
+    __syncthreads();  // inv[] written by this workgroup is read below by other threads of it
     VC_PROBE(2)
     int* ol = lens + b;
-    float* xs = ((int64_t)n * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D;
-    cmvn_block<OutT>(f, D, pos, (int)T, n, D, cc, out + (int64_t)b * T * ldo, ldo, xs, gm, ol, bsp);
+    float* xs = LDSF ? stage : (((int64_t)n * D <= stage_floats) ? stage : work + (int64_t)b * T * 2 * D);
+    cmvn_block<OutT>(f, D, inv, n, D, cc, out + (int64_t)b * T * ldo, ldo, xs, gm, ol, bsp, split, nsplit);
     VC_PROBE(7)
 }
 
@@ -422,9 +484,15 @@ extern "C" int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int
     int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo;
     if ((VC_GM + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;     // block sums only when they fit beside the staged utterance
     const size_t lds = (VC_GM + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
-    KTF_LDS_ONCE(160 * 1024, cmvn_kernel);
-    hipLaunchKernelGGL(cmvn_kernel, dim3((unsigned)B), dim3(VC_THREADS), lds, (hipStream_t)stream, x, T, D, ldx, lens, *cfg,
-                       out, ldo, out_lens, work, stage_floats, bs_floats);
+    if (stage_floats) {
+        KTF_LDS_ONCE(160 * 1024, cmvn_kernel<true>);
+        hipLaunchKernelGGL(cmvn_kernel<true>, dim3((unsigned)B), dim3(VC_THREADS), lds, (hipStream_t)stream, x, T, D, ldx, lens, *cfg,
+                           out, ldo, out_lens, work, stage_floats, bs_floats);
+    } else {
+        KTF_LDS_ONCE(160 * 1024, cmvn_kernel<false>);
+        hipLaunchKernelGGL(cmvn_kernel<false>, dim3((unsigned)B), dim3(VC_THREADS), lds, (hipStream_t)stream, x, T, D, ldx, lens, *cfg,
+                           out, ldo, out_lens, work, stage_floats, bs_floats);
+    }
     KTF_CHECK_LAUNCH("ktf_cmvn_f32");
     return KTF_OK;
 }
@@ -454,20 +522,29 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     if ((VC_GM + pos_ints + stage_floats) * 4 > 158 * 1024) stage_floats = 0;
     int64_t bs_floats = 2 * ((T + CMVN_CHUNK - 1) / CMVN_CHUNK) * ldo;
     if ((VC_GM + pos_ints + bs_floats + stage_floats) * 4 > 158 * 1024) bs_floats = 0;
-    const size_t lds = (VC_GM + (size_t)pos_ints + (size_t)bs_floats + (size_t)stage_floats) * sizeof(float);
-    if (out_dtype == KTF_F32) {
-        KTF_LDS_ONCE(160 * 1024, vad_cmvn_kernel<float>);
-        hipLaunchKernelGGL(vad_cmvn_kernel<float>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad, *cmvn,
-                           (float*)out, ldo, lens, idx_work, work, stage_floats, bs_floats, pos_ints);
-    } else if (out_dtype == KTF_F16) {
-        KTF_LDS_ONCE(160 * 1024, vad_cmvn_kernel<_Float16>);
-        hipLaunchKernelGGL(vad_cmvn_kernel<_Float16>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
-                           *cmvn, (_Float16*)out, ldo, lens, idx_work, work, stage_floats, bs_floats, pos_ints);
-    } else {
-        KTF_LDS_ONCE(160 * 1024, vad_cmvn_kernel<unsigned short>);
-        hipLaunchKernelGGL(vad_cmvn_kernel<unsigned short>, dim3((unsigned)B), dim3(VC_THREADS), lds, st, feats, T, D, *vad,
-                           *cmvn, (unsigned short*)out, ldo, lens, idx_work, work, stage_floats, bs_floats, pos_ints);
+    int64_t col_floats = (T + 3) & ~3ll;
+    if ((VC_GM + pos_ints + bs_floats + col_floats + stage_floats) * 4 > 158 * 1024) col_floats = 0;
+    const size_t lds = (VC_GM + (size_t)pos_ints + (size_t)bs_floats + (size_t)col_floats + (size_t)stage_floats) * sizeof(float);
+    // small batches: up to eight workgroups share an utterance (cmvn_block), while the utterance and its map are staged in LDS
+    // (a split workgroup of the global-workspace form would write rows its siblings write too)
+    unsigned nsplit = 1;
+    if (pos_ints && stage_floats && col_floats) nsplit = (unsigned)(B >= 256 ? 1 : (256 / B > 8 ? 8 : 256 / B));
+    const dim3 grid((unsigned)B, nsplit);
+    const bool ldsf = pos_ints && stage_floats && col_floats;       // map, energy column and rows all in LDS
+#define VC_LAUNCH(OutT, F)                                                                                             \
+    {                                                                                                                  \
+        KTF_LDS_ONCE(160 * 1024, (vad_cmvn_kernel<OutT, F>));                                                          \
+        hipLaunchKernelGGL((vad_cmvn_kernel<OutT, F>), grid, dim3(VC_THREADS), lds, st, feats, T, D, *vad, *cmvn, (OutT*)out, ldo, \
+                           lens, idx_work, work, stage_floats, bs_floats, pos_ints, col_floats);                       \
     }
+    if (out_dtype == KTF_F32) {
+        if (ldsf) VC_LAUNCH(float, true) else VC_LAUNCH(float, false)
+    } else if (out_dtype == KTF_F16) {
+        if (ldsf) VC_LAUNCH(_Float16, true) else VC_LAUNCH(_Float16, false)
+    } else {
+        if (ldsf) VC_LAUNCH(unsigned short, true) else VC_LAUNCH(unsigned short, false)
+    }
+#undef VC_LAUNCH
     KTF_CHECK_LAUNCH("ktf_vad_cmvn");
     return KTF_OK;
 }
