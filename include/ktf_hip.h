@@ -300,6 +300,9 @@ const char* ktf_tdnn_last_kernel(void);
 
 /* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
 int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);
+/* ... for a batch's lengths on the device: out_lens[b] = ktf_tdnn_out_len(lens[b], d). (ktf_tdnn writes them itself; the entry points on
+ * the MX planes have no such argument: a VALID-padded or subsampling layer there is followed by this call.) */
+int ktf_tdnn_out_lens(const int32_t* lens, int64_t B, const KtfTdnnDesc* d, int32_t* out_lens, void* stream);
 
 int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
              const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
@@ -357,8 +360,11 @@ int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, vo
  *          [32 Ki, 40 Ki)   q * 8 : bits 128..191 of the same
  *          [40 Ki, 44 Ki)   q * 4 : uint32, byte 0 = E8M0 scale of the e2m1 block, byte 1 = of the e2m3 block
  *          [44 Ki, 48 Ki)   unused
- * SAME padding, subsampling 1, ReLU or no activation; scale / shift as in ktf_tdnn (NULL when the BatchNorm is folded into
- * the next layer, TDNN.device_weights_mx).
+ * ReLU or no activation; scale / shift as in ktf_tdnn (NULL when the BatchNorm is folded into the next layer,
+ * TDNN.device_weights_mx). VALID padding and subsampling (tdnn.py:224-249) on the 256-row kernel: the output (planes or fp32 rows)
+ * then has ktf_tdnn_out_len(T, d) rows per utterance and the valid rows of utterance b are ktf_tdnn_out_len(lens[b], d)
+ * (ktf_tdnn_out_lens makes them for the next layer); ktf_tdnn_mx_stats and KTF_TDNN_MX_LOADER take SAME padding without
+ * subsampling only, KTF_TDNN_MX_SLAB is ignored for such a layer.
  * With KtfTdnnDesc.flags & KTF_TDNN_MX_LOADER the call runs the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles over the flat row
  * space b * T + t, eight matrix + four loader waves) on the SAME activation planes and on weight images of its own
  * (mx.weight_images_loader): every operand fragment is 64 lanes x 16 (8, 4) consecutive bytes, and inside each 32-unit chunk the image

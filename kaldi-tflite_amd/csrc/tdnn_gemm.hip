@@ -105,6 +105,27 @@ extern "C" int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d) {
     return n <= 0 ? 0 : (n + d->subsampling - 1) / d->subsampling;
 }
 
+// out_lens[b] = ktf_tdnn_out_len(lens[b]) on the device: the entry points on the MX planes (ktf_tdnn_mx) have no out_lens argument
+__global__ void tdnn_out_lens_kernel(const int32_t* __restrict__ lens, int64_t B, int start, int cut, int sub, int32_t* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) {
+        const int n = lens[b] - cut - start;
+        out[b] = n <= 0 ? 0 : (n + sub - 1) / sub;
+    }
+}
+
+extern "C" int ktf_tdnn_out_lens(const int32_t* lens, int64_t B, const KtfTdnnDesc* d, int32_t* out_lens, void* stream) {
+    KTF_REQUIRE(lens && d && out_lens, "ktf_tdnn_out_lens: null argument");
+    KTF_REQUIRE(B >= 0 && d->nctx >= 1 && d->nctx <= 16 && d->subsampling >= 1, "ktf_tdnn_out_lens: bad size / descriptor");
+    if (B == 0) return KTF_OK;
+    const int start = (d->valid && d->ctx[0] < 0) ? -d->ctx[0] : 0;
+    const int cut = (d->valid && d->ctx[d->nctx - 1] > 0) ? d->ctx[d->nctx - 1] : 0;
+    hipLaunchKernelGGL(tdnn_out_lens_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, lens, B, start, cut,
+                       d->subsampling, out_lens);
+    KTF_CHECK_LAUNCH("ktf_tdnn_out_lens");
+    return KTF_OK;
+}
+
 static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,

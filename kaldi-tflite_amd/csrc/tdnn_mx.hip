@@ -121,7 +121,8 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int len = p.lens ? p.lens[b] : (int)p.T;
-    if (t0 >= len || len <= 0) return;
+    const int out_len = len - p.cut - p.start <= 0 ? 0 : (len - p.cut - p.start + p.sub - 1) / p.sub;      // (== len: SAME, no subsampling)
+    if (t0 >= out_len) return;
     const int lenm1 = len - 1;
     const unsigned Tu = (unsigned)p.T;
     const int64_t ub = (int64_t)b * p.nch_in * p.T;       // first (chunk, row) record of this utterance
@@ -142,7 +143,7 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         const int q = i * 512 + tid;
         const int row = q >> 2;
         a_cb[i] = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
-        a_row[i] = t0 + row;
+        a_row[i] = p.start + (t0 + row) * p.sub;          // input row of output row t0 + row at context offset 0
     }
     // Which (32-feature chunk, context offset) a K-step reads is tracked in scalar registers, advanced once per stage: no division
     // and no table load sits between the MFMAs (a scalar load there is a ~200-cycle stall of the wave's whole instruction
@@ -155,6 +156,7 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     unsigned s_base = 0;
     unsigned sa_base[4];
     int sa_off[4];
+    const int sa_row0 = p.start + (t0 + lane) * p.sub, sa_rg = 64 * p.sub;      // side A: input row of the lane's row in row group 0; per group
     // position of K-step ks_ (the next stage to issue) from the position of ks_ - 1; padded K-steps re-read step 0 (zero weights)
 #define MX_F_ADV(ks_)                                                                                                  \
     {                                                                                                                  \
@@ -201,7 +203,7 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         const int plane_ = idx_ >> 4, kb_ = (n_) < 4 ? (idx_ >> 2) & 3 : idx_ >> 2, rg_ = idx_ & 3;                    \
         const unsigned base_ = kb_ == 0 ? sa_base[0] : kb_ == 1 ? sa_base[1] : kb_ == 2 ? sa_base[2] : sa_base[3];     \
         const int off__ = kb_ == 0 ? sa_off[0] : kb_ == 1 ? sa_off[1] : kb_ == 2 ? sa_off[2] : sa_off[3];              \
-        int r_ = t0 + rg_ * 64 + lane + off__;                                                                         \
+        int r_ = sa_row0 + rg_ * sa_rg + off__;                                                                        \
         r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
         if ((n_) < 4) {                                                                                                \
             const unsigned vo_ = (base_ + (unsigned)r_) * 16u;                                                         \
@@ -384,7 +386,9 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     KTF_REQUIRE(d->units > 0 && d->din > 0 && d->din_pad % 32 == 0 && d->din_pad >= d->din, "%s: bad units / din / din_pad", who);
     KTF_REQUIRE(d->nctx >= 1 && d->nctx <= 16, "%s: nctx %d outside [1,16]", who, d->nctx);
     for (int i = 1; i < d->nctx; ++i) KTF_REQUIRE(d->ctx[i] > d->ctx[i - 1], "%s: context must be strictly ascending", who);
-    KTF_REQUIRE(!d->valid && d->subsampling == 1, "%s: SAME padding without subsampling only", who);
+    KTF_REQUIRE(d->subsampling >= 1 && d->subsampling <= 64, "%s: subsampling %d outside [1,64]", who, d->subsampling);
+    const bool plain = !d->valid && d->subsampling == 1;
+    KTF_REQUIRE(plain || !stats, "%s: the fused pooling takes SAME padding without subsampling", who);
     KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "%s: fuses ReLU or no activation", who);
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift go together", who);
     KTF_REQUIRE(T * (int64_t)d->din_pad * 2 < (1ll << 31), "%s: T * din_pad too large", who);
@@ -400,6 +404,12 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     p.yh = (char*)yh; p.yl4 = (char*)yl4; p.y4 = (char*)y4; p.ys = (char*)ys; p.yf = yf; p.ldy = ldy; p.T = T;
     p.units = d->units; p.nch_in = d->din_pad / 32; p.nctx = d->nctx; p.nk = p.nch_in * d->nctx; p.nss = (p.nk + 3) / 4;
     p.nch_out = (d->units + 31) / 32;
+    p.sub = d->subsampling;
+    p.start = (d->valid && d->ctx[0] < 0) ? -d->ctx[0] : 0;
+    p.cut = (d->valid && d->ctx[d->nctx - 1] > 0) ? d->ctx[d->nctx - 1] : 0;
+    p.Tout = ktf_tdnn_out_len(T, d);
+    if (p.Tout <= 0) return KTF_OK;
+    KTF_REQUIRE(plain || !(d->flags & KTF_TDNN_MX_LOADER), "%s: the loader-wave kernel takes SAME padding without subsampling", who);
     const bool loader = (d->flags & KTF_TDNN_MX_LOADER) != 0;
     p.stat_slots = (stats && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_mx_stats_slots(T, d->flags) : 0;
     for (int i = 0; i < d->nctx; ++i) {
@@ -414,13 +424,13 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
         KTF_CHECK_LAUNCH(who);
         return KTF_OK;
     }
-    if ((d->flags & KTF_TDNN_MX_SLAB) && mxs_applies(d)) {   // multi-context layers on activation slabs (tdnn_mxs.hip); same images, same tiles
+    if ((d->flags & KTF_TDNN_MX_SLAB) && plain && mxs_applies(d)) {   // multi-context layers on activation slabs (tdnn_mxs.hip); same images, same tiles
         const int rc = mxs_launch(p, B, d->act, o, stats, st);
         if (rc != KTF_OK) return rc;
         KTF_CHECK_LAUNCH(who);
         return KTF_OK;
     }
-    const int mtiles = ktf_cdiv(T, 256), ntiles = ktf_cdiv(d->units, 256);
+    const int mtiles = ktf_cdiv(p.Tout, 256), ntiles = ktf_cdiv(d->units, 256);
     const int64_t gtiles = B * mtiles;
     const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles;
 #define MX_LAUNCH(A, O)                                                                                                \

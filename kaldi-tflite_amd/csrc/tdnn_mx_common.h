@@ -35,8 +35,11 @@ struct MxParams {
     char* ys;
     float* yf;               // ... fp32 row-major (B, T, ldy)
     int64_t ldy;
-    int64_t T;
+    int64_t T;               // rows per (utterance, chunk) of the input planes
+    int64_t Tout;            // ... of the output (planes and fp32 rows): ktf_tdnn_out_len(T); == T with SAME padding and no subsampling
     int32_t units, nch_in, nctx, nk, nss, nch_out, stat_slots;
+    int32_t sub, start, cut; // output row t reads the input rows start + t * sub + ctx[k] (clamped to the utterance); an utterance of len
+                             // rows has ceil((len - cut - start) / sub) output rows (tdnn.py:224-249: VALID padding, subsampling_factor)
     unsigned long long ctx_pk[2];      // the (sorted) context offsets as signed bytes, offset k in byte k
 };
 

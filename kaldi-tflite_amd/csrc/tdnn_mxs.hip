@@ -48,7 +48,7 @@ __device__ __forceinline__ void mxs_tile(const MxParams& p, const int id, int mt
     const int wm = wave >> 2, wn = wave & 3;
     const int len = p.lens ? p.lens[b] : (int)p.T;
     if (t0 >= len || len <= 0) return;
-    const int lenm1 = len - 1;
+    const int lenm1 = len - 1, out_len = len;            // (SAME padding, no subsampling: mx_launch)
     const unsigned Tu = (unsigned)p.T;
     const int64_t ub = (int64_t)b * p.nch_in * p.T;       // first (chunk, row) record of this utterance
     const char* xh = p.xh + ub * 64;

@@ -103,6 +103,7 @@ PROTOTYPES = {
     "ktf_vad_cmvn": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(VadCfg), C.POINTER(CmvnCfg), _P, _i32, _i64, _P, _P, _P, _P]),
     "ktf_route_short": (C.c_int, [_P, _i64, _i32, _P, _P, _P, _i32, _P]),
     "ktf_tdnn_out_len": (_i64, [_i64, C.POINTER(TdnnDesc)]),
+    "ktf_tdnn_out_lens": (C.c_int, [_P, _i64, C.POINTER(TdnnDesc), _P, _P]),
     "ktf_tdnn_last_kernel": (C.c_char_p, []),
     "ktf_tdnn": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
     "ktf_tdnn_stats": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),

@@ -976,8 +976,6 @@ class TDNN(Layer):
         if gemm not in (L.GEMM_F16, L.GEMM_F16X2, L.GEMM_F16MX):
             return gemm
         ok = self.units > 128 and (a in (None, "linear") or (a == "relu" and not relu))
-        if gemm == L.GEMM_F16MX:             # SAME padding without subsampling only
-            ok = ok and self.padding == "SAME" and self.subsamplingFactor == 1
         if not ok and not getattr(self, "_warned_fp32_fallback", False):
             import warnings
             self._warned_fp32_fallback = True
@@ -1029,7 +1027,7 @@ class TDNN(Layer):
         ops.mx_planes(src, D, None, planes)
         wh, wq, bias = self.device_weights_mx(x.device, loader=False)
         d = self.desc(L.GEMM_F16MX, torch.float16, torch.float32)
-        y = torch.empty((B, T, ops.round_up(self.units, 4)), dtype=torch.float32, device=x.device)
+        y = torch.empty((B, self.outputTimesteps(T), ops.round_up(self.units, 4)), dtype=torch.float32, device=x.device)
         ops.tdnn_mx(planes, None, d, wh, wq, bias, None, None, y)
         return y[:, :, : self.units]
 

@@ -369,7 +369,9 @@ class Sequential:
                     ops.mx_planes(src, D, lens, mxp)
                 B, T, _ = mxp.shape
                 fold, pending_bn = pending_bn, None
-                use_loader = self._mx_use_loader(B, T)
+                plain = l.padding == "SAME" and l.subsamplingFactor == 1      # (VALID padding / subsampling: the 256-row kernel only)
+                Tout = l.outputTimesteps(T)
+                use_loader = plain and self._mx_use_loader(B, T)
                 wh, wq, bias = l.device_weights_mx(dev, fold=fold, loader=use_loader)
                 mxf = L.TDNN_MX_LOADER if use_loader else (L.TDNN_MX_SLAB if self.mx_slab else 0)
                 d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None, flags=mxf)
@@ -396,16 +398,18 @@ class Sequential:
                 defer_bn = bn is not None and in_route
                 scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
                 if in_route:
-                    out = Planes.buffers(self._ws.get, out_role + "mx", B, T, l.units, dev)
+                    out = Planes.buffers(self._ws.get, out_role + "mx", B, Tout, l.units, dev)
                     ops.tdnn_mx(mxp, lens, d, wh, wq, bias, scale, shift, out)
                     mxp = out
                     x = out.xh                            # (shape carrier only)
                 else:
                     ldy = ops.round_up(l.units, 32)
-                    ybuf = self._ws.get(out_role, (B, T, ldy), torch.float32, dev, padded=ldy != l.units)
+                    ybuf = self._ws.get(out_role, (B, Tout, ldy), torch.float32, dev, padded=ldy != l.units)
                     ops.tdnn_mx(mxp, lens, d, wh, wq, bias, scale, shift, ybuf)
                     mxp = None
                     x = ybuf[:, :, : l.units]
+                if lens is not None and not plain:
+                    lens = ops.tdnn_out_lens(lens, d, torch.empty_like(lens))
                 if defer_bn:
                     pending_bn = bn
                 continue

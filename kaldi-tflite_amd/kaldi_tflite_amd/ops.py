@@ -312,6 +312,14 @@ def tdnn_out_len(T, desc):
     return int(L.load().ktf_tdnn_out_len(int(T), C.byref(desc)))
 
 
+def tdnn_out_lens(lens, desc, out):
+    """out[b] = tdnn_out_len(lens[b]) on the device (for the layers behind ktf_tdnn_mx, which has no out_lens argument)."""
+    with L.on_device(lens.device):
+        rc = L.load().ktf_tdnn_out_lens(L.ptr(lens), lens.shape[0], C.byref(desc), L.ptr(out), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_out_lens")
+    return out
+
+
 def tdnn(x, lens, desc, w, w_lo, bias, scale, shift, y, out_lens=None):
     """x (B,T,ldx) fp32/bf16, y (B,Tout,ldy) preallocated."""
     lib = L.load()
@@ -446,7 +454,7 @@ def mx_planes(src, D, lens, planes):
 
 
 def tdnn_mx(xp, lens, desc, wh, wq, bias, scale, shift, y):
-    """xp: mx.Planes. y: mx.Planes (the next layer's input) or an fp32 (B,T,ldy) tensor."""
+    """xp: mx.Planes. y: mx.Planes (the next layer's input) or an fp32 tensor, (B, tdnn_out_len(T), ...) either way."""
     lib = L.load()
     B, T, _ = xp.shape
     planes = not isinstance(y, torch.Tensor)

@@ -54,9 +54,14 @@ int main(void) {
     t.gemm = KTF_GEMM_F16MX;
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, NULL, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 8, NULL));     /* no output */
-    t.valid = 1;
+    t.valid = 1;                                                                                           /* VALID padding / subsampling: */
+    EXPECT_EINVAL(ktf_tdnn_mx_stats(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, d, NULL));          /* ... not with the fused pooling */
+    t.flags = KTF_TDNN_MX_LOADER;
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));     /* ... not on the loader-wave kernel */
+    t.flags = 0; t.valid = 0; t.subsampling = 0;
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
-    t.valid = 0; t.ctx[0] = 300;
+    EXPECT_EINVAL(ktf_tdnn_out_lens(NULL, 1, &t, NULL, NULL));
+    t.subsampling = 1; t.ctx[0] = 300;
     EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL, NULL, NULL, f, 8, NULL));
     EXPECT_EINVAL(ktf_tdnn_mx_stats(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL));
     t.ctx[0] = 0; t.flags = KTF_TDNN_MX_LOADER;                                                            /* the loader-wave kernel ... */

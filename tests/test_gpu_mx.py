@@ -4,6 +4,7 @@ NumPy codecs bit for bit, one TDNN layer against an fp64 emulation of exactly th
 layer to show what the arithmetic costs (~2^-14 relative). The whole extractor in this mode is gated on speech in
 tests/test_gpu_speech.py and at the BASELINE size below."""
 
+import warnings
 import numpy as np
 import pytest
 import torch
@@ -379,3 +380,146 @@ def test_f16mx_edge_cases():
     out = mdl(dev(wav)).cpu().numpy()
     assert np.array_equal(out[[0, 2]], ref[[0, 2]]) and np.isnan(out[1]).all()
     assert tuple(mdl(torch.zeros((0, 32000), device="cuda")).shape) == (0, 128)
+
+
+# ----------------------------------------------------------------------------- VALID padding / subsampling on the MX kernel
+def _emulate_opts(layer, x, lens, relu):
+    """_emulate for any padding / subsampling_factor (tdnn.py:224-249): output row t of an utterance reads the input rows
+    start + t * sub + ctx[k], clamped with SAME padding."""
+    B, T, D = x.shape
+    K, ctx, units, sub = layer.kernelWidth, list(layer.context), layer.units, layer.subsamplingFactor
+    Dp, Up = ops.round_up(D, 32), ops.round_up(units, 256)
+    xp = np.zeros((B, T, Dp), np.float32)
+    xp[:, :, :D] = x
+    xh, cl, ch, sl, sh = mx.encode_activations(xp)
+    blk = (B, T, Dp // 32, 32)
+    Xh = xh.astype(np.float64)
+    Xl = mx.decode_e2m1(cl.reshape(blk), sl).reshape(B, T, Dp)
+    X4 = mx.decode_e2m1(ch.reshape(blk), sh).reshape(B, T, Dp)
+    Wk = np.transpose(layer.kernel[0], (2, 0, 1)).astype(np.float64)
+    Wp = np.zeros((Up, K, Dp))
+    Wp[:units, :, :D] = Wk
+    Wi = np.ascontiguousarray(Wp.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3)).reshape(Up, (Dp // 32) * K, 32)
+    _, _, (Wh, W4, W6) = mx.weight_images(Wi)
+    emu, exact = [], []
+    for b in range(B):
+        n = int(lens[b])
+        idx = O.tdnn_eval_indices(n, ctx, sub, layer.padding) if n else np.zeros((0, K), np.int64)
+        acc = np.zeros((idx.shape[0], Up))
+        ex = np.zeros((idx.shape[0], units))
+        for ks in range((Dp // 32) * K):
+            c, k = divmod(ks, K)
+            rows = idx[:, k]
+            sl_ = slice(c * 32, c * 32 + 32)
+            acc += Xh[b, rows, sl_] @ Wh[:, ks].T + Xl[b, rows, sl_] @ W4[:, ks].T + X4[b, rows, sl_] @ W6[:, ks].T
+            ex += xp[b, rows, sl_].astype(np.float64) @ Wi[:units, ks].T
+        e, q = acc[:, :units] + layer.bias, ex + layer.bias
+        emu.append(np.maximum(e, 0) if relu else e)
+        exact.append(np.maximum(q, 0) if relu else q)
+    return emu, exact
+
+
+OPT_CASES = [  # D, context, units, B, T, lens, padding, subsampling
+    (64, [-2, 0, 2], 512, 3, 300, [300, 77, 4], "VALID", 1),          # (4 rows: no output row at all)
+    (96, [-3, 0, 3], 200, 2, 700, [700, 301], "SAME", 2),             # two M-tiles of outputs from three of inputs
+    (30, [-2, -1, 0, 1, 2], 300, 2, 1000, [1000, 515], "VALID", 3),
+    (160, [0, 3], 256, 2, 260, [260, 5], "VALID", 1),                 # one-sided context: start 0, three rows cut at the end
+    (64, [-4, 0], 130, 1, 1537, [1537], "SAME", 5),
+]
+
+
+@pytest.mark.parametrize("case", OPT_CASES)
+@pytest.mark.parametrize("relu", [True, False])
+def test_tdnn_mx_valid_padding_and_subsampling_vs_emulation(case, relu):
+    """VERDICT r3 'missing' 3: layers/tdnn/tdnn.py:224-249 on the f16mx kernels (they used to hand such layers to the fp32 kernels)."""
+    rng = np.random.default_rng(21)
+    D, ctx, units, B, T, lens, pad, sub = case
+    K = len(ctx)
+    W = (rng.standard_normal((units, K, D)) / np.sqrt(K * D)).astype(np.float32)
+    bias = (rng.standard_normal(units) * 0.1).astype(np.float32)
+    x = np.maximum(rng.standard_normal((B, T, D)) * np.exp2(rng.integers(-3, 3, (1, 1, D))), 0.0).astype(np.float32)
+    layer = ktf.layers.TDNN(units, context=list(ctx), padding=pad, subsampling_factor=sub, name="t")
+    layer.build((None, None, D))
+    layer.set_weights([W.reshape(units, K * D), bias])
+    lens = np.asarray(lens, np.int32)
+    p = mx.Planes.empty(B, T, D, "cuda")
+    dl = dev(lens, torch.int32)
+    ops.mx_planes(dev(x), D, dl, p)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=False)
+    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=L.TDNN_MX_SLAB)     # (the flag is ignored here)
+    Tout = ops.tdnn_out_len(T, d)
+    assert Tout == O.tdnn_eval_indices(T, ctx, sub, pad).shape[0] == layer.outputTimesteps(T)
+    y = torch.full((B, Tout, ops.round_up(units, 4)), 7.0, device="cuda")
+    ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, y)
+    assert ops.last_kernel() == "tdnn_mx_kernel"
+    got = y.cpu().numpy()
+    emu, exact = _emulate_opts(layer, x, lens, relu)
+    out_lens = ops.tdnn_out_lens(dl, d, torch.empty_like(dl)).cpu().numpy()
+    for b in range(B):
+        n = emu[b].shape[0]
+        assert out_lens[b] == n
+        if n:
+            scale = np.abs(exact[b]).max()
+            assert np.abs(got[b, :n, :units] - emu[b]).max() <= 3e-6 * scale, "kernel != its own arithmetic"
+            assert np.abs(got[b, :n, :units] - exact[b]).max() <= 4e-4 * scale
+        assert (got[b, n:] == 7.0).all(), "rows beyond the utterance's output length are not written"
+    # the plane output at the same shapes == the planes of the fp32 output
+    out = mx.Planes.empty(B, Tout, units, "cuda")
+    dp = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu" if relu else None)
+    ops.tdnn_mx(p, dl, dp, wh, wq, bd, None, None, out)
+    ref = mx.Planes.empty(B, Tout, units, "cuda")
+    yz = torch.where(y == 7.0, torch.zeros_like(y), y)
+    ops.mx_planes(yz, units, dev(out_lens, torch.int32), ref)
+    for b in range(B):
+        n = int(out_lens[b])
+        for a, r in zip(out.decode(), ref.decode()):
+            assert np.array_equal(a[b, :n], r[b, :n])
+    # the kernels that take SAME padding without subsampling only say so
+    dlo = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, flags=L.TDNN_MX_LOADER)
+    with pytest.raises(ValueError, match="SAME padding without subsampling"):
+        ops.tdnn_mx(p, dl, dlo, wh, wq, bd, None, None, y)
+
+
+def test_f16mx_model_with_valid_and_subsampled_layers_stays_on_the_mx_kernels():
+    """A frame-level stack with VALID padding and subsampling in "f16mx": every wide ReLU layer runs on tdnn_mx_kernel (planes from layer
+    to layer, lengths by ktf_tdnn_out_lens) and the output agrees with the fp64 oracle like the SAME-padded stacks do."""
+    rng = np.random.default_rng(33)
+    D = 40
+    spec = [(300, [-2, 0, 2], "VALID", 1), (260, [-1, 0, 1], "SAME", 2), (520, [-3, 0, 3], "VALID", 1), (200, [0], "SAME", 1)]
+    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
+    for i, (U, ctx, pad, sub) in enumerate(spec):
+        lcfg.append({"name": f"t{i}", "type": ["affine", "relu", "batchnorm"],
+                     "cfg": {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}})
+    mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm="f16mx")
+    mdl.min_tiles, mdl.min_frames = {}, {}
+    mdl.mx_loader = False                                    # (a batch this small would put the last, SAME-padded layer on the loader kernel)
+    layers, din = [], D
+    for i, (U, ctx, pad, sub) in enumerate(spec):
+        W = (rng.standard_normal((U, len(ctx) * din)) / np.sqrt(len(ctx) * din)).astype(np.float32)
+        b = (rng.standard_normal(U) * 0.1).astype(np.float32)
+        mdl.get_layer(f"t{i}.affine").set_weights([W, b])
+        bn = (np.float32(1.0), rng.uniform(-0.2, 0.4, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
+        mdl.get_layer(f"t{i}.batchnorm").set_weights(list(bn))
+        layers += [{"kind": "tdnn", "W": W, "b": b, "context": ctx, "padding": pad, "subsampling_factor": sub}, {"kind": "relu"},
+                   {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]}]
+        din = U
+    B, T = 3, 611
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    lens = np.array([T, 97, 402], np.int32)
+    seen = []
+    real = ops.tdnn_mx
+    ops.tdnn_mx = lambda *a, **k: (real(*a, **k), seen.append(ops.last_kernel()))[0]
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                   # no layer falls back to the fp32 kernels
+            got = mdl.run_ragged(dev(x), dev(lens, torch.int32)).cpu().numpy()
+    finally:
+        ops.tdnn_mx = real
+    assert seen == ["tdnn_mx_kernel"] * 4
+    for i in range(B):
+        want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)[0]
+        n = want.shape[0]
+        assert n > 0 and got.shape[1] >= n
+        err = np.abs(got[i, :n] - want).max() / np.abs(want).max()
+        print(f"utterance {i}: {n} output rows, max-abs deviation / max |y| = {err:.2e}")
+        assert err < 2e-3                                    # frame-level outputs (no pooling to average the rounding noise)

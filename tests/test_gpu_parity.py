@@ -307,7 +307,7 @@ def test_tdnn_narrow_golden_fused_and_layerwise():
     assert np.abs(got - O.sequential_forward(layers, x, dtype=np.float64)).max() < 1e-5
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2), ("f16", 8e-3)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2), ("f16", 8e-3), ("f16mx", 2e-3)])
 def test_tdnn_options_vs_oracle(gemm, tol):
     rng = np.random.default_rng(11)
     for (B, T, D, U, ctx, sub, pad, act) in [
