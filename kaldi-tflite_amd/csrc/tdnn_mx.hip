@@ -108,7 +108,9 @@ extern "C" int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, 
 }
 
 // ------------------------------------------------------------------------------------ the GEMM
-template <int ACT, int OUT>
+// PADK: the layer's K-steps do not fill its last super-step (nk % 4 != 0: the first layer, 5 x 32 features): the zero-padded K-steps
+// skip their fragments, MFMAs and stage. An instantiation of its own: as a run-time test inside every K-step it costs the other layers 3-4 %.
+template <int ACT, int OUT, bool PADK>
 __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mtiles, int ntiles, int gtiles, double* __restrict__ stats,
                                         unsigned char* rsm) {
     const int xcd = id & 7, slot = id >> 3;             // an XCD runs all N-tiles of an M-tile back to back (its L2 keeps the A tile)
@@ -259,8 +261,8 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            constexpr bool live = true;
-            const bool next = ks + 1 < nkp;
+            const bool live = PADK ? ks < p.nk : true;
+            const bool next = ks + 1 < (PADK ? p.nk : nkp);
             const unsigned char* sa = rsm + (ks & 1) * MX_STAGE;
             const unsigned char* sw = sa + MX_TILE;
             hfrag8 bh[4];
@@ -370,10 +372,10 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
 // (The tile body is a function of its own: a persistent form -- one workgroup per CU looping over tiles, tried for the pooled
 // layer so that a tile's statistics stores drain under the next tile's prologue -- keeps the 160-byte parameter block live across
 // the loop, spills 67 scalar registers and runs 5 % slower than one workgroup per tile.)
-template <int ACT, int OUT>
+template <int ACT, int OUT, bool PADK>
 __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, int ntiles, int gtiles, double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-    mx_tile<ACT, OUT>(p, blockIdx.x, mtiles, ntiles, gtiles, stats, rsm);
+    mx_tile<ACT, OUT, PADK>(p, blockIdx.x, mtiles, ntiles, gtiles, stats, rsm);
 }
 
 // x planes (see the head of this file) -> one TDNN layer. Exactly one of {y planes, yf, stats} is written.
@@ -436,8 +438,13 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
 #define MX_LAUNCH(A, O)                                                                                                \
     {                                                                                                                  \
         KTF_NOTE_KERNEL("tdnn_mx_kernel");                                                                             \
-        KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O>);                                                              \
-        hipLaunchKernelGGL((tdnn_mx_kernel<A, O>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
+        if (p.nk & 3) {                                                                                                \
+            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, true>);                                                    \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, true>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
+        } else {                                                                                                       \
+            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, false>);                                                   \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, false>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
+        }                                                                                                              \
     }
     if (d->act == KTF_ACT_RELU) {
         if (o == MX_OUT_STATS) MX_LAUNCH(KTF_ACT_RELU, MX_OUT_STATS) else if (o == MX_OUT_F32) MX_LAUNCH(KTF_ACT_RELU, MX_OUT_F32) else MX_LAUNCH(KTF_ACT_RELU, MX_OUT_PLANES)
