@@ -204,11 +204,14 @@ __device__ __forceinline__ void cmvn_block(const float* __restrict__ x, int64_t 
                 mean = ts / (float)len;
                 if (c.norm_vars) sd = sqrtf(ts2 / (float)len - mean * mean);
             }
-            for (int r = rg; r < len; r += VC_RG) {
+            // VALID keeps the frames [N/2, len - (N-1)/2) (cmvn.py:238-243): none of an utterance shorter than the window, one of an
+            // utterance exactly as long
+            const int r0 = c.valid ? N / 2 : 0, nout = c.valid ? (len == N ? 1 : 0) : len;
+            for (int r = rg; r < nout; r += VC_RG) {
                 if (d < ldo_i) {
                     float v = 0.0f;
                     if (d < D) {
-                        v = xs[r * D + d] - mean;
+                        v = xs[(r0 + r) * D + d] - mean;
                         if (c.norm_vars) v = v / sd;
                     }
                     store_out<OutT>(out + (int64_t)r * ldo + d, v);
@@ -216,7 +219,7 @@ __device__ __forceinline__ void cmvn_block(const float* __restrict__ x, int64_t 
             }
             __syncthreads();
         }
-        if (out_len && tid == 0) *out_len = len;
+        if (out_len && tid == 0) *out_len = c.valid ? (len == N ? 1 : 0) : len;
         return;
     }
     // cmvn.py:172-182: frame t uses the window starting at clamp(t - N/2, 0, len - N); VALID keeps [N/2, len-(N-1)/2)

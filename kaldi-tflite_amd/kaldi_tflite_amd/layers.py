@@ -570,7 +570,7 @@ class CMVN(Layer):
             x = x.unsqueeze(0)
         B, T, D = x.shape
         out = ops.cmvn(x, self.cfg())
-        if self.padding == "VALID" and T > self.N:
+        if self.padding == "VALID":         # (cmvn.py:238-243: an input no longer than the window leaves no valid frame -- one when exactly as long)
             a, b = self.N // 2, T - (self.N - 1) // 2
             return out[:, : max(b - a, 0), :].contiguous()
         return out

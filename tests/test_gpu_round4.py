@@ -20,6 +20,7 @@ import torch
 import synth
 import kaldi_tflite_amd as ktf
 from kaldi_tflite_amd import ops
+from kaldi_tflite_amd import layers as Ls
 from oracle import ktf_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -395,3 +396,69 @@ def test_short_windows_run_flat_rows_and_equal_the_tiled_route():
     finally:
         ops.tdnn_split_flat = real
     assert not calls
+
+
+# ----------------------------------------------------------------------------- fused VAD / CMVN: utterances split over workgroups
+def dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_fused_vad_cmvn_split_over_workgroups_matches_the_oracle(out_dtype):
+    """Batches below 256 utterances spread each utterance over up to eight workgroups (csrc/vad_cmvn.hip: `gridDim.y` splits by
+    window-start chunks); batches of 256 and more run one workgroup per utterance. Both against vad.py:156-203 -> gather ->
+    cmvn.py:186-250 (oracle), over windows shorter / longer than the utterance, VALID and SAME, norm_vars, utterance lengths
+    around the chunk and window sizes, and: a split batch equals the same utterances inside a big batch bit for bit."""
+    rng = np.random.default_rng(77)
+    D = 30
+    vcfg = dict(energy_mean_scale=0.5, energy_threshold=5.5, frames_context=2, proportion_threshold=0.12)
+    tol = {torch.float32: 2e-4, torch.float16: 2e-2, torch.bfloat16: 1.5e-1}[out_dtype]
+    for (T, window, nv, pad) in [(998, 300, False, "SAME"), (998, 300, True, "SAME"), (700, 300, False, "VALID"), (335, 300, True, "VALID"),
+                                 (333, 300, False, "SAME"), (250, 300, False, "SAME"), (64, 300, True, "SAME"), (1500, 64, False, "SAME"),
+                                 (401, 201, True, "VALID")]:
+        B = 5
+        feats = (rng.standard_normal((B, T, D)) * 4 + 6).astype(np.float32)
+        feats[1, T // 3:, 0] = -50.0                       # an utterance that loses two thirds of its frames
+        feats[2, :, 0] = -50.0                             # ... and one that loses all of them
+        ccfg = Ls.CMVN(window=window, norm_vars=nv, padding=pad).cfg()
+
+        def run(f):
+            n = f.shape[0]
+            out = torch.full((n, T, 32), 9.0, device="cuda", dtype=out_dtype)
+            lens = torch.zeros((n,), dtype=torch.int32, device="cuda")
+            idx = torch.zeros((n, T), dtype=torch.int32, device="cuda")
+            work = torch.zeros((n * T * 2 * D + 64,), device="cuda")
+            ktf.ops.vad_cmvn(dev(f), Ls.VAD(**vcfg).cfg(), ccfg, out, lens, idx, work)
+            return out.float().cpu().numpy(), lens.cpu().numpy(), idx.cpu().numpy()
+
+        got, lens, idx = run(feats)                        # 5 utterances: eight workgroups each
+        big = np.concatenate([feats, np.repeat(feats[:1], 256, axis=0)])
+        got_big, lens_big, _ = run(big)                    # 261: one workgroup each
+        assert np.array_equal(lens, lens_big[:B])
+        keep = O.vad(feats, **vcfg, return_indexes=False)[..., 0] > 0
+        for b in range(B):
+            sel = np.nonzero(keep[b])[0]
+            want = O.cmvn(feats[b:b + 1, sel], norm_vars=nv, window=window, padding=pad, dtype=np.float64)[0] if len(sel) else np.zeros((0, D))
+            n = want.shape[0]
+            assert lens[b] == n, (T, window, nv, pad, b, lens[b], n)
+            assert np.array_equal(idx[b, : len(sel)], sel)
+            assert np.array_equal(got[b, :n], got_big[b, :n]), "split workgroups == one workgroup, bit for bit"
+            if n:
+                assert np.abs(got[b, :n, :D] - want).max() < tol * max(1.0, np.abs(want).max()), (T, window, nv, pad, b)
+                assert not got[b, :n, D:].any(), "pad columns are written as zeros"
+            assert (got[b, n:] == 9.0).all(), "rows beyond the utterance's output length are not written"
+
+
+def test_cmvn_valid_padding_of_inputs_no_longer_than_the_window():
+    """cmvn.py:238-243 (and its TODO): VALID padding keeps the frames [N/2, T - (N-1)/2) -- none when T < N, one when T == N -- normalised
+    with the whole input's statistics. (The kernels used to return all T rows in that case.)"""
+    rng = np.random.default_rng(3)
+    for N in (300, 301):
+        for T in (1, N // 2, N - 1, N, N + 1):
+            x = rng.standard_normal((2, T, 30)).astype(np.float32) * 3 + 1
+            for nv in (False, True):
+                got = Ls.CMVN(window=N, norm_vars=nv, padding="VALID")(dev(x)).cpu().numpy()
+                want = O.cmvn(x, norm_vars=nv, window=N, padding="VALID", dtype=np.float64)
+                assert got.shape == want.shape == (2, max(T - N + 1, 0), 30), (N, T, got.shape, want.shape)
+                if want.size:
+                    assert np.abs(got - want).max() < 1e-4
