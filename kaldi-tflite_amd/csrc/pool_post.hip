@@ -4,6 +4,10 @@
 //           layers/plda/plda.py:163-263 of the reference.
 #include "common.h"
 
+// tf.nn.relu of the variance (stats_pooling.py:238, 293): a NaN -- the 0 / 0 of a window without a sampled frame -- stays a NaN (fmax
+// would return 0 and the standard deviation sqrt(epsilon))
+__device__ __forceinline__ double relu_keep_nan(double v) { return v < 0.0 ? 0.0 : v; }
+
 // ------------------------------------------------------------------------------------ stats pooling (reduce)
 // One workgroup = one utterance x CW columns; row groups stride the time axis, each thread owns two adjacent columns
 // (8-byte fp32 / 4-byte bf16 or half loads).
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(SP_THREADS) void stats_pool_kernel(const T* __restr
             out[(int64_t)b * ldo + c] = (float)mean;
             if (include_std) {
                 const double var = q / n - mean * mean;
-                out[(int64_t)b * ldo + D + c] = (float)sqrt(fmax(var, 0.0) + (double)eps);
+                out[(int64_t)b * ldo + D + c] = (float)sqrt(relu_keep_nan(var) + (double)eps);
             }
         }
     }
@@ -132,7 +136,7 @@ __global__ void stats_pool_windowed_kernel(const float* __restrict__ x, int64_t 
         }
         const double mean = s / n;
         out[(b * Tout + j) * od + c] = (float)mean;
-        if (include_std) out[(b * Tout + j) * od + D + c] = (float)sqrt(fmax(q / n - mean * mean, 0.0) + (double)eps);
+        if (include_std) out[(b * Tout + j) * od + D + c] = (float)sqrt(relu_keep_nan(q / n - mean * mean) + (double)eps);
     }
 }
 
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(XT_THREADS) void xvec_tail_kernel(const float* __re
                 }
                 const double m = sv / n;
                 xs[c] = (float)m;
-                if (include_std) xs[D + c] = (float)sqrt(fmax(q / n - m * m, 0.0) + (double)eps);
+                if (include_std) xs[D + c] = (float)sqrt(relu_keep_nan(q / n - m * m) + (double)eps);
             }
             for (int i = in_dim + tid; i < XT_MAXIT * 256; i += XT_THREADS) xs[i] = 0.0f;
         }

@@ -394,6 +394,7 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "%s: fuses ReLU or no activation", who);
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift go together", who);
     KTF_REQUIRE(T * (int64_t)d->din_pad * 2 < (1ll << 31), "%s: T * din_pad too large", who);
+    if (B == 0 || T == 0 || ktf_tdnn_out_len(T, d) <= 0) return KTF_OK;       // (no output row: VALID padding of an input shorter than the context)
     const int outs = (yh ? 1 : 0) + (yf ? 1 : 0) + (stats ? 1 : 0);
     KTF_REQUIRE(outs == 1, "%s: exactly one of the plane / fp32 / pooled outputs", who);
     if (yh) KTF_REQUIRE(yl4 && y4 && ys, "%s: a plane output needs all four planes", who);

@@ -23,6 +23,14 @@
 // phase stamps of workgroup 0 (probe builds only: tools/vc_phase_probe.py)
 #define VC_PROBE(k)
 
+// m * m rounded to fp32 before anything is subtracted from it (cmvn.py:206, 222: tf.pow(mean, 2) is a tensor of its own). HIP contracts
+// a * b - c into a fused multiply-add by default (and __fmul_rn is a plain product there); with ONE frame the reference's variance is
+// exactly 0 and its output 0 / 0, a fused form leaves the rounding residual of the square instead.
+__device__ __forceinline__ float sq_rounded(float m) {
+#pragma clang fp contract(off)
+    return m * m;
+}
+
 __device__ __forceinline__ float block_sum(float v, float* red /* VC_WAVES floats in LDS */) {
     v = wave_sum(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -202,7 +210,8 @@ __device__ __forceinline__ void cmvn_block(const float* __restrict__ x, int64_t 
                     ts2 += gm[VC_RG * 32 + g * 32 + dl];
                 }
                 mean = ts / (float)len;
-                if (c.norm_vars) sd = sqrtf(ts2 / (float)len - mean * mean);
+                if (c.norm_vars) sd = sqrtf(ts2 / (float)len - sq_rounded(mean));      // (cmvn.py:206, 222: the square is rounded before the
+                                                                                             // subtraction, no fused multiply-add: one frame -> exactly 0)
             }
             // VALID keeps the frames [N/2, len - (N-1)/2) (cmvn.py:238-243): none of an utterance shorter than the window, one of an
             // utterance exactly as long
@@ -314,7 +323,7 @@ __device__ __forceinline__ void cmvn_block(const float* __restrict__ x, int64_t 
                             if (NV) a2 += vn[k] * vn[k] - vo[k] * vo[k];
                         }
                         mean = a / fN;
-                        if (NV) sd = sqrtf(a2 / fN - mean * mean);
+                        if (NV) sd = sqrtf(a2 / fN - sq_rounded(mean));
                         if (i == 0) { mean0 = mean; sd0 = sd; }
                         if (i == cnt - 1) { meanl = mean; sdl = sd; }
                         float v = xc[k] - mean;

@@ -1010,8 +1010,9 @@ class TDNN(Layer):
         # the 16-bit ring kernels want an output row stride that is a multiple of 8 (16-byte stores); the pad columns
         # are sliced off again
         ldy = ops.round_up(self.units, 8) if gemm in (L.GEMM_BF16, L.GEMM_F16) else self.units
-        if T == 1 and self.kernelWidth == 1 and self.padding == "SAME" and self.subsamplingFactor == 1 and B > 1:
-            # one row per utterance (e.g. the affine after stats pooling): run as ONE B-row GEMM
+        if T == 1 and list(self.context) == [0] and self.subsamplingFactor == 1 and B > 1:
+            # one row per utterance (e.g. the affine after stats pooling): run as ONE B-row GEMM (context [0] only: another offset
+            # would clamp to the neighbouring UTTERANCES' rows there, not to the utterance's single frame)
             y = self.forward(self.prepare_input(x.reshape(1, B, D), gemm), gemm=gemm, ldy=ldy)
             return y[:, :, : self.units].reshape(B, 1, self.units)
         return self.forward(self.prepare_input(x, gemm), gemm=gemm, ldy=ldy)[:, :, : self.units]
@@ -1027,6 +1028,8 @@ class TDNN(Layer):
         ops.mx_planes(src, D, None, planes)
         wh, wq, bias = self.device_weights_mx(x.device, loader=False)
         d = self.desc(L.GEMM_F16MX, torch.float16, torch.float32)
+        if self.outputTimesteps(T) <= 0:               # VALID padding of an input shorter than the context: no output row
+            return torch.empty((B, 0, self.units), dtype=torch.float32, device=x.device)
         y = torch.empty((B, self.outputTimesteps(T), ops.round_up(self.units, 4)), dtype=torch.float32, device=x.device)
         ops.tdnn_mx(planes, None, d, wh, wq, bias, None, None, y)
         return y[:, :, : self.units]

@@ -211,9 +211,14 @@ class Sequential:
     def _plan(self):
         """Group [TDNN(no act), ReLU, BatchNorm] runs; returns None if a layer outside the fusable set is present."""
         steps, i, Ls = [], 0, self.layers
+        pooled = False
         while i < len(Ls):
             l = Ls[i]
             if isinstance(l, TDNN):
+                # behind a reducing StatsPooling the runner stacks the pooled vectors as ONE B-row matrix: right for a layer that looks
+                # at its own frame only (every x-vector network); any other context would read the neighbouring UTTERANCES' rows
+                if pooled and (list(l.context) != [0] or l.subsamplingFactor != 1):
+                    return None
                 relu, bn = False, None
                 j = i + 1
                 if l.activation in (None, "linear") and j < len(Ls) and isinstance(Ls[j], ReLU):
@@ -226,6 +231,7 @@ class Sequential:
                 i = j
             elif isinstance(l, StatsPooling) and l.reduce:
                 steps.append(("stats", l))
+                pooled = True
                 i += 1
             elif isinstance(l, (ReLU, BatchNorm)):
                 steps.append(("eltwise", l))

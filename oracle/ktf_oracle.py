@@ -354,7 +354,7 @@ def tdnn(x, W, b=None, context=(0,), subsampling_factor=1, padding="SAME", activ
     x = np.asarray(x, dtype=dtype)
     B, T, D = x.shape
     idx = tdnn_eval_indices(T, list(context), subsampling_factor, padding)
-    g = x[:, idx, :].reshape(B, idx.shape[0], -1)          # (B,T_out,K*D) im2col, k-major
+    g = x[:, idx, :].reshape(B, idx.shape[0], idx.shape[1] * D)          # (B,T_out,K*D) im2col, k-major (T_out may be 0)
     y = g @ np.asarray(W, dtype=dtype).T
     if b is not None:
         y = y + np.asarray(b, dtype=dtype)

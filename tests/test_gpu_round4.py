@@ -462,3 +462,50 @@ def test_cmvn_valid_padding_of_inputs_no_longer_than_the_window():
                 assert got.shape == want.shape == (2, max(T - N + 1, 0), 30), (N, T, got.shape, want.shape)
                 if want.size:
                     assert np.abs(got - want).max() < 1e-4
+
+
+# ----------------------------------------------------------------------------- found by differential fuzzing (tools/fuzz_layers.py)
+def test_single_frame_inputs_with_a_shifted_context_stay_inside_their_utterance():
+    """TDNN(context=[c != 0]) on a batch of one-frame inputs: SAME padding clamps every offset to the utterance's only frame
+    (tdnn.py:246-247). The layer's 'one B-row GEMM' short cut for T == 1 used to apply the offset across the batch."""
+    rng = np.random.default_rng(0)
+    for gemm, tol in (("f32", 1e-5), ("bf16x3", 1e-4), ("f16mx", 2e-3)):       # (16 units: an f16mx layer this narrow runs in fp32)
+        for ctx, U in (([6], 16), ([-3], 16), ([3], 300), ([0, 6], 16)):
+            x = rng.standard_normal((3, 1, 24)).astype(np.float32)
+            W = (rng.standard_normal((U, len(ctx) * 24)) / np.sqrt(len(ctx) * 24)).astype(np.float32)
+            b = rng.standard_normal(U).astype(np.float32)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                t = Ls.TDNN(U, context=list(ctx), gemm=gemm)
+                t.build(x.shape)
+                t.set_weights([W, b])
+                got = t(dev(x)).cpu().numpy()
+            want = O.tdnn(x, W, b, ctx, 1, "SAME", None, dtype=np.float64)
+            assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), (gemm, ctx, U)
+
+
+def test_layers_without_an_output_row_and_degenerate_statistics_follow_the_reference():
+    rng = np.random.default_rng(1)
+    # VALID padding of an input shorter than the context: an empty output, in every mode (the f16mx layer used to raise)
+    x = rng.standard_normal((2, 5, 64)).astype(np.float32)
+    for gemm in ("f32", "bf16x3", "f16mx"):
+        t = Ls.TDNN(256, context=[-5, -3, 3], padding="VALID", activation="relu", gemm=gemm)
+        t.build(x.shape)
+        assert tuple(t(dev(x)).shape) == (2, 0, 256)
+    # one frame with norm_vars: the reference's variance is exactly 0 and its output 0 / 0 (cmvn.py:222-246)
+    one = rng.standard_normal((2, 1, 30)).astype(np.float32)
+    assert np.isnan(Ls.CMVN(window=100, norm_vars=True)(dev(one)).cpu().numpy()).all()
+    assert np.isnan(O.cmvn(one, norm_vars=True, window=100)).all()
+    # a pooling window without a sampled frame (input_period 3 on one frame): mean 0 / 0, and tf.nn.relu keeps the NaN of the variance
+    sp = dict(left_context=-7, right_context=10, input_period=3, output_period=6, include_std=True, padding="SAME")
+    got = Ls.StatsPooling(**sp)(dev(one)).cpu().numpy()
+    want = O.stats_pooling(one, **sp, dtype=np.float64)
+    assert got.shape == want.shape and np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).any()
+
+
+def test_differential_fuzzing_of_the_layer_api_finds_nothing():
+    """tools/fuzz_layers.py: random StatsPooling / CMVN / TDNN / VAD / Framing / MFCC configurations (degenerate lengths included)
+    against the oracle; a fixed seed here, more rounds by hand."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_layers.py"), "120", "11"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "120 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
