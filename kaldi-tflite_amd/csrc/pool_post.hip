@@ -50,7 +50,7 @@ __global__ __launch_bounds__(SP_THREADS) void stats_pool_kernel(const T* __restr
     constexpr int NG = 64 / RG;                  // canonical groups per thread: 4 or 1
     __shared__ double red[RG][2][CW];            // fp64 sums: E[x^2]-mean^2 of a (near-)constant channel must not cancel to noise
     const int b = blockIdx.y;
-    const int len = lens ? lens[b] : (int)Tmax;
+    const int len = lens ? min(lens[b], (int)Tmax) : (int)Tmax;
     const int lc = threadIdx.x % LPR, rg = threadIdx.x / LPR;
     const int c0 = blockIdx.x * CW + lc * 2;
     const T* xb = x + (int64_t)b * Tmax * ldx;
@@ -604,7 +604,7 @@ extern "C" int ktf_plda_f32(const float* x, int64_t B, int32_t dim, const float*
 extern "C" int ktf_stats_pool(const void* x, int32_t x_dtype, int64_t B, int64_t T, int32_t D, int64_t ldx,
                               const int32_t* lens, int32_t input_period, int32_t include_std, float eps, float* out,
                               int64_t ld_out, void* stream) {
-    KTF_REQUIRE(x && out, "ktf_stats_pool: null argument");
+    KTF_REQUIRE(out && (x || T == 0), "ktf_stats_pool: null argument");      // (no frame at all: x may be an empty tensor; the means are 0 / 0 as in the reference)
     KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ldx >= D, "ktf_stats_pool: bad sizes");
     KTF_REQUIRE(input_period > 0, "ktf_stats_pool: input_period must be > 0");
     KTF_REQUIRE(B < 65536, "ktf_stats_pool: B too large");

@@ -83,7 +83,8 @@ __device__ __forceinline__ int tdnn_out_len(int len, const TdnnParams& p, int& s
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == KTF_ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == KTF_ACT_RELU) return v < 0.0f ? 0.0f : v;      // tf.nn.relu propagates NaN (Eigen cwiseMax<PropagateNaN>): the pooled row of an
+                                                              // utterance without a frame stays NaN through the layers behind the pooling; fmaxf would return 0
     if (act == KTF_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
     if (act == KTF_ACT_TANH) return tanhf(v);
     return v;

@@ -130,7 +130,12 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,
                        const void* x_lo = nullptr, void* y_lo = nullptr, const int32_t* row_starts = nullptr) {
-    KTF_REQUIRE(x && d && w && (y || stats_sums), "ktf_tdnn: null argument");
+    KTF_REQUIRE(d, "ktf_tdnn: null descriptor");
+    if (B >= 0 && T == 0) {                              // an empty input (its tensors may be empty: null pointers): no output row, every length 0
+        if (B > 0 && out_lens) (void)hipMemsetAsync(out_lens, 0, sizeof(int32_t) * B, (hipStream_t)stream);
+        return KTF_OK;
+    }
+    KTF_REQUIRE(x && w && (y || stats_sums), "ktf_tdnn: null argument");
     const bool split_in = d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16;     // activations as hi/lo bf16 planes
     const bool half2 = d->gemm == KTF_GEMM_F16X2;                                    // one half plane in, hi + lo half weights
     if (split_in) KTF_REQUIRE(x_lo, "ktf_tdnn_split: null lo plane");

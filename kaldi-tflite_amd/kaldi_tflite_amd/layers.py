@@ -965,6 +965,8 @@ class TDNN(Layer):
         scale, shift = bn if bn is not None else (None, None)
         if Tout > 0 and B > 0:
             ops.tdnn(x, lens, d, w, w_lo, bias, scale, shift, out, out_lens)
+        elif out_lens is not None:                  # no output row (VALID padding of inputs shorter than the context): every utterance is empty
+            out_lens.zero_()
         return out
 
     def effective_gemm(self, gemm, relu=False):

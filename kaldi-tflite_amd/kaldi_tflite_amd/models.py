@@ -330,7 +330,8 @@ class Sequential:
             self._xbar, self._xvar = {}, {}      # the weights changed since calibrate(): its statistics describe another network
         gemm, pairs = self._batch_route(x.shape[0], x.shape[1], mode=mode)
         x_pair = False                                   # x holds KTF_BF16P pairs (in a float32 tensor)
-        row_starts = None                                # prefix sums of lens, made once per call when a layer runs flat row tiles
+        row_starts = None                                # prefix sums of lens for the layers on flat row tiles: made when the first one runs,
+                                                         # again when a VALID-padded or subsampling layer has changed the lengths
         act_dtype = L.act_torch_dtype(gemm)
         tail_at = self._tail_step(steps) if defer_tail else -1
         self._deferred = None        # set by a pooling step whose consumer is the deferred tail
@@ -415,7 +416,7 @@ class Sequential:
                     mxp = None
                     x = ybuf[:, :, : l.units]
                 if lens is not None and not plain:
-                    lens = ops.tdnn_out_lens(lens, d, torch.empty_like(lens))
+                    lens, row_starts = ops.tdnn_out_lens(lens, d, torch.empty_like(lens)), None
                 if defer_bn:
                     pending_bn = bn
                 continue
@@ -479,7 +480,7 @@ class Sequential:
                     pending_bn = bn
                 x = ybuf[:, :, : l.units]
                 if out_lens is not None:
-                    lens = out_lens
+                    lens, row_starts = out_lens, None
                 continue
             if pending_bn is not None:
                 raise RuntimeError("internal: a deferred BatchNorm reached a layer that cannot fold it")
@@ -526,7 +527,7 @@ class Sequential:
                     planes = None
                     x = ybuf[:, :, : l.units]
                 if out_lens is not None:
-                    lens = out_lens
+                    lens, row_starts = out_lens, None
                 continue
             if planes is not None:
                 raise RuntimeError("internal: split planes reached a layer that cannot read them")
@@ -586,7 +587,7 @@ class Sequential:
                           pair_in=pair_in, pair_out=pair_out)
                 x_pair = pair_out
                 if out_lens is not None:
-                    lens = out_lens
+                    lens, row_starts = out_lens, None
                 x = ybuf[:, :, : l.units]
             elif st[0] == "stats":
                 l = st[1]

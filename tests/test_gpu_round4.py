@@ -509,3 +509,91 @@ def test_differential_fuzzing_of_the_layer_api_finds_nothing():
     against the oracle; a fixed seed here, more rounds by hand."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_layers.py"), "120", "11"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "120 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def _stack(spec, D, gemm, rng, pooled_at=None):
+    """(model, oracle layer list) of a TDNN stack: spec rows (units, context, padding, subsampling, form), form in affine / affine+relu /
+    affine+relu+bn / own_<activation>; a reducing StatsPooling behind layer `pooled_at`."""
+    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
+    for i, (U, ctx, pad, sub, form) in enumerate(spec):
+        kinds = {"affine+relu+bn": ["affine", "relu", "batchnorm"], "affine+relu": ["affine", "relu"]}.get(form, "affine")
+        c = {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}
+        if form.startswith("own_"):
+            c["activation"] = form[4:]
+        lcfg.append({"name": f"t{i}", "type": kinds, "cfg": c})
+        if pooled_at == i + 1:
+            lcfg.append({"name": "stats", "type": "stats", "cfg": {"left_context": 0, "right_context": 10000, "reduce_time_axis": True, "include_std": True}})
+    mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm=gemm)
+    layers, din = [], D
+    for i, (U, ctx, pad, sub, form) in enumerate(spec):
+        W = (rng.standard_normal((U, len(ctx) * din)) / np.sqrt(len(ctx) * din)).astype(np.float32)
+        b = (rng.standard_normal(U) * 0.1).astype(np.float32)
+        mdl.get_layer(f"t{i}.affine").set_weights([W, b])
+        lay = {"kind": "tdnn", "W": W, "b": b, "context": ctx, "padding": pad, "subsampling_factor": sub}
+        if form.startswith("own_"):
+            lay["activation"] = form[4:]
+        layers.append(lay)
+        if "relu" in form and not form.startswith("own_"):
+            layers.append({"kind": "relu"})
+        if form.endswith("bn"):
+            bn = (np.float32(1.0), rng.uniform(-0.2, 0.4, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
+            mdl.get_layer(f"t{i}.batchnorm").set_weights(list(bn))
+            layers.append({"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]})
+        din = U
+        if pooled_at == i + 1:
+            layers.append({"kind": "stats", "left_context": 0, "right_context": 10000, "reduce_time_axis": True, "include_std": True})
+            din = 2 * U
+    return mdl, layers
+
+
+def test_flat_row_tiles_follow_the_lengths_a_valid_padded_layer_changed():
+    """bf16x3 on flat row tiles (ktf_tdnn_split_flat) behind a VALID-padded, subsampling layer: the prefix sums of the lengths were made
+    once per call, so a second flat layer behind such a layer tiled with the lengths of the first (found by tools/fuzz_models.py)."""
+    rng = np.random.default_rng(5)
+    spec = [(16, [-4, 4], "SAME", 1, "own_relu"), (130, [-1], "SAME", 1, "own_relu"), (96, [-1, 3], "VALID", 3, "affine+relu+bn"),
+            (130, [-2], "SAME", 1, "affine")]
+    mdl, layers = _stack(spec, 24, "bf16x3", rng)
+    B, T = 40, 300
+    lens = rng.integers(T // 3, T + 1, B).astype(np.int32)
+    lens[0] = T
+    x = rng.standard_normal((B, T, 24)).astype(np.float32)
+    seen = []
+    real = ops.tdnn_split_flat
+    ops.tdnn_split_flat = lambda *a, **k: (seen.append(1), real(*a, **k))[1]
+    try:
+        got = mdl.run_ragged(dev(x), dev(lens)).cpu().numpy()
+    finally:
+        ops.tdnn_split_flat = real
+    assert len(seen) == 2, "both 130-unit layers run on flat row tiles"
+    for b in range(B):
+        want = O.sequential_forward(layers, x[b:b + 1, : lens[b]], dtype=np.float64)[0]
+        assert np.abs(got[b, : want.shape[0]] - want).max() < 3e-4 * np.abs(want).max(), b
+
+
+@pytest.mark.parametrize("gemm", ["f32", "bf16", "f16mx"])
+def test_utterances_that_lose_every_frame_give_nan_like_the_reference(gemm):
+    """VALID padding can leave an utterance (or the whole batch) without a frame in front of the pooling: its mean is 0 / 0 and the NaN
+    travels through the layers behind the pooling -- tf.nn.relu propagates it -- instead of turning into zeros or a null-pointer launch."""
+    rng = np.random.default_rng(6)
+    spec = [(300, [-2, 3], "VALID", 1, "affine+relu"), (256, [-4], "VALID", 1, "own_tanh"), (130, [-3, 4], "SAME", 2, "affine+relu+bn"),
+            (130, [0], "SAME", 1, "affine"), (512, [0], "SAME", 1, "own_relu")]
+    mdl, layers = _stack(spec, 40, gemm, rng, pooled_at=3)
+    tol = {"f32": 2e-5, "bf16": 1.5e-1, "f16mx": 4e-3}[gemm]
+    for lens in ([8, 11, 12, 12, 4], [5, 9, 8]):                   # some utterances / every utterance without a frame behind layer 2
+        T = 12
+        lens = np.asarray(lens, np.int32)
+        x = rng.standard_normal((len(lens), T, 40)).astype(np.float32)
+        got = mdl.run_ragged(dev(x), dev(lens)).float().cpu().numpy()
+        for b in range(len(lens)):
+            want = O.sequential_forward(layers, x[b:b + 1, : lens[b]], dtype=np.float64)[0]
+            assert np.array_equal(np.isnan(got[b, :1]), np.isnan(want)), (gemm, lens.tolist(), b)
+            if not np.isnan(want).any():
+                assert np.abs(got[b, :1] - want).max() < tol * np.abs(want).max()
+            else:
+                assert np.isnan(want).all() and lens[b] < 10
+
+
+def test_differential_fuzzing_of_the_sequential_runner_finds_nothing():
+    """tools/fuzz_models.py: random TDNN stacks on ragged batches in every arithmetic mode against the oracle; a fixed seed here."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "60", "21"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "60 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
