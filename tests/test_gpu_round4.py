@@ -597,3 +597,11 @@ def test_differential_fuzzing_of_the_sequential_runner_finds_nothing():
     """tools/fuzz_models.py: random TDNN stacks on ragged batches in every arithmetic mode against the oracle; a fixed seed here."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "60", "21"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "60 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_differential_fuzzing_of_the_extractor_finds_nothing():
+    """tools/fuzz_extractor.py: batches mixing long, short, partly silent and completely silent utterances (NaN x-vectors, as in the
+    reference), fp32 / int16 input, eager and captured, f32 / bf16x3 / f16mx with the shipped routing: every x-vector <= 1e-4 from the
+    fp64 oracle; a fixed seed here."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_extractor.py"), "16", "31"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "16 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

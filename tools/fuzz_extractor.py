@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of XvectorExtractor (wav -> x-vector, full-size 0008 topology, synthetic weights) against the fp64 oracle on the
+GPU box: batches that mix long, short (per-utterance routing), partly silent and completely silent utterances, fp32 and int16 input,
+every compliant mode (f32 / bf16x3 / f16mx), default routing, eager and captured. The bar is north_star's: max-abs deviation <= 1e-4;
+an utterance without a voiced frame must come out NaN as in the reference (0 / 0 in the pooling).
+Test infrastructure: the oracle is the checker.   python tools/fuzz_extractor.py [rounds] [seed]"""
+import os, sys, warnings
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import synth
+import kaldi_tflite_amd as ktf
+from oracle import ktf_oracle as O
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+cfg = synth.extractor_cfg()
+w = synth.make_weights(seed=4321 + seed)
+olayers = synth.oracle_layers(w)
+models = {m: synth.build_extractor(ktf, cfg, w, gemm=m) for m in ("f32", "bf16x3", "f16mx")}
+speech = synth.speech_wavs()[0][0]
+bad = 0
+seen = {"utterances": 0, "nan_expected": 0, "skipped_rounds": 0}
+worst = {m: 0.0 for m in models}
+for r in range(rounds):
+    B = int(rng.choice([1, 2, 3, 5]))
+    N = int(rng.choice([16000 * 2, 16000 * 3 + 77, 16000 * 5, 16000 * 7 + 5, 16000 * 10, 400, 1200, 16000]))
+    wav = np.zeros((B, N), np.float32)
+    kinds = []
+    for b in range(B):
+        k = str(rng.choice(["noise", "ragged", "speech", "short_then_silence", "silence", "quiet"]))
+        kinds.append(k)
+        if k == "noise":
+            wav[b] = synth.make_wav(1, N, seed=int(rng.integers(1 << 30)))[0]
+        elif k == "ragged":
+            wav[b] = synth.make_wav(1, N, seed=int(rng.integers(1 << 30)), ragged=True)[0]
+        elif k == "speech":
+            o = int(rng.integers(0, len(speech) - N))
+            wav[b] = speech[o:o + N]
+        elif k == "short_then_silence":                  # a burst at the head, digital silence behind it: few voiced frames
+            n = min(N, int(rng.integers(800, 8000)))
+            wav[b, :n] = synth.make_wav(1, n, seed=int(rng.integers(1 << 30)))[0]
+        elif k == "quiet":
+            wav[b] = synth.make_wav(1, N, seed=int(rng.integers(1 << 30)), sigma=3.0)[0]
+        # "silence": zeros
+    try:
+        want, inter = O.xvector_forward(wav, cfg, olayers, w["mean"], w["lda"], dtype=np.float64, return_intermediates=True)
+        voiced = [len(i["voiced"]) for i in inter]
+    except Exception as e:
+        print(f"round {r}: oracle raises ({type(e).__name__}: {e}) for kinds {kinds}, N {N}; skipped")
+        seen["skipped_rounds"] += 1
+        continue
+    seen["utterances"] += B
+    seen["nan_expected"] += int(np.isnan(want).any(axis=1).sum())
+    for mode, mdl in models.items():
+        for form in ("fp32", "int16", "graph"):
+            x = torch.as_tensor(wav if form != "int16" else wav.astype(np.int16), device="cuda")
+            try:
+                got = (mdl.compile(x)(x) if form == "graph" else mdl(x)).float().cpu().numpy().reshape(B, -1)
+            except Exception as e:
+                bad += 1
+                print(f"MISMATCH round {r} {mode} {form} kinds {kinds} N {N} voiced {voiced}: raises {type(e).__name__}: {e}", flush=True)
+                continue
+            for b in range(B):
+                wn, gn = np.isnan(want[b]).any(), np.isnan(got[b]).any()
+                if wn != gn:
+                    bad += 1
+                    print(f"MISMATCH round {r} {mode} {form} utterance {b} ({kinds[b]}, {voiced[b]} voiced frames, N {N}): NaN {gn}, oracle {wn}", flush=True)
+                elif not wn:
+                    err = np.abs(got[b] - want[b]).max()
+                    worst[mode] = max(worst[mode], float(err))
+                    if mode == "f32" and form == "fp32" and err > 1e-5:
+                        print(f"note: round {r} f32 utterance {b} ({kinds[b]}, {voiced[b]} voiced frames, N {N}): {err:.2e}", flush=True)
+                    if not err <= 1e-4:
+                        bad += 1
+                        print(f"MISMATCH round {r} {mode} {form} utterance {b} ({kinds[b]}, {voiced[b]} voiced frames, N {N}): max-abs deviation {err:.3e}", flush=True)
+print(f"{rounds} rounds, {bad} mismatches")
+print(seen, {m: f"{v:.2e}" for m, v in worst.items()})
+sys.exit(min(bad, 255))
