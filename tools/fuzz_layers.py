@@ -123,5 +123,44 @@ for case in range(n_cases):
                   remove_dc_offset=bool(rng.integers(0, 2)), preemphasis_coefficient=float(rng.choice([0.0, 0.97])), raw_energy=bool(rng.integers(0, 2)))
         frames = O.framing(wav, **fc)
         guarded("MFCC", dict(mc, **fc, n=n), lambda: Ls.MFCC(**mc)(dev(frames)), lambda: O.mfcc(frames, **mc, dtype=np.float64), 2e-3)
+    # ---- Windowing / FilterBank / DCT on random frames
+    M = int(rng.choice([200, 256, 400, 512]))
+    fr = (rng.standard_normal((B, int(rng.integers(1, 6)), M)) * 300).astype(np.float32)
+    wc = dict(window_type=str(rng.choice(["povey", "hamming", "hanning", "rectangular", "blackman"])), blackman_coeff=float(rng.choice([0.42, 0.3])),
+              remove_dc_offset=bool(rng.integers(0, 2)), preemphasis_coefficient=float(rng.choice([0.0, 0.5, 0.97, 1.0])),
+              raw_energy=bool(rng.integers(0, 2)), energy_floor=float(rng.choice([0.0, 1.0])), return_energy=True)
+    try:
+        gw, ge = Ls.Windowing(**wc)(dev(fr))
+        ww, we = O.windowing(fr, **wc, dtype=np.float64)
+        compare("Windowing", dict(wc, M=M), gw, ww, 1e-5)
+        compare("Windowing.energy", dict(wc, M=M), ge, we, 1e-5)
+    except Exception as e:
+        report("Windowing", dict(wc, M=M), f"raises {type(e).__name__}: {e}")
+    sfb = float(rng.choice([8000.0, 16000.0]))
+    bc = dict(num_bins=int(rng.choice([10, 23, 40, 64])), sample_frequency=sfb, low_freq_cutoff=float(rng.choice([0.0, 20.0, 300.0])),
+              high_freq_cutoff=float(rng.choice([0.0, -100.0, sfb / 2 - 500])), use_log_fbank=bool(rng.integers(0, 2)), use_power=bool(rng.integers(0, 2)))
+    guarded("FilterBank", dict(bc, M=M), lambda: Ls.FilterBank(**bc)(dev(fr)), lambda: O.filterbank(fr, **bc, dtype=np.float64), 3e-4)
+    nin = int(rng.choice([10, 23, 40]))
+    nout = int(rng.integers(1, nin + 1))
+    z = rng.standard_normal((B, 7, nin)).astype(np.float32)
+    guarded("DCT", dict(nin=nin, nout=nout), lambda: Ls.DCT(nout)(dev(z)), lambda: O.dct(z, nout, dtype=np.float64), 1e-5)
+    # ---- PLDA
+    dim = int(rng.choice([5, 29, 64, 128, 200]))
+    nb = int(rng.choice([1, 2, 9, 70]))
+    mean = rng.standard_normal(dim)
+    A = rng.standard_normal((dim, dim)) / np.sqrt(dim)
+    psi = rng.uniform(0.1, 5.0, dim)
+    xv = rng.standard_normal((nb, dim))
+    pc = dict(normalize_length=bool(rng.integers(0, 2)), simple_length_norm=bool(rng.integers(0, 2)))
+    for dt, tolp in ((np.float64, 1e-9), (np.float32, 2e-3)):
+        def run_plda():
+            sc, tr = Ls.PLDA(dim, mean, A, psi, dtype=dt, **pc)(dev(xv.astype(dt)))
+            return sc
+        guarded("PLDA", dict(pc, dim=dim, B=nb, dtype=dt.__name__), run_plda, lambda: O.plda(xv, mean, A, psi, **pc, dtype=np.float64)[0], tolp)
+    # ---- Framing with snip_edges=False == framing of the mirror-padded waveform (kaldi_numpy.PadWaveform)
+    if n >= 2:
+        fsz, fsh, _ = O.frame_params(**fc)
+        guarded("Framing(snip_edges=False)", dict(fc, n=n), lambda: Ls.Framing(**fc, snip_edges=False)(dev(wav)),
+                lambda: O.framing(O.pad_waveform(wav, fsz, fsh), **fc).astype(np.float64), 0.0)
 print(f"{n_cases} rounds, {bad} mismatches")
 sys.exit(min(bad, 255))
