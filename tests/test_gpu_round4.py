@@ -605,3 +605,10 @@ def test_differential_fuzzing_of_the_extractor_finds_nothing():
     fp64 oracle; a fixed seed here."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_extractor.py"), "16", "31"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "16 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_captured_graphs_replayed_on_other_inputs_equal_eager_calls():
+    """tools/fuzz_graph_replay.py: a graph captured on stationary noise, replayed on batches mixing speech, bursts + silence, quiet noise and
+    digital silence (voiced lengths and the per-utterance routing change from replay to replay): bit-identical to the eager call."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_graph_replay.py"), "3", "41"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "3 replays per graph, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
