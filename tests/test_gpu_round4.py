@@ -612,3 +612,10 @@ def test_captured_graphs_replayed_on_other_inputs_equal_eager_calls():
     digital silence (voiced lengths and the per-utterance routing change from replay to replay): bit-identical to the eager call."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_graph_replay.py"), "3", "41"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "3 replays per graph, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_models_on_concurrent_host_threads_and_streams():
+    """tools/thread_probe.py: four host threads, each with its own extractor (f16mx / bf16x3 / f32) and HIP stream, 20 calls each: every
+    x-vector equals the single-threaded result bit for bit."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "thread_probe.py"), "20"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "equals the single-threaded result" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Two host threads, each with its own XvectorExtractor and its own HIP stream, calling concurrently: every x-vector must equal the
+single-threaded result bit for bit (per-model workspaces, thread-local launch scopes, no shared mutable dispatch state).
+   python tools/thread_probe.py [calls per thread]"""
+import os, sys, threading, warnings
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import synth
+import kaldi_tflite_amd as ktf
+
+calls = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+cfg, w = synth.extractor_cfg(), synth.make_weights(seed=9)
+jobs = [("f16mx", 6, 160000), ("bf16x3", 3, 48000), ("f32", 2, 80000), ("f16mx", 1, 160000)]
+wavs = [[torch.as_tensor(synth.make_wav(B, N, seed=100 * j + c, ragged=True), device="cuda") for c in range(4)] for j, (_, B, N) in enumerate(jobs)]
+want = []
+for j, (mode, B, N) in enumerate(jobs):
+    m = synth.build_extractor(ktf, cfg, w, gemm=mode)
+    want.append([m(x).float().cpu().numpy() for x in wavs[j]])
+torch.cuda.synchronize()
+errors = []
+
+
+def worker(j):
+    mode, B, N = jobs[j]
+    try:
+        m = synth.build_extractor(ktf, cfg, w, gemm=mode)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for c in range(calls):
+                got = m(wavs[j][c % 4]).float().cpu().numpy()
+                if not np.array_equal(got, want[j][c % 4]):
+                    errors.append(f"thread {j} ({mode}, B {B}) call {c}: differs from the single-threaded result by {np.abs(got - want[j][c % 4]).max():.3e}")
+                    return
+    except Exception as e:
+        errors.append(f"thread {j} ({mode}): {type(e).__name__}: {e}")
+
+
+ts = [threading.Thread(target=worker, args=(j,)) for j in range(len(jobs))]
+[t.start() for t in ts]
+[t.join() for t in ts]
+print("\n".join(errors) if errors else f"{len(jobs)} threads x {calls} calls: every x-vector equals the single-threaded result")
+sys.exit(1 if errors else 0)
