@@ -254,6 +254,31 @@ def _stagger_dma(s):
 
 V["stagger_dma"] = _stagger_dma
 
+# A/B (correct results): cache policy of the LDS-DMA loads -- nt (aux = 2) on the activation pieces (half stage A + side A), on the weight pieces
+# (half stage W + side W), or on both
+def _nt(s, a, w):
+    if a:
+        s = rep(s, "(lds_ptr_t*)(st_ + ((n_) & 1) * 8192), 16, 0, 0);", "(lds_ptr_t*)(st_ + ((n_) & 1) * 8192), 16, 0, 2);")
+        s = rep(s, "(lds_ptr_t*)(rsm + MX_SA_OFF + plane_ * 16384 + (kb_ * 256 + rg_ * 64) * 16), 16, 0, 0);", "(lds_ptr_t*)(rsm + MX_SA_OFF + plane_ * 16384 + (kb_ * 256 + rg_ * 64) * 16), 16, 0, 2);")
+        s = rep(s, "(lds_ptr_t*)(rsm + MX_SA_OFF + 32768 + (kb_ * 256 + rg_ * 64) * 4), 4, 0, 0);", "(lds_ptr_t*)(rsm + MX_SA_OFF + 32768 + (kb_ * 256 + rg_ * 64) * 4), 4, 0, 2);")
+    if w:
+        s = rep(s, "(lds_ptr_t*)(st_ + MX_TILE + ((n_) & 1) * 8192), 16, 0, 0);", "(lds_ptr_t*)(st_ + MX_TILE + ((n_) & 1) * 8192), 16, 0, 2);")
+        s = rep(s, "(lds_ptr_t*)(rsm + MX_SW_OFF + idx_ * 1024), 16, 0, 0);", "(lds_ptr_t*)(rsm + MX_SW_OFF + idx_ * 1024), 16, 0, 2);")
+    return s
+
+
+def _aux(s, v):
+    s = _nt(s, True, True)
+    return s.replace(", 16, 0, 2);", f", 16, 0, {v});").replace(", 4, 0, 2);", f", 4, 0, {v});")
+
+
+V["aux_sc0"] = lambda s: _aux(s, 1)          # every LDS-DMA load with sc0 (aux bit 0) / sc1 (bit 4) / both
+V["aux_sc1"] = lambda s: _aux(s, 16)
+V["aux_sc0sc1"] = lambda s: _aux(s, 17)
+V["nt_a"] = lambda s: _nt(s, True, False)
+V["nt_w"] = lambda s: _nt(s, False, True)
+V["nt_aw"] = lambda s: _nt(s, True, True)
+
 names = sys.argv[1:] or list(V)
 objs = [o for o in _product_objects() if o != "tdnn_mx.o"]
 FLAGS = {
