@@ -1084,7 +1084,7 @@ class StatsPooling(Layer):
             D = D * 2
         if self.reduce:
             return (B, 1, D)
-        if self.padding == "SAME":
+        if self.padding == "SAME" or T is None:          # (a model built for any number of frames: the time axis stays unknown)
             return (B, T, D)
         return (B, self.numOutputSteps(T), D)
 
@@ -1110,6 +1110,8 @@ class StatsPooling(Layer):
         od = 2 * D if self.includeStd else D
         if self.reduce:
             return self.reduce_all(x, D).reshape(B, 1, od)
+        if T == 0:                                   # no frame, no window (a VALID-padded layer in front left nothing)
+            return torch.empty((B, 0, od), dtype=torch.float32, device=x.device)
         x = x.to(torch.float32)
         if self.padding == "SAME":
             n = self.numOutputSteps(T)

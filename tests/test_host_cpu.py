@@ -562,3 +562,18 @@ def test_abi_argument_validation_from_c(tmp_path):
     if os.environ.get("KTF_SKIP_SANITIZERS") != "1" and os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
         san = subprocess.run(["bash", os.path.join(root, "tools", "asan_abi.sh")], capture_output=True, text=True, timeout=900)
         assert san.returncode == 0 and "all rejected as KTF_EINVAL" in san.stdout and "ERROR: AddressSanitizer" not in san.stderr, san.stdout + san.stderr
+
+
+def test_sequential_with_a_valid_padded_windowed_pooling_builds_for_any_number_of_frames():
+    """Found by tools/fuzz_models.py: StatsPooling.compute_output_shape compared the unknown time axis of a dynamically shaped model with
+    the window width (TypeError at SequentialFromConfig); the time axis stays unknown and the layer behind sees the doubled width."""
+    import kaldi_tflite_amd as ktf
+    cfg = {"type": "sequential", "layers": [
+        {"name": "input", "type": "input", "shape": [None, None, 30]},
+        {"name": "t0", "type": "affine", "cfg": {"units": 96, "context": [2], "subsampling_factor": 3}},
+        {"name": "w", "type": "stats", "cfg": {"left_context": -2, "right_context": 4, "input_period": 2, "output_period": 2, "padding": "VALID"}},
+        {"name": "t1", "type": "affine", "cfg": {"units": 16, "context": [0]}}]}
+    m = ktf.models.SequentialFromConfig(cfg, None, "m")
+    assert m.get_layer("t1.affine").inputDim == 192
+    assert m.get_layer("w").compute_output_shape((None, None, 96)) == (None, None, 192)
+    assert m.get_layer("w").compute_output_shape((2, 40, 96)) == (2, m.get_layer("w").numOutputSteps(40), 192)

@@ -42,6 +42,15 @@ for case in range(n_cases):
         if pooled_at is not None and i + 1 == n_frame:
             lcfg.append({"name": "stats", "type": "stats", "cfg": {"left_context": 0, "right_context": 10000, "reduce_time_axis": True,
                                                                      "include_std": bool(rng.integers(0, 2))}})
+    # a third of the small cases go through Sequential.__call__ on a dense batch instead of the ragged runner, some of them with a WINDOWED
+    # StatsPooling behind the last frame-level layer (the fused runner hands such stacks to the layer-by-layer path)
+    dense = (not BIG) and rng.random() < 0.33
+    win_stats = None
+    if dense and pooled_at is None and rng.random() < 0.6:
+        ip = int(rng.choice([1, 1, 2]))
+        win_stats = {"left_context": -int(rng.integers(0, 6)), "right_context": int(rng.integers(0, 6)), "input_period": ip,
+                     "output_period": ip * int(rng.choice([1, 2])), "include_std": bool(rng.integers(0, 2)), "padding": str(rng.choice(["SAME", "VALID"]))}
+        lcfg.append({"name": "wstats", "type": "stats", "cfg": win_stats})
     try:
         mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm=gemm)
     except Exception as e:
@@ -69,14 +78,21 @@ for case in range(n_cases):
             din = 2 * U if sc["include_std"] else U
             # the layer behind the pooling was built for din: rebuild the weight shapes lazily below
     # widths behind the pooling: the config builder sized them from the pooled width; regenerate consistent weights
+    if win_stats is not None:
+        layers.append({"kind": "stats", **win_stats})
     B = int(rng.choice([1, 2, 3, 7, 40])) if not BIG else int(rng.choice([130, 257, 600, 1024]))
     T = int(rng.choice([12, 40, 150, 300, 700])) if not BIG else int(rng.choice([100, 257, 998]))
     lens = rng.integers(max(1, T // 3), T + 1, B).astype(np.int32)
     lens[int(rng.integers(0, B))] = T
     x = rng.standard_normal((B, T, D)).astype(np.float32)
-    desc = dict(gemm=gemm, D=D, B=B, T=T, lens=lens.tolist(), spec=spec, pooled_at=pooled_at)
+    if dense:
+        lens[:] = T
+    desc = dict(gemm=gemm, D=D, B=B, T=T, lens=lens.tolist() if not dense else "dense", spec=spec, pooled_at=pooled_at, win_stats=win_stats)
     try:
-        got = mdl.run_ragged(torch.as_tensor(x, device="cuda"), torch.as_tensor(lens, device="cuda")).float().cpu().numpy()
+        if dense:
+            got = mdl(torch.as_tensor(x, device="cuda")).float().cpu().numpy()
+        else:
+            got = mdl.run_ragged(torch.as_tensor(x, device="cuda"), torch.as_tensor(lens, device="cuda")).float().cpu().numpy()
     except NotImplementedError:
         continue
     except Exception as e:
