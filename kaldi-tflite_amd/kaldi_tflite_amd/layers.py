@@ -89,6 +89,9 @@ class Layer:
 
     @classmethod
     def from_config(cls, config):
+        # `trainable` and `dtype` are the base layer's own entries of get_config() (keras.layers.Layer takes them back); the layers here fix
+        # both in their constructors, so a get_config() -> from_config() round trip drops them instead of passing them twice
+        config = {k: v for k, v in dict(config).items() if k not in ("trainable", "dtype")}
         return cls(**config)
 
     def get_weights(self):
