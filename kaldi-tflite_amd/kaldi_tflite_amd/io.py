@@ -88,7 +88,7 @@ class KaldiObjReader:
         end = self.data.find(b"\n", self.curPos)
         if end < 0:
             raise ValueError("expected new line but did not get any")
-        line = self.data[self.curPos:end].decode()
+        line = self.data[self.curPos:end].decode("utf-8", "replace")
         self.curPos = end + 1
         return line
 
