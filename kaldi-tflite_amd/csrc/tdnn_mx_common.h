@@ -16,7 +16,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define MX_WQ_BLOCK 49152                   // bytes of one (N-tile, super-step) block of the MX weight planes (last 4 KiB unused)
 #define MX_PRM_OFF (MX_SW_OFF + MX_WQ_BLOCK)        // bias | scale | shift of the tile's 256 columns (read by the epilogue)
 #define MX_LDS_BYTES (MX_PRM_OFF + 3 * 256 * 4)     // 154,624 B
-#define MX_EPI_PITCH 260
+static_assert(8 * 64 * 68 * 4 <= MX_PRM_OFF, "epilogue staging regions");
+#define MX_EPW_PITCH 68                             // wave-private epilogue staging: 64 rows x 64 columns per wave and pass, 8 x 17,408 B
 
 struct MxParams {
     const char* xh;

@@ -32,7 +32,7 @@
 #define XS_PRM_OFF (XS_SW_OFF + XS_SW_BYTES)
 #define XS_LDS_BYTES (XS_PRM_OFF + 3 * 256 * 4)      // 161,792 B
 
-static_assert(XS_LDS_BYTES <= 163840 && 128 * MX_EPI_PITCH * 4 <= XS_PRM_OFF, "LDS budget (K-loop, epilogue staging image)");
+static_assert(XS_LDS_BYTES <= 163840 && 8 * 64 * MX_EPW_PITCH * 4 <= XS_PRM_OFF, "LDS budget (K-loop, epilogue staging image)");
 
 template <int ACT, int OUT>
 __device__ __forceinline__ void mxs_tile(const MxParams& p, const int id, int mtiles, int ntiles, int gtiles, double* __restrict__ stats,
