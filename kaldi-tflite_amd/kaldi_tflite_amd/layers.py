@@ -1113,8 +1113,8 @@ class StatsPooling(Layer):
         od = 2 * D if self.includeStd else D
         if self.reduce:
             return self.reduce_all(x, D).reshape(B, 1, od)
-        if T == 0:                                   # no frame, no window (a VALID-padded layer in front left nothing)
-            return torch.empty((B, 0, od), dtype=torch.float32, device=x.device)
+        if T == 0 and self.padding == "SAME":        # no frame, no window (a VALID-padded layer in front left nothing); with VALID
+            return torch.empty((B, 0, od), dtype=torch.float32, device=x.device)      # padding the reference pools "all" frames: one NaN row, below
         x = x.to(torch.float32)
         if self.padding == "SAME":
             n = self.numOutputSteps(T)
