@@ -596,7 +596,8 @@ class Sequential:
                 sbuf = self._ws.get("pooled", (B, ops.round_up(od, 32)), torch.float32, dev)
                 l.reduce_all(x, D, lens=lens, out=sbuf)
                 if si + 1 == tail_at:
-                    return DeferredTail(steps[tail_at][1], B, D, l.includeStd, l.epsilon, pooled=sbuf)
+                    return DeferredTail(steps[tail_at][1], B, D, l.includeStd, l.epsilon, pooled=sbuf, lens=lens, T=T)      # (lens: KTF_TAIL_SKIP_EMPTY of the
+                                                                                                                         # short-utterance pass reads them)
                 x = sbuf[:, :od].unsqueeze(0)       # (1, B, od): the pooled vectors form ONE B-row matrix
                 lens = None
                 pooled = True

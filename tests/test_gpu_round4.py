@@ -605,6 +605,9 @@ def test_differential_fuzzing_of_the_extractor_finds_nothing():
     fp64 oracle; a fixed seed here."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_extractor.py"), "16", "31"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "16 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    # ... with random settings of the runner's A/B knobs (kernel choices, fusion, routing) per round: they change schedules, not the contract
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_extractor.py"), "12", "33", "--knobs"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "12 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
     # ... and with a random front-end per round (sampling rate, frame sizes, mel / cepstrum options, VAD, CMVN: the generic front-end kernel)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_extractor.py"), "16", "32", "--cfg"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "16 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]

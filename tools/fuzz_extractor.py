@@ -18,6 +18,8 @@ from oracle import ktf_oracle as O
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
+KNOBS = "--knobs" in sys.argv        # ... with random settings of the runner's A/B knobs per round (kernel choices, fusion, routing): every
+                                      # combination must stay inside the tolerance -- they change schedules and kernels, not the arithmetic contract
 RANDOM_CFG = "--cfg" in sys.argv     # ... with a random front-end per round as well (sampling rate, frame length / shift, mel / cepstrum sizes and
                                       # options, VAD and CMVN settings: the generic front-end kernel beside the nfft-512 one), narrow network
 
@@ -89,6 +91,22 @@ for r in range(rounds):
         cond = np.zeros(B)
     seen["utterances"] += B
     seen["nan_expected"] += int(np.isnan(want).any(axis=1).sum())
+    knobs = {}
+    if KNOBS:
+        knobs = {"mx_slab": bool(rng.integers(0, 2)), "mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)),
+                 "split_planes": bool(rng.integers(0, 2)), "fuse_stats": bool(rng.integers(0, 2)), "deterministic": bool(rng.integers(0, 2)),
+                 "small_tile_pairs": bool(rng.integers(0, 2)), "min_tiles": [None, {}][int(rng.integers(0, 2))]}
+        xk = {"fuse_tail": bool(rng.integers(0, 2)), "route_short_utterances": True}
+        for mdl in models.values():
+            for k, v in knobs.items():
+                if k == "min_tiles":
+                    mdl.xvec.min_tiles = dict(mdl.xvec.MIN_TILES) if v is None else {}
+                elif hasattr(mdl.xvec, k):
+                    setattr(mdl.xvec, k, v)
+            for k, v in xk.items():
+                setattr(mdl, k, v)
+            mdl._graphs = {}
+        knobs.update(xk)
     for mode, mdl in models.items():
         for form in ("fp32", "int16", "graph"):
             x = torch.as_tensor(wav if form != "int16" else wav.astype(np.int16), device="cuda")
@@ -96,7 +114,7 @@ for r in range(rounds):
                 got = (mdl.compile(x)(x) if form == "graph" else mdl(x)).float().cpu().numpy().reshape(B, -1)
             except Exception as e:
                 bad += 1
-                print(f"MISMATCH round {r} {mode} {form} kinds {kinds} N {N} voiced {voiced}: raises {type(e).__name__}: {e}", flush=True)
+                print(f"MISMATCH round {r} {mode} {form} kinds {kinds} N {N} voiced {voiced}: raises {type(e).__name__}: {e}" + (f" knobs {knobs}" if KNOBS else ""), flush=True)
                 continue
             for b in range(B):
                 wn, gn = np.isnan(want[b]).any(), np.isnan(got[b]).any()
@@ -111,7 +129,7 @@ for r in range(rounds):
                     if not err <= max(1e-4, 10.0 * cond[b]):
                         bad += 1
                         print(f"MISMATCH round {r} {mode} {form} utterance {b} ({kinds[b]}, {voiced[b]} voiced frames, N {N}): max-abs deviation {err:.3e} (oracle fp32 vs fp64: {cond[b]:.1e})"
-                              + (f" cfg {cfg}" if RANDOM_CFG else ""), flush=True)
+                              + (f" cfg {cfg}" if RANDOM_CFG else "") + (f" knobs {knobs}" if KNOBS else ""), flush=True)
 print(f"{rounds} rounds, {bad} mismatches")
 print(seen, {m: f"{v:.2e}" for m, v in worst.items()})
 sys.exit(min(bad, 255))
