@@ -59,8 +59,8 @@ static int act_rows_launch(float* y, int64_t B, int64_t T, int32_t D, int64_t ld
 
 extern "C" int ktf_activation_f32(float* y, int64_t B, int64_t T, int32_t D, int64_t ld, const int32_t* lens, int32_t act,
                                   const float* scale, const float* shift, void* stream) {
-    KTF_REQUIRE(y, "ktf_activation_f32: null argument");
     KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ld >= D, "ktf_activation_f32: bad sizes");
+    KTF_REQUIRE(y || B * T == 0, "ktf_activation_f32: null argument");
     KTF_REQUIRE(act >= KTF_ACT_NONE && act <= KTF_ACT_SOFTMAX, "ktf_activation_f32: bad activation %d", act);
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_activation_f32: scale and shift go together");
     const int rc = act_rows_launch(y, B, T, D, ld, lens, T, 0, 1, act, scale, shift, (hipStream_t)stream);
@@ -131,7 +131,8 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,
                        const void* x_lo = nullptr, void* y_lo = nullptr, const int32_t* row_starts = nullptr) {
     KTF_REQUIRE(d, "ktf_tdnn: null descriptor");
-    if (B >= 0 && T == 0) {                              // an empty input (its tensors may be empty: null pointers): no output row, every length 0
+    if (B >= 0 && (T == 0 || ktf_tdnn_out_len(T, d) == 0)) {      // an empty input, or one shorter than a VALID-padded layer's context (the
+        // tensors of either may be empty: null pointers): no output row, every length 0
         if (B > 0 && out_lens) (void)hipMemsetAsync(out_lens, 0, sizeof(int32_t) * B, (hipStream_t)stream);
         return KTF_OK;
     }
@@ -258,7 +259,7 @@ extern "C" int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, 
 extern "C" int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* lens,
                               const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                               const float* shift, void* y, void* y_lo, int64_t ldy, int32_t* out_lens, void* stream) {
-    KTF_REQUIRE(y && d, "ktf_tdnn_split: null argument");
+    KTF_REQUIRE(d && (y || T == 0 || ktf_tdnn_out_len(T, d) == 0), "ktf_tdnn_split: null argument");
     KTF_REQUIRE((d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16) || d->gemm == KTF_GEMM_F16X2,
                 "ktf_tdnn_split: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes) or KTF_GEMM_F16X2 (one half plane)");
     return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, y, ldy, out_lens, nullptr, stream, x_lo, y_lo);
@@ -375,8 +376,9 @@ extern "C" int ktf_stats_finalize_slots(const double* sums, int64_t slots, int32
 
 extern "C" int ktf_affine_act_f32(const float* x, int64_t rows, int32_t D, int32_t act, const float* scale,
                                   const float* shift, float* y, void* stream) {
-    KTF_REQUIRE(x && y, "ktf_affine_act_f32: null argument");
     KTF_REQUIRE(rows >= 0 && D > 0, "ktf_affine_act_f32: bad sizes");
+    if (rows == 0) return KTF_OK;                         // (an empty tensor: null pointers)
+    KTF_REQUIRE(x && y, "ktf_affine_act_f32: null argument");
     KTF_REQUIRE(act >= KTF_ACT_NONE && act < KTF_ACT_SOFTMAX, "ktf_affine_act_f32: bad activation %d (KTF_ACT_SOFTMAX: ktf_activation_f32)", act);
     const int64_t total = rows * D;
     if (total == 0) return KTF_OK;

@@ -56,6 +56,17 @@ for case in range(n_cases):
     except Exception as e:
         print(f"SKIP (config) {lcfg}: {e}")
         continue
+    knobs = {}
+    if "--knobs" in sys.argv:                            # random settings of the runner's A/B knobs: schedules and kernels change, the contract does not
+        knobs = {"mx_slab": bool(rng.integers(0, 2)), "mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)),
+                 "split_planes": bool(rng.integers(0, 2)), "fuse_stats": bool(rng.integers(0, 2)), "deterministic": bool(rng.integers(0, 2)),
+                 "small_tile_pairs": bool(rng.integers(0, 2))}
+        for k, v in knobs.items():
+            setattr(mdl, k, v)
+        if rng.random() < 0.5:
+            mdl.min_tiles, knobs["min_tiles"] = {}, {}
+        if rng.random() < 0.5:
+            mdl.min_frames, knobs["min_frames"] = {}, {}
     layers, din = [], D
     for i, (U, ctx, pad, sub, form) in enumerate(spec):
         W = (rng.standard_normal((U, len(ctx) * din)) / np.sqrt(len(ctx) * din)).astype(np.float32)
@@ -87,7 +98,7 @@ for case in range(n_cases):
     x = rng.standard_normal((B, T, D)).astype(np.float32)
     if dense:
         lens[:] = T
-    desc = dict(gemm=gemm, D=D, B=B, T=T, lens=lens.tolist() if not dense else "dense", spec=spec, pooled_at=pooled_at, win_stats=win_stats)
+    desc = dict(gemm=gemm, D=D, B=B, T=T, lens=lens.tolist() if not dense else "dense", spec=spec, pooled_at=pooled_at, win_stats=win_stats, knobs=knobs)
     try:
         if dense:
             got = mdl(torch.as_tensor(x, device="cuda")).float().cpu().numpy()
