@@ -95,7 +95,7 @@ thread_local const char* g_ktf_last_kernel = "";
 extern "C" const char* ktf_tdnn_last_kernel(void) { return g_ktf_last_kernel; }
 
 extern "C" int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d) {
-    if (!d || d->nctx <= 0 || d->subsampling <= 0) return -1;
+    if (!d || d->nctx <= 0 || d->nctx > 16 || d->subsampling <= 0) return -1;      // (ctx[] holds 16 offsets)
     int64_t start = 0, end = len;
     if (d->valid) {
         if (d->ctx[0] < 0) start = -d->ctx[0];
