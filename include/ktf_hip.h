@@ -293,6 +293,14 @@ typedef struct KtfTdnnDesc {
                                    * offsets, all within [-4, 4], run the slab form of the 256 x 256 kernel (csrc/tdnn_mxs.hip): a
                                    * 32-feature chunk's rows are fetched once per tile and shared by the chunk's K-steps. Same weight
                                    * images, tiles, slots and results as without the flag; other layers are unaffected */
+#define KTF_TDNN_MX_PERSIST (1 << 26) /* ktf_tdnn_mx / ktf_tdnn_mx_stats only (KTF_TDNN_MX_LOADER wins over it): the persistent form of the
+                                   * 256 x 256 kernel (csrc/tdnn_mxp.hip): one workgroup per CU walks its tiles, the operand ring never
+                                   * drains between them, a tile's planes are encoded from registers inside the first K-step of the next.
+                                   * Same planes, tiles, slots and arithmetic (the accumulators start at the bias instead of having it
+                                   * added last); `wh` / `wq` are the images of ktf_tdnn_mx with the units of each 32-unit chunk in the
+                                   * order unit(cb, m) = (cb >> 1) * 32 + (m >> 2) * 8 + (cb & 1) * 4 + (m & 3) for image column m of
+                                   * 16-unit block cb of the N-tile (mx.weight_images(permuted=True)); every layer shape, padding,
+                                   * subsampling and output form of ktf_tdnn_mx */
 
 /* name of the kernel family the calling thread's last ktf_tdnn* / ktf_tdnn_mx* call launched ("" before the first; a static
  * string). For the dispatch tests: which kernel a (gemm mode, layer shape) pair runs on is part of the library's contract. */

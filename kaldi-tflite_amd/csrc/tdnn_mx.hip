@@ -427,6 +427,12 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
         KTF_CHECK_LAUNCH(who);
         return KTF_OK;
     }
+    if (d->flags & KTF_TDNN_MX_PERSIST) {         // one workgroup per CU walking its tiles (tdnn_mxp.hip); weight images in the permuted unit order
+        const int rc = mxp_launch(p, B, d->act, o, stats, st);
+        if (rc != KTF_OK) return rc;
+        KTF_CHECK_LAUNCH(who);
+        return KTF_OK;
+    }
     if ((d->flags & KTF_TDNN_MX_SLAB) && plain && mxs_applies(d)) {   // multi-context layers on activation slabs (tdnn_mxs.hip); same images, same tiles
         const int rc = mxs_launch(p, B, d->act, o, stats, st);
         if (rc != KTF_OK) return rc;

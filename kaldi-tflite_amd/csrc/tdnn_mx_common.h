@@ -216,6 +216,8 @@ __device__ __forceinline__ void mx_stats_out(double* __restrict__ stats, const M
 
 // tdnn_mxl.hip: the loader-wave kernel (include/ktf_hip.h, KTF_TDNN_MX_LOADER); `p` as filled by mx_launch
 int mxl_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);
+// tdnn_mxp.hip: the persistent form of the 256 x 256 kernel (KTF_TDNN_MX_PERSIST; weight images with the permuted unit order)
+int mxp_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);
 // tdnn_mxs.hip: the slab form of the 256 x 256 kernel for layers with context offsets (KTF_TDNN_MX_SLAB)
 bool mxs_applies(const KtfTdnnDesc* d);
 int mxs_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);

@@ -125,18 +125,20 @@ CASES = [  # D, context, units, B, T, lens
 ]
 
 
-KERNELS = ["loader_waves", "tile256", "slab"]     # KTF_TDNN_MX_LOADER / no flag / KTF_TDNN_MX_SLAB
+KERNELS = ["loader_waves", "tile256", "slab", "persist"]     # KTF_TDNN_MX_LOADER / no flag / KTF_TDNN_MX_SLAB / KTF_TDNN_MX_PERSIST
 
 
 def _kernel(kernel, layer):
-    """(flags, loader weight images?, kernel family that must run) of a KERNELS entry for `layer`."""
+    """(flags, weight images (TDNN.device_weights_mx `kernel`), kernel family that must run) of a KERNELS entry for `layer`."""
     if kernel == "loader_waves":
-        return L.TDNN_MX_LOADER, True, "tdnn_mxl_kernel"
+        return L.TDNN_MX_LOADER, "loader", "tdnn_mxl_kernel"
+    if kernel == "persist":
+        return L.TDNN_MX_PERSIST, "persist", "tdnn_mxp_kernel"
     if kernel == "slab":
         ctx = list(layer.context)
         applies = len(ctx) >= 2 and min(ctx) >= -4 and max(ctx) <= 4
-        return L.TDNN_MX_SLAB, False, "tdnn_mxs_kernel" if applies else "tdnn_mx_kernel"
-    return 0, False, "tdnn_mx_kernel"
+        return L.TDNN_MX_SLAB, "tile", "tdnn_mxs_kernel" if applies else "tdnn_mx_kernel"
+    return 0, "tile", "tdnn_mx_kernel"
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -149,8 +151,8 @@ def test_tdnn_mx_fp32_output_vs_emulation(case, relu, kernel):
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    mxf, loader, family = _kernel(kernel, layer)
-    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
+    mxf, images, family = _kernel(kernel, layer)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel=images)
     d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=mxf)
     ldy = ops.round_up(layer.units, 4)
     y = torch.full((B, T, ldy), 7.0, device="cuda")
@@ -180,8 +182,8 @@ def test_tdnn_mx_plane_output_feeds_the_next_layer(case, kernel):
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    mxf, loader, family = _kernel(kernel, layer)
-    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
+    mxf, images, family = _kernel(kernel, layer)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel=images)
     d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=mxf)
     out = mx.Planes.empty(B, T, layer.units, "cuda")
     ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, out)
@@ -210,8 +212,8 @@ def test_tdnn_mx_fused_pooling_vs_emulation(kernel, shape):
     p = mx.Planes.empty(B, T, D, "cuda")
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
-    mxf, loader, family = _kernel(kernel, layer)
-    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=loader)
+    mxf, images, family = _kernel(kernel, layer)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel=images)
     emu, _ = _emulate(layer, x, lens, True)
     for det in (True, False):
         d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=mxf | (L.TDNN_DET_STATS if det else 0))

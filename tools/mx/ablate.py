@@ -101,6 +101,41 @@ extern "C" void ktf_prof_dump(void) {
     return s
 V["prof"] = _prof
 
+
+# instrumented build (correct results), two stamps per tile: the K-loop (accumulator init .. last M) in shader clocks and 100 MHz wall
+# ticks, and the rest of the tile (entry .. K-loop, K-loop .. exit) -- the same quantities tools/mx/prof_mxp.py prints for tdnn_mxp.hip
+def _prof2(s):
+    s = rep(s, '#include "tdnn_mx_common.h"', '#include "tdnn_mx_common.h"\n__device__ unsigned long long g_prof2[48][2][8];')
+    s = rep(s, "    const int n0 = nt * 256, t0 = mt * 256;", "    const int n0 = nt * 256, t0 = mt * 256;\n    const unsigned long long pc0 = __builtin_amdgcn_s_memtime(), pr0 = __builtin_amdgcn_s_memrealtime();")
+    s = rep(s, "    f32x4 acc[8][4];\n", "    const unsigned long long pc1 = __builtin_amdgcn_s_memtime(), pr1 = __builtin_amdgcn_s_memrealtime();\n    f32x4 acc[8][4];\n")
+    s = rep(s, "#undef MX_DMA_F16\n", "    const unsigned long long pc2 = __builtin_amdgcn_s_memtime(), pr2 = __builtin_amdgcn_s_memrealtime();\n#undef MX_DMA_F16\n")
+    dump = ("{ const unsigned long long pc3 = __builtin_amdgcn_s_memtime(), pr3 = __builtin_amdgcn_s_memrealtime();"
+            " const int pw = wave == 0 ? 0 : (wave == 4 ? 1 : -1);"
+            " if (pw >= 0 && lane == 0) { unsigned long long* g = g_prof2[(p.nss < 15 ? p.nss : 15) + 16 * OUT][pw]; atomicAdd(g + 3, pc2 - pc1); atomicAdd(g + 4, pr2 - pr1);"
+            " atomicAdd(g + 6, (pc1 - pc0) + (pc3 - pc2)); atomicAdd(g + 5, (pr1 - pr0) + (pr3 - pr2)); atomicAdd(g + 7, 1ull); } }")
+    inc = open(os.path.join(CS, "tdnn_mx_epilogue.inc")).read()
+    inc = rep(inc, "        return;\n    } else {", "        " + dump + "\n        return;\n    } else {")
+    s = rep(s, '#include "tdnn_mx_epilogue.inc"\n}', inc + "\n" + dump + "\n}")
+    s += """
+extern "C" void ktf_prof_dump(void) {
+    unsigned long long h[48][2][8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_prof2), sizeof(h));
+    for (int i = 0; i < 48; ++i)
+        for (int w = 0; w < 2; ++w)
+            if (h[i][w][7]) {
+                const double n = (double)h[i][w][7];
+                printf("out %d nss %2d wave %d: %llu tiles | K-loop %.0f clk = %.2f us (%.0f MHz) | rest of the tile %.0f clk = %.2f us\\n",
+                       i / 16, i % 16, w * 4, h[i][w][7], h[i][w][3] / n, h[i][w][4] / n / 100.0, 100.0 * (double)h[i][w][3] / (double)h[i][w][4],
+                       h[i][w][6] / n, h[i][w][5] / n / 100.0);
+            }
+    memset(h, 0, sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof2), h, sizeof(h));
+}
+"""
+    return s
+V["prof2"] = _prof2
+
 V["head"] = lambda s: subprocess.check_output(["git", "show", "HEAD:kaldi-tflite_amd/csrc/tdnn_mx.hip"], cwd=ROOT).decode()
 
 # ring-depth experiment: the half-precision K-steps alone (no side DMAs / weight loads, no scaled MFMAs; WRONG results), on the
