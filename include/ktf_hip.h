@@ -101,6 +101,14 @@ extern "C" {
 int32_t ktf_version(void);
 /* copies the calling thread's last error text (NUL-terminated) into buf; returns its length */
 size_t ktf_last_error(char* buf, size_t cap);
+/* 16 hex digits of the sha256 over the library's sources (csrc/Makefile): measurements kept under profiles/ name the build they were
+ * made on with it (bench.py attaches a stored HBM-traffic figure only to the build it belongs to). A static string. */
+const char* ktf_build_id(void);
+/* measurement aid (bench.py): ONE wave that stays resident for `us` microseconds beside whatever else runs on `stream`'s device
+ * and reads the shader clock (s_memtime) against the constant 100 MHz counter (s_memrealtime). out (device, 4 x uint64):
+ * [0] shader clocks and [1] 100 MHz ticks over the whole stay, [2] / [3] the lowest / highest clock in kHz over ~1 ms windows.
+ * Launch it on a stream of its own next to the timed work. 0 < us <= 10 000 000. */
+int ktf_clock_probe(unsigned long long* out, int64_t us, void* stream);
 
 /* ------------------------------------------------------------------ front-end (a1-a5)
  * Framing   layers/dsp/framing.py:243-265       (tf.gather of frame indexes)
@@ -305,6 +313,7 @@ typedef struct KtfTdnnDesc {
 /* name of the kernel family the calling thread's last ktf_tdnn* / ktf_tdnn_mx* call launched ("" before the first; a static
  * string). For the dispatch tests: which kernel a (gemm mode, layer shape) pair runs on is part of the library's contract. */
 const char* ktf_tdnn_last_kernel(void);
+
 
 /* number of output rows for an utterance with `len` input rows (tdnn.py:224-234) */
 int64_t ktf_tdnn_out_len(int64_t len, const KtfTdnnDesc* d);

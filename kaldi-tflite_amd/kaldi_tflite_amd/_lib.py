@@ -94,6 +94,8 @@ _i64, _i32, _f32, _u64 = C.c_int64, C.c_int32, C.c_float, C.c_uint64
 PROTOTYPES = {
     "ktf_version": (_i32, []),
     "ktf_last_error": (C.c_size_t, [C.c_char_p, C.c_size_t]),
+    "ktf_build_id": (C.c_char_p, []),
+    "ktf_clock_probe": (C.c_int, [_P, _i64, _P]),
     "ktf_num_frames": (_i64, [_i64, _i32, _i32]),
     "ktf_num_frames_padded": (_i64, [_i64, _i32, _i32, _i32]),
     "ktf_frontend_f32": (C.c_int, [_P, _i64, _i64, _i32, C.POINTER(FrontendCfg), C.POINTER(FrontendTables), _i32, _P, _P, _u64, _P]),

@@ -298,6 +298,20 @@ def last_kernel():
     return (L.load().ktf_tdnn_last_kernel() or b"").decode()
 
 
+def build_id():
+    """16 hex digits naming the sources the loaded library was built from (ktf_build_id)."""
+    return (L.load().ktf_build_id() or b"").decode()
+
+
+def clock_probe(out, us, stream):
+    """Launches the one-wave shader-clock probe on `stream` (a torch.cuda.Stream of its own, next to the measured work): out is a
+    (4,) int64 CUDA tensor that receives shader clocks, 100 MHz ticks, lowest / highest kHz over 1 ms windows (ktf_clock_probe)."""
+    with L.on_device(out.device):
+        rc = L.load().ktf_clock_probe(L.ptr(out), int(us), stream.cuda_stream)
+    L.check(rc, "ktf_clock_probe")
+    return out
+
+
 def route_short(lens, min_frames, lens_main, lens_short, host_flag=None, seq=0):
     """lens -> (lens_main, lens_short) by voiced length (ktf_route_short); host_flag: pinned int32[2] CPU tensor that receives the number
     of short utterances and then `seq`."""

@@ -79,6 +79,16 @@ def max_over_ranks(seconds, world, device):
     return float(t.item())
 
 
+def gather_floats(value, world, device):
+    """[value of rank 0, ..., value of rank world - 1] on every rank (per-rank timings of bench.py)."""
+    if world == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
+    parts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def barrier(world):
     if world > 1:
         if dist.get_backend() == "nccl":
