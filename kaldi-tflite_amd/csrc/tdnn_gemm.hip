@@ -131,15 +131,15 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,
                        const void* x_lo = nullptr, void* y_lo = nullptr, const int32_t* row_starts = nullptr) {
     KTF_REQUIRE(d, "ktf_tdnn: null descriptor");
-    if (B >= 0 && (T == 0 || ktf_tdnn_out_len(T, d) == 0)) {      // an empty input, or one shorter than a VALID-padded layer's context (the
-        // tensors of either may be empty: null pointers): no output row, every length 0
-        if (B > 0 && out_lens) (void)hipMemsetAsync(out_lens, 0, sizeof(int32_t) * B, (hipStream_t)stream);
-        return KTF_OK;
-    }
-    KTF_REQUIRE(x && w && (y || stats_sums), "ktf_tdnn: null argument");
+    // Everything that does not depend on the data is validated first -- descriptor, gemm / dtype combination, activation, scale / shift
+    // pairing, sizes --, so that a malformed call is rejected whether or not its input happens to be empty; only the null-pointer checks
+    // are relaxed for tensors without an element (an empty input: x, x_lo; no output row -- T == 0, or a VALID-padded layer's context
+    // longer than the input --: y, y_lo).
+    const bool no_in = B == 0 || T == 0;
     const bool split_in = d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16;     // activations as hi/lo bf16 planes
     const bool half2 = d->gemm == KTF_GEMM_F16X2;                                    // one half plane in, hi + lo half weights
-    if (split_in) KTF_REQUIRE(x_lo, "ktf_tdnn_split: null lo plane");
+    KTF_REQUIRE(w && (no_in || x), "ktf_tdnn: null argument");
+    if (split_in) KTF_REQUIRE(no_in || x_lo, "ktf_tdnn_split: null lo plane");
     if (half2) {
         KTF_REQUIRE(d->x_dtype == KTF_F16 && d->w_dtype == KTF_F16 && !x_lo && !y_lo,
                     "ktf_tdnn: F16X2 takes ONE half activation plane (x_lo, y_lo NULL) and half weights as w (hi) + w_lo (w_lo NULL: one pass)");
@@ -176,11 +176,12 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_tdnn: scale and shift go together");
     KTF_REQUIRE(T < (1ll << 30) && B < 65536, "ktf_tdnn: T or B too large");
     const int64_t Tout = ktf_tdnn_out_len(T, d);
-    if (B == 0 || T == 0) return KTF_OK;
-    if (Tout == 0) {
-        if (out_lens) (void)hipMemsetAsync(out_lens, 0, sizeof(int32_t) * B, (hipStream_t)stream);
+    if (B == 0) return KTF_OK;
+    if (T == 0 || Tout <= 0) {                           // no output row: every length 0, nothing else is touched (callers of
+        if (out_lens) (void)hipMemsetAsync(out_lens, 0, sizeof(int32_t) * B, (hipStream_t)stream);      // ktf_tdnn_stats zero the sums)
         return KTF_OK;
     }
+    KTF_REQUIRE(y || stats_sums, "ktf_tdnn: null output");
     TdnnParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.lens = lens; p.w = w; p.w_lo = w_lo; p.bias = bias; p.scale = scale; p.shift = shift; p.y = y;

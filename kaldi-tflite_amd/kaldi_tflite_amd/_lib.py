@@ -195,8 +195,8 @@ _scope = _Scope()
 class launch_scope:
     """One extraction = ~10 launches on one device and one stream: looked up once here instead of once per launch (torch's
     current_stream / device context managers were a quarter of the host time of a batch-1 call). Inside the scope `on_device(d)` is a
-    no-op for the scope's device and `stream_ptr()` returns the stream that was current at entry; nested scopes and other devices
-    fall back to the per-call lookups. Code that switches streams must do so OUTSIDE (as extract_stream does)."""
+    no-op for the scope's device and `stream_ptr()` returns the stream that was current at entry; nested scopes fall back to the
+    per-call lookups, and `on_device(another device)` suspends the scope (device and stream) until it exits. Code that switches streams must do so OUTSIDE (as extract_stream does)."""
 
     def __init__(self, device):
         import torch
@@ -233,13 +233,37 @@ class _Noop:
 _NOOP = _Noop()
 
 
+class _OtherDevice:
+    """`on_device(d)` for a device that is not the enclosing launch_scope's: makes it current and hides the scope's cached stream
+    for the duration -- that stream belongs to the scope's device, and `stream_ptr()` must hand the call the target device's
+    current stream (an invalid handle or a launch on the wrong queue otherwise)."""
+
+    def __init__(self, device):
+        import torch
+        self.ctx = torch.cuda.device(device)
+        self.saved = None
+
+    def __enter__(self):
+        self.saved = (_scope.dev, _scope.stream)
+        _scope.dev, _scope.stream = None, None
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.ctx.__exit__(*exc)
+        _scope.dev, _scope.stream = self.saved
+        return False
+
+
 def on_device(device):
     """`with on_device(t.device):` around a library call: makes the device current (torch.cuda.device), unless an enclosing
-    launch_scope already did."""
+    launch_scope already did; for any other device the scope is suspended (its cached stream is not that device's)."""
     import torch
     idx = device.index if isinstance(device, torch.device) else device
     if _scope.dev is not None and (idx is None or idx == _scope.dev):
         return _NOOP
+    if _scope.dev is not None:
+        return _OtherDevice(device)
     return torch.cuda.device(device)
 
 

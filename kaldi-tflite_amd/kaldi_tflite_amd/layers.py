@@ -8,6 +8,7 @@ API difference is the tensor type (torch.Tensor on an MI355X instead of tf.Tenso
 """
 
 import collections
+import itertools
 import zlib
 
 import numpy as np
@@ -246,7 +247,7 @@ class Windowing(Layer):
         self.eps = float(epsilon)
         self.windowFunc = None
         self.sampleAxis = -1
-        self._seed = 0x5EED
+        self._seed = itertools.count(0x5EED + 1)      # (next() of a count is atomic: concurrent callers never draw the same dither seed)
 
     def build(self, input_shape):
         M = input_shape[self.sampleAxis]
@@ -279,9 +280,8 @@ class Windowing(Layer):
         lead = x.shape[:-1]
         rows = int(np.prod(lead))
         tables = _per_device(self, x.device, lambda: ops.FrontendTables(M, window=self.windowFunc, device=x.device))
-        self._seed += 1
         r = ops.frontend(x.reshape(1, rows, M), L.IN_FRAMES, self._cfg(M), tables, L.OUT_WINDOWED, rows, 1, rows,
-                         seed=self._seed, want_energy=self.returnEnergy)
+                         seed=next(self._seed), want_energy=self.returnEnergy)
         if self.returnEnergy:
             out, en = r
             return out.reshape(*lead, M), en.reshape(*lead, 1)
@@ -418,7 +418,7 @@ class MFCC(Layer):
                                      high_freq_cutoff=high_freq_cutoff, low_freq_cutoff=low_freq_cutoff,
                                      use_log_fbank=use_log_fbank, use_power=use_power, epsilon=epsilon)
         self.dct = DCT(length=num_mfccs, dct_type=2, norm="ortho")
-        self._seed = 0xC0FFEE
+        self._seed = itertools.count(0xC0FFEE + 1)    # (next() of a count is atomic: concurrent callers never draw the same dither seed)
         self._tables = {}
 
     def build(self, input_shape):
@@ -462,8 +462,7 @@ class MFCC(Layer):
         return c
 
     def next_seed(self):
-        self._seed += 1
-        return self._seed
+        return next(self._seed)
 
     def call(self, inputs):
         x = inputs.to(torch.float32).contiguous()
@@ -772,6 +771,7 @@ class TDNN(Layer):
         self._dev = {}
         self._version += 1
         WEIGHTS_EPOCH[0] += 1
+        self._warned_fp32_fallback = set()       # (warn_fallback speaks again for the new weights)
         self.built = True
 
     def kaldi_matrix(self):
@@ -978,22 +978,37 @@ class TDNN(Layer):
         return out
 
     def effective_gemm(self, gemm, relu=False):
-        """The half-precision mode runs on the ring kernels only (units > 128, ReLU or no activation); any other layer
-        of an "f16" model is evaluated by the exact fp32 kernel instead."""
+        """The half-precision modes run on the ring / MX kernels only (units > 128, ReLU or no activation); any other layer of
+        such a model is evaluated by the exact fp32 kernel instead. A pure query (the fused runner's planner asks it for every
+        layer, and for the layer behind it): `warn_fallback` is what tells the user."""
+        return L.GEMM_F32 if self.fallback_reason(gemm, relu) else gemm
+
+    def fallback_reason(self, gemm, relu=False):
+        """Why this layer runs on the exact fp32 kernels in a model of mode `gemm` (None: it does not)."""
         a = self.activation.lower() if isinstance(self.activation, str) else self.activation
+        if gemm == L.GEMM_F32:
+            return None
         if _ACTS[a] > L.ACT_TANH:            # activations no epilogue fuses: the fp32 kernels + an activation pass, in every mode
-            return L.GEMM_F32
+            return f"activation {self.activation!r} is not fused by any reduced-precision epilogue"
         if gemm not in (L.GEMM_F16, L.GEMM_F16X2, L.GEMM_F16MX):
-            return gemm
-        ok = self.units > 128 and (a in (None, "linear") or (a == "relu" and not relu))
-        if not ok and not getattr(self, "_warned_fp32_fallback", False):
-            import warnings
-            self._warned_fp32_fallback = True
-            mode = {L.GEMM_F16: "f16", L.GEMM_F16X2: "f16x2", L.GEMM_F16MX: "f16mx"}[gemm]
-            warnings.warn(f"TDNN layer '{self.name}' (units {self.units}, padding {self.padding}, subsampling {self.subsamplingFactor}, "
-                          f"activation {self.activation}) is outside what the '{mode}' kernels serve: it runs on the exact fp32 kernels "
-                          f"(several times slower per flop; results are the more accurate ones)", RuntimeWarning, stacklevel=3)
-        return gemm if ok else L.GEMM_F32
+            return None
+        if self.units <= 128:
+            return f"units = {self.units} (these kernels tile 256 units: layers of up to 128 stay on fp32)"
+        if not (a in (None, "linear") or (a == "relu" and not relu)):
+            return (f"activation {self.activation!r}" + (" followed by a ReLU" if relu else "") + " (these kernels fuse ReLU or no activation)")
+        return None
+
+    def warn_fallback(self, gemm, relu=False):
+        """One RuntimeWarning per (layer, mode) naming the condition that keeps the layer off the mode's kernels; called where the
+        layer is about to run (TDNN.call, the fused runner), re-armed by set_weights."""
+        why = self.fallback_reason(gemm, relu)
+        if why is None or gemm in self.__dict__.setdefault("_warned_fp32_fallback", set()):
+            return
+        import warnings
+        self._warned_fp32_fallback.add(gemm)
+        mode = {v: k for k, v in _GEMM.items()}.get(gemm, str(gemm))
+        warnings.warn(f"TDNN layer '{self.name}' runs on the exact fp32 kernels in this '{mode}' model: {why} "
+                      f"(several times slower per flop; its results are the more accurate ones)", RuntimeWarning, stacklevel=3)
 
     def prepare_input(self, x, gemm):
         """Dense user tensor (B,T,D) -> operand the GEMM can read (padded to a multiple of 32 columns, right dtype)."""
@@ -1013,6 +1028,7 @@ class TDNN(Layer):
             raise ValueError(f"expected a (batch, time, feat) input, got shape {tuple(x.shape)}")
         if x.shape[-1] != self.inputDim:
             raise ValueError(f"expected input feature dim {self.inputDim}, got {x.shape[-1]}")
+        self.warn_fallback(_GEMM[self.gemm])
         gemm = self.effective_gemm(_GEMM[self.gemm])
         B, T, D = x.shape
         if gemm == L.GEMM_F16MX:

@@ -11,6 +11,7 @@ batch of B utterances equals B independent batch-1 calls of the reference.
 
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -64,19 +65,25 @@ def cfg2layers(layerCfg):
 
 
 class _Workspace:
-    """Device scratch of one model. One byte arena per (role, device, stream), grown to the largest request seen and
-    re-viewed for every call: memory is bounded by the largest batch processed, not by the number of distinct
-    (batch, length) shapes (variable-length audio used to allocate a full activation set per shape). Arenas are keyed
-    by the CURRENT stream as well, so two streams / threads driving one model never share scratch; calls on one stream
-    are ordered by the stream."""
+    """Device scratch of one model. One byte arena per (role, device, stream, host thread), grown to the largest request seen
+    and re-viewed for every call: memory is bounded by the largest batch processed, not by the number of distinct
+    (batch, length) shapes (variable-length audio used to allocate a full activation set per shape). Arenas are keyed by the
+    CURRENT stream and by the CALLING THREAD: two streams never share scratch, and two host threads driving ONE model never do
+    either, not even on one stream (threads that set no stream all sit on the default one, where their launches interleave:
+    each call's kernels must then find their own buffers). Calls of one thread on one stream are ordered by the stream.
+    The binding made by enter() is per thread as well."""
 
     def __init__(self):
         self._arenas = {}
-        self._where = None
+        self._tl = threading.local()
+
+    @property
+    def _where(self):
+        return getattr(self._tl, "where", None)
 
     def enter(self, device):
-        """Bind the following get() calls to `device` and its current stream (looked up once per model call)."""
-        self._where = (str(device), torch.cuda.current_stream(device).cuda_stream)
+        """Bind the following get() calls of this thread to `device` and its current stream (looked up once per model call)."""
+        self._tl.where = (str(device), torch.cuda.current_stream(device).cuda_stream, threading.get_ident())
 
     def get(self, role, shape, dtype, device, padded=True):
         """`padded`: the view has pad columns nobody writes (they must read as finite zeros): True zeroes the whole view when
@@ -176,7 +183,8 @@ class Sequential:
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"
-        self._ws = _Workspace()
+        self._ws_own = _Workspace()
+        self._tl = threading.local()  # per host thread: a workspace override (XvectorExtractor.compile), the deferred tail of the call in flight
         self._xbar = {}              # calibrate(): id(layer) -> (D,) float64 mean of the layer's stored input plane
         self._xvar = {}              # ... and its variance
         self._calibrating = None
@@ -263,6 +271,24 @@ class Sequential:
         if gemm != L.GEMM_F32 and -(-(B * T) // 256) < self.min_tiles.get(mode, 0):
             return L.GEMM_F32, bool(self.small_tile_pairs)
         return gemm, False
+
+    # ---- per-thread call state: a model object may be driven by several host threads at once (the reference's layers are stateless
+    # after build: layers/tdnn/tdnn.py:251-280, normalization/cmvn.py:186-250), so nothing a call sets lives on the instance
+    @property
+    def _ws(self):
+        return getattr(self._tl, "ws", None) or self._ws_own
+
+    @_ws.setter
+    def _ws(self, ws):                       # XvectorExtractor.compile: private workspaces for the capturing thread only
+        self._tl.ws = None if ws is self._ws_own else ws
+
+    @property
+    def _deferred(self):
+        return getattr(self._tl, "deferred", None)
+
+    @_deferred.setter
+    def _deferred(self, d):
+        self._tl.deferred = d
 
     def _mx_use_loader(self, B, T):
         """f16mx: the loader-wave kernel for this batch? (`mx_loader` None: rounds of 256 workgroups x rows per tile, two N-tiles)"""
@@ -366,6 +392,8 @@ class Sequential:
                     raise ValueError("cannot fuse a ReLU after a TDNN that already has an activation")
                 can_pool = (self.fuse_stats and not pooled and nxt is not None and nxt[0] == "stats" and
                             nxt[1].inputPeriod == 1 and l.units > 128 and l.padding == "SAME" and l.subsamplingFactor == 1)
+                if not pooled:                           # (frame-level layers: behind the pooling everything is fp32 by design)
+                    l.warn_fallback(gemm, relu)
             if gemm == L.GEMM_F16MX and st[0] == "tdnn" and not pooled and l.effective_gemm(gemm, relu) == gemm:
                 # one half pass + two block-scaled residual passes (csrc/tdnn_mx.hip): activations travel as four chunk-major
                 # planes (half value, e2m1 images of the residual and of the value, block scales) holding the ReLU outputs; a
@@ -789,7 +817,8 @@ class XvectorExtractor:
         self.ldaOffset = np.ascontiguousarray(lda[..., -1:].T)          # (1, out)
         self.ldaMat = np.ascontiguousarray(lda[..., :-1].T)             # (in, out)
         self._post_dev = {}
-        self._ws = _Workspace()
+        self._ws_own = _Workspace()
+        self._tl = threading.local()      # per host thread: workspace override (compile), pinned short-utterance flag, last_lens / last_short_count
         self._graphs = {}
         self.fuse_tail = True        # pooling finalize + tdnn6 + mean-sub + LDA + length-norm as ONE launch (False: three, for A/B)
         self.fuse_tail_below = 512   # ... for batches below this size: from there on tdnn6 is a 256-workgroup fp32 MFMA GEMM over the
@@ -798,11 +827,35 @@ class XvectorExtractor:
                                      # batch an utterance arrives in, bit for bit.
         self.route_short_utterances = True    # utterances with fewer voiced frames than the mode's Sequential.MIN_FRAMES go through the
                                               # tighter SHORT_MODE kernels, decided per utterance from the device's frame counts (_extract)
-        self._short_flag = None               # pinned int32[2]: short utterances of the batch in flight, call sequence number
-        self._short_seq = 0
-        self.last_short_count = 0             # short utterances of the last call
-        self._warming_for_capture = False     # compile(): the warm-up calls run the short-utterance pass unconditionally
-        self.last_lens = None
+        self._warming_for_capture = False     # compile(): the warm-up calls run the short-utterance pass unconditionally (set and cleared by the
+                                              # compiling thread; compile() is configuration, not a concurrent call: INTEGRATION.md)
+
+    # ---- per-thread call state (see Sequential): `last_lens` / `last_short_count` are those of the CALLING thread's last call
+    @property
+    def _ws(self):
+        return getattr(self._tl, "ws", None) or self._ws_own
+
+    @_ws.setter
+    def _ws(self, ws):
+        self._tl.ws = None if ws is self._ws_own else ws
+
+    @property
+    def last_lens(self):
+        """voiced-frame counts (B,) int32 of this thread's last call: a workspace view, valid until its next call"""
+        return getattr(self._tl, "last_lens", None)
+
+    @last_lens.setter
+    def last_lens(self, v):
+        self._tl.last_lens = v
+
+    @property
+    def last_short_count(self):
+        """short utterances (below MIN_FRAMES voiced frames) of this thread's last eager call"""
+        return getattr(self._tl, "last_short_count", 0)
+
+    @last_short_count.setter
+    def last_short_count(self, v):
+        self._tl.last_short_count = v
 
     @property
     def layers(self):
@@ -894,10 +947,12 @@ class XvectorExtractor:
         if capturing:
             ops.route_short(lens, nshort, lens_main, lens_short)
         else:
-            if self._short_flag is None:
-                self._short_flag = torch.zeros(2, dtype=torch.int32).pin_memory()     # [count, sequence number]: written by the kernel
-            self._short_seq = (self._short_seq % 0x3FFFFFFF) + 1
-            ops.route_short(lens, nshort, lens_main, lens_short, self._short_flag, self._short_seq)
+            tl = self._tl                                          # (a pinned flag and a sequence counter per calling thread)
+            if getattr(tl, "short_flag", None) is None:
+                tl.short_flag = torch.zeros(2, dtype=torch.int32).pin_memory()         # [count, sequence number]: written by the kernel
+                tl.short_seq = 0
+            tl.short_seq = (tl.short_seq % 0x3FFFFFFF) + 1
+            ops.route_short(lens, nshort, lens_main, lens_short, tl.short_flag, tl.short_seq)
         y = self._xvectors(feats, lens_main, out)
         if not capturing:
             self.last_short_count = self._await_short_count(feats.device)
@@ -915,9 +970,17 @@ class XvectorExtractor:
         """The number of short utterances ktf_route_short wrote to pinned memory for this call: the host polls the sequence number
         (the GPU is busy with the first pass's launches meanwhile); after 2 s without it, one stream synchronisation."""
         import time
-        flag, want = self._short_flag, self._short_seq
+        flag, want = self._tl.short_flag, self._tl.short_seq
         t0 = time.perf_counter()
+        spins = 0
         while int(flag[1]) != want:
+            # The kernel sits behind everything this stream was given before it, so the wait can be as long as that work. The first
+            # polls are back to back (a call on an idle stream has its answer within ~10 us); from then on the thread yields its
+            # time slice and the interpreter lock between polls, then sleeps 50 us at a time: other host threads (extract_stream's
+            # feeder, other ranks' Python on a shared core, concurrent extractors) run meanwhile instead of watching this one spin.
+            spins += 1
+            if spins > 200:
+                time.sleep(0 if spins < 2000 else 50e-6)
             if time.perf_counter() - t0 > 2.0:
                 torch.cuda.current_stream(dev).synchronize()
                 if int(flag[1]) != want:

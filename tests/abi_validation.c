@@ -29,8 +29,11 @@ int main(void) {
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
     t.din_pad = 32; t.subsampling = 0;
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
+    EXPECT_EINVAL(ktf_tdnn(NULL, 1, 0, 32, NULL, &t, f, NULL, NULL, NULL, NULL, NULL, 8, NULL, NULL));  /* ... also when the input is EMPTY (T == 0): the contract does not depend on the data */
     t.subsampling = 1;
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, f, NULL, f, 8, NULL, NULL));       /* scale without shift */
+    EXPECT_EINVAL(ktf_tdnn(NULL, 1, 0, 32, NULL, &t, f, NULL, NULL, f, NULL, NULL, 8, NULL, NULL)); /* ... on an empty input too */
+    EXPECT_EINVAL(ktf_tdnn(NULL, 1, 0, 32, NULL, &t, NULL, NULL, NULL, NULL, NULL, NULL, 8, NULL, NULL)); /* the weights are never optional */
     EXPECT_EINVAL(ktf_tdnn(f, -1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));
     t.gemm = 77;
     EXPECT_EINVAL(ktf_tdnn(f, 1, 1, 32, NULL, &t, f, NULL, NULL, NULL, NULL, f, 8, NULL, NULL));

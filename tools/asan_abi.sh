@@ -8,8 +8,9 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/ktf_asan
 mkdir -p $OUT
 cd $ROOT/kaldi-tflite_amd/csrc
-SRCS="api.hip tdnn_gemm.hip tdnn_mx.hip tdnn_mxl.hip pool_post.hip tdnn_f32.hip tdnn_bf16.hip tdnn_split.hip frontend.hip frontend512.hip vad_cmvn.hip"
-KEY=$(cat $SRCS *.h $ROOT/include/ktf_hip.h $ROOT/tests/abi_validation.c $0 | sha256sum | cut -d' ' -f1)
+# every source of the product library (csrc/Makefile: SRCS), so that no launcher stays an undefined symbol behind lazy binding
+SRCS=$(sed -n 's/^SRCS := //p' Makefile)
+KEY=$(cat *.hip *.h *.inc Makefile $ROOT/include/ktf_hip.h $ROOT/tests/abi_validation.c $0 | sha256sum | cut -d' ' -f1)
 if [ "$(cat $OUT/key 2>/dev/null)" != "$KEY" ] || [ ! -x $OUT/abi_validation ]; then
     rm -f $OUT/key
     # one compile per source, in parallel (the single-command build took ~90 s)
@@ -24,4 +25,5 @@ if [ "$(cat $OUT/key 2>/dev/null)" != "$KEY" ] || [ ! -x $OUT/abi_validation ]; 
         -L$OUT -lktf_asan -Wl,-rpath,$OUT -Wl,-rpath,/opt/rocm/lib
     echo $KEY > $OUT/key
 fi
-$OUT/abi_validation
+# (every symbol resolved at load time: a source missing from the build is an error here, not a lazily bound stub nobody calls)
+LD_BIND_NOW=1 $OUT/abi_validation
