@@ -75,9 +75,23 @@ def test_persistent_f16mx_kernel_matches_the_tile_kernel_on_the_whole_extractor(
         m = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
         m.xvec.mx_persist = persist
         m.xvec.mx_loader = False
+        m.xvec.min_tiles, m.xvec.min_frames = {}, {}             # (small batches / short utterances stay on the MX kernels)
         m.route_short_utterances = False
-        got[persist] = m(torch.as_tensor(wav, device="cuda")).float().cpu().numpy()
-        assert ops.last_kernel() in ("tdnn_mxp_kernel" if persist else "tdnn_mx_kernel", "tdnn_f32t_kernel", "tdnn_f32s_kernel", "tdnn_x4s_kernel", "tdnn_f32_kernel")
+        seen, orig = [], (ops.tdnn_mx, ops.tdnn_mx_stats)
+
+        def spy(fn):
+            def run(*a, **k):
+                r = fn(*a, **k)
+                seen.append(ops.last_kernel())
+                return r
+            return run
+
+        ops.tdnn_mx, ops.tdnn_mx_stats = spy(orig[0]), spy(orig[1])
+        try:
+            got[persist] = m(torch.as_tensor(wav, device="cuda")).float().cpu().numpy()
+        finally:
+            ops.tdnn_mx, ops.tdnn_mx_stats = orig
+        assert seen == ["tdnn_mxp_kernel" if persist else "tdnn_mx_kernel"] * 5, seen
     ok = np.isfinite(got[False]).all(axis=1)
     assert ok.sum() >= B - 1 and np.array_equal(ok, np.isfinite(got[True]).all(axis=1))
     assert np.abs(got[True][ok] - got[False][ok]).max() <= 2e-5
