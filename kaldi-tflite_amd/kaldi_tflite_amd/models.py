@@ -154,6 +154,14 @@ class Sequential:
                                                                                      # 4 tiles each: bf16 from 3, f16mx from 5, bf16x3 from 8)
     MIN_FRAMES = {"f16mx": 400}
     SHORT_MODE = {"f16mx": "bf16x3"}
+    # ... and where the weights themselves are what the block-scaled images like least: one E8M0 scale per 32 weights means that a weight
+    # tens of standard deviations out takes the scale of its block with it and the other 31 are rounded against it. Measured
+    # (tests/test_gpu_margin.py, round 5: Student-t rows with outliers of 30-150 sigma): one of 128 windows of 500-540 frames at 8.9e-5
+    # where Gaussian rows and BatchNorm variances over two decades stay below 5.5e-5, and 2.6e-5 at 10 s. A model whose frame-level
+    # layers hold a weight beyond OUTLIER_SIGMAS standard deviations of its layer routes below MIN_FRAMES_OUTLIERS instead
+    # (frames_floor; trained x-vector networks: unknown until the pretrained weights are at hand -- verify_fraction measures them).
+    OUTLIER_SIGMAS = 20.0
+    MIN_FRAMES_OUTLIERS = {"f16mx": 640}
 
     def __init__(self, layers=None, name=None, gemm="f32"):
         self.input = None
@@ -169,6 +177,8 @@ class Sequential:
         self.gemm = gemm
         self.min_tiles = dict(self.MIN_TILES)
         self.min_frames = dict(self.MIN_FRAMES)
+        self.min_frames_outliers = dict(self.MIN_FRAMES_OUTLIERS)
+        self._outlier_score = (None, 0.0)                 # (weights signature, largest |w| / std(w) over the frame-level layers)
         self.mx_loader = None        # f16mx: which kernel runs the frame-level layers. False = the 256 x 256 eight-wave kernel (csrc/tdnn_mx.hip),
                                      # True = the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles on the flat row space, eight matrix +
                                      # four loader waves), None = per call, whichever needs less time by rounds of 256 workgroups x rows
@@ -200,6 +210,28 @@ class Sequential:
             if not l.built:
                 l.build(shape)
             shape = tuple(l.compute_output_shape(shape))
+
+    def weight_outlier_score(self):
+        """Largest |w| / std(w) over the wide frame-level TDNN layers (cached per weights signature)."""
+        sig = self.weights_signature()
+        if self._outlier_score[0] != sig:
+            score = 0.0
+            for l in self.layers:
+                if isinstance(l, TDNN) and l.built and l.units > 128:
+                    k = np.asarray(l.kernel, np.float64)
+                    sd = float(k.std())
+                    if sd > 0:
+                        score = max(score, float(np.abs(k).max()) / sd)
+            self._outlier_score = (sig, score)
+        return self._outlier_score[1]
+
+    def frames_floor(self, mode):
+        """Utterances (batches) of fewer frames than this run `SHORT_MODE[mode]` instead of `mode`: `min_frames`, or `min_frames_outliers`
+        for a model with a weight beyond OUTLIER_SIGMAS standard deviations of its layer (0: no floor)."""
+        base = self.min_frames.get(mode, 0)
+        if base and mode in self.min_frames_outliers and self.weight_outlier_score() > self.OUTLIER_SIGMAS:
+            return max(base, self.min_frames_outliers[mode])
+        return base
 
     def weights_signature(self):
         """Changes whenever a TDNN / BatchNorm layer's weights change (set_weights, a re-build): calibration statistics and
@@ -263,7 +295,7 @@ class Sequential:
         kernel) writes pairs, the layers behind it read and write pairs, the last one in front of the pooling writes fp32."""
         if mode is None:
             mode = self.gemm
-            if T < self.min_frames.get(mode, 0):         # short utterances: the tighter mode (MIN_FRAMES)
+            if T < self.frames_floor(mode):              # short utterances: the tighter mode (MIN_FRAMES)
                 mode = self.SHORT_MODE.get(mode, "f32")
         gemm = _GEMM[mode]
         # (the batch's rows in units of 256: what the small tiles' time follows -- a 3 s utterance is 1.2 of them, not two tiles;
@@ -827,6 +859,12 @@ class XvectorExtractor:
                                      # batch an utterance arrives in, bit for bit.
         self.route_short_utterances = True    # utterances with fewer voiced frames than the mode's Sequential.MIN_FRAMES go through the
                                               # tighter SHORT_MODE kernels, decided per utterance from the device's frame counts (_extract)
+        self.verify_fraction = 0.0            # run-time guard of a reduced-precision mode on weights it was never tested on: this fraction of every
+                                              # batch (at least one utterance) is extracted once more on the tighter SHORT_MODE kernels
+                                              # (split-bf16: ~1e-5 from fp64) from the same features, and the largest difference is kept in
+                                              # `last_verify` -- what the mode costs on THIS model and THIS audio (tolerance 1e-4;
+                                              # tests/test_gpu_margin.py is where the shipped margin comes from). Eager calls only.
+        self.verify_seed = 0x5EED
         self._warming_for_capture = False     # compile(): the warm-up calls run the short-utterance pass unconditionally (set and cleared by the
                                               # compiling thread; compile() is configuration, not a concurrent call: INTEGRATION.md)
 
@@ -856,6 +894,34 @@ class XvectorExtractor:
     @last_short_count.setter
     def last_short_count(self, v):
         self._tl.last_short_count = v
+
+    @property
+    def last_verify(self):
+        """{"n": utterances re-extracted, "max_abs_dev": largest |x-vector difference| against the tighter mode, "rows": their batch
+        indices, "running_max": the largest seen by this thread so far} of this thread's last call with verify_fraction > 0 (else None)"""
+        return getattr(self._tl, "last_verify", None)
+
+    def _verify(self, feats, lens, y):
+        """verify_fraction: a random subset of the batch through the SHORT_MODE kernels, compared with the rows of `y`."""
+        seq = self.xvec
+        B = feats.shape[0]
+        mode = seq.SHORT_MODE.get(seq.gemm)
+        if mode is None or B == 0:
+            return
+        tl = self._tl
+        if getattr(tl, "verify_rng", None) is None:
+            tl.verify_rng = np.random.default_rng(self.verify_seed + (threading.get_ident() & 0xFFFF))
+        n = max(1, min(B, int(math.ceil(self.verify_fraction * B))))
+        rows = np.sort(tl.verify_rng.choice(B, size=n, replace=False))
+        idx = torch.as_tensor(rows, device=feats.device)
+        sub_f = feats.index_select(0, idx).contiguous()
+        sub_l = lens.index_select(0, idx).contiguous()
+        y2 = self._xvectors(sub_f, sub_l, None, mode=mode)
+        d = (y.index_select(0, idx) - y2).abs()
+        d = torch.where(torch.isfinite(d), d, torch.zeros_like(d))           # (utterances without a voiced frame are NaN in both)
+        dev = float(d.max().item())
+        run = max(dev, (tl.last_verify or {}).get("running_max", 0.0)) if getattr(tl, "last_verify", None) else dev
+        tl.last_verify = {"n": int(n), "max_abs_dev": dev, "rows": rows.tolist(), "mode": mode, "running_max": run}
 
     @property
     def layers(self):
@@ -924,14 +990,21 @@ class XvectorExtractor:
             yield y
 
     def _extract(self, inputs, out=None):
+        y, feats, lens = self._extract_routed(inputs, out)
+        if (self.verify_fraction > 0 and self.gemm in self.xvec.SHORT_MODE and not torch.cuda.is_current_stream_capturing()
+                and not self._warming_for_capture):
+            self._verify(feats, lens, y)
+        return y
+
+    def _extract_routed(self, inputs, out=None):
         _, feats, lens = self._features(inputs)
         self.last_lens = lens                                          # voiced-frame counts of the last call (workspace view)
         B, T = feats.shape[0], feats.shape[1]
         seq = self.xvec
-        nshort = seq.min_frames.get(seq.gemm, 0)
+        nshort = seq.frames_floor(seq.gemm)
         if not (self.route_short_utterances and nshort > 0 and T >= nshort and seq.gemm in seq.SHORT_MODE
                 and seq.batch_gemm(B, T) == _GEMM[seq.gemm]):
-            return self._xvectors(feats, lens, out)
+            return self._xvectors(feats, lens, out), feats, lens
         # Per-utterance routing: the batch runs in the model's mode with the utterances of fewer than `nshort` voiced frames masked out
         # (length 0: their tiles leave at once), then once more in the tighter mode with only those utterances live; the second tail
         # writes just their rows. The masks are made on the device (ktf_route_short, one small launch behind VAD / CMVN). Whether the
@@ -957,14 +1030,14 @@ class XvectorExtractor:
         if not capturing:
             self.last_short_count = self._await_short_count(feats.device)
             if self.last_short_count == 0 and not self._warming_for_capture:
-                return y
+                return y, feats, lens
         short_mode = seq.SHORT_MODE[seq.gemm]
         if self._tail_fusable() and self.fuse_tail:
             self._xvectors(feats, lens_short, y, mode=short_mode, skip_empty=True)
         else:                                                          # (tails that write every row: select afterwards)
             y2 = self._xvectors(feats, lens_short, None, mode=short_mode)
             y.copy_(torch.where((lens_short > 0)[:, None], y2, y))
-        return y
+        return y, feats, lens
 
     def _await_short_count(self, dev):
         """The number of short utterances ktf_route_short wrote to pinned memory for this call: the host polls the sequence number

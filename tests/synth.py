@@ -50,9 +50,12 @@ def model_config(narrow=False, feat_dim=30, out_dim=512):
     return {"type": "sequential", "layers": layers}
 
 
-def make_weights(seed=4321, narrow=False, feat_dim=30, out_dim=512):
+def make_weights(seed=4321, narrow=False, feat_dim=30, out_dim=512, bn="default", tails="normal"):
     """W ~ N(0, 1/(K*D)), b ~ N(0, 0.1), BN mean ~ U(0.2,1), var ~ U(0.5,2), target-rms 1; real LDA/mean
-    (synthetic mean / LDA when the embedding is not 512-dimensional)."""
+    (synthetic mean / LDA when the embedding is not 512-dimensional). Variants for the margin tests (the default draws are
+    unchanged): bn="wide": BatchNorm var ~ U(0.05, 4), mean ~ U(-0.5, 1.5) (units far from unit scale, dead and hot ones);
+    tails="t3": W from a Student t with 3 degrees of freedom scaled to the same variance (a few large weights per row, the rest
+    smaller: what the block-scaled e2m1 / e2m3 images of a weight row like least)."""
     rng = np.random.default_rng(seed)
     h, p = (64, 96) if narrow else (512, 1500)
     dims = {"h": h, "p": p}
@@ -60,10 +63,15 @@ def make_weights(seed=4321, narrow=False, feat_dim=30, out_dim=512):
     din = feat_dim
     for name, ctx, d in TOPOLOGY:
         u, K = dims[d], len(ctx)
-        w[f"{name}.affine"] = ((rng.standard_normal((u, K * din)) / np.sqrt(K * din)).astype(np.float32),
-                               (rng.standard_normal(u) * 0.1).astype(np.float32))
-        w[f"{name}.batchnorm"] = (np.float32(1.0), rng.uniform(0.2, 1.0, u).astype(np.float32),
-                                  rng.uniform(0.5, 2.0, u).astype(np.float32))
+        W = rng.standard_normal((u, K * din))
+        if tails == "t3":
+            W = rng.standard_t(3.0, (u, K * din)) / np.sqrt(3.0)          # (variance of t_3 is 3)
+        w[f"{name}.affine"] = ((W / np.sqrt(K * din)).astype(np.float32), (rng.standard_normal(u) * 0.1).astype(np.float32))
+        if bn == "wide":
+            w[f"{name}.batchnorm"] = (np.float32(1.0), rng.uniform(-0.5, 1.5, u).astype(np.float32), rng.uniform(0.05, 4.0, u).astype(np.float32))
+        else:
+            w[f"{name}.batchnorm"] = (np.float32(1.0), rng.uniform(0.2, 1.0, u).astype(np.float32),
+                                      rng.uniform(0.5, 2.0, u).astype(np.float32))
         din = u
     w["tdnn6.affine"] = ((rng.standard_normal((out_dim, 2 * din)) / np.sqrt(2 * din)).astype(np.float32),
                          (rng.standard_normal(out_dim) * 0.1).astype(np.float32))
@@ -138,6 +146,12 @@ def make_wav(B, N, seed=1234, sigma=1000.0, ragged=False):
         g = np.repeat(np.where(quiet, 1e-3, 1.0), blk, axis=1)[:, :N].astype(np.float32)
         x = np.round(x * g).astype(np.float32)
     return x
+
+
+def second_speech_wav():
+    """The reference's OTHER recording: the 3 s clip its feature tests run on (testdata/feats/src/fbank_mfcc/16000_001/audio.wav,
+    committed as tests/golden/feats_fbank_mfcc.npz:wav_int16), fp32 in int16 scale, (48000,)."""
+    return np.load(os.path.join(GOLDEN, "feats_fbank_mfcc.npz"))["wav_int16"].astype(np.float32)
 
 
 def speech_wavs(n=160000):

@@ -206,3 +206,80 @@ def test_device_routing_on_the_large_batch_tail_route():
     s = torch.as_tensor(short, device="cuda")
     assert torch.equal(y[~s], yr[~s])
     assert (y[s] - yb[s]).abs().max().item() <= 2e-5 and not torch.equal(y[s], yr[s])
+
+
+# ------------------------------------------------------------------------------------------------ round 5: the thin spot, widened
+# the 1e-4 claim of the timed mode rested on four weight seeds, one recording and BatchNorm statistics of one family, and
+# the routing threshold (MIN_FRAMES = 400) was tuned on the same data. Here: 16 weight draws of three families -- the synthetic
+# default, BatchNorm variances over two orders of magnitude (U(0.05, 4): units far from unit scale), heavy-tailed weight rows
+# (Student t, 3 degrees of freedom) --, every voiced length from 400 to 600 frames in steps of 20 (just above the threshold: where the
+# block-scaled rounding noise is averaged over the fewest frames), windows of both recordings the reference ships (the 22.5 s
+# end-to-end input and its 3 s feature-test clip, looped), and three input gains (the MFCC / CMVN front-end is gain-invariant up to the
+# VAD's absolute energy threshold and the dither-free log floor). Everything through the SHIPPED routing, against the fp64 oracle.
+SWEEP_FRAMES = list(range(400, 601, 20))
+SWEEP_FRAMES_OUTLIERS = [640, 680, 720, 760]          # ... and for the weight families the model routes below 640 frames (frames_floor)
+SWEEP_FAMILIES = [("synthetic", {}), ("wide_bn", {"bn": "wide"}), ("t3_rows", {"tails": "t3"}), ("wide_bn_t3_rows", {"bn": "wide", "tails": "t3"})]
+SWEEP_BOUND = 8e-5
+
+
+def sweep_windows(frames):
+    """(8, samples) windows of `frames` frames: seven of the long recording 2.5 s apart, one of the 3 s clip looped to length."""
+    n = (frames - 1) * 160 + 400
+    sp = synth.speech_wavs()[0][0]
+    clip = synth.second_speech_wav()
+    rows = [sp[s:s + n] for s in range(0, len(sp) - n + 1, 40000)][:7]
+    rows.append(np.tile(clip, 1 + n // len(clip))[:n])
+    return np.stack(rows, 0)
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_f16mx_margin_sweep_400_to_600_frames(seed):
+    """One weight draw, 11 window lengths x 8 windows: the shipped f16mx model stays inside 8e-5 of the fp64 oracle on every one
+    (tolerance 1e-4). Seeds 0-3 also run at input gains 0.01 and 30. The Student-t families hold weights 30-150 standard deviations out
+    (seed 1014: one window of 520 frames at 8.9e-5 on the f16mx kernels): `Sequential.frames_floor` sees them and routes below 640
+    frames, so for those families the sweep goes on to 760 frames, where the f16mx kernels take over."""
+    name, kw = SWEEP_FAMILIES[seed % 4]
+    w = synth.make_weights(seed=1000 + seed, **kw)
+    cfg = synth.extractor_cfg()
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+    mdl.xvec.min_tiles = {}                               # (eight windows are a handful of tiles: keep them off the small-tile route)
+    outliers = "tails" in kw
+    assert (mdl.xvec.weight_outlier_score() > mdl.xvec.OUTLIER_SIGMAS) == outliers
+    assert mdl.xvec.frames_floor("f16mx") == (640 if outliers else 400)
+    layers = synth.oracle_layers(w)
+    worst = {}
+    for gain in ([0.01, 1.0, 30.0] if seed < 4 else [1.0]):
+        for frames in SWEEP_FRAMES + (SWEEP_FRAMES_OUTLIERS if outliers else []):
+            wav = (sweep_windows(frames) * gain).astype(np.float32)
+            got = mdl(torch.as_tensor(wav, device="cuda")).cpu().numpy().reshape(wav.shape[0], -1)
+            want = O.xvector_forward(wav, cfg, layers, w["mean"], w["lda"], dtype=np.float64)
+            ok = np.isfinite(want).all(1)                 # (a window the VAD empties is NaN in both: the reference's 0 / 0)
+            assert np.array_equal(ok, np.isfinite(got).all(1)), (gain, frames)
+            if ok.any():
+                worst[(gain, frames)] = float(np.abs(got[ok] - want[ok]).max())
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print(f"{name} weights, seed {1000 + seed}: max {top[0][1]:.2e} at (gain, frames) {top[0][0]}; next {top[1][1]:.2e} {top[1][0]}, {top[2][1]:.2e} {top[2][0]}")
+    assert top[0][1] <= SWEEP_BOUND, top
+
+
+def test_verify_fraction_reports_what_the_mode_costs_on_this_model():
+    """XvectorExtractor.verify_fraction: a random part of every batch is extracted again on the tighter kernels and the largest
+    difference lands in `last_verify` -- a deployment on weights nobody tested sees its own margin. On the synthetic weights it agrees with
+    what the oracle says about the same rows to ~1e-5 (the tighter mode's own distance from fp64)."""
+    w = weights("synthetic", 4321)
+    cfg = synth.extractor_cfg()
+    mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+    mdl.xvec.min_tiles = {}
+    wav = windows(5.0)                                    # 18 windows of 498 frames: f16mx kernels
+    assert mdl.last_verify is None
+    y0 = mdl(torch.as_tensor(wav, device="cuda")).cpu().numpy()
+    assert mdl.last_verify is None                        # off by default
+    mdl.verify_fraction = 0.25
+    y1 = mdl(torch.as_tensor(wav, device="cuda")).cpu().numpy()
+    v = mdl.last_verify
+    assert np.array_equal(y0, y1)                         # the guard does not touch the result
+    assert v["n"] == 5 and len(v["rows"]) == 5 and v["mode"] == "bf16x3" and 0 < v["max_abs_dev"] <= TOL
+    dev_oracle = np.abs(y1[v["rows"]] - oracle("synthetic", 4321, 5.0)[v["rows"]]).max()
+    assert abs(v["max_abs_dev"] - dev_oracle) <= 2.5e-5, (v, dev_oracle)
+    mdl(torch.as_tensor(wav, device="cuda"))
+    assert mdl.last_verify["running_max"] >= v["max_abs_dev"]
