@@ -45,6 +45,7 @@
 #define DPP_ROW_SHR4 0x114
 #define DPP_ROW_ROR4 0x124
 #define DPP_ROW_ROR8 0x128
+#define DPP_WAVE_SHL1 0x130
 #define DPP_WAVE_SHR1 0x138
 #define DPP_WAVE_ROR1 0x13C
 
@@ -76,25 +77,31 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // Complex product on the packed fp32 pipe: two instructions, the operand swizzles and the sign in the op_sel / neg modifiers (from C
 // the compiler builds the same product from v_pk_mul + scalar v_mul / v_sub / v_add and two to four register moves).
 //   t = (a.x b.x, a.y b.x);   r = (-a.y b.y + t.x, a.x b.y + t.y)
+// Complex values live in ONE 64-bit register pair from the loads to the LDS write (an ext-vector, not HIP's float2 struct: as two
+// scalars the compiler re-formed the pairs the packed instructions need with ~50 register moves per frame -- a seventh of the
+// kernel's instructions; the cross-lane steps below read and write the halves of the pairs in place).
 typedef float f5v2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float2 cmulf(float2 a, float2 b) {
-    const f5v2 av = {a.x, a.y}, bv = {b.x, b.y};
-    f5v2 t, r;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t) : "v"(av), "v"(bv));
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[0,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
-    return make_float2(r.x, r.y);
+__device__ __forceinline__ f5v2 cmulf(f5v2 av, f5v2 bv) {
+    f5v2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[0,0,0]" : "=&v"(r) : "v"(av), "v"(bv));
+    return r;
 }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ f5v2 cadd(f5v2 a, f5v2 b) { return a + b; }
+__device__ __forceinline__ f5v2 csub(f5v2 a, f5v2 b) { return a - b; }
 
 // radix-4 DIF butterfly with W4 = -i:  y_r = sum_k z_k (-i)^{kr}
-__device__ __forceinline__ void bfly4(float2 (&z)[4]) {
-    const float2 apc = cadd(z[0], z[2]), amc = csub(z[0], z[2]), bpd = cadd(z[1], z[3]);
-    const float2 jbmd = make_float2(-(z[1].y - z[3].y), z[1].x - z[3].x);   // i*(b-d)
-    z[0] = cadd(apc, bpd);
-    z[1] = csub(amc, jbmd);
-    z[2] = csub(apc, bpd);
-    z[3] = cadd(amc, jbmd);
+__device__ __forceinline__ void bfly4(f5v2 (&z)[4]) {
+    const f5v2 apc = z[0] + z[2], amc = z[0] - z[2], bpd = z[1] + z[3], bmd = z[1] - z[3];
+    // i (b - d) = (-bmd.y, bmd.x) never exists as a value: the two sums that use it take bmd with its halves exchanged (op_sel) and
+    // one of them negated, one packed instruction each (built from C the compiler spends an xor and a move per butterfly on it)
+    f5v2 y1, y3;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(y1) : "v"(amc), "v"(bmd));   // (amc.x + bmd.y, amc.y - bmd.x)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(y3) : "v"(amc), "v"(bmd));   // (amc.x - bmd.y, amc.y + bmd.x)
+    z[0] = apc + bpd;
+    z[1] = y1;
+    z[2] = apc - bpd;
+    z[3] = y3;
 }
 
 // One step of a 4x4 register/lane transpose: lanes whose bit BIT is 0 hand register `b` to their partner (lane ^ 2^BIT)
@@ -158,19 +165,22 @@ __device__ __forceinline__ void swap4_quad(float& a0, float& b0, float& a1, floa
 // 4x4 transpose between the 4 registers of a lane and the 4 lanes that differ only in lane bits (BH, BL):
 // afterwards the lane at group position p = 2*bit(BH) + bit(BL) holds in register q what position q held in register p.
 template <int BH, int BL>
-__device__ __forceinline__ void transpose4(float2 (&r)[4], int lane) {
+__device__ __forceinline__ void transpose4(f5v2 (&r)[4], int lane) {
+#define F5_SS(B_, p_, q_, c_) { float a_ = r[p_].c_, b_ = r[q_].c_; swap_step<B_>(a_, b_, lane); r[p_].c_ = a_; r[q_].c_ = b_; }
+#define F5_SQ(B_, p0, q0, p1, q1) { float a0 = r[p0].x, b0 = r[q0].x, a1 = r[p0].y, b1 = r[q0].y, a2 = r[p1].x, b2 = r[q1].x, a3 = r[p1].y, b3 = r[q1].y; \
+        swap4_quad<B_>(a0, b0, a1, b1, a2, b2, a3, b3); r[p0].x = a0; r[q0].x = b0; r[p0].y = a1; r[q0].y = b1; r[p1].x = a2; r[q1].x = b2; r[p1].y = a3; r[q1].y = b3; }
     if constexpr (BH <= 1) {
-        swap4_quad<BH>(r[0].x, r[2].x, r[0].y, r[2].y, r[1].x, r[3].x, r[1].y, r[3].y);
+        F5_SQ(BH, 0, 2, 1, 3)
     } else {
-        swap_step<BH>(r[0].x, r[2].x, lane); swap_step<BH>(r[0].y, r[2].y, lane);
-        swap_step<BH>(r[1].x, r[3].x, lane); swap_step<BH>(r[1].y, r[3].y, lane);
+        F5_SS(BH, 0, 2, x) F5_SS(BH, 0, 2, y) F5_SS(BH, 1, 3, x) F5_SS(BH, 1, 3, y)
     }
     if constexpr (BL <= 1) {
-        swap4_quad<BL>(r[0].x, r[1].x, r[0].y, r[1].y, r[2].x, r[3].x, r[2].y, r[3].y);
+        F5_SQ(BL, 0, 1, 2, 3)
     } else {
-        swap_step<BL>(r[0].x, r[1].x, lane); swap_step<BL>(r[0].y, r[1].y, lane);
-        swap_step<BL>(r[2].x, r[3].x, lane); swap_step<BL>(r[2].y, r[3].y, lane);
+        F5_SS(BL, 0, 1, x) F5_SS(BL, 0, 1, y) F5_SS(BL, 2, 3, x) F5_SS(BL, 2, 3, y)
     }
+#undef F5_SS
+#undef F5_SQ
 }
 
 // Dither (windowing.py:182-183: x += N(0,1) * dither): counter-based Philox4x32-10 keyed by `seed`, counter (frame, lane). ONE call
@@ -215,7 +225,10 @@ __device__ __forceinline__ void gauss_noise8(uint64_t seed, uint64_t row, uint32
 // and KtfFrontendCfg.pad_mode.
 // MFIX: frame size known at compile time (400 = 25 ms at 16 kHz, the shipped configuration) or 0 = cfg.frame_size: with
 // a constant M the `sample index < M` predicates of the loads, DC removal and pre-emphasis fold away.
-template <bool DITHER, int KIND, int MFIX>
+// STD: the configuration of the shipped models (MFCC's defaults, data/kaldi_models/configs/*.yml) known at compile time -- waveform in,
+// MFCC out, DC removal, raw log-energy into C0, pre-emphasis, power spectrum, log mel: the run-time tests of those switches, and the
+// register copies the compiler keeps for values a skipped branch would have left unchanged, fold away (~25 instructions per frame).
+template <bool DITHER, int KIND, int MFIX, bool STD = false>
 __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 4) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                                  int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                                  int out_stage, float* __restrict__ out,
@@ -223,10 +236,18 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     constexpr int NF = 512, N2 = 256, NV = 8;
     constexpr bool PLAIN = KIND != 0;
     extern __shared__ __attribute__((aligned(16))) float lds5[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = MFIX ? MFIX : cfg.frame_size;
     const int nm = cfg.num_mels, nc = cfg.num_ceps;
     const int maxw = tab.reserved;          // bins per mel work item actually used (<= F5_MAXW)
+    if (STD) { in_kind = (KIND == 2) ? KTF_IN_WAV_I16 : KTF_IN_WAV; out_stage = KTF_OUT_MFCC; }
+    const bool c_dc = STD ? true : cfg.remove_dc != 0;
+    const bool c_energy = STD ? true : cfg.use_energy != 0;
+    const bool c_raw_e = STD ? true : (cfg.use_energy && cfg.raw_energy);
+    const bool c_post_e = STD ? false : (cfg.use_energy && !cfg.raw_energy);
+    const bool c_pre = STD ? true : cfg.preemph > 0.0f;
+    const bool c_pow = STD ? true : cfg.use_power != 0;
+    const bool c_log = STD ? true : cfg.use_log != 0;
 
     // LDS: window[512] | dct4[8][64] f32x4 | melw4[4][64] f32x4 | (twiddle records) | per wave: Z[256] float2 = P[256] float, feat[64] float
     float* win = lds5;
@@ -240,7 +261,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     float* feat = wbase + 2 * N2;
     if (in_kind != KTF_IN_WINDOWED)
         for (int i = tid; i < NF; i += F5_THREADS) win[i] = (i < M) ? tab.window[i] : 0.0f;
-    if (lane < 64) feat[lane] = 0.0f;
+    feat[lane] = 0.0f;
 
     // ---- per-lane constants (registers for the whole kernel)
 #if F5_TW_LDS
@@ -304,11 +325,14 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     const int t_step = gridDim.x * F5_WAVES;
     for (int t0 = blockIdx.x * F5_WAVES; t0 < Ti; t0 += t_step) {
         const int t = t0 + wave;
-        const bool valid = t < Ti;   // wave-uniform
+        if (t >= Ti) continue;       // wave-uniform; nothing below synchronises across waves (wave-level barriers only)
+        constexpr bool valid = true;
         const int64_t row = row_base + t;
-        float v[NV];
         float logE = 0.0f;
         const int g0 = t * src_step - pad_left;          // first sample of the frame (wav kinds)
+        f5v2 z[4];
+        {
+        float v[NV];
         if (!PLAIN && valid && in_kind == KTF_IN_WAV && (g0 < 0 || g0 + M > ni)) {
             // edge frame of KtfFrontendCfg.pad_mode 1: mirrored samples
 #pragma unroll
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                 for (int j = 0; j < NV; ++j)
                     if (lane + KTF_WAVE * j < M) v[j] += g[j] * cfg.dither;
             }
-            if (cfg.remove_dc) {
+            if (c_dc) {
                 float s = 0.0f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) s += v[j];
@@ -383,14 +407,14 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                     if (i < M) v[j] -= mean;
                 }
             }
-            if (cfg.use_energy && cfg.raw_energy) {
+            if (c_raw_e) {
                 float s = 0.0f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) s = fmaf(v[j], v[j], s);
                 const float e = logf(fmaxf(wave_sum_f(s), 0.0f) + cfg.eps);
                 logE = fmaxf(e, cfg.energy_floor);
             }
-            if (cfg.preemph > 0.0f) {
+            if (c_pre) {
                 // y[i] = x[i] - c x[i-1] (x[-1] := x[0]). Sample i - 1 lives in lane l - 1 of the same register, for lane 0 in lane 63
                 // of the previous one: a whole-wave rotate of v[j-1] puts that value into lane 0, where the whole-wave shift of v[j]
                 // (which has no source for lane 0) leaves it -- two DPP moves per register, no readlane / select
@@ -407,7 +431,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
             }
 #pragma unroll
             for (int j = 0; j < NV; ++j) v[j] *= win[lane + KTF_WAVE * j];       // window is zero beyond M
-            if (cfg.use_energy && !cfg.raw_energy) {
+            if (c_post_e) {
                 float s = 0.0f;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) s = fmaf(v[j], v[j], s);
@@ -416,18 +440,19 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
             }
         }
 
-        // ---- 256-point complex FFT of z[n] = x[2n] + i x[2n+1], in registers.
-        // lane l holds samples l + 64 j; after one lane^1 exchange it holds z[n0 + 64 k], n0 = (l>>1) + 32 (l&1)
-        float2 z[4];
         swap4_quad<0>(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]);    // even lanes: (own, partner's) v[2k]; odd: (partner's, own) v[2k+1]
 #pragma unroll
-        for (int k = 0; k < 4; ++k) z[k] = make_float2(v[2 * k], v[2 * k + 1]);
+        for (int k = 0; k < 4; ++k) z[k] = f5v2{v[2 * k], v[2 * k + 1]};
+        }
+
+        // ---- 256-point complex FFT of z[n] = x[2n] + i x[2n+1], in registers.
+        // lane l holds samples l + 64 j; after one lane^1 exchange it holds z[n0 + 64 k], n0 = (l>>1) + 32 (l&1)
 #if F5_TW_LDS
         // record floats: tw1 = 0..5, tw2 = 6..11, tw3 = 12..17, rw = 18..25
         const f32x4 q0 = F5_TWQ(0), q1 = F5_TWQ(1), q2 = F5_TWQ(2), q3 = F5_TWQ(3), q4 = F5_TWQ(4);
-        const float2 tw1[3] = {make_float2(q0.x, q0.y), make_float2(q0.z, q0.w), make_float2(q1.x, q1.y)};
-        const float2 tw2[3] = {make_float2(q1.z, q1.w), make_float2(q2.x, q2.y), make_float2(q2.z, q2.w)};
-        const float2 tw3[3] = {make_float2(q3.x, q3.y), make_float2(q3.z, q3.w), make_float2(q4.x, q4.y)};
+        const f5v2 tw1[3] = {f5v2{q0.x, q0.y}, f5v2{q0.z, q0.w}, f5v2{q1.x, q1.y}};
+        const f5v2 tw2[3] = {f5v2{q1.z, q1.w}, f5v2{q2.x, q2.y}, f5v2{q2.z, q2.w}};
+        const f5v2 tw3[3] = {f5v2{q3.x, q3.y}, f5v2{q3.z, q3.w}, f5v2{q4.x, q4.y}};
 #endif
         bfly4(z);                                   // over k (stride 64)
 #pragma unroll
@@ -444,7 +469,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         bfly4(z);
         // natural order through LDS (wave-private): Z[mo + 64 r4]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Zb[mo + 64 * r] = z[r];
+        for (int r = 0; r < 4; ++r) Zb[mo + 64 * r] = make_float2(z[r].x, z[r].y);
         F5_WAVE_SYNC();
         // ---- split the packed spectrum, |X[k]|(^2)  (filterbank.py:232-235; bin 256 carries no mel weight)
         float pw[4];
@@ -467,7 +492,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
             // |X|^2 directly (what Kaldi's ComputePowerSpectrum does; the reference's abs-then-square differs by an ulp)
             pw[j] = 0.25f * fmaf(x2.x, x2.x, x2.y * x2.y);
         }
-        if (!cfg.use_power) {                        // wave-uniform branch: the magnitude spectrum pays for its sqrt only when asked
+        if (!c_pow) {                        // wave-uniform branch: the magnitude spectrum pays for its sqrt only when asked
 #pragma unroll
             for (int j = 0; j < 4; ++j) pw[j] = sqrtf(pw[j]);
             asm volatile("" ::: "memory");
@@ -488,14 +513,16 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                 if (4 * j4 + 3 < maxw) acc = fmaf(Pb[mel_start + 4 * j4 + 3], w.w, acc);
             }
         }
-        {
-            const float t1 = __shfl_down(acc, 1, 64);
-            if (mel_flags & 1) acc += t1;
-            const float t2 = __shfl_down(acc, 2, 64);
-            if (mel_flags & 2) acc += t2;
+        {   // segmented reduction over <= 4 adjacent lanes: lane i takes lane i + 1, then lane i + 2, by whole-wave DPP shifts (no
+            // ds_bpermute and none of its address arithmetic)
+            const float t1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), DPP_WAVE_SHL1, 0xF, 0xF, false));
+            acc += (mel_flags & 1) ? t1 : 0.0f;
+            float t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), DPP_WAVE_SHL1, 0xF, 0xF, false));
+            t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t2), DPP_WAVE_SHL1, 0xF, 0xF, false));
+            acc += (mel_flags & 2) ? t2 : 0.0f;
         }
         // (v_log_f32 is log2 to 1 ulp; its argument here is >= eps, a normal number: none of logf's denormal handling is needed)
-        if (cfg.use_log) acc = 0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(acc, 0.0f) + cfg.eps);
+        if (c_log) acc = 0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(acc, 0.0f) + cfg.eps);
         if (mel_flags & 4) {
             if (out_stage == KTF_OUT_FBANK) {
                 if (valid) out[row * (int64_t)nm + mel_filter] = acc;
@@ -517,7 +544,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
             c = fmaf(f.w, d.w, c);
         }
         c *= lift;
-        if (lane == 0 && cfg.use_energy) c = logE;
+        if (lane == 0 && c_energy) c = logE;
         if (valid && lane < nc) out[row * (int64_t)nc + lane] = c;
         F5_WAVE_SYNC();
     }
@@ -541,6 +568,15 @@ int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind
 #define F5_LAUNCH(DI, KI, MF)                                                                                          \
     hipLaunchKernelGGL((frontend512_kernel<DI, KI, MF>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg,    \
                        *tab, out_stage, out, seed, T)
+    const bool std_cfg = !dither && !padded && cfg->frame_size == 400 && (in_kind == KTF_IN_WAV || in_kind == KTF_IN_WAV_I16) &&
+                         out_stage == KTF_OUT_MFCC && cfg->remove_dc && cfg->use_energy && cfg->raw_energy && cfg->preemph > 0.0f &&
+                         cfg->use_power && cfg->use_log;
+    if (std_cfg) {
+        if (kind == 2) hipLaunchKernelGGL((frontend512_kernel<false, 2, 400, true>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab, out_stage, out, seed, T);
+        else hipLaunchKernelGGL((frontend512_kernel<false, 1, 400, true>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab, out_stage, out, seed, T);
+        KTF_CHECK_LAUNCH("ktf_frontend_f32(fast512)");
+        return KTF_OK;
+    }
 #define F5_KINDS(DI, MF)                                                                                               \
     do {                                                                                                               \
         if (kind == 1) F5_LAUNCH(DI, 1, MF);                                                                           \
