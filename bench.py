@@ -69,9 +69,6 @@ def parse_args(argv=None):
     ap.add_argument("--dump-xvectors", default=None, help="rank 0 saves the x-vectors of the last timed step (all ranks' when gathered) as .npy (tests)")
     ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (other modes, latency, PLDA)")
     ap.add_argument("--no-parity", action="store_true", help="measurement runs of timing-only ablation builds (tools/mx): no oracle comparison, no finite check")
-    ap.add_argument("--mx-slab", action="store_true", help="A/B: f16mx layers with context offsets on the slab form of the 256 x 256 kernel (csrc/tdnn_mxs.hip)")
-    ap.add_argument("--mx-persist", dest="mx_persist", action="store_true", default=None, help="f16mx on the persistent 256 x 256 kernel (csrc/tdnn_mxp.hip)")
-    ap.add_argument("--mx-classic", dest="mx_persist", action="store_false", help="A/B: f16mx on the one-tile-per-workgroup 256 x 256 kernel (csrc/tdnn_mx.hip)")
     ap.add_argument("--mx-loader", action="store_true", help="A/B: f16mx on the loader-wave kernel (csrc/tdnn_mxl.hip) instead of the 256 x 256 eight-wave kernel")
     ap.add_argument("--no-short-routing", action="store_true", help="A/B: without the device-side second pass over utterances below MIN_FRAMES voiced frames")
     ap.add_argument("--atomic-pooling", action="store_true", help="fp64-atomic fused pooling instead of the reproducible form")
@@ -138,9 +135,6 @@ def main(argv=None):
         mdl.xvec.lo_fraction = 0.0
     mdl.xvec.deterministic = not args.atomic_pooling
     mdl.xvec.mx_loader = True if args.mx_loader else None          # (None: the model picks per batch; 1024 x 10 s takes the 256-row kernel)
-    mdl.xvec.mx_slab = args.mx_slab
-    if args.mx_persist is not None:
-        mdl.xvec.mx_persist = args.mx_persist
     mdl.route_short_utterances = not args.no_short_routing
     mdl.xvec.k_interleaved = not args.ctx_major_k
     mdl.xvec.w_tiled = not args.row_major_w

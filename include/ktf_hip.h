@@ -297,18 +297,9 @@ typedef struct KtfTdnnDesc {
                                    * (mx.weight_images_loader; layout below) and, with KTF_TDNN_DET_STATS, writes one slot per 96-row
                                    * block: `sums` is (B, ktf_mx_stats_slots(T, flags), 2, units), reduced with slot_rows =
                                    * ktf_mx_slot_rows(flags) */
-#define KTF_TDNN_MX_SLAB (1 << 25)    /* ktf_tdnn_mx / ktf_tdnn_mx_stats only (ignored with KTF_TDNN_MX_LOADER): layers with 2+ context
-                                   * offsets, all within [-4, 4], run the slab form of the 256 x 256 kernel (csrc/tdnn_mxs.hip): a
-                                   * 32-feature chunk's rows are fetched once per tile and shared by the chunk's K-steps. Same weight
-                                   * images, tiles, slots and results as without the flag; other layers are unaffected */
-#define KTF_TDNN_MX_PERSIST (1 << 26) /* ktf_tdnn_mx / ktf_tdnn_mx_stats only (KTF_TDNN_MX_LOADER wins over it): the persistent form of the
-                                   * 256 x 256 kernel (csrc/tdnn_mxp.hip): one workgroup per CU walks its tiles, the operand ring never
-                                   * drains between them, a tile's planes are encoded from registers inside the first K-step of the next.
-                                   * Same planes, tiles, slots and arithmetic (the accumulators start at the bias instead of having it
-                                   * added last); `wh` / `wq` are the images of ktf_tdnn_mx with the units of each 32-unit chunk in the
-                                   * order unit(cb, m) = (cb >> 1) * 32 + (m >> 2) * 8 + (cb & 1) * 4 + (m & 3) for image column m of
-                                   * 16-unit block cb of the N-tile (mx.weight_images(permuted=True)); every layer shape, padding,
-                                   * subsampling and output form of ktf_tdnn_mx */
+/* (1 << 25 was KTF_TDNN_MX_SLAB, the slab form of the 256-row kernel: measured as fast as the gathering kernel, not faster; 1 << 26 was
+ * KTF_TDNN_MX_PERSIST, its persistent form -- one workgroup per CU walking its tiles, the operand ring running on across tile boundaries, the
+ * previous tile encoded from registers under the next tile's first K-step: correct, 6 % slower. Both live on under tools/mx/experiments/.) */
 
 /* name of the kernel family the calling thread's last ktf_tdnn* / ktf_tdnn_mx* call launched ("" before the first; a static
  * string). For the dispatch tests: which kernel a (gemm mode, layer shape) pair runs on is part of the library's contract. */
@@ -381,7 +372,7 @@ int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, vo
  * TDNN.device_weights_mx). VALID padding and subsampling (tdnn.py:224-249) on the 256-row kernel: the output (planes or fp32 rows)
  * then has ktf_tdnn_out_len(T, d) rows per utterance and the valid rows of utterance b are ktf_tdnn_out_len(lens[b], d)
  * (ktf_tdnn_out_lens makes them for the next layer); ktf_tdnn_mx_stats and KTF_TDNN_MX_LOADER take SAME padding without
- * subsampling only, KTF_TDNN_MX_SLAB is ignored for such a layer.
+ * subsampling only.
  * With KtfTdnnDesc.flags & KTF_TDNN_MX_LOADER the call runs the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles over the flat row
  * space b * T + t, eight matrix + four loader waves) on the SAME activation planes and on weight images of its own
  * (mx.weight_images_loader): every operand fragment is 64 lanes x 16 (8, 4) consecutive bytes, and inside each 32-unit chunk the image

@@ -427,18 +427,6 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
         KTF_CHECK_LAUNCH(who);
         return KTF_OK;
     }
-    if (d->flags & KTF_TDNN_MX_PERSIST) {         // one workgroup per CU walking its tiles (tdnn_mxp.hip); weight images in the permuted unit order
-        const int rc = mxp_launch(p, B, d->act, o, stats, st);
-        if (rc != KTF_OK) return rc;
-        KTF_CHECK_LAUNCH(who);
-        return KTF_OK;
-    }
-    if ((d->flags & KTF_TDNN_MX_SLAB) && plain && mxs_applies(d)) {   // multi-context layers on activation slabs (tdnn_mxs.hip); same images, same tiles
-        const int rc = mxs_launch(p, B, d->act, o, stats, st);
-        if (rc != KTF_OK) return rc;
-        KTF_CHECK_LAUNCH(who);
-        return KTF_OK;
-    }
     const int mtiles = ktf_cdiv(p.Tout, 256), ntiles = ktf_cdiv(d->units, 256);
     const int64_t gtiles = B * mtiles;
     const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles;

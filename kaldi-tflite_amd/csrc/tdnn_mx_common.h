@@ -1,4 +1,4 @@
-// Shared by the KTF_GEMM_F16MX kernels (tdnn_mx.hip: 256 x 256 tile on eight waves, tdnn_mxs.hip its slab form; tdnn_mxl.hip: 192 x 256
+// Shared by the KTF_GEMM_F16MX kernels (tdnn_mx.hip: 256 x 256 tile on eight waves, tdnn_mxl.hip: 192 x 256
 // tile on eight matrix waves + four loader waves): operand types, the parameter block, the E8M0 scale rule.
 #pragma once
 #include "tdnn_common.h"
@@ -216,8 +216,3 @@ __device__ __forceinline__ void mx_stats_out(double* __restrict__ stats, const M
 
 // tdnn_mxl.hip: the loader-wave kernel (include/ktf_hip.h, KTF_TDNN_MX_LOADER); `p` as filled by mx_launch
 int mxl_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);
-// tdnn_mxp.hip: the persistent form of the 256 x 256 kernel (KTF_TDNN_MX_PERSIST; weight images with the permuted unit order)
-int mxp_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);
-// tdnn_mxs.hip: the slab form of the 256 x 256 kernel for layers with context offsets (KTF_TDNN_MX_SLAB)
-bool mxs_applies(const KtfTdnnDesc* d);
-int mxs_launch(const MxParams& p, int64_t B, int act, int out_kind, double* stats, hipStream_t st);

@@ -25,9 +25,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
  ACT_SOFTMAX) = range(4, 13)         # run as a pass of their own (ktf_activation_f32)
 TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED, TDNN_X_CHUNKED, TDNN_Y_CHUNKED = 1, 2, 4, 8, 16, 32   # KtfTdnnDesc.flags
 TAIL_SKIP_EMPTY = 1                 # ktf_xvec_tail_f32 flags
-TDNN_MX_SLAB = 1 << 25            # ktf_tdnn_mx*: multi-context layers on the slab form of the 256-row kernel (csrc/tdnn_mxs.hip)
 TDNN_MX_LOADER = 1 << 24          # ktf_tdnn_mx*: the loader-wave kernel (csrc/tdnn_mxl.hip) and its weight images
-TDNN_MX_PERSIST = 1 << 26         # ktf_tdnn_mx*: the persistent 256-row kernel (csrc/tdnn_mxp.hip); weight images with permuted unit order
 
 
 def TDNN_LO_PREFIX(chunks):

@@ -876,15 +876,14 @@ class TDNN(Layer):
 
     def device_weights_mx(self, device, fold=None, loader=True, kernel=None):
         """KTF_GEMM_F16MX operands on the device: (wh, wq, bias) -- the half plane and the block-scaled e2m1 / e2m3 planes of
-        the weights as the LDS images of the kernel that will read them (include/ktf_hip.h, ktf_tdnn_mx). `kernel`: "persist" =
-        the persistent 256-row kernel (KTF_TDNN_MX_PERSIST: mx.weight_images with the permuted unit order), "loader" = the
-        loader-wave kernel (KTF_TDNN_MX_LOADER: mx.weight_images_loader), "tile" = the one-tile-per-workgroup 256-row kernel
-        (mx.weight_images); None: "loader" / "tile" by `loader`. K ordered (32-feature chunk, context, feature) and zero-padded to
+        the weights as the LDS images of the kernel that will read them (include/ktf_hip.h, ktf_tdnn_mx). `kernel`: "tile" = the
+        256 x 256 kernel (mx.weight_images), "loader" = the loader-wave kernel (KTF_TDNN_MX_LOADER: mx.weight_images_loader);
+        None: "loader" / "tile" by `loader`. K ordered (32-feature chunk, context, feature) and zero-padded to
         whole super-steps. `fold`: the BatchNorm in front of this layer folded INTO it (see device_weights): the stored
         activations are then the ReLU outputs themselves."""
         from . import mx
         kernel = kernel or ("loader" if loader else "tile")
-        if kernel not in ("persist", "loader", "tile"):
+        if kernel not in ("loader", "tile"):
             raise ValueError(f"unknown f16mx kernel {kernel!r}")
         key = ("mx", str(device), None if fold is None else (id(fold), fold._version), kernel)
         if key in self._dev:
@@ -903,7 +902,7 @@ class TDNN(Layer):
         W = np.zeros((Up, K, Dp), np.float64)
         W[: self.units, :, :D] = Wk
         W = np.ascontiguousarray(W.reshape(Up, K, Dp // 32, 32).transpose(0, 2, 1, 3)).reshape(Up, (Dp // 32) * K, 32)
-        wh, wq, _ = mx.weight_images_loader(W) if kernel == "loader" else mx.weight_images(W, permuted=kernel == "persist")
+        wh, wq, _ = mx.weight_images_loader(W) if kernel == "loader" else mx.weight_images(W)
         out = (torch.as_tensor(wh, device=device), torch.as_tensor(wq, device=device),
                ops.to_device_f32(bias64, device) if bias64 is not None else None)
         # one MX image set per (layer, device, kernel): a re-fold replaces the set of its own device and kernel only

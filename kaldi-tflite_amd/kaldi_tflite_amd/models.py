@@ -187,9 +187,6 @@ class Sequential:
                                      # partly empty and run 8-16 % faster on the smaller flat tiles (tools/mid_batch.py)
         self.flat_rows = True        # bf16x3 plane layers of short utterances: M-tiles over the valid rows laid end to end (ktf_tdnn_split_flat)
         self.small_tile_pairs = True # batches below `min_tiles` of a reduced-precision model: bf16-pair small tiles instead of fp32 ones
-        self.mx_slab = False         # f16mx, 256-row kernel: multi-context layers on activation slabs (csrc/tdnn_mxs.hip, KTF_TDNN_MX_SLAB)
-        self.mx_persist = False      # f16mx, 256-row tiles: the persistent kernel (csrc/tdnn_mxp.hip, KTF_TDNN_MX_PERSIST: one workgroup per
-                                     # CU walks its tiles, the operand ring runs on across them, planes encoded from registers)
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
         self.dtype = "float32"
@@ -441,9 +438,9 @@ class Sequential:
                 plain = l.padding == "SAME" and l.subsamplingFactor == 1      # (VALID padding / subsampling: the 256-row kernel only)
                 Tout = l.outputTimesteps(T)
                 use_loader = plain and self._mx_use_loader(B, T)
-                kern = "loader" if use_loader else ("persist" if self.mx_persist else "tile")
+                kern = "loader" if use_loader else "tile"
                 wh, wq, bias = l.device_weights_mx(dev, fold=fold, kernel=kern)
-                mxf = L.TDNN_MX_LOADER if use_loader else (L.TDNN_MX_PERSIST if self.mx_persist else (L.TDNN_MX_SLAB if self.mx_slab else 0))
+                mxf = L.TDNN_MX_LOADER if use_loader else 0
                 d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None, flags=mxf)
                 if can_pool:                             # ... -> reducing StatsPooling inside the epilogue (BatchNorm applied there)
                     sp = nxt[1]

@@ -143,16 +143,17 @@ class Planes:
 # ------------------------------------------------------------------------------------------------ weight images
 def weight_images(Wk, permuted=False):
     """Wk: float64 (Up, nk, 32) -- units padded to a multiple of 256, K-steps in the KTF_TDNN_K_INTERLEAVED order -> (wh bytes,
-    wq bytes, decoded (w_h, w_4, w_l6) float64 (Up, nkp, 32)) in the layouts of include/ktf_hip.h (ktf_tdnn_mx). `permuted`: the
-    image rows of every 256-unit tile hold the units in loader_unit_order() (KTF_TDNN_MX_PERSIST, csrc/tdnn_mxp.hip); the decoded
-    operands stay in unit order."""
+    wq bytes, decoded (w_h, w_4, w_l6) float64 (Up, nkp, 32)) in the layouts of include/ktf_hip.h (ktf_tdnn_mx). `permuted` (the
+    experiments under tools/mx/experiments/ that run the MFMAs with the weights as the A operand): the image rows of every 256-unit
+    tile hold the units in loader_unit_order(), so that a lane owns eight consecutive units of a frame. The decoded operands stay
+    in unit order."""
     Up, nk, _ = Wk.shape
     nkp = (nk + 3) // 4 * 4
     W = np.zeros((Up, nkp, 32), np.float64)
     W[:, :nk] = Wk
     if permuted:
-        wh, wq, _ = weight_images(W.reshape(Up // 256, 256, nkp, 32)[:, loader_unit_order()].reshape(Up, nkp, 32))
-        return wh, wq, weight_images(W)[2]
+        wh, wq, _ = weight_images(W.reshape(Up // 256, 256, nkp, 32)[:, loader_unit_order()].reshape(Up, nkp, 32), permuted=False)
+        return wh, wq, weight_images(W, permuted=False)[2]
     Wh = W.astype(np.float16)
     Wl = W - Wh.astype(np.float64)
     s4, s6 = scale_bytes(np.abs(W).max(-1), "e2m1"), scale_bytes(np.abs(Wl).max(-1), "e2m3")

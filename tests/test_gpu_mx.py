@@ -125,19 +125,13 @@ CASES = [  # D, context, units, B, T, lens
 ]
 
 
-KERNELS = ["loader_waves", "tile256", "slab", "persist"]     # KTF_TDNN_MX_LOADER / no flag / KTF_TDNN_MX_SLAB / KTF_TDNN_MX_PERSIST
+KERNELS = ["loader_waves", "tile256"]     # KTF_TDNN_MX_LOADER / no flag
 
 
 def _kernel(kernel, layer):
     """(flags, weight images (TDNN.device_weights_mx `kernel`), kernel family that must run) of a KERNELS entry for `layer`."""
     if kernel == "loader_waves":
         return L.TDNN_MX_LOADER, "loader", "tdnn_mxl_kernel"
-    if kernel == "persist":
-        return L.TDNN_MX_PERSIST, "persist", "tdnn_mxp_kernel"
-    if kernel == "slab":
-        ctx = list(layer.context)
-        applies = len(ctx) >= 2 and min(ctx) >= -4 and max(ctx) <= 4
-        return L.TDNN_MX_SLAB, "tile", "tdnn_mxs_kernel" if applies else "tdnn_mx_kernel"
     return 0, "tile", "tdnn_mx_kernel"
 
 
@@ -269,34 +263,6 @@ def test_loader_wave_kernel_against_the_256_row_kernel():
         for b in (0, 6):
             assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), y[b]), "batch != single"
     assert np.abs(np.delete(got[True] - got[False], 5, 0)).max() <= 1e-5
-
-
-def test_slab_kernel_is_bit_identical_to_the_gathering_kernel():
-    """KTF_TDNN_MX_SLAB changes what the K-loop FETCHES (a chunk's rows once per tile instead of once per context offset), not what it
-    computes: same operands into the same MFMAs in the same order, so the x-vectors are equal bit for bit."""
-    cfg = synth.extractor_cfg()
-    w = synth.make_weights(seed=977)
-    wav = np.concatenate([synth.make_wav(3, 52000, seed=71), synth.make_wav(5, 52000, seed=72, ragged=True)], 0)
-    got = {}
-    for slab in (False, True):
-        mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
-        mdl.xvec.mx_slab = slab
-        mdl.xvec.mx_loader = False              # (a batch this small would otherwise take the loader-wave kernel: Sequential._mx_use_loader)
-        seen = []
-        real = ops.tdnn_mx
-
-        def spy(*a, **k):
-            r = real(*a, **k)
-            seen.append(ops.last_kernel())
-            return r
-        ops.tdnn_mx = spy
-        try:
-            got[slab] = mdl(dev(wav))
-        finally:
-            ops.tdnn_mx = real
-        assert seen[:3] == (["tdnn_mxs_kernel"] * 3 if slab else ["tdnn_mx_kernel"] * 3), seen    # tdnn1-3 have contexts, tdnn4 none
-        assert seen[3] == "tdnn_mx_kernel"
-    assert torch.equal(got[True], got[False])
 
 
 @pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16mx"])
@@ -448,7 +414,7 @@ def test_tdnn_mx_valid_padding_and_subsampling_vs_emulation(case, relu):
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=False)
-    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=L.TDNN_MX_SLAB)     # (the flag is ignored here)
+    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=0)
     Tout = ops.tdnn_out_len(T, d)
     assert Tout == O.tdnn_eval_indices(T, ctx, sub, pad).shape[0] == layer.outputTimesteps(T)
     y = torch.full((B, Tout, ops.round_up(units, 4)), 7.0, device="cuda")

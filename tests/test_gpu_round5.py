@@ -1,5 +1,5 @@
 """GPU tests added in round 5 (run with `-m gpu` on an MI355X): one model object under concurrent host threads, the library's build
-id and clock probe, the persistent f16mx kernel at the model level."""
+id and clock probe."""
 
 import os
 import subprocess
@@ -60,38 +60,3 @@ def test_build_id_and_clock_probe():
     assert 1_900_000 <= ticks <= 2_600_000               # 100 MHz ticks of 20 ms (+ the loop's last sleep)
     mhz = 100.0 * clk / ticks
     assert 400.0 <= mhz <= 2500.0 and 0 < lo <= hi <= 2_600_000, (mhz, lo, hi)
-
-
-@pytest.mark.parametrize("B", [3, 40])
-def test_persistent_f16mx_kernel_matches_the_tile_kernel_on_the_whole_extractor(B):
-    """Sequential.mx_persist: the persistent 256-row kernel (csrc/tdnn_mxp.hip) against the one-tile-per-workgroup kernel on ragged
-    batches (utterances of different voiced lengths, one silent): same planes, same products, the bias added first instead of last --
-    x-vectors agree to summation-order noise, both inside the tolerance of the oracle-checked tile kernel."""
-    cfg, w = synth.extractor_cfg(), synth.make_weights(seed=11)
-    wav = synth.make_wav(B, 160000, seed=5, ragged=True)
-    wav[1] = 0.0
-    got = {}
-    for persist in (False, True):
-        m = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
-        m.xvec.mx_persist = persist
-        m.xvec.mx_loader = False
-        m.xvec.min_tiles, m.xvec.min_frames = {}, {}             # (small batches / short utterances stay on the MX kernels)
-        m.route_short_utterances = False
-        seen, orig = [], (ops.tdnn_mx, ops.tdnn_mx_stats)
-
-        def spy(fn):
-            def run(*a, **k):
-                r = fn(*a, **k)
-                seen.append(ops.last_kernel())
-                return r
-            return run
-
-        ops.tdnn_mx, ops.tdnn_mx_stats = spy(orig[0]), spy(orig[1])
-        try:
-            got[persist] = m(torch.as_tensor(wav, device="cuda")).float().cpu().numpy()
-        finally:
-            ops.tdnn_mx, ops.tdnn_mx_stats = orig
-        assert seen == ["tdnn_mxp_kernel" if persist else "tdnn_mx_kernel"] * 5, seen
-    ok = np.isfinite(got[False]).all(axis=1)
-    assert ok.sum() >= B - 1 and np.array_equal(ok, np.isfinite(got[True]).all(axis=1))
-    assert np.abs(got[True][ok] - got[False][ok]).max() <= 2e-5

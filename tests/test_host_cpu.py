@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ktf_version() == 115
+    assert lib.ktf_version() == 116
 
 
 def test_abi_argument_validation_without_gpu():
@@ -532,15 +532,13 @@ def test_library_kernel_families():
     fam = collections.Counter(k.split("<")[0] for k in kernels)
     assert set(fam) == {"tdnn_f32_kernel", "tdnn_f32s_kernel", "tdnn_f32t_kernel", "tdnn_f32_rowvec_kernel", "tdnn_bf16_kernel",
                         "tdnn_bf16g_kernel", "tdnn_bf16r_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16h_kernel", "tdnn_x3r_kernel",
-                        "tdnn_x3s_kernel", "tdnn_x4s_kernel", "tdnn_mx_kernel", "tdnn_mxp_kernel", "tdnn_mxl_kernel", "tdnn_mxs_kernel",
+                        "tdnn_x3s_kernel", "tdnn_x4s_kernel", "tdnn_mx_kernel", "tdnn_mxl_kernel",
                         "tdnn_out_lens_kernel"}, fam          # (the last one: ktf_tdnn_out_lens, lengths only)
     assert fam["tdnn_x3r_kernel"] == 8                  # 4 activations x {store, pooled}: fp32 activations only
     assert fam["tdnn_x3s_kernel"] == 8 + 8 + 2 + 4 + 4  # split-bf16 (4 activations x 2, plain and row-group-skipping; flat rows: ReLU / none), half two-pass and one-pass (2 x 2 each)
     assert fam["tdnn_x4s_kernel"] == 8                  # bf16-pair small tiles: 64 x 32 / 64 / 96 and the K-step-32 form, x {rows, pooled}
     assert fam["tdnn_mx_kernel"] == 12                  # {ReLU, none} x {planes, fp32, pooled} x {K-steps fill the super-steps, padded}
-    assert fam["tdnn_mxp_kernel"] == 20                 # ... x {planes, fp32} x {no affine, scale / shift} + the pooled form: 2 x 2 x (2 x 2 + 1)
     assert fam["tdnn_mxl_kernel"] == 6                  # the same on the loader-wave kernel (KTF_TDNN_MX_LOADER)
-    assert fam["tdnn_mxs_kernel"] == 6                  # ... and on the slab form of the 256-row kernel (KTF_TDNN_MX_SLAB)
     assert not any("probe" in k for k in kernels)
     assert "getenv" not in out
 

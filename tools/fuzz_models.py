@@ -58,7 +58,7 @@ for case in range(n_cases):
         continue
     knobs = {}
     if "--knobs" in sys.argv:                            # random settings of the runner's A/B knobs: schedules and kernels change, the contract does not
-        knobs = {"mx_slab": bool(rng.integers(0, 2)), "mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)),
+        knobs = {"mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)),
                  "split_planes": bool(rng.integers(0, 2)), "fuse_stats": bool(rng.integers(0, 2)), "deterministic": bool(rng.integers(0, 2)),
                  "small_tile_pairs": bool(rng.integers(0, 2))}
         for k, v in knobs.items():
