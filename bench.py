@@ -14,8 +14,8 @@ bits on both operands and NO calibration. It is the fastest mode that meets nort
 INPUT: the line's `max_abs_dev_vs_fp64_oracle` is the maximum over stationary noise (the timed workload), utterances with quiet
 blocks AND the reference's own end-to-end speech recording (whole and in 10 s chunks), and `timed_batch_vs_f32` compares all
 1024 timed x-vectors with the exact fp32 kernels. `--gemm bf16x3` (split-bf16) and `--gemm f32` (exact) are the tighter
-modes (bf16x3 carries its own roofline block in `other_configs`); `--gemm f16x2` is round 2's calibrated half-precision form,
-which passes on noise and is 4-7e-4 on speech (reported with tolerance_ok false), like one-pass bf16 / f16.
+modes (bf16x3 carries its own roofline block in `other_configs`); one-pass `--gemm bf16` is outside the tolerance (reported
+with tolerance_ok false).
 
     python bench.py                      # 1 GPU
     python bench.py --gpus 8             # starts 8 ranks itself (torch.distributed.run) when WORLD_SIZE is unset
@@ -43,15 +43,13 @@ for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "test
 
 FLOP_PER_FRAME_TDNN = 2 * 2_679_808          # 5 frame-level layers
 MFCC_FLOP_PER_FRAME = 25_000                 # FFT-512 + window + sparse mel + DCT
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "bf16x3": 2500.0, "f16x2": 2500.0, "f16mx": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
-MFMA_PASSES = {"bf16": 1, "f16": 1, "bf16x3": 3, "f16x2": 2, "f16mx": 1.5, "f32": 1}                            # MFMA passes per algorithmic FLOP
+PEAK_TFLOPS = {"bf16": 2500.0, "bf16x3": 2500.0, "f16mx": 2500.0, "f32": 157.3}   # MI355X_MICROARCH.md dense MFMA peaks
+MFMA_PASSES = {"bf16": 1, "bf16x3": 3, "f16mx": 1.5, "f32": 1}                        # MFMA passes per algorithmic FLOP
 TOLERANCE = 1e-4                             # north_star: max-abs x-vector deviation vs the fp32 reference path
 KERNELS = {"bf16": "tdnn_bf16r16_kernel (K=1536 layers) + tdnn_bf16h_kernel (K<=768 layers)",
            "bf16x3": "tdnn_x3r_kernel<.., SPLIT> (tdnn2-4) + tdnn_x3s_kernel (tdnn5 + pooling) + tdnn_x3r_kernel (tdnn1)",
-           "f16x2": "tdnn_x3s_kernel<.., F16, TERMS = 2> (tdnn1-3; tdnn2 / tdnn3 with a residual prefix of half their K-steps) and "
-                    "<.., TERMS = 1> (tdnn4, tdnn5 with fused pooling); --full-residual / --two-pass-everywhere are the A/Bs",
            "f16mx": "tdnn_mx_kernel (csrc/tdnn_mx.hip): v_mfma_f32_16x16x32_f16 + 2 x v_mfma_scale_f32_16x16x128_f8f6f4 (fp4 x fp4, fp4 x fp6) per 128 K",
-           "f32": "tdnn_f32t_kernel", "f16": "tdnn_bf16r16_kernel<.., F16> + tdnn_bf16h_kernel<.., F16>"}
+           "f32": "tdnn_f32t_kernel"}
 
 
 def parse_args(argv=None):
@@ -63,7 +61,7 @@ def parse_args(argv=None):
                                                            "times back to back; `value` / `ms_per_step` are the MEDIAN region, `value_runs` lists all")
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU per step")
     ap.add_argument("--seconds", type=float, default=10.0)
-    ap.add_argument("--gemm", default="f16mx", choices=["bf16", "f16", "bf16x3", "f16x2", "f16mx", "f32"])
+    ap.add_argument("--gemm", default="f16mx", choices=["bf16", "bf16x3", "f16mx", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--dump-xvectors", default=None, help="rank 0 saves the x-vectors of the last timed step (all ranks' when gathered) as .npy (tests)")
@@ -74,9 +72,6 @@ def parse_args(argv=None):
     ap.add_argument("--atomic-pooling", action="store_true", help="fp64-atomic fused pooling instead of the reproducible form")
     ap.add_argument("--ctx-major-k", action="store_true", help="A/B: weights in (context, feature) K order instead of the chunk-interleaved one")
     ap.add_argument("--row-major-w", action="store_true", help="A/B: row-major weights instead of the LDS-image tiles")
-    ap.add_argument("--row-major-x", action="store_true", help="A/B: row-major half planes between the f16x2 layers instead of chunk-major")
-    ap.add_argument("--two-pass-everywhere", action="store_true", help="A/B: f16x2 without the one-pass layers in front of the pooling")
-    ap.add_argument("--full-residual", action="store_true", help="A/B: f16x2 two-pass layers keep the weight residual of every input feature")
     return ap.parse_args(argv)
 
 
@@ -130,15 +125,12 @@ def main(argv=None):
 
     cfg = synth.extractor_cfg(dither=0.0)
     w = synth.make_weights(seed=4321, narrow=False)
-    mdl = synth.build_extractor(ktf, cfg, w, gemm=args.gemm, calibrate=not args.two_pass_everywhere)
-    if args.full_residual:
-        mdl.xvec.lo_fraction = 0.0
+    mdl = synth.build_extractor(ktf, cfg, w, gemm=args.gemm)
     mdl.xvec.deterministic = not args.atomic_pooling
     mdl.xvec.mx_loader = True if args.mx_loader else None          # (None: the model picks per batch; 1024 x 10 s takes the 256-row kernel)
     mdl.route_short_utterances = not args.no_short_routing
     mdl.xvec.k_interleaved = not args.ctx_major_k
     mdl.xvec.w_tiled = not args.row_major_w
-    mdl.xvec.chunked = not args.row_major_x
 
     B, N = args.batch, int(args.seconds * 16000)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -220,24 +212,13 @@ def main(argv=None):
         "config": {"workload": f"0008_sitw_v2_1a wav->x-vector, {args.seconds:g} s @16 kHz utterances, {B} per GPU "
                                f"(BASELINE config: 8192 utterances batch-sharded over 8 GPUs = 1024 per GPU), dither 0, all {T} frames voiced",
                    "utterances_per_gpu": B, "samples_per_utterance": N, "frames_per_utterance": T,
-                   "tdnn_gemm": args.gemm, "one_pass_layers": (mdl.xvec.one_pass_tail if (args.gemm == "f16x2" and mdl.xvec._xbar) else 0),
-                   "residual_free_input_fraction_of_the_other_layers": (mdl.xvec.lo_fraction if (args.gemm == "f16x2" and mdl.xvec._xbar) else 0.0),
+                   "tdnn_gemm": args.gemm,
                    "weights": "synthetic seed 4321 (pretrained final.raw not shipped)",
                    "gather": bool(world > 1 and not args.no_gather), "ranks_seen_by_collective_backend": ranks_seen,
                    "collective_backend": backend, "fused_pooling": "atomic" if args.atomic_pooling else "reproducible"},
     }
     # ---- roofline of the dominant kernel: TDNN GEMM launches (5 per step), algorithmic FLOPs / measured duration
     passes = float(MFMA_PASSES[args.gemm])
-    if args.gemm == "f16x2" and not args.two_pass_everywhere and mdl.xvec._xbar:
-        # MAC per frame: tdnn1 76 800, tdnn2 / tdnn3 786 432 each, tdnn4 262 144, tdnn5 768 000; the last one_pass_tail of them run one pass
-        mac = [76800, 786432, 786432, 262144, 768000]
-        per = [2.0] * 5
-        for i in range(5):
-            if mdl.xvec.one_pass_tail and i >= 5 - mdl.xvec.one_pass_tail:
-                per[i] = 1.0
-            elif i >= 1 and mdl.xvec.lo_fraction > 0 and mdl.xvec.k_interleaved:      # tdnn2 / tdnn3: residual for the high-variance half only
-                per[i] = 2.0 - mdl.xvec.lo_fraction
-        passes = sum(m * q for m, q in zip(mac, per)) / float(sum(mac))
     out["roofline"] = _roofline(args.gemm, gemm_stats, args.steps, B, T, passes)
     if clocks_mhz[med]:
         # the dense-MFMA peak is quoted at the 2.4 GHz maximum clock; the governor holds less under this load, by amounts that differ from
@@ -254,8 +235,8 @@ def main(argv=None):
     # side measurements and the CPU baseline belong to the single-GPU run only (rank 0 at N = 1)
     if world == 1 and not args.no_parity:
         # the deviation of the TIMED mode from the fp64 CPU oracle at the full utterance length: part of the headline
-        modes = [args.gemm] if args.no_extra else sorted({"f32", "bf16x3", "f16mx", "f16x2", "f16", "bf16", args.gemm})
-        dev_info = _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N, calibrate=not args.two_pass_everywhere)
+        modes = [args.gemm] if args.no_extra else sorted({"f32", "bf16x3", "f16mx", "bf16", args.gemm})
+        dev_info = _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N)
         out["max_abs_dev_vs_fp64_oracle"] = dev_info[args.gemm]["max"]
         out["max_abs_dev_by_input"] = dev_info[args.gemm]
         out["tolerance"] = TOLERANCE
@@ -375,7 +356,7 @@ def _bench_mfcc(torch, mdl, wav, ops, iters=20, warm=5):
             "valu_peak_TFLOPs": PEAK_TFLOPS["f32"], "frac_of_valu_peak": fps * MFCC_FLOP_PER_FRAME / 1e12 / PEAK_TFLOPS["f32"]}
 
 
-def _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N, calibrate=True):
+def _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N):
     """max-abs deviation from the fp64 CPU oracle (the checker), per GEMM mode, over three kinds of input at the FULL utterance
     length: stationary noise as timed (all-voiced), noise with quiet blocks (ragged), and the reference's end-to-end speech
     recording (testdata/librispeech_2.wav = tests/golden/e2e_0008.npz: 22.5 s whole, and its first two 10 s chunks). A mode is
@@ -396,7 +377,7 @@ def _parity_sample(torch, ktf, synth, cfg, w, modes, dev, N, calibrate=True):
                      f"XvectorExtractor.route_short_utterances send utterances below 400 voiced frames of an f16mx model through the "
                      f"split-bf16 kernels); only the small-batch hand-over to the fp32 kernels (min_tiles) is off"}
     for g in modes:
-        m = synth.build_extractor(ktf, cfg, w, gemm=g, calibrate=calibrate)
+        m = synth.build_extractor(ktf, cfg, w, gemm=g)
         m.xvec.min_tiles = {}          # a few utterances would be handed to the fp32 kernels: measure the mode's own (routing by length stays)
         r = {}
         for k, v in inputs.items():
@@ -512,17 +493,14 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     res = {}
     B = wav.shape[0]
     T = mdl.framing.numFrames(wav.shape[1])
-    for g in ("f32", "bf16x3", "f16mx", "f16x2", "f16", "bf16"):
+    for g in ("f32", "bf16x3", "f16mx", "bf16"):
         if g == gemm:
             continue
-        m = synth.build_extractor(ktf, cfg, w, gemm=g, calibrate=True)
+        m = synth.build_extractor(ktf, cfg, w, gemm=g)
         ms = _time_ms(torch, lambda: m(wav), 5)
         res[g] = {"x_vectors_per_s": B / (ms * 1e-3), "ms_per_step": ms, "max_abs_dev_vs_fp64_oracle": dev_info[g]["max"],
                   "max_abs_dev_by_input": {k: v for k, v in dev_info[g].items() if k != "max"},
                   "tolerance_ok": bool(dev_info[g]["max"] <= TOLERANCE)}
-        if g == "f16x2":
-            res[g]["note"] = ("round 2's calibrated form (one-pass tail + residual prefix, calibrated on stationary noise): inside the "
-                              "tolerance on noise only")
         if g in ("bf16x3", "f16mx"):      # the modes that are compliant on any input: a driver-timed roofline block of their own
             prof = _GemmProfiler(ops, torch)
             for _ in range(3):

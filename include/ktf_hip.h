@@ -40,8 +40,7 @@ extern "C" {
 /* element types of activation / weight buffers */
 #define KTF_F32 0
 #define KTF_BF16 1
-#define KTF_F16 2           /* IEEE half: same 16-bit MFMA rate as bf16, 3 more mantissa bits (activations of this
-                             * network are BatchNorm-scaled, far inside the half range) */
+/* (2 was KTF_F16, the element type of the half-precision modes below) */
 #define KTF_BF16P 3         /* a bf16 PAIR in an fp32-sized slot: bits 0-15 = bf16(v) (round to nearest even), bits 16-31 =
                              * bf16(v - bf16(v)): 16 mantissa bits, the shapes / strides / padding of fp32 (zero = 0x00000000).
                              * Operands of KTF_GEMM_BF16X4; KTF_GEMM_F32 and KTF_GEMM_BF16X4 can write it (y_dtype) */
@@ -50,19 +49,9 @@ extern "C" {
 #define KTF_GEMM_F32 0      /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate (parity path) */
 #define KTF_GEMM_BF16 1     /* v_mfma_f32_*_bf16: bf16 operands, fp32 accumulate */
 #define KTF_GEMM_BF16X3 2   /* split-bf16: x=hi+lo, w=hi+lo, 3 bf16 MFMA passes, fp32 accumulate */
-#define KTF_GEMM_F16 3      /* v_mfma_f32_16x16x32_f16: half operands (x, w of KTF_F16), fp32 accumulate; ring kernels only
-                             * (units > 128, ReLU or no activation) */
-#define KTF_GEMM_F16X2 4    /* two half-precision MFMA passes, fp32 accumulate: acc += x * w_hi + x * w_lo with w = w_hi + w_lo
-                             * (both KTF_F16: the weights are exact to ~22 bits) and the activations as ONE half plane. Meets
-                             * the 1e-4 x-vector tolerance when the stored activations are the ReLU outputs with the following
-                             * BatchNorm folded into the NEXT layer's weights (dead units are then exact zeros instead of a
-                             * rounded constant; the host side does this): 2.8e-5 .. 4.8e-5 measured. Through
-                             * ktf_tdnn_split / ktf_tdnn_split_stats with x_lo = y_lo = NULL; units > 128.
-                             * w_lo = NULL runs ONE pass (acc += x * w): for a layer whose output is pooled over the frames right
-                             * away, with the weights rounded to nearest half and the constant part of the rounding error,
-                             * (w_half - w) . E[x], subtracted from the fp32 bias by the host, the x-vector deviation stays where
-                             * two passes put it (4.6e-5 .. 7.0e-5 against 4.0e-5 .. 6.3e-5 over six weight seeds) */
-
+/* (3 and 4 were KTF_GEMM_F16, one half-precision pass, and KTF_GEMM_F16X2, two half passes with a calibrated one-pass tail: round 2's
+ * timed mode, superseded by KTF_GEMM_F16MX -- faster, tighter on speech, no calibration. Removed from the library in round 5;
+ * tools/mx/experiments/README.md names the commit at which they were last part of it.) */
 #define KTF_GEMM_F16MX 5    /* ONE half-precision MFMA pass plus two block-scaled (OCP MX) residual passes on
                              * v_mfma_scale_f32_16x16x128_f8f6f4, which runs fp4 / fp6 operands at four times the half rate:
                              *   y = x_h * w_h + x_l4 * w_4 + x_4 * w_l6
@@ -71,8 +60,7 @@ extern "C" {
                              * flop with ~15 significant bits on BOTH operands, no calibration. What is left is zero-mean rounding
                              * noise per frame that the statistics pooling averages, so the max-abs x-vector deviation depends on
                              * the voiced length: 1.2e-5 on 10 s of noise, 2-5e-5 on 10 s of speech, 4-6.5e-5 on 5 s, up to 1.2e-4
-                             * on 1-1.5 s (tests/test_gpu_margin.py; KTF_GEMM_F16X2's two half passes are 7e-5 .. 1e-4 on 10 s of
-                             * speech). The host side (Sequential.MIN_FRAMES, XvectorExtractor.route_short_utterances) sends
+                             * on 1-1.5 s (tests/test_gpu_margin.py). The host side (Sequential.MIN_FRAMES, XvectorExtractor.route_short_utterances) sends
                              * utterances below 400 voiced frames through KTF_GEMM_BF16X3. Through ktf_tdnn_mx / ktf_tdnn_mx_stats
                              * on the four-plane activation format ktf_mx_planes produces */
 #define KTF_GEMM_BF16X4 6   /* all four bf16 products of (x_hi + x_lo)(w_hi + w_lo), fp32 accumulate, on SMALL tiles (64 x 32..96,
@@ -220,7 +208,7 @@ int ktf_vad_index(const float* feats, int64_t B, int64_t T, int32_t D, const Ktf
 int ktf_cmvn_f32(const float* x, int64_t B, int64_t T, int32_t D, int64_t ldx, const int32_t* lens,
                  const KtfCmvnCfg* cfg, float* out, int64_t ldo, int32_t* out_lens, float* work, void* stream);
 /* Fused hot path: VAD -> per-utterance compaction -> CMVN (xvector_extractor.py:162-166).
- * out_dtype KTF_F32, KTF_BF16 or KTF_F16. idx_work = B*T int32 (on return: the kept frame numbers of each utterance),
+ * out_dtype KTF_F32 or KTF_BF16. idx_work = B*T int32 (on return: the kept frame numbers of each utterance),
  * work = B*T*2*D floats (touched only by recordings too long for the LDS: more than ~38,000 frames). Any T < 2^31 / ldo.
  * Batches of fewer than 256 utterances spread each utterance over up to eight workgroups (same values, bit for bit). */
 int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D, const KtfVadCfg* vad, const KtfCmvnCfg* cmvn,
@@ -279,18 +267,7 @@ typedef struct KtfTdnnDesc {
                                    * holding for row r and 16-byte position q the columns 32 ks + 8 (q ^ ((4 - (r >> 2)) & 3))
                                    * .. + 7 of unit 256 nt + r at byte 64 r + 16 q. A weight DMA instruction then copies 1 KiB of
                                    * consecutive bytes (8 whole cache lines) instead of gathering 16 rows x 64 B */
-#define KTF_TDNN_X_CHUNKED 16     /* ktf_tdnn_split* only: the 16-bit input plane(s) are stored chunk-major: element (b, t, d) at
-                                   * ((b * ldx / 32 + d / 32) * T + t) * 32 + d % 32 (ldx = din_pad). The row gather of a K-step
-                                   * (256 rows x one 32-feature chunk) then reads consecutive 64-byte row pieces: 1 KiB of
-                                   * consecutive bytes per DMA instruction, and the context-shifted re-reads of the same chunk in
-                                   * the next K-steps (KTF_TDNN_K_INTERLEAVED) touch the same cache lines */
-#define KTF_TDNN_Y_CHUNKED 32     /* ... and the 16-bit output plane(s) are written in that layout (ldy a multiple of 32; pad columns
-                                   * of the last chunk are written as zeros): what the next layer reads with KTF_TDNN_X_CHUNKED */
-#define KTF_TDNN_LO_PREFIX(chunks) (((chunks) + 1) << 8)   /* KTF_GEMM_F16X2 with KTF_TDNN_K_INTERLEAVED: only the first `chunks`
-                                   * 32-feature chunks of the input have a weight residual -- their K-steps run two passes,
-                                   * the rest one (the blocks of w_lo behind them are not read). The host orders the input
-                                   * features by decreasing activation variance and folds the constant part of the dropped
-                                   * residual into the bias (TDNN.device_weights). Bits 8..23; 0 = every chunk two passes */
+/* (16, 32 and bits 8..23 were KTF_TDNN_X_CHUNKED / KTF_TDNN_Y_CHUNKED / KTF_TDNN_LO_PREFIX of KTF_GEMM_F16X2) */
 
 #define KTF_TDNN_MX_LOADER (1 << 24)  /* ktf_tdnn_mx / ktf_tdnn_mx_stats only: the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles,
                                    * eight matrix waves + four loader waves). It reads the weight images of its own
@@ -320,8 +297,8 @@ int ktf_tdnn(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* le
  * output is never written; instead sums[b, 0, u] += sum_t y[b,t,u] and sums[b, 1, u] += sum_t y[b,t,u]^2 (fp64, over
  * the valid rows). `sums` (B, 2, units) must be zeroed by the caller before the call (the order of the fp64 atomic adds
  * of an utterance's row blocks is not fixed: results can differ in the last fp64 bits from run to run; see
- * KTF_TDNN_DET_STATS for the reproducible form). Implemented by the 16-bit ring kernels -- KTF_GEMM_BF16 (bf16 x), KTF_GEMM_F16,
- * KTF_GEMM_BF16X3 (fp32 x, w_lo given), KTF_GEMM_F16X2: units > 128, SAME padding, subsampling 1 -- and by the bf16-pair small
+ * KTF_TDNN_DET_STATS for the reproducible form). Implemented by the 16-bit ring kernels -- KTF_GEMM_BF16 (bf16 x),
+ * KTF_GEMM_BF16X3 (fp32 x, w_lo given): units > 128, SAME padding, subsampling 1 -- and by the bf16-pair small
  * tiles (KTF_GEMM_BF16X4: any layer shape; its KTF_TDNN_DET_STATS slots are ktf_tdnn_stats_slots(T, gemm) of
  * ktf_tdnn_slot_rows(gemm) = 64 rows). */
 int ktf_tdnn_stats(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,

@@ -67,15 +67,6 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
     return *reinterpret_cast<unsigned short*>(&h);
 }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
-// IEEE half <-> float on raw 16-bit patterns (round to nearest even)
-__device__ __forceinline__ unsigned short f2h(float f) {
-    const _Float16 h = (_Float16)f;
-    return __builtin_bit_cast(unsigned short, h);
-}
-__device__ __forceinline__ float h2f(unsigned short b) { return (float)__builtin_bit_cast(_Float16, b); }
-// 16-bit activation formats by tag: F16 = IEEE half, else bfloat16
-template <bool F16>
-__device__ __forceinline__ unsigned short f2x16(float f) { return F16 ? f2h(f) : f2bf(f); }
 
 // Sample g of an utterance's waveform in "frame coordinates" (frame t starts at t*shift - pad_left): outside [0, n) the
 // waveform is mirrored with the edge sample repeated, as kaldi_numpy MirrorPad does (frame_extraction.py:28-51).

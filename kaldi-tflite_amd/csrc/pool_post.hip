@@ -26,13 +26,6 @@ template <>
 __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float load1<unsigned short>(const unsigned short* p) { return bf2f(*p); }
-template <>
-__device__ __forceinline__ float2 load2<_Float16>(const _Float16* p) {
-    const unsigned v = *reinterpret_cast<const unsigned*>(p);
-    return make_float2(h2f((unsigned short)(v & 0xffffu)), h2f((unsigned short)(v >> 16)));
-}
-template <>
-__device__ __forceinline__ float load1<_Float16>(const _Float16* p) { return (float)*p; }
 
 // Column statistics of one utterance. Rows are summed in 64 interleaved groups (row j -> group j mod 64, fp64), the
 // groups are combined in ONE fixed association ((g + g+16) + g+32) + g+48 for g = 0..15, then over g -- independent of how
@@ -623,7 +616,6 @@ extern "C" int ktf_stats_pool(const void* x, int32_t x_dtype, int64_t B, int64_t
 #define SP_LAUNCH_T(TY) do { if (narrow) SP_LAUNCH(TY, 32); else SP_LAUNCH(TY, 128); } while (0)
     if (x_dtype == KTF_F32) SP_LAUNCH_T(float);
     else if (x_dtype == KTF_BF16) SP_LAUNCH_T(unsigned short);
-    else if (x_dtype == KTF_F16) SP_LAUNCH_T(_Float16);
     else KTF_REQUIRE(false, "ktf_stats_pool: bad dtype");
 #undef SP_LAUNCH_T
 #undef SP_LAUNCH

@@ -1,4 +1,4 @@
-// KTF_GEMM_BF16 / KTF_GEMM_F16 (one 16-bit MFMA pass; outside the 1e-4 tolerance, BASELINE config 3's precision) and the small-layer
+// KTF_GEMM_BF16 (one bf16 MFMA pass; outside the 1e-4 tolerance, BASELINE config 3's precision) and the small-layer
 // forms of KTF_GEMM_BF16X3: 128 x 128 register-/DMA-staged tiles, the 256 x 256 ring kernels on 32x32x16 (sigmoid / tanh) and
 // 16x16x32 MFMAs, and the 128 x 256 two-workgroups-per-CU kernel for K <= 768.
 #include "tdnn_ring.h"
@@ -614,7 +614,7 @@ __device__ __forceinline__ void r16_store_staged(const TdnnParams& p, const unsi
         }
     }
 }
-template <int ACT, bool F16>
+template <int ACT>
 __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const TdnnParams& p, unsigned char* rsm, int b,
                                                    int t0, int n0, int out_len, int wm, int wn, int wave, int lane) {
     const int c = lane & 15, g = lane >> 4;
@@ -642,8 +642,8 @@ __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const Td
                 v[e] = t * sc[j][e] + sh[j][e];
             }
             uint2 pk;
-            pk.x = (unsigned)f2x16<F16>(v[0]) | ((unsigned)f2x16<F16>(v[1]) << 16);
-            pk.y = (unsigned)f2x16<F16>(v[2]) | ((unsigned)f2x16<F16>(v[3]) << 16);
+            pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+            pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
             *reinterpret_cast<uint2*>(stg + i * 16 * R16_PK_PITCH + j * 32) = pk;
         }
     }
@@ -651,7 +651,7 @@ __device__ __forceinline__ void ring_epilogue16_pk(f32x4v (&acc)[8][4], const Td
     r16_store_staged(p, rsm, reinterpret_cast<unsigned short*>(p.y), b, t0, n0, out_len, wave, lane);
 }
 
-template <int ACT, bool STATS, bool F16>
+template <int ACT, bool STATS>
 __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int ntiles, int gtiles,
                                          double* __restrict__ stats, unsigned char* rsm, const int id) {
     const int xcd = id & 7, slot = id >> 3;
@@ -760,7 +760,7 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? mfma16x16x32<F16>(a[i], bq[j], acc[i][j]) : mfma16x16x32<F16>(bq[j], a[i], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? mfma16x16x32(a[i], bq[j], acc[i][j]) : mfma16x16x32(bq[j], a[i], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0) {
 #pragma unroll
@@ -775,7 +775,7 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
 #pragma unroll
         for (int i = 4; i < 8; ++i) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? mfma16x16x32<F16>(a[i], bq[j], acc[i][j]) : mfma16x16x32<F16>(bq[j], a[i], acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = STATS ? mfma16x16x32(a[i], bq[j], acc[i][j]) : mfma16x16x32(bq[j], a[i], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 4 && ks + 1 < nk) {
                 // next stage (certified by this K-step's barrier): first-half A fragments; a[0..3] are no longer needed
@@ -806,15 +806,15 @@ __device__ __forceinline__ void r16_tile(const TdnnParams& p, int mtiles, int nt
         ring_epilogue16_direct<ACT>(acc, p, b, t0, n0, out_len, wm, wn, lane);
     } else {
         __syncthreads();          // every wave's fragment reads are done before the ring is reused as staging
-        ring_epilogue16_pk<ACT, F16>(acc, p, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
+        ring_epilogue16_pk<ACT>(acc, p, rsm, b, t0, n0, out_len, wm, wn, wave, lane);
     }
 }
 
-template <int ACT, bool STATS, bool F16>
+template <int ACT, bool STATS>
 __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                            double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-    r16_tile<ACT, STATS, F16>(p, mtiles, ntiles, gtiles, stats, rsm, blockIdx.x);
+    r16_tile<ACT, STATS>(p, mtiles, ntiles, gtiles, stats, rsm, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------ BF16, 128x256 tile, 2 workgroups/CU
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(512) void tdnn_bf16r16_kernel(TdnnParams p, int mti
 #define H_PK_PITCH 520
 
 
-template <int ACT, bool STATS, bool F16>
+template <int ACT, bool STATS>
 __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                             double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -962,7 +962,7 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
         for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                acc[i][j] = STATS ? mfma16x16x32<F16>(a[i], bq[j], acc[i][j]) : mfma16x16x32<F16>(bq[j], a[i], acc[i][j]);
+                acc[i][j] = STATS ? mfma16x16x32(a[i], bq[j], acc[i][j]) : mfma16x16x32(bq[j], a[i], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0) {
 #pragma unroll
@@ -1098,8 +1098,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
                 }
                 v = v * sc[j] + sh[j];
                 uint2 pk;
-                pk.x = (unsigned)f2x16<F16>(v[0]) | ((unsigned)f2x16<F16>(v[1]) << 16);
-                pk.y = (unsigned)f2x16<F16>(v[2]) | ((unsigned)f2x16<F16>(v[3]) << 16);
+                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
                 *reinterpret_cast<uint2*>(stg + i * 16 * H_PK_PITCH + j * 32) = pk;
             }
         }
@@ -1137,16 +1137,8 @@ __global__ __launch_bounds__(256, 2) void tdnn_bf16h_kernel(TdnnParams p, int mt
 int tdnn_launch_16(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t Tout, int64_t ldy, double* stats_sums, hipStream_t st) {
     const unsigned ntiles = (unsigned)ktf_cdiv(d->units, 128);
     {
-        const bool f16 = d->gemm == KTF_GEMM_F16;
-        if (f16) {
-            KTF_REQUIRE(d->w_dtype == KTF_F16 && d->x_dtype == KTF_F16, "ktf_tdnn: F16 gemm needs half x and w");
-            KTF_REQUIRE(d->y_dtype == KTF_F16 || d->y_dtype == KTF_F32, "ktf_tdnn: F16 gemm writes half or fp32");
-            KTF_REQUIRE(d->units > 128 && ldy % 4 == 0 && (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE),
-                        "ktf_tdnn: F16 gemm runs on the ring kernels only (units > 128, ldy %% 4 == 0, ReLU or no activation)");
-        } else {
-            KTF_REQUIRE(d->w_dtype == KTF_BF16, "ktf_tdnn: bf16 gemm needs bf16 weights");
-            KTF_REQUIRE(d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F32, "ktf_tdnn: bf16 gemm writes bf16 or fp32");
-        }
+        KTF_REQUIRE(d->w_dtype == KTF_BF16, "ktf_tdnn: bf16 gemm needs bf16 weights");
+        KTF_REQUIRE(d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F32, "ktf_tdnn: bf16 gemm writes bf16 or fp32");
         const bool x3 = d->gemm == KTF_GEMM_BF16X3;
         dim3 grid(ntiles, (unsigned)ktf_cdiv(Tout, BF_BM), (unsigned)B);
         // K-step: 64 when the per-context width allows it, else 32
@@ -1164,7 +1156,7 @@ int tdnn_launch_16(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t
         } else if (d->x_dtype == KTF_F32) {
             if (k64) BF_LAUNCH(64, true, false); else BF_LAUNCH(32, true, false);
         } else {
-            KTF_REQUIRE(d->x_dtype == (f16 ? KTF_F16 : KTF_BF16), "ktf_tdnn: bad x_dtype");
+            KTF_REQUIRE(d->x_dtype == KTF_BF16, "ktf_tdnn: bad x_dtype");
             if (d->units > 128 && ldy % 4 == 0) {
                 // W must be padded to a multiple of 256 rows for this kernel (documented in ktf_hip.h)
                 const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
@@ -1192,14 +1184,9 @@ int tdnn_launch_16(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t
                     KTF_REQUIRE(nb_h < (1ll << 31), "ktf_tdnn: grid too large");
 #define H_LAUNCH(A, ST)                                                                                                \
     do {                                                                                                               \
-        KTF_NOTE_KERNEL(f16 ? "tdnn_bf16h_kernel<f16>" : "tdnn_bf16h_kernel<bf16>");                                   \
-        if (f16) {                                                                                                     \
-            KTF_LDS_ONCE(H_LDS_BYTES, tdnn_bf16h_kernel<A, ST, true>); \
-            hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST, true>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums); \
-        } else {                                                                                                       \
-            KTF_LDS_ONCE(H_LDS_BYTES, tdnn_bf16h_kernel<A, ST, false>); \
-            hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST, false>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums); \
-        }                                                                                                              \
+        KTF_NOTE_KERNEL("tdnn_bf16h_kernel");                                                                          \
+        KTF_LDS_ONCE(H_LDS_BYTES, tdnn_bf16h_kernel<A, ST>);                                                           \
+        hipLaunchKernelGGL((tdnn_bf16h_kernel<A, ST>), dim3((unsigned)nb_h), dim3(256), H_LDS_BYTES, st, p, mt_h, ntiles_r, (int)gt_h, stats_sums); \
     } while (0)
                     if (d->act == KTF_ACT_RELU) { if (stats_sums) H_LAUNCH(KTF_ACT_RELU, true); else H_LAUNCH(KTF_ACT_RELU, false); }
                     else { if (stats_sums) H_LAUNCH(KTF_ACT_NONE, true); else H_LAUNCH(KTF_ACT_NONE, false); }
@@ -1210,14 +1197,9 @@ int tdnn_launch_16(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t
                 if (d->act == KTF_ACT_RELU || d->act == KTF_ACT_NONE) {       // 16x16x32 MFMAs; sigmoid / tanh stay on the 32x32x16 kernel
 #define S_LAUNCH(A, ST)                                                                                                \
     do {                                                                                                               \
-        KTF_NOTE_KERNEL(f16 ? "tdnn_bf16r16_kernel<f16>" : "tdnn_bf16r16_kernel<bf16>");                               \
-        if (f16) {                                                                                                     \
-            KTF_LDS_ONCE(R16_LDS_BYTES, tdnn_bf16r16_kernel<A, ST, true>); \
-            hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST, true>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
-        } else {                                                                                                       \
-            KTF_LDS_ONCE(R16_LDS_BYTES, tdnn_bf16r16_kernel<A, ST, false>); \
-            hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST, false>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
-        }                                                                                                              \
+        KTF_NOTE_KERNEL("tdnn_bf16r16_kernel");                                                                        \
+        KTF_LDS_ONCE(R16_LDS_BYTES, tdnn_bf16r16_kernel<A, ST>);                                                       \
+        hipLaunchKernelGGL((tdnn_bf16r16_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), R16_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
     } while (0)
                     if (d->act == KTF_ACT_RELU) { if (stats_sums) S_LAUNCH(KTF_ACT_RELU, true); else S_LAUNCH(KTF_ACT_RELU, false); }
                     else { if (stats_sums) S_LAUNCH(KTF_ACT_NONE, true); else S_LAUNCH(KTF_ACT_NONE, false); }

@@ -16,7 +16,6 @@
 
 // Fixed choices of the split-plane kernel (each was an A/B in round 2; DESIGN.md section 5 has the numbers)
 #define KTF_X3_Y_NT 1         // the 16-bit activation planes are written with non-temporal stores (the XCD's L2 keeps weights / shared tiles)
-#define KTF_X1_STAGES 3       // one-pass form: three 32 KiB stages in the LDS ring
 #define KTF_X3_WFIRST 1       // the W half of stage 0 is issued before the utterance length is loaded
 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -41,11 +40,9 @@ struct TdnnParams {
     int64_t T, ldx, ldy, Tout;
     int32_t units, din_pad, nctx, sub, valid, act, y_dtype, ktot;
     int32_t ctx[16];
-    int32_t xchunk, ychunk; // KTF_TDNN_X_CHUNKED / KTF_TDNN_Y_CHUNKED: 16-bit activations stored (utterance, 32-feature chunk, row, 32)
     int32_t wtiled;         // KTF_TDNN_W_TILED: W stored as the kernel's LDS images, one contiguous 16 KiB block per (N-tile, K-step)
     int32_t kinter;         // KTF_TDNN_K_INTERLEAVED: K runs (32-wide feature chunk, context, feature) instead of (context, feature)
     int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
-    int32_t lo_steps;       // F16X2: K-steps [0, lo_steps) run two passes, the rest one (KTF_TDNN_LO_PREFIX); >= ktot / 32: all of them
     int32_t y_pair;         // fp32-sized output slots hold the KTF_BF16P pair of the value (y_dtype is KTF_F32 to the store paths)
     const int32_t* row_starts;  // ktf_tdnn_split_flat: (B + 1) exclusive prefix sums of lens (flat row tiling of tdnn_x3s_kernel), else NULL
 };

@@ -73,12 +73,10 @@ template <typename S>
 __device__ __forceinline__ float cp_load(const S* p);
 template <> __device__ __forceinline__ float cp_load<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float cp_load<unsigned short>(const unsigned short* p) { return bf2f(*p); }
-template <> __device__ __forceinline__ float cp_load<_Float16>(const _Float16* p) { return (float)*p; }
 template <typename Dd>
 __device__ __forceinline__ void cp_store(Dd* p, float v);
 template <> __device__ __forceinline__ void cp_store<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void cp_store<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
-template <> __device__ __forceinline__ void cp_store<_Float16>(_Float16* p, float v) { *p = (_Float16)v; }
 
 template <typename S, typename Dd>
 __global__ void convert_pad_kernel(const S* __restrict__ src, int64_t rows, int D, int64_t lds_, Dd* __restrict__ dst,
@@ -137,26 +135,20 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     // longer than the input --: y, y_lo).
     const bool no_in = B == 0 || T == 0;
     const bool split_in = d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16;     // activations as hi/lo bf16 planes
-    const bool half2 = d->gemm == KTF_GEMM_F16X2;                                    // one half plane in, hi + lo half weights
     KTF_REQUIRE(w && (no_in || x), "ktf_tdnn: null argument");
     if (split_in) KTF_REQUIRE(no_in || x_lo, "ktf_tdnn_split: null lo plane");
-    if (half2) {
-        KTF_REQUIRE(d->x_dtype == KTF_F16 && d->w_dtype == KTF_F16 && !x_lo && !y_lo,
-                    "ktf_tdnn: F16X2 takes ONE half activation plane (x_lo, y_lo NULL) and half weights as w (hi) + w_lo (w_lo NULL: one pass)");
-        KTF_REQUIRE(d->units > 128 && (stats_sums || (ldy % 8 == 0 && (d->y_dtype == KTF_F16 || d->y_dtype == KTF_F32))),
-                    "ktf_tdnn: F16X2 runs on the 256x256 kernel only (units > 128, ldy %% 8 == 0, half or fp32 output)");
-    }
     if (y_lo) KTF_REQUIRE(split_in && d->y_dtype == KTF_BF16, "ktf_tdnn_split: a split output needs split input and y_dtype bf16");
     if (stats_sums && d->gemm == KTF_GEMM_BF16X4) {
         ldy = d->units;                                  // (any shape: the pair kernel pools the rows it would have written)
     } else if (stats_sums) {
-        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) || split_in || half2 ||
-                     (d->gemm == KTF_GEMM_F16 && d->x_dtype == KTF_F16)) &&
+        KTF_REQUIRE(((d->gemm == KTF_GEMM_BF16 && d->x_dtype == KTF_BF16) || (d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_F32) || split_in) &&
                         d->units > 128 && !d->valid && d->subsampling == 1,
-                    "ktf_tdnn_stats: needs a ring kernel (bf16, f16 or bf16x3 gemm, units > 128, SAME padding, no subsampling) or KTF_GEMM_BF16X4");
+                    "ktf_tdnn_stats: needs a ring kernel (bf16 or bf16x3 gemm, units > 128, SAME padding, no subsampling) or KTF_GEMM_BF16X4");
         ldy = (d->units + 3) / 4 * 4;
     }
     KTF_REQUIRE(B >= 0 && T >= 0, "ktf_tdnn: negative size");
+    KTF_REQUIRE(!(d->flags & ~(KTF_TDNN_REF_TILES | KTF_TDNN_DET_STATS | KTF_TDNN_K_INTERLEAVED | KTF_TDNN_W_TILED | KTF_TDNN_MX_LOADER)),
+                "ktf_tdnn: unknown bits in KtfTdnnDesc.flags (0x%x)", (unsigned)d->flags);
     KTF_REQUIRE(d->units > 0 && d->din > 0, "ktf_tdnn: units/din must be > 0");
     KTF_REQUIRE(d->nctx >= 1 && d->nctx <= 16, "ktf_tdnn: nctx %d outside [1,16]", d->nctx);
     for (int i = 1; i < d->nctx; ++i) KTF_REQUIRE(d->ctx[i] > d->ctx[i - 1], "ktf_tdnn: context must be strictly ascending");
@@ -171,8 +163,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     const bool y_pair = d->y_dtype == KTF_BF16P;        // pairs in fp32-sized slots: the fp32 and the pair kernels write them
     if (y_pair) KTF_REQUIRE((d->gemm == KTF_GEMM_F32 || d->gemm == KTF_GEMM_BF16X4) && (y || stats_sums) && !act_pass,
                             "ktf_tdnn: a KTF_BF16P output comes from KTF_GEMM_F32 or KTF_GEMM_BF16X4 (no fused pooling, fused activations only)");
-    KTF_REQUIRE(y_pair || d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16 || d->y_dtype == KTF_F16, "ktf_tdnn: bad y_dtype");
-    KTF_REQUIRE(d->y_dtype != KTF_F16 || d->gemm == KTF_GEMM_F16 || half2, "ktf_tdnn: half output needs KTF_GEMM_F16 or KTF_GEMM_F16X2");
+    KTF_REQUIRE(y_pair || d->y_dtype == KTF_F32 || d->y_dtype == KTF_BF16, "ktf_tdnn: bad y_dtype");
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "ktf_tdnn: scale and shift go together");
     KTF_REQUIRE(T < (1ll << 30) && B < 65536, "ktf_tdnn: T or B too large");
     const int64_t Tout = ktf_tdnn_out_len(T, d);
@@ -191,23 +182,10 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.act = act_pass ? KTF_ACT_NONE : d->act; p.y_dtype = y_pair ? KTF_F32 : d->y_dtype; p.y_pair = y_pair ? 1 : 0; p.ktot = d->nctx * d->din_pad;
     if (act_pass) p.scale = p.shift = nullptr;          // (the BatchNorm affine follows the activation: applied by the pass)
     p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
-    {
-        const int pre = (d->flags >> 8) & 0xffff;             // KTF_TDNN_LO_PREFIX(chunks) = (chunks + 1) << 8
-        p.lo_steps = pre ? (pre - 1) * d->nctx : INT32_MAX;
-        if (pre) KTF_REQUIRE(d->gemm == KTF_GEMM_F16X2 && (d->flags & KTF_TDNN_K_INTERLEAVED) && w_lo,
-                             "ktf_tdnn: KTF_TDNN_LO_PREFIX needs KTF_GEMM_F16X2 with K-interleaved weights and a residual plane");
-    }
     p.kinter = (d->flags & KTF_TDNN_K_INTERLEAVED) ? 1 : 0;
     p.wtiled = (d->flags & KTF_TDNN_W_TILED) ? 1 : 0;
-    p.xchunk = (d->flags & KTF_TDNN_X_CHUNKED) ? 1 : 0;
-    p.ychunk = (d->flags & KTF_TDNN_Y_CHUNKED) ? 1 : 0;
-    if (p.xchunk || p.ychunk) {
-        KTF_REQUIRE(half2 || (split_in && d->units > 128), "ktf_tdnn: chunk-major activations are implemented by the split-plane kernel only");
-        KTF_REQUIRE(!p.xchunk || ldx == d->din_pad, "ktf_tdnn: KTF_TDNN_X_CHUNKED needs ldx == din_pad (whole 32-feature chunks)");
-        KTF_REQUIRE(!p.ychunk || (!stats_sums && ldy % 32 == 0 && d->y_dtype != KTF_F32), "ktf_tdnn: KTF_TDNN_Y_CHUNKED needs a 16-bit output with ldy %% 32 == 0");
-    }
-    if (p.wtiled) KTF_REQUIRE(half2 || (split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_W_TILED is implemented by the split-plane kernel only");
-    if (p.kinter) KTF_REQUIRE(half2 || (split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_K_INTERLEAVED is implemented by the split-plane kernel only (ktf_tdnn_split*, units > 128)");
+    if (p.wtiled) KTF_REQUIRE((split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_W_TILED is implemented by the split-plane kernel only");
+    if (p.kinter) KTF_REQUIRE((split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_K_INTERLEAVED is implemented by the split-plane kernel only (ktf_tdnn_split*, units > 128)");
     for (int i = 0; i < d->nctx; ++i) p.ctx[i] = d->ctx[i];
     hipStream_t st = (hipStream_t)stream;
     if (d->gemm == KTF_GEMM_F32) {
@@ -227,8 +205,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
         p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_tdnn_stats_slots(Tout, d->gemm) : 0;
         return tdnn_launch_x4(p, d, B, Tout, stats_sums, st);
     }
-    if (half2) return tdnn_launch_split(p, d, B, Tout, ldy, false, stats_sums, st);
-    if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3 || d->gemm == KTF_GEMM_F16) {
+    if (d->gemm == KTF_GEMM_BF16 || d->gemm == KTF_GEMM_BF16X3) {
         const bool x3 = d->gemm == KTF_GEMM_BF16X3;
         if (x3) KTF_REQUIRE((d->x_dtype == KTF_F32 || split_in) && w_lo, "ktf_tdnn: BF16X3 needs fp32 activations (or hi/lo planes) and w_lo");
         if (split_in) KTF_REQUIRE(d->units > 128 && ldy % 4 == 0, "ktf_tdnn_split: runs on the 256x256 kernel only (units > 128, ldy %% 4 == 0)");
@@ -261,8 +238,7 @@ extern "C" int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int
                               const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                               const float* shift, void* y, void* y_lo, int64_t ldy, int32_t* out_lens, void* stream) {
     KTF_REQUIRE(d && (y || T == 0 || ktf_tdnn_out_len(T, d) == 0), "ktf_tdnn_split: null argument");
-    KTF_REQUIRE((d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16) || d->gemm == KTF_GEMM_F16X2,
-                "ktf_tdnn_split: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes) or KTF_GEMM_F16X2 (one half plane)");
+    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes)");
     return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, y, ldy, out_lens, nullptr, stream, x_lo, y_lo);
 }
 
@@ -279,8 +255,7 @@ extern "C" int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t 
                                     const int32_t* lens, const KtfTdnnDesc* d, const void* w, const void* w_lo,
                                     const float* bias, const float* scale, const float* shift, double* sums, void* stream) {
     KTF_REQUIRE(sums && d, "ktf_tdnn_split_stats: null argument");
-    KTF_REQUIRE((d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16) || d->gemm == KTF_GEMM_F16X2,
-                "ktf_tdnn_split_stats: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes) or KTF_GEMM_F16X2 (one half plane)");
+    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_stats: needs KTF_GEMM_BF16X3 with x_dtype KTF_BF16 (hi/lo planes)");
     return tdnn_launch(x_hi, B, T, ldx, lens, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream, x_lo, nullptr);
 }
 
@@ -406,9 +381,8 @@ extern "C" int ktf_convert_pad(const void* src, int32_t src_dtype, int64_t rows,
         launched = true;                                                                                               \
     }
     bool launched = false;
-    CP_CASE(KTF_F32, float, KTF_F32, float) CP_CASE(KTF_F32, float, KTF_BF16, unsigned short) CP_CASE(KTF_F32, float, KTF_F16, _Float16)
+    CP_CASE(KTF_F32, float, KTF_F32, float) CP_CASE(KTF_F32, float, KTF_BF16, unsigned short)
     CP_CASE(KTF_BF16, unsigned short, KTF_F32, float) CP_CASE(KTF_BF16, unsigned short, KTF_BF16, unsigned short)
-    CP_CASE(KTF_F16, _Float16, KTF_F32, float) CP_CASE(KTF_F16, _Float16, KTF_F16, _Float16)
 #undef CP_CASE
     KTF_REQUIRE(launched, "ktf_convert_pad: unsupported dtype pair %d -> %d", src_dtype, dst_dtype);
     KTF_CHECK_LAUNCH("ktf_convert_pad");

@@ -128,13 +128,8 @@ __device__ __forceinline__ void ring_epilogue(f32x16 (&acc)[4][2], const TdnnPar
 // conflict-free chunk permutation is c ^ ((4 - (row>>2)) & 3) (each ds_read_b128 lane group then covers all 16 slots).
 typedef __attribute__((ext_vector_type(4))) float f32x4v;
 typedef __attribute__((ext_vector_type(8))) _Float16 hfrag8;
-// one 16x16x32 MFMA on 16-bit fragments held as raw 16 bytes: bf16 or (F16) IEEE half operands
-template <bool F16>
 __device__ __forceinline__ f32x4v mfma16x16x32(const bfrag8& a, const bfrag8& b, const f32x4v& c) {
-    if constexpr (F16)
-        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(hfrag8, a), __builtin_bit_cast(hfrag8, b), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
 // per-lane epilogue constants of the 16x16 accumulator layout: bias / BatchNorm scale / shift of the lane's four columns
@@ -162,7 +157,7 @@ __device__ __forceinline__ void st16(u32x4* dst, const u32x4& v) {
 
 // FLAT (tdnn_x3s_kernel's flat row tiling; row-major outputs only): tile row m is output row rowmap[m] of the (B * Tout)-row output
 // (an LDS table behind the staging image), t0 = 0 and out_len = the tile's valid rows.
-template <int ACT, bool STATS, bool F16 = false, bool FLAT = false>
+template <int ACT, bool STATS, bool FLAT = false>
 __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats,
                                                 unsigned char* rsm, int b, int t0, int n0, int out_len, int wm, int wn,
                                                 int wave, int lane, const Epi16Prm& prm, const int* rowmap = nullptr) {
@@ -236,43 +231,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
             }
         }
         __syncthreads();
-        if (p.y_dtype != KTF_F32 && p.ychunk) {
-            // chunk-major 16-bit output: an instruction stores 16 rows of ONE 32-column chunk = 1 KiB of consecutive bytes.
-            // Columns beyond `units` inside the last chunk are stored too: they are exact zeros (zero weight rows, no bias),
-            // which is what the consumer's pad columns must hold.
-            const int piece = lane & 3, rr = lane >> 2;
-            const int64_t nchy = p.ldy >> 5;
-#pragma unroll
-            for (int sp = 0; sp < 4; ++sp) {
-                const int item = sp * 8 + wave;                       // (chunk of the tile, group of 16 staged rows)
-                const int cidx = item & 7, srow = (item >> 3) * 16 + rr;
-                const int m = (srow >> 5) * 128 + pass * 32 + (srow & 31);
-                const int n8 = n0 + cidx * 32 + piece * 8;
-                if (m < rows_valid && n8 < p.ldy) {
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + cidx * 32 + piece * 8);
-                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(et + srow * R_EPI_PITCH + cidx * 32 + piece * 8 + 4);
-                    const int64_t off = (((int64_t)b * nchy + (n8 >> 5)) * p.Tout + (t0 + m)) * 32 + (n8 & 31);
-                    const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    unsigned short hh[8];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(F16 ? fminf(fmaxf(vv[e], -65504.0f), 65504.0f) : vv[e]);   // half planes saturate instead of overflowing to inf
-                    u32x4 pk;
-                    pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);
-                    pk.y = (unsigned)hh[2] | ((unsigned)hh[3] << 16);
-                    pk.z = (unsigned)hh[4] | ((unsigned)hh[5] << 16);
-                    pk.w = (unsigned)hh[6] | ((unsigned)hh[7] << 16);
-                    st16(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y) + off), pk);
-                    if (p.y_lo) {
-                        u32x4 pl;
-                        pl.x = (unsigned)f2bf(vv[0] - bf2f(hh[0])) | ((unsigned)f2bf(vv[1] - bf2f(hh[1])) << 16);
-                        pl.y = (unsigned)f2bf(vv[2] - bf2f(hh[2])) | ((unsigned)f2bf(vv[3] - bf2f(hh[3])) << 16);
-                        pl.z = (unsigned)f2bf(vv[4] - bf2f(hh[4])) | ((unsigned)f2bf(vv[5] - bf2f(hh[5])) << 16);
-                        pl.w = (unsigned)f2bf(vv[6] - bf2f(hh[6])) | ((unsigned)f2bf(vv[7] - bf2f(hh[7])) << 16);
-                        st16(reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(p.y_lo) + off), pl);
-                    }
-                }
-            }
-        } else if (p.y_dtype != KTF_F32) {
+        if (p.y_dtype != KTF_F32) {
             // bf16 output: 16-byte stores (8 columns per lane, two staged rows per wave instruction)
             const int n8 = n0 + (lane & 31) * 8;
 #pragma unroll
@@ -287,7 +246,7 @@ __device__ __forceinline__ void ring_epilogue16(f32x4v (&acc)[8][4], const TdnnP
                     const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     unsigned short hh[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) hh[e] = f2x16<F16>(F16 ? fminf(fmaxf(vv[e], -65504.0f), 65504.0f) : vv[e]);   // half planes saturate instead of overflowing to inf
+                    for (int e = 0; e < 8; ++e) hh[e] = f2bf(vv[e]);
                     if (n8 + 8 <= p.units) {
                         u32x4 pk;
                         pk.x = (unsigned)hh[0] | ((unsigned)hh[1] << 16);

@@ -1,6 +1,5 @@
-// The plane kernels: KTF_GEMM_BF16X3 (split-bf16: x = hi + lo, w = hi + lo, three bf16 MFMA passes, fp32-grade accuracy) and
-// KTF_GEMM_F16X2 (half activations as one plane, weights as hi + lo half planes: two passes, or one where the host dropped the
-// residual) on the 256 x 256 ring tile.
+// The plane kernels of KTF_GEMM_BF16X3 (split-bf16: x = hi + lo, w = hi + lo, three bf16 MFMA passes, fp32-grade accuracy) on the
+// 256 x 256 ring tile.
 #include "tdnn_ring.h"
 
 // ------------------------------------------------------------------------------------ BF16X3, 256x256 tile
@@ -158,12 +157,9 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 }
 
 // ------------------------------------------------------------------------------------ BF16X3 on 16x16x32, split planes
-// The plane kernel. Split-bf16 (TERMS = 3): hi / lo activation planes, hi / lo weight planes, acc += hi*hi + lo*hi + hi*lo on
+// The plane kernel: hi / lo activation planes, hi / lo weight planes, acc += hi*hi + lo*hi + hi*lo on
 // v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on this shape than on 32x32x16): 256 x 256 tile, 8 waves of 128 x 64, a
 // stage = A hi | A lo | W hi | W lo (4 x 16 KiB, the chunk permutation of the 16x16x32 bf16 kernel), double buffered.
-// F16 / TERMS = 2 (KTF_GEMM_F16X2): IEEE-half operands, activations as ONE half plane (no residual plane: the A lo DMAs, fragments
-// and the lo*hi pass drop out; the stage keeps its layout), weights as hi + lo half planes: acc += x*w_hi + x*w_lo. TERMS = 1: no
-// weight residual either (w_lo NULL; three 32 KiB stages).
 // Hand-scheduled K-step: the stage's operand DMAs are not issued in one burst behind the barrier (all eight waves then sit in
 // DMA issue and LDS latency together while the matrix pipes idle) but one at a time between groups of MFMAs, and the A fragments
 // of row group g+1 are read while the MFMAs of group g run (two fragment register sets).
@@ -179,14 +175,14 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // context offsets clamp against the row's own utterance, and the epilogue scatters rows through the same table. `mtiles` carries B.
 #define XS_FLAT_OFF XS_LDS_BYTES                        // rs[260] | out_row[256] | t[256] | len[256]
 #define XS_FLAT_BYTES (260 * 4 + 3 * 256 * 4)
-template <int ACT, bool STATS, bool F16 = false, int TERMS = 3, bool SKIP = false, bool FLAT = false>
+template <int ACT, bool STATS, bool SKIP = false, bool FLAT = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
-    static_assert(!FLAT || (SKIP && !STATS && TERMS == 3 && !F16), "flat row tiling: the split-bf16 plane kernel, rows out");
-    // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered; the 2-pass form leaves the A lo plane unused
-    constexpr int NST = (TERMS == 1) ? KTF_X1_STAGES : 2;
-    constexpr int STG = (TERMS == 1) ? 2 * R_TILE_BYTES : (NST == 3) ? 3 * R_TILE_BYTES : XS_STAGE_BYTES;      // one pass: A | W
-    constexpr int WOFF = (TERMS == 1 || NST == 3) ? R_TILE_BYTES : 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
+    static_assert(!FLAT || (SKIP && !STATS), "flat row tiling: rows out");
+    // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered
+    constexpr int NST = 2;
+    constexpr int STG = XS_STAGE_BYTES;
+    constexpr int WOFF = 2 * R_TILE_BYTES;       // W hi plane inside a stage; W lo follows it
     int fill_slot = 0, cur_slot = 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     const int id = blockIdx.x;
@@ -220,7 +216,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         for (int i = 0; i < 2; ++i) {
             unsigned char* st_ = rsm + wave * 1024;
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);
-            if (TERMS > 1) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + w_ob[i]), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0);
         }
     }
     // (Tried on top: the A half too, clamped to the buffer instead of the utterance -- valid while ctx[0] <= 0 -- and the
@@ -321,10 +317,9 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int nk = p.ktot / R_BK;
     int is_ks = 0, is_c = 0, is_db = 0, is_off = p.ctx[0];
     const int dpad_b = p.din_pad * 2;
-    // A-piece address = row * x_rm + is_xb + chunk: row-major planes x_rm = row pitch, is_xb = byte offset of the 32-feature chunk in
-    // the row; chunk-major planes x_rm = 64, is_xb = chunk index * T * 64 (branch-free: both are wave-uniform scalars)
-    const unsigned x_rm = p.xchunk ? 64u : ldxb;
-    const unsigned x_cs = p.xchunk ? (unsigned)p.T * 64u : (unsigned)(R_BK * 2);
+    // A-piece address = row * x_rm + is_xb + chunk: x_rm = row pitch, is_xb = byte offset of the 32-feature chunk in the row
+    const unsigned x_rm = ldxb;
+    const unsigned x_cs = (unsigned)(R_BK * 2);
     unsigned is_xb = 0;
 #define XS_STAGE()                                                                                                     \
     {                                                                                                                  \
@@ -334,13 +329,13 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             r_ = r_ < 0 ? 0 : (r_ > a_len1[i] ? a_len1[i] : r_);                                                       \
             const unsigned vo_ = a_base[i] + (unsigned)r_ * x_rm + a_cb[i] + is_xb;                                    \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + i * 8192), 16, 0, 0);          \
-            if (TERMS == 3) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xl + vo_), (lds_ptr_t*)(st_ + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         if (!(KTF_X3_WFIRST && is_ks == 0))                  /* stage 0's W half went out at kernel entry */           \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                \
             const unsigned vo_ = w_ob[i] + (unsigned)is_ks * w_step;                                                   \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + WOFF + i * 8192), 16, 0, 0);   \
-            if (TERMS > 1) __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wl + vo_), (lds_ptr_t*)(st_ + WOFF + R_TILE_BYTES + i * 8192), 16, 0, 0); \
         }                                                                                                              \
         fill_slot = (fill_slot + 1 == NST) ? 0 : fill_slot + 1;                                                        \
         ++is_ks;                                                                                                       \
@@ -363,8 +358,6 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         }                                                                                                              \
     }
     XS_STAGE()
-    if (NST >= 3 && nk > 1) XS_STAGE()
-    if (NST >= 4 && nk > 2) XS_STAGE()
     const Epi16Prm eprm = epi16_load(p, n0, wn, lane);      // issued here: the ~1 us of global-load latency hides under the K-loop
     const int fr = (4 - (((lane & 15) >> 2) & 3)) & 3;
     const int coff = (((lane >> 4) ^ fr) << 4);
@@ -374,13 +367,8 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     const int nblk = SKIP ? __builtin_amdgcn_readfirstlane(min(8, max(0, (out_len - t0 - wm * 128 + 15) >> 4))) : 8;
     {
         for (int ks = 0; ks < nk; ++ks) {
-            // stage ks landed: nothing else is in flight (two stages), or only the DMAs of stage ks+1 are (three stages)
-            if (NST == 4 && ks + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // (one-pass form) stages ks + 1, ks + 2 in flight
-            else if (NST >= 3 && ks + 1 < nk) {             // stage ks + 1 may stay in flight: four DMAs per thread, six with a residual plane
-                if (TERMS == 1 || ks + 1 >= p.lo_steps) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // stage ks landed: nothing else is in flight (two stages)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             
@@ -397,8 +385,6 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             (lds_ptr_t*)(st_ + (((n) < 4) ? ((n) & 1) * R_TILE_BYTES : WOFF + ((n) & 1) * R_TILE_BYTES) + (((n) >> 1) & 1) * 8192), 16, 0, \
             0);                                                                  \
     }
-            const bool two = TERMS != 2 || ks < p.lo_steps;              // this step has a weight residual (always, outside the 2-pass form)
-            const bool two_next = TERMS != 2 || is_ks < p.lo_steps;     // ... and so has the stage being fetched
             bfrag8 bh[4], bl[4], af[2][4];                      // af[set][0,1] = hi fragments of the group's two rows, [2,3] = lo
             // fragment reads in the order the MFMAs consume them (LDS returns in order: the first MFMA waits for two reads, not twelve)
             af[0][0] = *reinterpret_cast<const bfrag8*>(sa + a_row_off);
@@ -407,13 +393,11 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 #pragma unroll
             for (int j = 1; j < 4; ++j) bh[j] = *reinterpret_cast<const bfrag8*>(sw + b_row_off + j * 16 * 64);
             __builtin_amdgcn_sched_barrier(0);
-            if (TERMS == 3) af[0][2] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off);
-            if (TERMS > 1 && two) {
+            af[0][2] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
-            }
+            for (int j = 0; j < 4; ++j) bl[j] = *reinterpret_cast<const bfrag8*>(sw + R_TILE_BYTES + b_row_off + j * 16 * 64);
             af[0][1] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + 16 * 64);
-            if (TERMS == 3) af[0][3] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + 16 * 64);
+            af[0][3] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + 16 * 64);
             unsigned va[2], vw[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -423,41 +407,32 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
                 vw[i] = w_ob[i] + (unsigned)is_ks * w_step;
             }
             __builtin_amdgcn_sched_barrier(0);
-            constexpr int PER_ROW = 4 * TERMS, PER_CHUNK = PER_ROW / 2;      // MFMAs per tile row / per chunk (4 chunks per 2-row group)
+            constexpr int PER_ROW = 12, PER_CHUNK = PER_ROW / 2;      // MFMAs per tile row / per chunk (4 chunks per 2-row group)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int cur = g & 1;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24 (4c .. 4c+3 of 16)
-                    // 2-pass form: the odd chunks are the residual passes of the group's two rows; a step behind the residual
-                    // prefix skips them (wave-uniform)
-                    if ((TERMS != 2 || !(c & 1) || two) && (!SKIP || 2 * g < nblk))
+                for (int c = 0; c < 4; ++c) {                  // chunk c = MFMAs 6c .. 6c+5 of the group's 24
+                    if (!SKIP || 2 * g < nblk)
 #pragma unroll
                     for (int m = PER_CHUNK * c; m < PER_CHUNK * c + PER_CHUNK; ++m) {
                         const int r = m / PER_ROW, j = m & 3;                  // row, column block
-                        const int t = (TERMS == 3) ? (m % PER_ROW) / 4 : 2 * ((m % PER_ROW) / 4);   // term: 0 hh, 1 lh, 2 hl
+                        const int t = (m % PER_ROW) / 4;                        // term: 0 hh, 1 lh, 2 hl
                         f32x4v& cc = acc[2 * g + r][j];
-                        cc = mfma16x16x32<F16>(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc);
+                        cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(t == 1 ? af[cur][2 + r] : af[cur][r], t == 2 ? bl[j] : bh[j], cc, 0, 0, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (c == 0 && g < 3) {
 #pragma unroll
                         for (int r = 0; r < 2; ++r) {
                             af[cur ^ 1][r] = *reinterpret_cast<const bfrag8*>(sa + a_row_off + (2 * (g + 1) + r) * 16 * 64);
-                            if (TERMS == 3) af[cur ^ 1][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + (2 * (g + 1) + r) * 16 * 64);
+                            af[cur ^ 1][2 + r] = *reinterpret_cast<const bfrag8*>(sa + R_TILE_BYTES + a_row_off + (2 * (g + 1) + r) * 16 * 64);
                         }
                     }
                     if (refill) {
                         const int n = 4 * g + c;                // slot -> DMA index
-                        if constexpr (TERMS == 3) {
-                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
-                            else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
-                        } else if constexpr (TERMS == 1) {         // one pass: no residual plane at all, four DMAs
-                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) XS_DMA(6)
-                        } else {                                   // no residual plane of the activations: six DMAs
-                            if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(2) else if (n == 2) XS_DMA(4) else if (n == 3) { if (two_next) XS_DMA(5) }
-                            else if (n == 4) XS_DMA(6) else if (n == 5) { if (two_next) XS_DMA(7) }
-                        }
+                        if (n == 0) XS_DMA(0) else if (n == 1) XS_DMA(1) else if (n == 2) XS_DMA(2) else if (n == 3) XS_DMA(3)
+                        else if (n == 4) XS_DMA(4) else if (n == 5) XS_DMA(5) else if (n == 6) XS_DMA(6) else if (n == 7) XS_DMA(7)
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -488,7 +463,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     }
 #undef XS_STAGE
     if (!STATS) __syncthreads();      // all fragment reads done before the LDS is reused as the store staging area
-    ring_epilogue16<ACT, STATS, F16, FLAT>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm,
+    ring_epilogue16<ACT, STATS, FLAT>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm,
                                            FLAT ? reinterpret_cast<const int*>(rsm + XS_FLAT_OFF) + 260 : nullptr);
 }
 
@@ -496,30 +471,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
 // ------------------------------------------------------------------------------------ launcher
 int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int64_t Tout, int64_t ldy, bool split_in, double* stats_sums,
                       hipStream_t st) {
-    const bool half2 = d->gemm == KTF_GEMM_F16X2;
-    const void* w_lo = p.w_lo;
-    if (half2) {
-        const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
-        const int64_t gtiles = B * (int64_t)mtiles;
-        const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles_r;
-        KTF_REQUIRE(nblocks < (1ll << 31), "ktf_tdnn: grid too large");
-        KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn: F16X2 fuses ReLU or no activation");
-#define H2_LAUNCH(A, ST)                                                                                               \
-    do {                                                                                                               \
-        KTF_NOTE_KERNEL(w_lo ? "tdnn_x3s_kernel<f16, 2>" : "tdnn_x3s_kernel<f16, 1>");                                 \
-        if (!w_lo) {                                         /* no residual plane: ONE pass, three 32 KiB stages */     \
-            constexpr int lds1_ = KTF_X1_STAGES * 2 * R_TILE_BYTES > 5 * R_TILE_BYTES ? KTF_X1_STAGES * 2 * R_TILE_BYTES : 5 * R_TILE_BYTES;   /* >= the epilogue's staging image */ \
-            KTF_LDS_ONCE(lds1_, tdnn_x3s_kernel<A, ST, true, 1>);                                                      \
-            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, true, 1>), dim3((unsigned)nblocks), dim3(512), lds1_, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
-        } else {                                                                                                       \
-            KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST, true, 2>);                                               \
-            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, true, 2>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
-        }                                                                                                              \
-    } while (0)
-        if (d->act == KTF_ACT_RELU) { if (stats_sums) H2_LAUNCH(KTF_ACT_RELU, true); else H2_LAUNCH(KTF_ACT_RELU, false); }
-        else { if (stats_sums) H2_LAUNCH(KTF_ACT_NONE, true); else H2_LAUNCH(KTF_ACT_NONE, false); }
-#undef H2_LAUNCH
-    } else {
+    {
         {
             const int mtiles = ktf_cdiv(Tout, R_BM), ntiles_r = ktf_cdiv(d->units, R_BN);
             const int64_t gtiles = B * (int64_t)mtiles;
@@ -540,10 +492,10 @@ int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int6
             const bool skip = 5 * (int64_t)ktf_cdiv(Tout, 16) < 4 * (int64_t)mtiles * 16;
 #define XS_LAUNCH1(A, ST)                                                                                              \
     do {                                                                                                               \
-        KTF_NOTE_KERNEL("tdnn_x3s_kernel<bf16, 3>");                                                                   \
+        KTF_NOTE_KERNEL("tdnn_x3s_kernel");                                                                   \
         if (skip) {                                                                                                    \
-            KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST, false, 3, true>);                                        \
-            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, false, 3, true>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
+            KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST, true>);                                        \
+            hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST, true>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
         } else {                                                                                                       \
             KTF_LDS_ONCE(XS_LDS_BYTES, tdnn_x3s_kernel<A, ST>);                                                        \
             hipLaunchKernelGGL((tdnn_x3s_kernel<A, ST>), dim3((unsigned)nblocks), dim3(512), XS_LDS_BYTES, st, p, mtiles, ntiles_r, (int)gtiles, stats_sums); \
@@ -555,21 +507,20 @@ int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int6
     } while (0)
             // hi / lo planes in: the 16x16x32 plane kernel; fp32 activations in: the kernel that splits them in registers
             if (split_in && p.row_starts) {              // ktf_tdnn_split_flat: M-tiles over the batch's valid rows laid end to end
-                KTF_REQUIRE(!stats_sums && !d->valid && d->subsampling == 1 && !p.xchunk && !p.ychunk,
-                            "ktf_tdnn_split_flat: SAME padding, no subsampling, row-major planes, rows out");
+                KTF_REQUIRE(!stats_sums && !d->valid && d->subsampling == 1, "ktf_tdnn_split_flat: SAME padding, no subsampling, rows out");
                 KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn_split_flat: fuses ReLU or no activation");
                 KTF_REQUIRE(B <= 4095 && B * p.T * p.ldx * 2 < (1ll << 32), "ktf_tdnn_split_flat: B <= 4095 and B * T * ldx * 2 < 2^32");
                 const int64_t ftiles = ktf_cdiv(B * p.T, R_BM);
                 const int64_t fblocks = ((ftiles + 7) / 8) * 8 * ntiles_r;
                 KTF_REQUIRE(fblocks < (1ll << 31), "ktf_tdnn: grid too large");
                 constexpr int lds_ = XS_LDS_BYTES + XS_FLAT_BYTES;
-                KTF_NOTE_KERNEL("tdnn_x3s_kernel<bf16, 3, flat>");
+                KTF_NOTE_KERNEL("tdnn_x3s_kernel<flat>");
                 if (d->act == KTF_ACT_RELU) {
-                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, false, false, 3, true, true>);
-                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, false, false, 3, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
+                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, false, true, true>);
+                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, false, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
                 } else {
-                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, false, false, 3, true, true>);
-                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, false, false, 3, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
+                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, false, true, true>);
+                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, false, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
                 }
             } else
             if (split_in) {

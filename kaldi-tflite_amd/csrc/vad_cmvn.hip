@@ -130,8 +130,6 @@ template <>
 __device__ __forceinline__ void store_out<float>(float* p, float v) { *p = v; }
 template <>
 __device__ __forceinline__ void store_out<unsigned short>(unsigned short* p, float v) { *p = f2bf(v); }
-template <>
-__device__ __forceinline__ void store_out<_Float16>(_Float16* p, float v) { *p = (_Float16)v; }
 
 // CMVN of one utterance: rows r < len, row r read at x[(inv ? inv[r] : r) * ldx + d].
 // The (compacted) rows are first staged contiguously into `xs` (len*D floats: LDS when the utterance fits, else the
@@ -518,7 +516,7 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     if (rc) return rc;
     KTF_REQUIRE(out && lens && idx_work && work, "ktf_vad_cmvn: null argument");
     KTF_REQUIRE(ldo >= D && ldo <= VC_GM / 4, "ktf_vad_cmvn: ldo must be in [D, %d]", VC_GM / 4);
-    KTF_REQUIRE(out_dtype == KTF_F32 || out_dtype == KTF_BF16 || out_dtype == KTF_F16, "ktf_vad_cmvn: bad out_dtype");
+    KTF_REQUIRE(out_dtype == KTF_F32 || out_dtype == KTF_BF16, "ktf_vad_cmvn: bad out_dtype");
     KTF_REQUIRE(T < (1ll << 31) / (ldo > 0 ? ldo : 1), "ktf_vad_cmvn: T*ldo too large");
     if (B == 0) return KTF_OK;
     if (T == 0) {
@@ -551,8 +549,6 @@ extern "C" int ktf_vad_cmvn(const float* feats, int64_t B, int64_t T, int32_t D,
     }
     if (out_dtype == KTF_F32) {
         if (ldsf) VC_LAUNCH(float, true) else VC_LAUNCH(float, false)
-    } else if (out_dtype == KTF_F16) {
-        if (ldsf) VC_LAUNCH(_Float16, true) else VC_LAUNCH(_Float16, false)
     } else {
         if (ldsf) VC_LAUNCH(unsigned short, true) else VC_LAUNCH(unsigned short, false)
     }

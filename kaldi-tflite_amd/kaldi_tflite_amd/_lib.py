@@ -17,20 +17,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _OVERRIDE = os.environ.get("KTF_LIBRARY") if os.environ.get("KTF_ALLOW_LIBRARY_OVERRIDE") == "1" else None
 LIB_PATH = _OVERRIDE or os.path.join(_HERE, "libktf_hip.so")
 
-KTF_F32, KTF_BF16, KTF_F16, KTF_BF16P = 0, 1, 2, 3
+KTF_F32, KTF_BF16, KTF_BF16P = 0, 1, 3
 PAIR = "bf16p"                    # stands for KTF_BF16P where a torch dtype is expected: pairs live in float32 tensors
-GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16, GEMM_F16X2, GEMM_F16MX, GEMM_BF16X4 = 0, 1, 2, 3, 4, 5, 6
+GEMM_F32, GEMM_BF16, GEMM_BF16X3, GEMM_F16MX, GEMM_BF16X4 = 0, 1, 2, 5, 6
 ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
 (ACT_ELU, ACT_SELU, ACT_SOFTPLUS, ACT_SOFTSIGN, ACT_SWISH, ACT_GELU, ACT_EXPONENTIAL, ACT_HARD_SIGMOID,
  ACT_SOFTMAX) = range(4, 13)         # run as a pass of their own (ktf_activation_f32)
-TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED, TDNN_X_CHUNKED, TDNN_Y_CHUNKED = 1, 2, 4, 8, 16, 32   # KtfTdnnDesc.flags
+TDNN_REF_TILES, TDNN_DET_STATS, TDNN_K_INTERLEAVED, TDNN_W_TILED = 1, 2, 4, 8   # KtfTdnnDesc.flags
 TAIL_SKIP_EMPTY = 1                 # ktf_xvec_tail_f32 flags
 TDNN_MX_LOADER = 1 << 24          # ktf_tdnn_mx*: the loader-wave kernel (csrc/tdnn_mxl.hip) and its weight images
 
-
-def TDNN_LO_PREFIX(chunks):
-    """KtfTdnnDesc.flags bits 8..23: only the first `chunks` 32-feature chunks have a weight residual (include/ktf_hip.h)."""
-    return (int(chunks) + 1) << 8
 IN_WAV, IN_FRAMES, IN_WINDOWED, IN_WAV_I16 = 0, 1, 2, 3
 OUT_FRAMES, OUT_WINDOWED, OUT_FBANK, OUT_MFCC = 0, 1, 2, 3
 
@@ -42,13 +38,13 @@ class KtfBackendError(RuntimeError):
 def ktf_dtype(t):
     """torch dtype -> KTF_* element type of an activation / weight buffer."""
     import torch
-    return {torch.float32: KTF_F32, torch.bfloat16: KTF_BF16, torch.float16: KTF_F16, PAIR: KTF_BF16P}[t]
+    return {torch.float32: KTF_F32, torch.bfloat16: KTF_BF16, PAIR: KTF_BF16P}[t]
 
 
 def act_torch_dtype(gemm):
     """Storage dtype of the frame-level activations for a GEMM mode."""
     import torch
-    return {GEMM_BF16: torch.bfloat16, GEMM_F16: torch.float16, GEMM_F16X2: torch.float16}.get(gemm, torch.float32)
+    return {GEMM_BF16: torch.bfloat16}.get(gemm, torch.float32)
 
 
 class FrontendCfg(C.Structure):

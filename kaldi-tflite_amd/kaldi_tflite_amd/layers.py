@@ -35,7 +35,7 @@ def _to_device(x):
     if isinstance(x, torch.Tensor):
         if not x.is_cuda:
             x = x.to(dev)
-        if x.dtype not in (torch.float32, torch.float64, torch.bfloat16, torch.float16):
+        if x.dtype not in (torch.float32, torch.float64, torch.bfloat16):
             x = x.to(torch.float32)
         return x
     a = np.asarray(x)
@@ -669,7 +669,7 @@ def reshapeKaldiTdnnWeights(weights, units, kernel_width):
     return weights.flatten().reshape((1, -1, kernel_width, units), order="F").transpose([0, 2, 1, 3])
 
 
-WEIGHTS_EPOCH = [0]      # bumped by every set_weights / re-build / calibration in the process: a cheap "anything changed?" for captured graphs
+WEIGHTS_EPOCH = [0]      # bumped by every set_weights / re-build in the process: a cheap "anything changed?" for captured graphs
 
 # every name tf.keras.activations.get resolves in the reference's TensorFlow (2.8; layers/tdnn/tdnn.py:117-118). The GEMM epilogues
 # fuse the first four; the others run as a second launch over the layer's output (ktf_tdnn does that itself, fp32 kernels only)
@@ -677,13 +677,13 @@ _ACTS = {None: L.ACT_NONE, "linear": L.ACT_NONE, "relu": L.ACT_RELU, "sigmoid": 
          "elu": L.ACT_ELU, "selu": L.ACT_SELU, "softplus": L.ACT_SOFTPLUS, "softsign": L.ACT_SOFTSIGN, "swish": L.ACT_SWISH,
          "gelu": L.ACT_GELU, "exponential": L.ACT_EXPONENTIAL, "hard_sigmoid": L.ACT_HARD_SIGMOID, "softmax": L.ACT_SOFTMAX}
 _GEMM = {"f32": L.GEMM_F32, "float32": L.GEMM_F32, "bf16": L.GEMM_BF16, "bfloat16": L.GEMM_BF16, "bf16x3": L.GEMM_BF16X3,
-         "f16": L.GEMM_F16, "float16": L.GEMM_F16, "f16x2": L.GEMM_F16X2, "f16mx": L.GEMM_F16MX}
+         "f16mx": L.GEMM_F16MX}
 
 
 class TDNN(Layer):
     """layers/tdnn/tdnn.py:29 — irregular-context 1-D convolution as an implicit-im2col MFMA GEMM."""
 
-    MAX_DEVICE_SETS = 4        # device operand sets kept per layer AND DEVICE (keyed by mode / fold / calibration): the oldest set of
+    MAX_DEVICE_SETS = 4        # device operand sets kept per layer AND DEVICE (keyed by mode / layout): the oldest set of
                                # the same device is evicted; sets on other devices (other ranks' streams may be reading them) stay
 
     def __init__(self, units, context=[0], subsampling_factor=1, padding="SAME", use_bias=True, kernel_initializer=None,
@@ -720,7 +720,7 @@ class TDNN(Layer):
         self.bias = None
         self.kernelFlags = 0   # KtfTdnnDesc.flags of this layer's launches (L.TDNN_REF_TILES: bitwise-reference fp32 tiles)
         self._dev = {}
-        self._version = 0      # bumped whenever the weights change: models drop calibration / refuse stale captured graphs
+        self._version = 0      # bumped whenever the weights change: models refuse stale captured graphs
 
     # ---- weights
     def build(self, input_shape):
@@ -779,66 +779,17 @@ class TDNN(Layer):
         K, D = self.kernelWidth, self.inputDim
         return np.ascontiguousarray(self.kernel[0].reshape(K * D, self.units).T)
 
-    def device_weights(self, device, gemm, k_interleaved=False, fold=None, w_tiled=False, one_pass_mean=None,
-                       in_perm=None, out_perm=None, lo_keep=None):
-        """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for the two-part modes),
-        bias. `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, split-plane
-        kernel. `fold`: the BatchNorm whose affine y = s*x + h precedes this layer and is folded INTO it, so that the stored
-        activations are the ReLU outputs themselves: W'[u,k,d] = W[u,k,d] * s[d], b'[u] = b[u] + sum_kd W[u,k,d] * h[d]
-        (float64 on the host; exact for replicate padding, every context row carries the same per-feature affine).
-        `one_pass_mean` (F16X2 only): (D,) mean of the stored input activations -> the weights as ONE half plane (w_lo is
-        None: the kernel runs one pass): rounded to nearest, and the constant part of the rounding error,
-        sum_kd (w_half - w)[u,k,d] * mean[d], subtracted from the fp32 bias. What is left of the weight rounding is
-        zero-mean over the frames, which is why this is offered for layers whose output is pooled right away.
-        `in_perm` / `out_perm`: the stored input plane holds feature in_perm[j] at position j / this layer writes unit
-        out_perm[j] at position j (the model orders a plane by decreasing activation variance). `lo_keep` (F16X2, with
-        one_pass_mean): only the first lo_keep positions of the (permuted) input keep their weight residual
-        (KTF_TDNN_LO_PREFIX); the columns behind them are rounded to nearest half and bias-corrected like a one-pass layer.
-        Means and the folded BatchNorm are given in the ORIGINAL feature order."""
-        opm = None if one_pass_mean is None else np.asarray(one_pass_mean, np.float64)
-        ip = None if in_perm is None else np.asarray(in_perm, np.int64)
-        op = None if out_perm is None else np.asarray(out_perm, np.int64)
-        key = (str(device), gemm, bool(k_interleaved), None if fold is None else (id(fold), fold._version), bool(w_tiled),
-               None if opm is None else zlib.crc32(opm.tobytes()), None if ip is None else zlib.crc32(ip.tobytes()),
-               None if op is None else zlib.crc32(op.tobytes()), lo_keep)
+    def device_weights(self, device, gemm, k_interleaved=False, w_tiled=False):
+        """Padded GEMM operands on the device: W (units_pad, K*Dpad) in the GEMM's dtype (+ lo part for the split-bf16 mode),
+        bias. `k_interleaved`: K axis ordered (32-feature chunk, context, feature) — KTF_TDNN_K_INTERLEAVED, `w_tiled`: the
+        kernel's LDS stage images (KTF_TDNN_W_TILED); both for the split-plane kernel."""
+        key = (str(device), gemm, bool(k_interleaved), bool(w_tiled))
         if key in self._dev:
             return self._dev[key]
         K, D = self.kernelWidth, self.inputDim
         Dp, Up = ops.round_up(D, 32), ops.round_up(self.units, 256)
         Wk = np.transpose(self.kernel[0], (2, 0, 1)).astype(np.float64)       # [u, k, d]
         bias64 = self.bias.astype(np.float64) if self.useBias else None
-        if fold is not None:
-            s64, h64 = fold.affine64()
-            if s64.shape != (D,):
-                raise ValueError(f"cannot fold a {s64.shape[0]}-wide BatchNorm into a layer with input dim {D}")
-            extra = np.einsum("ukd,d->u", Wk, h64)
-            bias64 = extra if bias64 is None else bias64 + extra
-            Wk = Wk * s64[None, None, :]
-        if opm is not None:
-            if gemm != L.GEMM_F16X2:
-                raise ValueError("one_pass_mean applies to the F16X2 mode")
-            if opm.shape != (D,):
-                raise ValueError(f"one_pass_mean has shape {opm.shape}, the layer's input dim is {D}")
-            Wh = Wk.astype(np.float16).astype(np.float64)
-            if lo_keep is not None:                      # only the features stored behind position lo_keep lose their residual
-                order = np.arange(D) if ip is None else ip
-                keep = np.zeros(D, bool)
-                keep[order[:lo_keep]] = True
-                Wh[:, :, keep] = Wk[:, :, keep]
-            corr = np.einsum("ukd,d->u", Wh - Wk, opm)
-            bias64 = -corr if bias64 is None else bias64 - corr
-            Wk = Wh
-        elif lo_keep is not None:
-            raise ValueError("lo_keep needs one_pass_mean (the bias correction of the dropped residual columns)")
-        if ip is not None:
-            if sorted(ip.tolist()) != list(range(D)):
-                raise ValueError("in_perm is not a permutation of the input features")
-            Wk = Wk[:, :, ip]
-        if op is not None:
-            if sorted(op.tolist()) != list(range(self.units)):
-                raise ValueError("out_perm is not a permutation of the units")
-            Wk = Wk[op]
-            bias64 = None if bias64 is None else bias64[op]
         W = np.zeros((Up, K, Dp), np.float64)
         W[: self.units, :, :D] = Wk
         if k_interleaved:
@@ -858,18 +809,14 @@ class TDNN(Layer):
             w = W.to(torch.float32)
         elif gemm == L.GEMM_BF16X4:
             w = ops.pair_encode(W.to(torch.float32))
-        elif gemm == L.GEMM_F16X2:
-            w = W.to(torch.float16)
-            if opm is None or lo_keep is not None:       # (one pass: no residual plane at all)
-                w_lo = (W - w.to(torch.float64)).to(torch.float16)
         else:
             W = W.to(torch.float32)
-            w = W.to(torch.float16 if gemm == L.GEMM_F16 else torch.bfloat16)
+            w = W.to(torch.bfloat16)
             if gemm == L.GEMM_BF16X3:
                 w_lo = (W - w.to(torch.float32)).to(torch.bfloat16)
         bias = ops.to_device_f32(bias64, device) if bias64 is not None else None
         mine = [k for k in self._dev if k[0] == str(device)]
-        while len(mine) >= self.MAX_DEVICE_SETS:             # re-calibration / mode changes replace operand sets: evict this device's oldest
+        while len(mine) >= self.MAX_DEVICE_SETS:             # mode changes replace operand sets: evict this device's oldest
             self._dev.pop(mine.pop(0))
         self._dev[key] = (w, w_lo, bias)
         return self._dev[key]
@@ -879,8 +826,9 @@ class TDNN(Layer):
         the weights as the LDS images of the kernel that will read them (include/ktf_hip.h, ktf_tdnn_mx). `kernel`: "tile" = the
         256 x 256 kernel (mx.weight_images), "loader" = the loader-wave kernel (KTF_TDNN_MX_LOADER: mx.weight_images_loader);
         None: "loader" / "tile" by `loader`. K ordered (32-feature chunk, context, feature) and zero-padded to
-        whole super-steps. `fold`: the BatchNorm in front of this layer folded INTO it (see device_weights): the stored
-        activations are then the ReLU outputs themselves."""
+        whole super-steps. `fold`: the BatchNorm whose affine y = s*x + h precedes this layer, folded INTO it so that the stored
+        activations are the ReLU outputs themselves: W'[u,k,d] = W[u,k,d] * s[d], b'[u] = b[u] + sum_kd W[u,k,d] * h[d] (float64 on
+        the host; exact for replicate padding, every context row carries the same per-feature affine)."""
         from . import mx
         kernel = kernel or ("loader" if loader else "tile")
         if kernel not in ("loader", "tile"):
@@ -921,7 +869,7 @@ class TDNN(Layer):
         d.act = _ACTS[a.lower() if isinstance(a, str) else a]
         d.gemm = gemm
         d.x_dtype = L.ktf_dtype(x_dtype)
-        d.w_dtype = {L.GEMM_F32: L.KTF_F32, L.GEMM_F16: L.KTF_F16, L.GEMM_F16X2: L.KTF_F16, L.GEMM_BF16X4: L.KTF_BF16P}.get(gemm, L.KTF_BF16)
+        d.w_dtype = {L.GEMM_F32: L.KTF_F32, L.GEMM_BF16X4: L.KTF_BF16P}.get(gemm, L.KTF_BF16)
         d.y_dtype = L.ktf_dtype(y_dtype)
         return d
 
@@ -977,7 +925,7 @@ class TDNN(Layer):
         return out
 
     def effective_gemm(self, gemm, relu=False):
-        """The half-precision modes run on the ring / MX kernels only (units > 128, ReLU or no activation); any other layer of
+        """The f16mx mode runs on the MX kernels only (units > 128, ReLU or no activation); any other layer of
         such a model is evaluated by the exact fp32 kernel instead. A pure query (the fused runner's planner asks it for every
         layer, and for the layer behind it): `warn_fallback` is what tells the user."""
         return L.GEMM_F32 if self.fallback_reason(gemm, relu) else gemm
@@ -989,7 +937,7 @@ class TDNN(Layer):
             return None
         if _ACTS[a] > L.ACT_TANH:            # activations no epilogue fuses: the fp32 kernels + an activation pass, in every mode
             return f"activation {self.activation!r} is not fused by any reduced-precision epilogue"
-        if gemm not in (L.GEMM_F16, L.GEMM_F16X2, L.GEMM_F16MX):
+        if gemm != L.GEMM_F16MX:
             return None
         if self.units <= 128:
             return f"units = {self.units} (these kernels tile 256 units: layers of up to 128 stay on fp32)"
@@ -1016,7 +964,7 @@ class TDNN(Layer):
         want = L.act_torch_dtype(gemm)
         if D == Dp and x.dtype == want and x.is_contiguous():
             return x
-        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16) or (x.dtype != torch.float32 and x.dtype != want):
+        if x.dtype not in (torch.float32, torch.bfloat16) or (x.dtype != torch.float32 and x.dtype != want):
             x = x.to(torch.float32)
         dst = torch.empty((*x.shape[:-1], Dp), dtype=want, device=x.device)
         return ops.convert_pad(x.contiguous(), D, dst)
@@ -1034,7 +982,7 @@ class TDNN(Layer):
             return self._call_mx(x)
         # the 16-bit ring kernels want an output row stride that is a multiple of 8 (16-byte stores); the pad columns
         # are sliced off again
-        ldy = ops.round_up(self.units, 8) if gemm in (L.GEMM_BF16, L.GEMM_F16) else self.units
+        ldy = ops.round_up(self.units, 8) if gemm == L.GEMM_BF16 else self.units
         if T == 1 and list(self.context) == [0] and self.subsamplingFactor == 1 and B > 1:
             # one row per utterance (e.g. the affine after stats pooling): run as ONE B-row GEMM (context [0] only: another offset
             # would clamp to the neighbouring UTTERANCES' rows there, not to the utterance's single frame)
@@ -1052,7 +1000,7 @@ class TDNN(Layer):
         planes = mx.Planes.empty(B, T, D, x.device)
         ops.mx_planes(src, D, None, planes)
         wh, wq, bias = self.device_weights_mx(x.device, loader=False)
-        d = self.desc(L.GEMM_F16MX, torch.float16, torch.float32)
+        d = self.desc(L.GEMM_F16MX, torch.float32, torch.float32)
         if self.outputTimesteps(T) <= 0:               # VALID padding of an input shorter than the context: no output row
             return torch.empty((B, 0, self.units), dtype=torch.float32, device=x.device)
         y = torch.empty((B, self.outputTimesteps(T), ops.round_up(self.units, 4)), dtype=torch.float32, device=x.device)
@@ -1127,7 +1075,7 @@ class StatsPooling(Layer):
         return out
 
     def call(self, inputs):
-        x = inputs if inputs.dtype in (torch.float32, torch.bfloat16, torch.float16) else inputs.to(torch.float32)
+        x = inputs if inputs.dtype in (torch.float32, torch.bfloat16) else inputs.to(torch.float32)
         x = x.contiguous()
         B, T, D = x.shape
         od = 2 * D if self.includeStd else D

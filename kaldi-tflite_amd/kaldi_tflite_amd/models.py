@@ -128,21 +128,12 @@ class DeferredTail:
 class Sequential:
     """Keras-Sequential stand-in: `.layers`, `.name`, `mdl(x, training=False)`, `get_layer`, `summary`.
     `gemm` selects the TDNN arithmetic of the fused runner: "f32" (exact fp32 MFMA, default = the reference's
-    precision), "bf16x3" (split-bf16, fp32-grade), "f16x2" (two half-precision passes: exact weights, half activations with
-    BatchNorm folded forward — inside the 1e-4 x-vector tolerance at two thirds of the split-bf16 matrix work; after
-    calibrate() / calibrate_from_batchnorm() the weight residual, i.e. the second pass, is kept only where it matters:
-    `one_pass_tail`, `lo_fraction`), "bf16" or "f16" (one pass, outside that tolerance)."""
+    precision), "bf16x3" (split-bf16, fp32-grade), "f16mx" (one half-precision pass + two block-scaled residual passes:
+    inside the 1e-4 x-vector tolerance at half the split-bf16 matrix work, the timed mode), "bf16" (one pass, outside that tolerance)."""
 
     split_planes = True         # bf16x3: hi/lo bf16 activation planes between the wide layers (no in-loop conversion)
     k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
     w_tiled = True              # ... and the weights stored as the kernel's LDS stage images (contiguous 1 KiB per DMA instruction)
-    chunked = True              # f16x2: the half plane between two layers of the route is stored (chunk of 32 features, row, 32)
-    lo_fraction = 0.5           # f16x2, calibrated: in the two-pass layers in front of the one-pass tail, this fraction of the input
-                                # features -- the ones with the lowest activation variance; the producing layer writes its plane
-                                # in that order -- carries no weight residual (KTF_TDNN_LO_PREFIX); 0 = every feature keeps it
-    one_pass_tail = 2           # f16x2: the last N frame-level layers in front of the pooling run ONE half pass (weights rounded to
-                                # nearest half, the constant part of the rounding error moved into the fp32 bias) once calibrate()
-                                # has measured the mean of their input planes; 0 = every layer two passes
     # Routing defaults, copied into every instance (`self.min_tiles`, `self.min_frames`: per-model knobs, no shared mutable state).
     # MIN_TILES: batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times).
     # MIN_FRAMES: batches whose utterances are shorter than this many frames run the next tighter mode: the block-scaled residuals
@@ -150,7 +141,7 @@ class Sequential:
     # the utterance shrinks (measured on speech windows with BatchNorm statistics that are the network's own, tests/test_gpu_margin.py:
     # 10 s 2-5e-5, 5 s 5-6.5e-5, 3 s 6-7.5e-5, 1.5 s up to 1.2e-4 -- outside the 1e-4 tolerance); below 4 s the split-bf16 kernels
     # (1.5e-5) take the batch, and XvectorExtractor applies the same rule per utterance on the device (route_short_utterances).
-    MIN_TILES = {"bf16": 12, "f16": 12, "bf16x3": 32, "f16x2": 20, "f16mx": 20}      # (tools/small_batch_crossover.py, 10 s utterances =
+    MIN_TILES = {"bf16": 12, "bf16x3": 32, "f16mx": 20}      # (tools/small_batch_crossover.py, 10 s utterances =
                                                                                      # 4 tiles each: bf16 from 3, f16mx from 5, bf16x3 from 8)
     MIN_FRAMES = {"f16mx": 400}
     SHORT_MODE = {"f16mx": "bf16x3"}
@@ -192,10 +183,6 @@ class Sequential:
         self.dtype = "float32"
         self._ws_own = _Workspace()
         self._tl = threading.local()  # per host thread: a workspace override (XvectorExtractor.compile), the deferred tail of the call in flight
-        self._xbar = {}              # calibrate(): id(layer) -> (D,) float64 mean of the layer's stored input plane
-        self._xvar = {}              # ... and its variance
-        self._calibrating = None
-        self._cal_sig = None         # weights signature the calibration statistics belong to
         self._build()
 
     def _build(self):
@@ -231,8 +218,8 @@ class Sequential:
         return base
 
     def weights_signature(self):
-        """Changes whenever a TDNN / BatchNorm layer's weights change (set_weights, a re-build): calibration statistics and
-        captured graphs are tied to it."""
+        """Changes whenever a TDNN / BatchNorm layer's weights change (set_weights, a re-build): captured graphs
+        are tied to it."""
         return tuple((id(l), l._version) for l in self.layers if isinstance(l, (TDNN, BatchNorm)))
 
     def get_layer(self, name):
@@ -328,11 +315,9 @@ class Sequential:
         cost_loader = rounds(2 * ((B * T + 191) // 192)) * 192 * 1.05
         return cost_loader < cost_256
 
-    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, fold=None, flags=0, one_pass_mean=None,
-                        in_perm=None, defer_to=None):
+    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, defer_to=None):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
-        `split`: the input is a (2,B,T,ld) pair of bf16 planes or ONE (B,T,ld) half plane (F16X2) read by the split-plane
-        kernel; `fold`: the preceding BatchNorm folded into this layer's weights. Returns the pooled (1, B, od) view."""
+        `split`: the input is a (2,B,T,ld) pair of bf16 planes read by the split-plane kernel. Returns the pooled (1, B, od) view."""
         sp = nxt[1]
         D = l.units
         od = 2 * D if sp.includeStd else D
@@ -343,24 +328,17 @@ class Sequential:
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev, padded=od if ld != od else False)
         kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
         wt = bool(split and self.w_tiled)
-        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=wt, one_pass_mean=one_pass_mean,
-                                         in_perm=in_perm)
+        w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, w_tiled=wt)
         scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
         xdt = x_or_planes.dtype
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
-                   flags=flags | (L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if wt else 0))
+                   flags=(L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if wt else 0))
         (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
         if defer_to is not None:         # the caller's fused tail finalizes the sums itself
             self._deferred = DeferredTail(defer_to, B, D, sp.includeStd, sp.epsilon, sums=sums, slots=slots, lens=lens, T=T)
             return sbuf[:, :od].unsqueeze(0)
         ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf, slots=slots)
         return sbuf[:, :od].unsqueeze(0)
-
-    def _partial_ok(self, l, left):
-        """May layer `l` (with `left` frame-level layers up to and including the pooled one) drop the weight residual of its
-        low-variance input features? Calibrated, K-interleaved, at least two 32-feature chunks, not in the one-pass tail."""
-        return bool(self.lo_fraction > 0 and self._calibrating is None and id(l) in self._xvar and self.k_interleaved and
-                    l.kernelWidth > 1 and l.inputDim >= 64 and left > self.one_pass_tail)
 
     def _tail_step(self, steps):
         """Index of the last step if it is a plain affine (context [0], no activation / BatchNorm) right after a reducing
@@ -383,8 +361,6 @@ class Sequential:
             raise NotImplementedError("this layer stack is not supported by the fused ragged runner")
         dev = x.device
         self._ws.enter(dev)
-        if (self._xbar or self._xvar) and self._calibrating is None and self._cal_sig != self.weights_signature():
-            self._xbar, self._xvar = {}, {}      # the weights changed since calibrate(): its statistics describe another network
         gemm, pairs = self._batch_route(x.shape[0], x.shape[1], mode=mode)
         x_pair = False                                   # x holds KTF_BF16P pairs (in a float32 tensor)
         row_starts = None                                # prefix sums of lens for the layers on flat row tiles: made when the first one runs,
@@ -398,10 +374,7 @@ class Sequential:
         # of fp32, so the GEMM K-loop carries no conversion (ktf_tdnn_split); `planes` holds them while they exist
         use_planes = gemm == L.GEMM_BF16X3 and self.split_planes
         planes = None
-        stats_at = next((i for i, q in enumerate(steps) if q[0] == "stats"), -1)      # F16X2 one-pass policy counts layers back from here
-        pending_bn = None            # F16X2: the BatchNorm of the previous layer, to be folded into the next layer's weights
-        cur_perm = None              # F16X2: feature order of the current activation plane (None = natural)
-        x_chunked = False            # F16X2: the current activation buffer is chunk-major (KTF_TDNN_Y_CHUNKED of its producer)
+        pending_bn = None            # F16MX: the BatchNorm of the previous layer, to be folded into the next layer's weights
         mxp = None                   # F16MX: the current activations as the four MX planes (mx.Planes)
         for si, st in enumerate(steps):
             if skip:
@@ -441,7 +414,7 @@ class Sequential:
                 kern = "loader" if use_loader else "tile"
                 wh, wq, bias = l.device_weights_mx(dev, fold=fold, kernel=kern)
                 mxf = L.TDNN_MX_LOADER if use_loader else 0
-                d = l.desc(gemm, torch.float16, torch.float16, act="relu" if relu else None, flags=mxf)
+                d = l.desc(gemm, torch.float32, torch.float32, act="relu" if relu else None, flags=mxf)      # (the MX entry points read no dtype field)
                 if can_pool:                             # ... -> reducing StatsPooling inside the epilogue (BatchNorm applied there)
                     sp = nxt[1]
                     od = 2 * l.units if sp.includeStd else l.units
@@ -482,66 +455,6 @@ class Sequential:
                 continue
             if mxp is not None:
                 raise RuntimeError("internal: MX planes reached a layer that cannot read them")
-            if (gemm == L.GEMM_F16X2 and st[0] == "tdnn" and not pooled and l.effective_gemm(gemm, relu) == gemm):
-                # half passes (two per product; one where calibrate() lets the weight residual go: the layers in front of the
-                # pooling, the low-variance input features of the others): activations travel as ONE half plane holding the
-                # ReLU outputs; this layer's BatchNorm is not applied in its epilogue but folded into the weights of the next
-                # layer when that one runs here too
-                if x.dtype != torch.float16 or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32) \
-                        or x.stride(0) != x.shape[1] * x.stride(1):
-                    x = _padded_copy(x, torch.float16)
-                B, T, _ = x.shape
-                xin = x                                  # the kernel takes the row stride from the view
-                fold, pending_bn = pending_bn, None
-                if self._calibrating is not None:        # calibrate(): mean / variance of this layer's stored input plane over the valid frames
-                    self._calibrating[id(l)] = _plane_stats(xin, lens, l.inputDim, x_chunked)
-                left = sum(1 for q in steps[si:stats_at] if q[0] == "tdnn") if stats_at > si else 0      # 1 = the pooled layer
-                opm = self._xbar.get(id(l)) if (self.one_pass_tail and 0 < left <= self.one_pass_tail and self._calibrating is None) else None
-                kint = bool(self.k_interleaved and l.kernelWidth > 1)
-                kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if self.w_tiled else 0) | \
-                        (L.TDNN_X_CHUNKED if x_chunked else 0)
-                x_chunked = False
-                in_perm, cur_perm = cur_perm, None
-                if can_pool:
-                    x = self._pooled_by_gemm(l, relu, bn, nxt, xin, lens, gemm, True, dev, T, fold=fold, flags=kflag & L.TDNN_X_CHUNKED,
-                                             one_pass_mean=opm, in_perm=in_perm, defer_to=steps[tail_at][1] if si + 2 == tail_at else None)
-                    lens, pooled, skip = None, True, True
-                    continue
-                nl = nxt[1] if nxt is not None and nxt[0] == "tdnn" else None
-                defer_bn = (bn is not None and nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm)
-                # residual prefix: this layer's input plane was written in order of decreasing variance by its producer
-                lo_keep = None
-                if in_perm is not None and opm is None and self._partial_ok(l, left):
-                    keep = ops.round_up(int(math.ceil((1.0 - self.lo_fraction) * l.inputDim)), 32)
-                    if 32 <= keep < l.inputDim:
-                        lo_keep, opm = keep, self._xbar[id(l)]
-                        kflag |= L.TDNN_LO_PREFIX(keep // 32)
-                # ... and this layer orders ITS plane for a consumer that will do the same
-                out_perm = None
-                if defer_bn and nl is not None and self.chunked and self._partial_ok(nl, left - 1) and nl.inputDim == l.units:
-                    out_perm = np.argsort(-self._xvar[id(nl)], kind="stable")
-                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, fold=fold, w_tiled=self.w_tiled, one_pass_mean=opm,
-                                                 in_perm=in_perm, out_perm=out_perm, lo_keep=lo_keep)
-                cur_perm = out_perm
-                scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
-                Tout = l.outputTimesteps(T)
-                ldy = ops.round_up(l.units, 32)
-                out_lens = None
-                if lens is not None and (l.padding == "VALID" or l.subsamplingFactor != 1):
-                    out_lens = torch.empty_like(lens)
-                ydt = torch.float16 if nl is not None and nl.effective_gemm(gemm, nxt[2]) == gemm else torch.float32
-                ybuf = self._ws.get(out_role, (B, Tout, ldy), ydt, dev, padded=ldy != l.units)
-                if ydt == torch.float16 and self.chunked:          # only a layer of this route reads it: chunk-major plane
-                    kflag |= L.TDNN_Y_CHUNKED
-                    x_chunked = True
-                d = l.desc(gemm, torch.float16, ydt, act="relu" if relu else None, flags=kflag)
-                ops.tdnn_split(xin, lens, d, w, w_lo, bias, scale, shift, ybuf, None, out_lens)
-                if defer_bn:
-                    pending_bn = bn
-                x = ybuf[:, :, : l.units]
-                if out_lens is not None:
-                    lens, row_starts = out_lens, None
-                continue
             if pending_bn is not None:
                 raise RuntimeError("internal: a deferred BatchNorm reached a layer that cannot fold it")
             if use_planes and st[0] == "tdnn" and not pooled and l.units > 128 and l.effective_gemm(gemm, relu) == gemm:
@@ -592,7 +505,7 @@ class Sequential:
             if planes is not None:
                 raise RuntimeError("internal: split planes reached a layer that cannot read them")
             if st[0] == "tdnn":
-                if (can_pool and gemm in (L.GEMM_BF16, L.GEMM_BF16X3, L.GEMM_F16) and l.effective_gemm(gemm, relu) == gemm):
+                if (can_pool and gemm in (L.GEMM_BF16, L.GEMM_BF16X3) and l.effective_gemm(gemm, relu) == gemm):
                     xdt = L.act_torch_dtype(gemm)
                     if x.dtype != xdt or x.stride(2) != 1 or x.stride(1) % 8 != 0 or x.stride(1) < ops.round_up(x.shape[-1], 32):
                         x = _padded_copy(x, xdt)
@@ -667,46 +580,6 @@ class Sequential:
             return x.reshape(x.shape[1], 1, x.shape[2])
         return x
 
-    def calibrate(self, x, lens=None):
-        """Extension (F16X2): measures, on the utterances given, the mean of the activations every frame-level layer of the
-        two-pass route reads -- for a trained model the moving mean of the preceding BatchNorm; synthetic weights carry
-        statistics that are not their own, hence the measurement. With the means known, the last `one_pass_tail` layers in
-        front of the pooling run ONE half pass with bias-corrected weights (TDNN.device_weights). x as for run_ragged."""
-        if self.gemm != "f16x2":
-            return {}
-        self._calibrating = {}
-        mt = self.min_tiles
-        self.min_tiles = {}          # a handful of utterances would otherwise be routed to the exact fp32 kernels
-        try:
-            self._xbar, self._xvar = {}, {}        # (no one-pass layer, no permuted plane while measuring)
-            self.run_ragged(x, lens)
-            self._xbar = {k: v[0].cpu().numpy() for k, v in self._calibrating.items()}
-            self._xvar = {k: v[1].cpu().numpy() for k, v in self._calibrating.items()}
-            self._cal_sig = self.weights_signature()
-            WEIGHTS_EPOCH[0] += 1
-        finally:
-            self._calibrating = None
-            self.min_tiles = mt
-        return self._xbar
-
-    def calibrate_from_batchnorm(self):
-        """Extension (F16X2): the statistics calibrate() measures, taken from the model instead -- the plane a frame-level
-        layer reads holds the ReLU outputs the preceding BatchNorm was trained on, so its moving mean / variance ARE the
-        plane's mean / variance for a trained model (Kaldi's <StatsMean> / <StatsVar>). Not for synthetic weights, whose
-        BatchNorm statistics are not their own. Layers without a BatchNorm in front (the first one) stay uncalibrated."""
-        self._xbar, self._xvar = {}, {}
-        if self.gemm != "f16x2":
-            return {}
-        steps = self._plan() or []
-        for prev, cur in zip(steps, steps[1:]):
-            if prev[0] == "tdnn" and cur[0] == "tdnn" and prev[3] is not None and (prev[2] or prev[1].activation == "relu"):
-                bn = prev[3]
-                self._xbar[id(cur[1])] = np.asarray(bn.moving_mean, np.float64).copy()
-                self._xvar[id(cur[1])] = np.asarray(bn.moving_variance, np.float64).copy()
-        self._cal_sig = self.weights_signature()
-        WEIGHTS_EPOCH[0] += 1
-        return self._xbar
-
     def __call__(self, inputs, training=False):
         x = inputs
         if not (isinstance(x, torch.Tensor) and x.is_cuda):
@@ -726,31 +599,12 @@ class Sequential:
     call = __call__
 
 
-def _plane_stats(x, lens, D, chunked):
-    """(mean, variance) over the valid frames of a stored (B, T, ld) activation plane (row-major, or chunk-major: the same bytes as
-    (B, ld / 32, T, 32)), first D features, fp64 on the device."""
-    B, T, ld = x.shape[0], x.shape[1], x.stride(1) if not chunked else x.shape[2]
-    if chunked:
-        ld = ops.round_up(x.shape[2], 32)
-        v = torch.as_strided(x, (B, ld // 32, T, 32), (x.stride(0), T * 32, 32, 1)).permute(0, 2, 1, 3).reshape(B, T, ld)
-    else:
-        v = x
-    v = v[:, :, :D].double()
-    if lens is None:
-        mean = v.mean((0, 1))
-        return mean, (v * v).mean((0, 1)) - mean * mean
-    m = (torch.arange(T, device=x.device)[None, :] < lens[:, None]).double()
-    n = m.sum().clamp_min(1.0)
-    mean = (v * m[:, :, None]).sum((0, 1)) / n
-    return mean, (v * v * m[:, :, None]).sum((0, 1)) / n - mean * mean
-
-
 def _padded_copy(x, dtype):
     """(B,T,D) tensor/view -> view of a fresh (B,T,round_up(D,32)) buffer of `dtype` with zeroed pad columns."""
     B, T, D = x.shape
     Dp = ops.round_up(D, 32)
     src = x.contiguous()
-    if src.dtype not in (torch.float32, torch.bfloat16, torch.float16) or (src.dtype != torch.float32 and src.dtype != dtype):
+    if src.dtype not in (torch.float32, torch.bfloat16) or (src.dtype != torch.float32 and src.dtype != dtype):
         src = src.to(torch.float32)
     dst = torch.empty((B, T, Dp), dtype=dtype, device=x.device)
     ops.convert_pad(src, D, dst)
@@ -1111,13 +965,6 @@ class XvectorExtractor:
         layer = steps[at][1]
         return self.ldaMat.shape[1] <= 256 and layer.units == self.ldaMat.shape[0] and layer.kernelFlags == 0
 
-    def calibrate(self, inputs):
-        """Extension: `Sequential.calibrate` on the features of these utterances (a handful is enough: the statistic is a
-        per-feature mean over all their voiced frames). Returns the number of layers that will run one pass."""
-        _, feats, lens = self._features(inputs)
-        self.xvec.calibrate(feats, lens)
-        return min(self.xvec.one_pass_tail, len(self.xvec._xbar))
-
     def __call__(self, inputs, training=False):
         if hasattr(inputs, "shape") and len(inputs.shape) == 2 and inputs.shape[0] == 0:
             L.require_gpu()
@@ -1147,7 +994,7 @@ class XvectorExtractor:
         # The graph addresses scratch and weights by raw pointer. Scratch: PRIVATE workspaces for the capture (the model's own are
         # keyed by stream handle, and a later call on a recycled handle could grow -- i.e. free -- an arena the graph still
         # uses); they live as long as `run`. Weights: strong references to every device operand set the capture touched, and
-        # the weights signature at capture time -- `run` refuses to replay after set_weights / calibrate().
+        # the weights signature at capture time -- `run` refuses to replay after set_weights.
         own_ws, own_xws = self._ws, self.xvec._ws
         cap_ws, cap_xws = _Workspace(), _Workspace()
         self._ws, self.xvec._ws = cap_ws, cap_xws
@@ -1166,7 +1013,7 @@ class XvectorExtractor:
         finally:
             self._ws, self.xvec._ws = own_ws, own_xws
         torch.cuda.current_stream(dev).wait_stream(side)
-        sig = (self.xvec.weights_signature(), tuple(sorted(self.xvec._xbar)), self.xvec.lo_fraction, self.xvec.one_pass_tail)
+        sig = self.xvec.weights_signature()
         keep = [cap_ws, cap_xws, dict(self._post_dev)]
         for l in self.xvec.layers:
             if isinstance(l, TDNN):
@@ -1177,11 +1024,10 @@ class XvectorExtractor:
         epoch = [WEIGHTS_EPOCH[0]]
 
         def run(wav):
-            if WEIGHTS_EPOCH[0] != epoch[0] or (self.xvec.lo_fraction, self.xvec.one_pass_tail) != sig[2:]:
-                # some layer in the process changed: is it one of ours? (slow path, only after a set_weights / calibrate somewhere)
-                now = (self.xvec.weights_signature(), tuple(sorted(self.xvec._xbar)), self.xvec.lo_fraction, self.xvec.one_pass_tail)
-                if now != sig:
-                    raise RuntimeError("the model's weights or calibration changed after compile(): capture again")
+            if WEIGHTS_EPOCH[0] != epoch[0]:
+                # some layer in the process changed: is it one of ours? (slow path, only after a set_weights somewhere)
+                if self.xvec.weights_signature() != sig:
+                    raise RuntimeError("the model's weights changed after compile(): capture again")
                 epoch[0] = WEIGHTS_EPOCH[0]
             w, _ = self.framing.device_samples(wav)
             if w.dim() == 1:

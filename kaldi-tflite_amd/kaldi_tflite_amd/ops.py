@@ -405,14 +405,14 @@ def split_bf16(src, D, planes):
 
 
 def _planes(xp):
-    """(hi, lo, B, T, ldx) of a (2,B,T,ldx) pair of planes, or of ONE (B,T,ldx) plane (KTF_GEMM_F16X2: lo = None)."""
-    if xp.dim() == 4:
-        return xp[0], xp[1], xp.shape[1], xp.shape[2], xp.stride(2)
-    return xp, None, xp.shape[0], xp.shape[1], xp.stride(1)
+    """(hi, lo, B, T, ldx) of a (2,B,T,ldx) pair of bf16 planes."""
+    if xp.dim() != 4 or xp.shape[0] != 2:
+        raise ValueError(f"expected a (2, B, T, ldx) pair of bf16 planes, got shape {tuple(xp.shape)}")
+    return xp[0], xp[1], xp.shape[1], xp.shape[2], xp.stride(2)
 
 
 def tdnn_split(xp, lens, desc, w, w_lo, bias, scale, shift, y, y_lo=None, out_lens=None):
-    """xp: (2,B,T,ldx) bf16 hi/lo planes, or one (B,T,ldx) half plane (F16X2). y: (B,Tout,ldy) 16-bit plane (+ y_lo) or fp32."""
+    """xp: (2,B,T,ldx) bf16 hi/lo planes. y: (B,Tout,ldy) bf16 plane (+ y_lo) or fp32."""
     lib = L.load()
     hi, lo, B, T, ldx = _planes(xp)
     with L.on_device(xp.device):

@@ -121,16 +121,8 @@ def build_sequential(ktf, w, gemm="f32"):
     return mdl
 
 
-def build_extractor(ktf, cfg, w, gemm="f32", calibrate=False):
-    """`calibrate` (f16x2 only, needs the GPU): XvectorExtractor.calibrate on four fixed synthetic utterances that are neither
-    the timed nor the parity inputs (seed 777; two of them with quiet blocks), after which the two layers in front of the
-    pooling run one half pass. Synthetic BatchNorm statistics are not the network's own, so the means have to be measured."""
-    m = ktf.models.XvectorExtractor.from_parts(cfg, build_sequential(ktf, w, gemm), w["mean"], w["lda"])
-    if calibrate and gemm == "f16x2":
-        import torch
-        cal = np.concatenate([make_wav(2, 160000, seed=777), make_wav(2, 160000, seed=778, ragged=True)], 0)
-        m.calibrate(torch.as_tensor(cal, device="cuda"))
-    return m
+def build_extractor(ktf, cfg, w, gemm="f32"):
+    return ktf.models.XvectorExtractor.from_parts(cfg, build_sequential(ktf, w, gemm), w["mean"], w["lda"])
 
 
 def make_wav(B, N, seed=1234, sigma=1000.0, ragged=False):

@@ -50,10 +50,8 @@ def trace(mdl, wav):
 
 EXPECT = {   # mode -> kernel family of tdnn1 .. tdnn5 for a batch of full-length utterances
     "f32": ["tdnn_f32t_kernel"] * 5,
-    "bf16": ["tdnn_bf16h_kernel<bf16>", "tdnn_bf16r16_kernel<bf16>", "tdnn_bf16r16_kernel<bf16>", "tdnn_bf16h_kernel<bf16>", "tdnn_bf16h_kernel<bf16>"],
-    "f16": ["tdnn_bf16h_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16r16_kernel<f16>", "tdnn_bf16h_kernel<f16>", "tdnn_bf16h_kernel<f16>"],
-    "bf16x3": ["tdnn_x3s_kernel<bf16, 3>"] * 5,
-    "f16x2": ["tdnn_x3s_kernel<f16, 2>"] * 5,
+    "bf16": ["tdnn_bf16h_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16h_kernel", "tdnn_bf16h_kernel"],
+    "bf16x3": ["tdnn_x3s_kernel"] * 5,
     "f16mx": ["tdnn_mx_kernel"] * 5,
 }
 
@@ -99,20 +97,13 @@ def test_f16mx_loader_kernel_dispatch():
     assert got == ["tdnn_mxl_kernel"] * 5, got
 
 
-def test_calibrated_f16x2_runs_one_pass_in_front_of_the_pooling():
-    w = synth.make_weights(seed=4321)
-    mdl = synth.build_extractor(ktf, synth.extractor_cfg(), w, gemm="f16x2", calibrate=True)
-    got = [k for s, k in trace(mdl, synth.make_wav(32, 160000, seed=3)) if s in FRAME_LAYERS]
-    assert got == ["tdnn_x3s_kernel<f16, 2>"] * 3 + ["tdnn_x3s_kernel<f16, 1>"] * 2
-
-
 def test_single_utterance_dispatch():
     """One 10 s utterance: the 256-row tiles cannot fill the chip (Sequential.min_tiles). "f32" runs the exact fp32 small-tile kernels;
     the reduced modes run the bf16-pair small tiles (KTF_GEMM_BF16X4) behind an fp32 first layer that writes pairs, or -- with
     `small_tile_pairs` off -- the fp32 kernels throughout."""
     S = ktf.models.Sequential
     old = S.MIN_TILES
-    S.MIN_TILES = {"bf16": 6, "f16": 6, "bf16x3": 32, "f16x2": 32, "f16mx": 32}
+    S.MIN_TILES = {"bf16": 6, "bf16x3": 32, "f16mx": 32}
     try:
         w = synth.make_weights(seed=4321)
         wav = synth.make_wav(1, 160000, seed=3)

@@ -147,7 +147,7 @@ def test_tdnn_mx_fp32_output_vs_emulation(case, relu, kernel):
     ops.mx_planes(dev(x), D, dl, p)
     mxf, images, family = _kernel(kernel, layer)
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel=images)
-    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=mxf)
+    d = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu" if relu else None, flags=mxf)
     ldy = ops.round_up(layer.units, 4)
     y = torch.full((B, T, ldy), 7.0, device="cuda")
     ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, y)
@@ -178,12 +178,12 @@ def test_tdnn_mx_plane_output_feeds_the_next_layer(case, kernel):
     ops.mx_planes(dev(x), D, dl, p)
     mxf, images, family = _kernel(kernel, layer)
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel=images)
-    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=mxf)
+    d = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu", flags=mxf)
     out = mx.Planes.empty(B, T, layer.units, "cuda")
     ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, out)
     assert ops.last_kernel() == family
     y = torch.zeros((B, T, ops.round_up(layer.units, 4)), device="cuda")
-    d32 = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu", flags=mxf)
+    d32 = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu", flags=mxf)
     ops.tdnn_mx(p, dl, d32, wh, wq, bd, None, None, y)
     ref = mx.Planes.empty(B, T, layer.units, "cuda")
     ops.mx_planes(y, layer.units, dl, ref)
@@ -210,7 +210,7 @@ def test_tdnn_mx_fused_pooling_vs_emulation(kernel, shape):
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel=images)
     emu, _ = _emulate(layer, x, lens, True)
     for det in (True, False):
-        d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu", flags=mxf | (L.TDNN_DET_STATS if det else 0))
+        d = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu", flags=mxf | (L.TDNN_DET_STATS if det else 0))
         slots = ops.stats_slots(T, mx_flags=mxf) if det else 0
         sums = torch.full((B, max(slots, 1), 2, U), 3.0, dtype=torch.float64, device="cuda")
         ops.tdnn_mx_stats(p, dl, d, wh, wq, bd, dev(sc), dev(sh), sums, zero=not det)
@@ -414,7 +414,7 @@ def test_tdnn_mx_valid_padding_and_subsampling_vs_emulation(case, relu):
     dl = dev(lens, torch.int32)
     ops.mx_planes(dev(x), D, dl, p)
     wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), loader=False)
-    d = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, act="relu" if relu else None, flags=0)
+    d = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu" if relu else None, flags=0)
     Tout = ops.tdnn_out_len(T, d)
     assert Tout == O.tdnn_eval_indices(T, ctx, sub, pad).shape[0] == layer.outputTimesteps(T)
     y = torch.full((B, Tout, ops.round_up(units, 4)), 7.0, device="cuda")
@@ -433,7 +433,7 @@ def test_tdnn_mx_valid_padding_and_subsampling_vs_emulation(case, relu):
         assert (got[b, n:] == 7.0).all(), "rows beyond the utterance's output length are not written"
     # the plane output at the same shapes == the planes of the fp32 output
     out = mx.Planes.empty(B, Tout, units, "cuda")
-    dp = layer.desc(L.GEMM_F16MX, torch.float16, torch.float16, act="relu" if relu else None)
+    dp = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu" if relu else None)
     ops.tdnn_mx(p, dl, dp, wh, wq, bd, None, None, out)
     ref = mx.Planes.empty(B, Tout, units, "cuda")
     yz = torch.where(y == 7.0, torch.zeros_like(y), y)
@@ -443,7 +443,7 @@ def test_tdnn_mx_valid_padding_and_subsampling_vs_emulation(case, relu):
         for a, r in zip(out.decode(), ref.decode()):
             assert np.array_equal(a[b, :n], r[b, :n])
     # the kernels that take SAME padding without subsampling only say so
-    dlo = layer.desc(L.GEMM_F16MX, torch.float16, torch.float32, flags=L.TDNN_MX_LOADER)
+    dlo = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, flags=L.TDNN_MX_LOADER)
     with pytest.raises(ValueError, match="SAME padding without subsampling"):
         ops.tdnn_mx(p, dl, dlo, wh, wq, bd, None, None, y)
 

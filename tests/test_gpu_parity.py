@@ -307,7 +307,7 @@ def test_tdnn_narrow_golden_fused_and_layerwise():
     assert np.abs(got - O.sequential_forward(layers, x, dtype=np.float64)).max() < 1e-5
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2), ("f16", 8e-3), ("f16mx", 2e-3)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 2e-5), ("bf16x3", 2e-4), ("bf16", 6e-2), ("f16mx", 2e-3)])
 def test_tdnn_options_vs_oracle(gemm, tol):
     rng = np.random.default_rng(11)
     for (B, T, D, U, ctx, sub, pad, act) in [
@@ -470,14 +470,13 @@ def test_tdnn_f32_latency_kernels_are_bitwise_the_tile_kernels():
                 assert np.abs(got[i, : ol[i]] - want[0]).max() < 2e-5
 
 
-@pytest.mark.parametrize("gemm", ["bf16", "f16"])
+@pytest.mark.parametrize("gemm", ["bf16"])
 def test_tdnn_ring_kernels_random_shapes(gemm):
     """Seeded sweep over shapes that reach the 256x256 / 128x256 ring kernels with awkward tails: units not a multiple of
     8 (scalar store tail), K on both sides of the 768 switch, ragged batches, VALID padding, subsampling, ReLU on/off.
     Inputs and weights are pre-rounded to the operand format, so only the fp32 accumulation order differs from the oracle."""
     rng = np.random.default_rng(2024)
-    rnd = (lambda a: torch.as_tensor(a).to(torch.bfloat16).float().numpy()) if gemm == "bf16" else \
-          (lambda a: a.astype(np.float16).astype(np.float32))
+    rnd = lambda a: torch.as_tensor(a).to(torch.bfloat16).float().numpy()  # noqa: E731
     for trial in range(10):
         U = int(rng.choice([129, 200, 255, 256, 257, 300, 512, 770, 1500]))
         D = int(rng.choice([32, 40, 96, 160, 256, 512]))
@@ -667,7 +666,7 @@ def test_extractor_f32_vs_oracle(narrow):
         assert np.array_equal(host(one), got[b])
 
 
-@pytest.mark.parametrize("gemm,tol", [("bf16x3", 1e-4), ("bf16", 5e-2), ("f16", 1e-3)])
+@pytest.mark.parametrize("gemm,tol", [("bf16x3", 1e-4), ("bf16", 5e-2)])
 def test_extractor_reduced_precision_modes(gemm, tol):
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
@@ -679,29 +678,28 @@ def test_extractor_reduced_precision_modes(gemm, tol):
     assert err <= tol, (gemm, err)
 
 
-def test_half_mode_fused_stats_and_batch_independence():
-    # "f16": IEEE-half operands on the same MFMA rate as bf16; fused pooling vs separate kernels, and batch == single
+def test_bf16_mode_fused_stats_and_batch_independence():
+    # one-pass bf16: fused pooling vs separate kernels, and batch == single
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
     wav = synth.make_wav(3, 16000 * 3 + 77, seed=5, ragged=True)
     want, _ = _extract_oracle(wav, cfg, w)
-    fused = synth.build_extractor(ktf, cfg, w, gemm="f16")
-    plain = synth.build_extractor(ktf, cfg, w, gemm="f16")
+    fused = synth.build_extractor(ktf, cfg, w, gemm="bf16")
+    plain = synth.build_extractor(ktf, cfg, w, gemm="bf16")
     plain.xvec.fuse_stats = False
     a, b = host(fused(dev(wav))), host(plain(dev(wav)))
-    assert np.abs(a - want).max() < 1e-3 and np.abs(b - want).max() < 1e-3
-    assert np.abs(a - b).max() < 5e-4
+    assert np.abs(a - want).max() < 5e-2 and np.abs(b - want).max() < 5e-2
+    assert np.abs(a - b).max() < 5e-3
     assert np.array_equal(host(fused(dev(wav[1:2]))), a[1])
 
 
-@pytest.mark.parametrize("gemm,tol", [("bf16", 2e-4), ("f16", 2e-4), ("bf16x3", 2e-5), ("f16x2", 2e-5)])
+@pytest.mark.parametrize("gemm,tol", [("bf16", 2e-4), ("bf16x3", 2e-5)])
 def test_fused_tdnn_stats_random_shapes(gemm, tol):
     """[affine, relu, batchnorm] -> reducing StatsPooling, pooled inside the GEMM epilogue (ktf_tdnn_stats), over shapes
     with awkward widths and ragged utterance lengths; operands pre-rounded so only accumulation order differs."""
     rng = np.random.default_rng(77)
     rnd = {"bf16": lambda a: torch.as_tensor(a).to(torch.bfloat16).float().numpy(),
-           "f16": lambda a: a.astype(np.float16).astype(np.float32), "bf16x3": lambda a: a,
-           "f16x2": lambda a: a}[gemm]                  # f16x2: exact weights (hi + lo); the INPUT is pre-rounded below
+           "bf16x3": lambda a: a}[gemm]
     for U, D, ctx in [(129, 64, [0]), (300, 96, [-1, 0, 1]), (1500, 512, [0]), (257, 40, [-2, 0, 2])]:
         cfg = {"type": "sequential", "layers": [
             {"name": "input", "type": "input", "shape": [None, None, D]},
@@ -720,8 +718,6 @@ def test_fused_tdnn_stats_random_shapes(gemm, tol):
         mdl.get_layer("t.batchnorm").set_weights(list(bn))
         B, T = 3, 397
         x = rnd(rng.standard_normal((B, T, D)).astype(np.float32))
-        if gemm == "f16x2":
-            x = x.astype(np.float16).astype(np.float32)
         lens = np.array([T, 131, 260], np.int32)
         layers = [{"kind": "tdnn", "W": W, "b": b, "context": ctx}, {"kind": "relu"},
                   {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]},
@@ -911,7 +907,7 @@ def test_extractor_edge_cases():
     assert np.array_equal(a, b[::-1])
 
 
-@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16mx", 1e-4), ("f16x2", 2e-4), ("bf16", 5e-2), ("f16", 1e-3)])
+@pytest.mark.parametrize("gemm,tol", [("f32", 1e-4), ("bf16x3", 1e-4), ("f16mx", 1e-4), ("bf16", 5e-2)])
 def test_extractor_8khz_callhome_topology(gemm, tol):
     """The reference's second model family (0006_callhome_diarization_v2_1a.yml: 8 kHz, 23-dim MFCC, 128-dim embedding):
     200-sample frames -> nfft 256 takes the generic front-end kernel, tdnn6 has 128 units."""

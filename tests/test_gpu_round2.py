@@ -55,10 +55,10 @@ def test_xvec_post_kaldi_golden():
 
 
 # ----------------------------------------------------------------------------- whole pipeline at the BASELINE size
-@pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("gemm", ["f32", "bf16x3", "f16mx"])
 def test_extractor_full_topology_10s_vs_oracle(gemm):
     """0008 topology, full widths, 160 000-sample utterances (998 frames): max-abs deviation from the fp64 oracle within
-    the north_star bound (1e-4), for the exact path, the split-bf16 path and the two-pass half path bench.py times by default.
+    the north_star bound (1e-4), for the exact path, the split-bf16 path and the block-scaled path bench.py times by default.
     One utterance is all-voiced stationary noise (the bench workload), two have quiet blocks (ragged)."""
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
@@ -153,7 +153,7 @@ def test_long_recording_beyond_38400_frames():
 
 
 # ----------------------------------------------------------------------------- reproducible fused pooling
-@pytest.mark.parametrize("gemm", ["bf16x3", "f16mx", "f16x2", "bf16", "f16"])
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16mx", "bf16"])
 def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
     """KTF_TDNN_DET_STATS (the models' default): per-128-row partial sums added in block order -> bitwise identical
     x-vectors run after run and batch == single; the fp64-atomic form agrees to the last fp32 bits."""
@@ -174,11 +174,11 @@ def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
 
 
 # ----------------------------------------------------------------------------- hipGraph product path
-@pytest.mark.parametrize("gemm,B,cal", [("f32", 1, False), ("bf16x3", 16, False), ("f16mx", 16, False), ("f16x2", 16, False), ("f16x2", 16, True)])
-def test_compiled_extractor_replays_bitwise(gemm, B, cal):
+@pytest.mark.parametrize("gemm,B", [("f32", 1), ("bf16x3", 16), ("f16mx", 16)])
+def test_compiled_extractor_replays_bitwise(gemm, B):
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321, narrow=False)
-    mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm, calibrate=cal)     # cal: one-pass tail + residual prefix + permuted planes
+    mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
     x0 = dev(synth.make_wav(B, 160000, seed=3, ragged=True))
     run = mdl.compile(x0)
     for seed in (3, 4, 5):
@@ -239,221 +239,6 @@ def test_windowing_1000_frames_11_overrides():
         assert tuple(w.shape) == frames.shape and tuple(e.shape) == (1, 1000, 1)
         tol = 2 * cfg["dither"] if cfg["dither"] else 2e-7
         assert G.rmse(want_w, host(w)) < tol and G.rmse(want_e, host(e)) < tol, o
-
-
-# ----------------------------------------------------------------------------- two-pass half mode (KTF_GEMM_F16X2)
-def _emulate_f16x2(layers, x):
-    """fp64 evaluation of exactly what the f16x2 route computes up to accumulation order: activations rounded to IEEE half
-    where the route stores them (the network input, and every ReLU output that feeds another wide layer, BEFORE its
-    BatchNorm, which is folded into the consumer's weights), weights = half hi + half lo of the (folded) weights."""
-    h16 = lambda a: a.astype(np.float16).astype(np.float64)          # noqa: E731
-    tl = [i for i, l in enumerate(layers) if l["kind"] == "tdnn"]
-    a = np.asarray(x, np.float64)
-    pend = None
-    i = 0
-    while i < len(layers):
-        l = layers[i]
-        if l["kind"] != "tdnn":
-            a = O.sequential_forward([l], a[None], dtype=np.float64)[0]
-            i += 1
-            continue
-        W = np.asarray(l["W"], np.float64)
-        b = np.asarray(l["b"], np.float64)
-        K = len(l["context"])
-        if pend is not None:
-            s_, h_ = pend
-            b = b + W @ np.tile(h_, K)
-            W = W * np.tile(s_, K)
-            pend = None
-        Wq = h16(W) + h16(W - h16(W))
-        z = O.tdnn(h16(a)[None], Wq, b, l["context"], l.get("subsampling_factor", 1), l.get("padding", "SAME"), None, dtype=np.float64)[0]
-        nxt = layers[i + 1:i + 3]
-        if len(nxt) == 2 and nxt[0]["kind"] == "relu" and nxt[1]["kind"] == "bn":
-            r = np.maximum(z, 0.0)
-            bn = nxt[1]
-            s_ = np.float64(bn["rms"]) / np.sqrt(np.asarray(bn["var"], np.float64) + 1e-3)
-            h_ = -np.asarray(bn["mean"], np.float64) * s_
-            more = i + 3 < len(layers) and layers[i + 3]["kind"] == "tdnn" and np.asarray(layers[i + 3]["W"]).shape[0] > 128
-            if more:
-                a, pend = r.astype(np.float32).astype(np.float64), (s_, h_)
-            else:
-                a = r * s_ + h_
-            i += 3
-        else:
-            a = z
-            i += 1
-    return a
-
-
-def test_f16x2_route_equals_its_fp64_emulation_and_options():
-    """KTF_GEMM_F16X2 through the Sequential runner: BatchNorm folded forward, one half plane between wide layers, VALID
-    padding, subsampling, multi-context layers (chunk-interleaved K), ragged lengths, a frame-level fp32 output. A single
-    layer equals the fp64 emulation of the same roundings to fp32 accumulation noise (1e-6). Behind a STORED half plane the
-    two can only agree statistically: the fp32 accumulator and the fp64 emulation round a handful of ReLU outputs that sit on
-    a half rounding boundary to different neighbours (2e-4 of the elements; each such flip moves a consumer's output by
-    |w| * half-ulp = 3e-5), so: the typical output agrees to accumulation noise, the disagreements stay below the mode's
-    own deviation from the exact network, and both deviate from the exact network by the same amount."""
-    rng = np.random.default_rng(31)
-    D = 40
-    spec = [(300, [-2, 0, 2], "VALID", 1), (260, [-1, 0, 1], "SAME", 2), (520, [-3, 0, 3], "VALID", 1), (200, [0], "SAME", 1)]
-    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
-    for i, (U, ctx, pad, sub) in enumerate(spec):
-        lcfg.append({"name": f"t{i}", "type": ["affine", "relu", "batchnorm"],
-                     "cfg": {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}})
-    mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm="f16x2")
-    layers, din = [], D
-    for i, (U, ctx, pad, sub) in enumerate(spec):
-        W = (rng.standard_normal((U, len(ctx) * din)) / np.sqrt(len(ctx) * din)).astype(np.float32)
-        b = (rng.standard_normal(U) * 0.1).astype(np.float32)
-        bn = (np.float32(1.0), rng.uniform(-0.2, 0.4, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
-        mdl.get_layer(f"t{i}.affine").set_weights([W, b])
-        mdl.get_layer(f"t{i}.batchnorm").set_weights(list(bn))
-        layers += [{"kind": "tdnn", "W": W, "b": b, "context": ctx, "padding": pad, "subsampling_factor": sub}, {"kind": "relu"},
-                   {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]}]
-        din = U
-    B, T = 3, 301
-    x = rng.standard_normal((B, T, D)).astype(np.float32)
-    lens = np.array([T, 97, 222], np.int32)
-    got = host(mdl.run_ragged(dev(x), torch.as_tensor(lens, device="cuda")))
-    for i in range(B):
-        emu = _emulate_f16x2(layers, x[i, : lens[i]])
-        want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)[0]
-        n = want.shape[0]
-        assert n > 0 and emu.shape == want.shape
-        diff, err_emu, err_got = np.abs(got[i, :n] - emu), np.abs(emu - want).max(), np.abs(got[i, :n] - want).max()
-        assert np.median(diff) < 5e-6 and np.mean(diff > 3e-5) < 0.15 and diff.max() < err_emu, (np.median(diff), diff.max(), err_emu)
-        assert abs(err_got - err_emu) < 0.1 * err_emu and err_got < 5e-3     # half-rounded activations, frame level (no pooling)
-    # re-importing BatchNorm weights re-folds (the folded operands are keyed by the BatchNorm's version)
-    bn0 = mdl.get_layer("t0.batchnorm")
-    bn0.set_weights([np.float32(1.0), bn0.moving_mean * 0.5, bn0.moving_variance * 1.5])
-    layers[2] = {"kind": "bn", "rms": np.float32(1.0), "mean": bn0.moving_mean, "var": bn0.moving_variance}
-    got2 = host(mdl.run_ragged(dev(x), torch.as_tensor(lens, device="cuda")))
-    emu2 = _emulate_f16x2(layers, x[0, : lens[0]])
-    assert np.median(np.abs(got2[0, : emu2.shape[0]] - emu2)) < 5e-6 and np.abs(got2[0] - got[0]).max() > 1e-3
-    # one layer alone: no stored half plane between the roundings and the output -> equal to accumulation noise
-    one = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg[:2]}, None, "m1", gemm="f16x2")
-    one.get_layer("t0.affine").set_weights(mdl.get_layer("t0.affine").get_weights(), fmt="tensorflow")
-    one.get_layer("t0.batchnorm").set_weights(mdl.get_layer("t0.batchnorm").get_weights(), fmt="tensorflow")
-    g1 = host(one.run_ragged(dev(x), None))[0]
-    assert np.abs(g1 - _emulate_f16x2(layers[:3], x[0])).max() < 5e-6
-
-
-@pytest.mark.parametrize("seed", [1, 2, 3])
-def test_f16x2_tolerance_over_weight_seeds(seed):
-    # the 1e-4 bound of the half mode is a property of rounding, not of one weight draw: other seeds, other audio -- for the
-    # form with two passes everywhere and for the calibrated form bench.py times (one pass in the two layers before the pooling)
-    cfg = synth.extractor_cfg()
-    w = synth.make_weights(seed=seed, narrow=False)
-    wav = synth.make_wav(3, 160000, seed=100 + seed, ragged=True)
-    want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
-    for cal in (False, True):
-        m = synth.build_extractor(ktf, cfg, w, gemm="f16x2", calibrate=cal)
-        m.xvec.min_tiles = {}
-        assert len(m.xvec._xbar) == (5 if cal else 0)
-        got = host(m(dev(wav)))
-        err = np.abs(got - want).max()
-        print(f"f16x2 seed {seed} calibrated {cal}: {err:.3e}")
-        assert err <= 1e-4, (cal, err)
-
-
-def test_f16x2_one_pass_layer_and_its_bias_correction():
-    """KtfTdnnDesc gemm F16X2 with w_lo = NULL runs ONE pass. TDNN.device_weights(one_pass_mean=) rounds the (folded) weights to
-    nearest half and moves the constant part of the rounding error, (w_half - w) . mean, into the fp32 bias: the kernel then
-    computes exactly x_half . w_half + bias' (fp32 accumulation), and the error against the exact layer, averaged over the
-    frames, is what the activations' deviation from the calibration mean leaves -- far below the uncorrected one."""
-    rng = np.random.default_rng(11)
-    B, T, D, U, ctx = 3, 700, 256, 600, [-1, 0, 2]
-    x = np.abs(rng.standard_normal((B, T, D))).astype(np.float32) * rng.uniform(0.2, 3.0, D).astype(np.float32)     # ReLU-like, per-feature means
-    W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
-    b = rng.standard_normal(U).astype(np.float32)
-    t = Ls.TDNN(U, context=ctx)
-    t.build(x.shape)
-    t.set_weights([W, b])
-    xh = torch.as_tensor(x, device="cuda").to(torch.float16).contiguous()
-    xq = xh.float().cpu().numpy().astype(np.float64)
-    xbar = xq.mean((0, 1))
-
-    def layer(Wm, bias):                                     # fp64: y[t] = sum_k x[clip(t + ctx_k)] . Wm[:, k] + bias
-        y = np.zeros((B, T, U))
-        for k, o in enumerate(ctx):
-            idx = np.clip(np.arange(T) + o, 0, T - 1)
-            y += xq[:, idx, :] @ Wm[:, k * D:(k + 1) * D].T
-        return y + bias
-
-    exact = layer(W.astype(np.float64), b.astype(np.float64))
-    Wh = W.astype(np.float16).astype(np.float64)
-    corr = np.einsum("ukd,d->u", (Wh - W.astype(np.float64)).reshape(U, len(ctx), D), xbar)
-    for kint, tiled in ((False, False), (True, True)):
-        w, w_lo, bias = t.device_weights("cuda", ktf._lib.GEMM_F16X2, k_interleaved=kint, w_tiled=tiled, one_pass_mean=xbar)
-        assert w_lo is None and w.dtype == torch.float16
-        assert np.allclose(bias.cpu().numpy()[:U], b - corr, rtol=0, atol=1e-6)
-        y = torch.zeros((B, T, 608), dtype=torch.float32, device="cuda")
-        d = t.desc(ktf._lib.GEMM_F16X2, torch.float16, torch.float32,
-                   flags=(ktf._lib.TDNN_K_INTERLEAVED if kint else 0) | (ktf._lib.TDNN_W_TILED if tiled else 0))
-        ktf.ops.tdnn_split(xh, None, d, w, None, bias, None, None, y, None, None)
-        got = y[:, :, :U].cpu().numpy().astype(np.float64)
-        assert np.abs(got - layer(Wh, (b - corr).astype(np.float32).astype(np.float64))).max() < 2e-5      # the kernel: one pass, fp32 accumulation
-        err_mean = np.abs((got - exact).mean((0, 1)))                                                      # per unit, averaged over the frames
-        raw_mean = np.abs((layer(Wh, b.astype(np.float64)) - exact).mean((0, 1)))
-        assert err_mean.max() < 0.05 * raw_mean.max() and err_mean.max() < 2e-6, (err_mean.max(), raw_mean.max())
-    with pytest.raises(ValueError):
-        t.device_weights("cuda", ktf._lib.GEMM_F32, one_pass_mean=xbar)
-    with pytest.raises(ValueError):
-        t.device_weights("cuda", ktf._lib.GEMM_F16X2, one_pass_mean=xbar[:-1])
-
-
-def test_f16x2_permuted_planes_and_residual_prefix():
-    """TDNN.device_weights(in_perm=, out_perm=): a layer reading a plane stored in another feature order and writing its own
-    units in another order computes the same numbers (up to the fp32 summation order along K). lo_keep = n with the
-    KTF_TDNN_LO_PREFIX flag: the K-steps of the first n / 32 chunks run two passes, the rest one pass on nearest-rounded,
-    bias-corrected columns -- checked against fp64 with exactly those weights."""
-    rng = np.random.default_rng(12)
-    B, T, D, U, ctx = 2, 600, 128, 300, [-2, 0, 2]
-    x = np.abs(rng.standard_normal((B, T, D))).astype(np.float32) * rng.uniform(0.1, 2.0, D).astype(np.float32)
-    W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
-    b = rng.standard_normal(U).astype(np.float32)
-    t = Ls.TDNN(U, context=ctx)
-    t.build(x.shape)
-    t.set_weights([W, b])
-    ip, op = rng.permutation(D), rng.permutation(U)
-    xh = torch.as_tensor(x, device="cuda").to(torch.float16).contiguous()
-    xq = xh.float().cpu().numpy().astype(np.float64)
-    xbar = xq.mean((0, 1))
-
-    def layer(Wm, bias):
-        y = np.zeros((B, T, U))
-        for k, o in enumerate(ctx):
-            idx = np.clip(np.arange(T) + o, 0, T - 1)
-            y += xq[:, idx, :] @ Wm[:, k * D:(k + 1) * D].T
-        return y + bias
-
-    def run(xin, flags, **kw):
-        w, w_lo, bias = t.device_weights("cuda", ktf._lib.GEMM_F16X2, k_interleaved=True, w_tiled=True, **kw)
-        y = torch.zeros((B, T, 320), dtype=torch.float32, device="cuda")
-        d = t.desc(ktf._lib.GEMM_F16X2, torch.float16, torch.float32, flags=ktf._lib.TDNN_K_INTERLEAVED | ktf._lib.TDNN_W_TILED | flags)
-        ktf.ops.tdnn_split(xin, None, d, w, w_lo, bias, None, None, y, None, None)
-        return y[:, :, :U].cpu().numpy().astype(np.float64), bias.cpu().numpy()[:U]
-
-    nat, _ = run(xh, 0)
-    assert np.abs(nat - layer(W.astype(np.float64), b.astype(np.float64))).max() < 2e-5
-    xp = xh[:, :, torch.as_tensor(ip, device="cuda")].contiguous()
-    per, _ = run(xp, 0, in_perm=ip, out_perm=op)
-    assert np.abs(per - nat[:, :, op]).max() < 2e-5
-    # residual only for the first 64 stored features (two chunks of four)
-    keep = 64
-    got, bias = run(xp, ktf._lib.TDNN_LO_PREFIX(keep // 32), in_perm=ip, out_perm=op, lo_keep=keep, one_pass_mean=xbar)
-    Wd = W.astype(np.float64).reshape(U, len(ctx), D).copy()
-    dropped = ip[keep:]
-    Wd[:, :, dropped] = Wd[:, :, dropped].astype(np.float16).astype(np.float64)
-    corr = np.einsum("ukd,d->u", Wd - W.astype(np.float64).reshape(U, len(ctx), D), xbar)
-    assert np.allclose(bias, (b - corr)[op], rtol=0, atol=1e-6)
-    want = layer(Wd.reshape(U, -1), (b - corr).astype(np.float32).astype(np.float64))[:, :, op]
-    assert np.abs(got - want).max() < 2e-5
-    assert np.abs(got - nat[:, :, op]).max() > 1e-6          # (it IS a different computation)
-    with pytest.raises(ValueError):
-        t.device_weights("cuda", ktf._lib.GEMM_F16X2, lo_keep=64)
-    with pytest.raises(ValueError):
-        t.device_weights("cuda", ktf._lib.GEMM_F16X2, in_perm=np.zeros(D, np.int64))
 
 
 @pytest.mark.gpu

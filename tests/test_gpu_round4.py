@@ -309,12 +309,12 @@ def test_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case):
         got = torch.full(shape, 7.0, dtype=ydt, device="cuda")
         if out_planes:
             ops.tdnn_split(planes, dl, d, w, w_lo, bias, sc, sh, ref[0], ref[1])
-            assert ops.last_kernel() == "tdnn_x3s_kernel<bf16, 3>"
+            assert ops.last_kernel() == "tdnn_x3s_kernel"
             ops.tdnn_split_flat(planes, starts, d, w, w_lo, bias, sc, sh, got[0], got[1])
         else:
             ops.tdnn_split(planes, dl, d, w, w_lo, bias, sc, sh, ref, None)
             ops.tdnn_split_flat(planes, starts, d, w, w_lo, bias, sc, sh, got, None)
-        assert ops.last_kernel() == "tdnn_x3s_kernel<bf16, 3, flat>"
+        assert ops.last_kernel() == "tdnn_x3s_kernel<flat>"
         assert torch.equal(got, ref), case[-1]
         g = got.float().cpu().numpy()
         g = g if out_planes else g[None]
@@ -403,7 +403,7 @@ def dev(a):
     return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
 
 
-@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
 def test_fused_vad_cmvn_split_over_workgroups_matches_the_oracle(out_dtype):
     """Batches below 256 utterances spread each utterance over up to eight workgroups (csrc/vad_cmvn.hip: `gridDim.y` splits by
     window-start chunks); batches of 256 and more run one workgroup per utterance. Both against vad.py:156-203 -> gather ->
@@ -412,7 +412,7 @@ def test_fused_vad_cmvn_split_over_workgroups_matches_the_oracle(out_dtype):
     rng = np.random.default_rng(77)
     D = 30
     vcfg = dict(energy_mean_scale=0.5, energy_threshold=5.5, frames_context=2, proportion_threshold=0.12)
-    tol = {torch.float32: 2e-4, torch.float16: 2e-2, torch.bfloat16: 1.5e-1}[out_dtype]
+    tol = {torch.float32: 2e-4, torch.bfloat16: 1.5e-1}[out_dtype]
     for (T, window, nv, pad) in [(998, 300, False, "SAME"), (998, 300, True, "SAME"), (700, 300, False, "VALID"), (335, 300, True, "VALID"),
                                  (333, 300, False, "SAME"), (250, 300, False, "SAME"), (64, 300, True, "SAME"), (1500, 64, False, "SAME"),
                                  (401, 201, True, "VALID")]:

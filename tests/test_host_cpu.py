@@ -97,24 +97,27 @@ def test_host_side_size_helpers():
 
 def test_gemm_mode_selection_host_logic():
     import torch
-    assert L.ktf_dtype(torch.float16) == L.KTF_F16 and L.ktf_dtype(torch.bfloat16) == L.KTF_BF16
-    assert L.act_torch_dtype(L.GEMM_F16) == torch.float16 and L.act_torch_dtype(L.GEMM_BF16X3) == torch.float32
-    big = ktf.layers.TDNN(512, context=[-2, 0, 2], gemm="f16")
-    assert big.effective_gemm(L.GEMM_F16, relu=True) == L.GEMM_F16 and big.effective_gemm(L.GEMM_BF16) == L.GEMM_BF16
-    # the half mode runs on the ring kernels only: narrow layers and sigmoid / tanh layers are evaluated in fp32
-    assert ktf.layers.TDNN(64, context=[0], gemm="f16").effective_gemm(L.GEMM_F16) == L.GEMM_F32
-    assert ktf.layers.TDNN(512, context=[0], activation="tanh", gemm="f16").effective_gemm(L.GEMM_F16) == L.GEMM_F32
-    assert ktf.layers.TDNN(512, context=[0], activation="relu", gemm="f16").effective_gemm(L.GEMM_F16, relu=False) == L.GEMM_F16
+    assert L.ktf_dtype(torch.float32) == L.KTF_F32 and L.ktf_dtype(torch.bfloat16) == L.KTF_BF16
+    assert L.act_torch_dtype(L.GEMM_BF16) == torch.bfloat16 and L.act_torch_dtype(L.GEMM_BF16X3) == torch.float32
+    big = ktf.layers.TDNN(512, context=[-2, 0, 2], gemm="f16mx")
+    assert big.effective_gemm(L.GEMM_F16MX, relu=True) == L.GEMM_F16MX and big.effective_gemm(L.GEMM_BF16) == L.GEMM_BF16
+    # the block-scaled mode runs on the MX kernels only: narrow layers and sigmoid / tanh layers are evaluated in fp32
+    assert ktf.layers.TDNN(64, context=[0], gemm="f16mx").effective_gemm(L.GEMM_F16MX) == L.GEMM_F32
+    assert ktf.layers.TDNN(512, context=[0], activation="tanh", gemm="f16mx").effective_gemm(L.GEMM_F16MX) == L.GEMM_F32
+    assert ktf.layers.TDNN(512, context=[0], activation="relu", gemm="f16mx").effective_gemm(L.GEMM_F16MX, relu=False) == L.GEMM_F16MX
     big.build((None, None, 512))
-    d = big.desc(L.GEMM_F16, torch.float16, torch.float16, act="relu")
-    assert (d.x_dtype, d.w_dtype, d.y_dtype, d.gemm) == (L.KTF_F16, L.KTF_F16, L.KTF_F16, L.GEMM_F16)
+    d = big.desc(L.GEMM_BF16, torch.bfloat16, torch.bfloat16, act="relu")
+    assert (d.x_dtype, d.w_dtype, d.y_dtype, d.gemm) == (L.KTF_BF16, L.KTF_BF16, L.KTF_BF16, L.GEMM_BF16)
+    for gone in ("f16", "f16x2", "float16"):             # round 2's half-precision modes left the library in round 5
+        with pytest.raises(ValueError):
+            ktf.layers.TDNN(8, context=[0], gemm=gone)
     with pytest.raises(ValueError):
         ktf.layers.TDNN(8, context=[0], gemm="fp8")
     # batches of only a few 256-row tiles leave the 256-row kernels in every reduced mode (Sequential.batch_gemm: the crossovers of
     # tools/small_batch_crossover.py) -- for the bf16-pair small tiles (`small_tile_pairs`, the default) or the exact fp32 ones
     S = ktf.models.Sequential
     assert S([], gemm="bf16").batch_gemm(2, 998) == L.GEMM_F32 and S([], gemm="bf16").batch_gemm(3, 998) == L.GEMM_BF16
-    assert S([], gemm="f16").batch_gemm(14, 200) == L.GEMM_F32 and S([], gemm="f16").batch_gemm(15, 200) == L.GEMM_F16    # (rows / 256, rounded up)
+    assert S([], gemm="bf16").batch_gemm(14, 200) == L.GEMM_F32 and S([], gemm="bf16").batch_gemm(15, 200) == L.GEMM_BF16   # (rows / 256, rounded up)
     assert S([], gemm="bf16x3").batch_gemm(7, 998) == L.GEMM_F32 and S([], gemm="bf16x3").batch_gemm(8, 998) == L.GEMM_BF16X3
     assert S([], gemm="f16mx").batch_gemm(4, 998) == L.GEMM_F32 and S([], gemm="f16mx").batch_gemm(5, 998) == L.GEMM_F16MX
     assert S([], gemm="f32").batch_gemm(1024, 998) == L.GEMM_F32
@@ -503,23 +506,6 @@ def test_split_plane_weight_layouts_follow_the_header():
     assert "transpose(0, 2, 1, 3)" in body and "(4 - ((r >> 2) & 3)) & 3" in body and "transpose(2, 3, 0, 1, 4)" in body
 
 
-def test_calibrate_from_batchnorm_maps_each_layer_to_the_statistics_in_front_of_it():
-    """Sequential.calibrate_from_batchnorm (host only): the input plane of frame-level layer i + 1 is what the BatchNorm after
-    layer i was trained on, so that BatchNorm's moving mean / variance are handed to layer i + 1; the first layer (features
-    in, no BatchNorm in front) gets none, and nothing happens outside the f16x2 mode."""
-    import synth
-    w = synth.make_weights(seed=7, narrow=True)
-    m = synth.build_sequential(ktf, w, "f16x2")
-    got = m.calibrate_from_batchnorm()
-    steps = [q for q in m._plan() if q[0] == "tdnn"]
-    frame_level = steps[:5]
-    assert id(frame_level[0][1]) not in got
-    for prev, cur in zip(frame_level, frame_level[1:]):
-        assert np.array_equal(m._xbar[id(cur[1])], prev[3].moving_mean.astype(np.float64))
-        assert np.array_equal(m._xvar[id(cur[1])], prev[3].moving_variance.astype(np.float64))
-    assert synth.build_sequential(ktf, w, "bf16x3").calibrate_from_batchnorm() == {}
-
-
 def test_library_kernel_families():
     """The TDNN GEMM kernel instantiations shipped in libktf_hip.so are exactly the ones the dispatcher can reach (the map itself is
     pinned on the GPU by tests/test_gpu_dispatch.py): no probe / ablation / superseded generations in the product."""
@@ -535,7 +521,7 @@ def test_library_kernel_families():
                         "tdnn_x3s_kernel", "tdnn_x4s_kernel", "tdnn_mx_kernel", "tdnn_mxl_kernel",
                         "tdnn_out_lens_kernel"}, fam          # (the last one: ktf_tdnn_out_lens, lengths only)
     assert fam["tdnn_x3r_kernel"] == 8                  # 4 activations x {store, pooled}: fp32 activations only
-    assert fam["tdnn_x3s_kernel"] == 8 + 8 + 2 + 4 + 4  # split-bf16 (4 activations x 2, plain and row-group-skipping; flat rows: ReLU / none), half two-pass and one-pass (2 x 2 each)
+    assert fam["tdnn_x3s_kernel"] == 8 + 8 + 2          # split-bf16 (4 activations x {rows, pooled}, plain and row-group-skipping; flat rows: ReLU / none)
     assert fam["tdnn_x4s_kernel"] == 8                  # bf16-pair small tiles: 64 x 32 / 64 / 96 and the K-step-32 form, x {rows, pooled}
     assert fam["tdnn_mx_kernel"] == 12                  # {ReLU, none} x {planes, fp32, pooled} x {K-steps fill the super-steps, padded}
     assert fam["tdnn_mxl_kernel"] == 6                  # the same on the loader-wave kernel (KTF_TDNN_MX_LOADER)

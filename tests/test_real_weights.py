@@ -74,12 +74,8 @@ def test_oracle_tdnn6_affine_on_real_weights(model):
     assert cos_err(z[kout], got) <= 1.25e-3                          # sequential_test.py:30
 
 
-# the modes that claim the tolerance on any input, plus f16x2 in its uncalibrated (two-pass) and BatchNorm-calibrated forms
-REAL_MODES = ["f32", "bf16x3", "f16mx", "f16x2", "f16x2+bn"]
-
-
-def _mode(gemm):
-    return gemm.split("+")[0], gemm.endswith("+bn")
+# the modes that claim the tolerance on any input
+REAL_MODES = ["f32", "bf16x3", "f16mx"]
 
 
 @pytest.mark.gpu
@@ -90,17 +86,13 @@ def test_gpu_tdnn6_affine_on_real_weights(model, gemm):
     import torch
     feat, out, kin, kout = MODELS[model]
     z = G.load("tdnn.npz")
-    g, from_bn = _mode(gemm)
-    mdl = ktf.models.SequentialFromConfig(synth.model_config(False, feat, out), _raw(model), "cmvn2xvec", gemm=g)
+    mdl = ktf.models.SequentialFromConfig(synth.model_config(False, feat, out), _raw(model), "cmvn2xvec", gemm=gemm)
     mdl.min_tiles = {}
-    if from_bn:                       # a trained model's BatchNorm statistics ARE the statistics calibrate() measures
-        assert len(mdl.calibrate_from_batchnorm()) == 4
     got = mdl(z[kin]).cpu().numpy()
     assert got.shape == z[kout].shape
     assert cos_err(z[kout], got) <= 1.25e-3
     want = O.sequential_forward(_oracle_layers_from_raw(_raw(model)), z[kin], dtype=np.float64)
-    tol = 1e-4 if not from_bn else 1e-3            # the calibrated form is not a tolerance-compliant mode (tests/test_gpu_speech.py)
-    assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
 @pytest.mark.gpu
@@ -124,15 +116,12 @@ def test_gpu_wav_to_xvector_on_real_weights(gemm, tmp_path):
     ecfg["xvec"] = {"model_config_path": str(tmp_path / "kaldi.yml"), "model_path": _raw(model),
                     "global_mean_path": mean_p, "lda_matrix_path": lda_p}
     (tmp_path / "extractor.yml").write_text(yaml.safe_dump({"name": model, "extractor": ecfg}))
-    g, from_bn = _mode(gemm)
-    mdl = ktf.models.XvectorExtractorFromConfig(str(tmp_path / "extractor.yml"), gemm=g)
+    mdl = ktf.models.XvectorExtractorFromConfig(str(tmp_path / "extractor.yml"), gemm=gemm)
     mdl.xvec.min_tiles = {}
-    if from_bn:
-        assert len(mdl.xvec.calibrate_from_batchnorm()) == 4
     wav = e["wav_int16"].astype(np.float32)[None]
     got = mdl(torch.as_tensor(wav, device="cuda")).cpu().numpy()
     assert got.shape == (128,)
     assert cos_err(e["xvector"], got) <= 0.075                       # xvector_extractor_test.py:30
     want = O.xvector_forward(wav, ecfg, _oracle_layers_from_raw(_raw(model)), mdl.xvecGlobalMean,
                              np.concatenate([mdl.ldaMat.T, mdl.ldaOffset.T], 1), dtype=np.float64)
-    assert np.abs(got - want[0]).max() <= (1e-4 if not from_bn else 1e-3)       # north_star bound, on the real weights
+    assert np.abs(got - want[0]).max() <= 1e-4       # north_star bound, on the real weights

@@ -17,10 +17,10 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 BIG = "--big" in sys.argv       # batches of hundreds of utterances: the checker is this library's own fp32 mode (checked against the oracle at the
                                 # small sizes), the oracle would take minutes per case
-TOL = {"f32": 2e-5, "bf16x3": 3e-4, "f16mx": 4e-3, "f16": 3e-2, "bf16": 1.5e-1}       # relative to the output's largest magnitude
+TOL = {"f32": 2e-5, "bf16x3": 3e-4, "f16mx": 4e-3, "bf16": 1.5e-1}       # relative to the output's largest magnitude
 bad = 0
 for case in range(n_cases):
-    gemm = str(rng.choice(["f32", "bf16x3", "f16mx", "f16mx", "bf16", "f16"])) if not BIG else str(rng.choice(["bf16x3", "f16mx", "f16mx", "bf16", "f16"]))
+    gemm = str(rng.choice(["f32", "bf16x3", "f16mx", "f16mx", "bf16"])) if not BIG else str(rng.choice(["bf16x3", "f16mx", "f16mx", "bf16"]))
     D = int(rng.choice([24, 30, 40, 64, 100]))
     n_frame = int(rng.integers(1, 5))
     pooled_at = n_frame if rng.random() < 0.5 else None

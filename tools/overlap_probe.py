@@ -7,7 +7,7 @@ for p in (ROOT, os.path.join(ROOT, "kaldi-tflite_amd"), os.path.join(ROOT, "test
 import torch, synth
 import kaldi_tflite_amd as ktf
 dev = torch.device("cuda", 0)
-mdl = synth.build_extractor(ktf, synth.extractor_cfg(), synth.make_weights(seed=4321), gemm="f16x2", calibrate=True)
+mdl = synth.build_extractor(ktf, synth.extractor_cfg(), synth.make_weights(seed=4321), gemm="f16mx")
 g = torch.Generator(device=dev).manual_seed(1234)
 wav = torch.clamp(torch.round(1000.0 * torch.randn((1024, 160000), generator=g, device=dev)), -32767, 32767)
 wa, wb = wav[:512], wav[512:]

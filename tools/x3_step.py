@@ -9,8 +9,7 @@ import torch, synth, bench
 import kaldi_tflite_amd as ktf
 from kaldi_tflite_amd import ops
 dev = torch.device("cuda", 0)
-mdl = synth.build_extractor(ktf, synth.extractor_cfg(), synth.make_weights(seed=4321), gemm=os.environ.get("GEMM", "bf16x3"),
-                            calibrate=os.environ.get("CAL", "1") == "1")        # f16x2: the form bench.py times (CAL=0: two passes everywhere)
+mdl = synth.build_extractor(ktf, synth.extractor_cfg(), synth.make_weights(seed=4321), gemm=os.environ.get("GEMM", "bf16x3"))
 g = torch.Generator(device=dev).manual_seed(1234)
 wav = torch.clamp(torch.round(1000.0 * torch.randn((1024, 160000), generator=g, device=dev)), -32767, 32767)
 for _ in range(3): mdl(wav)
