@@ -255,7 +255,7 @@ def main(argv=None):
 class _GemmProfiler:
     """Brackets every ktf_tdnn launch of the frame-level layers with HIP events on the launch stream."""
 
-    NAMES = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_mx", "tdnn_mx_stats")
+    NAMES = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_split_flat", "tdnn_split_flat_stats", "tdnn_mx", "tdnn_mx_stats")
     AUX = ("mx_planes", "split_bf16")      # conversions a mode needs in front of its first GEMM: timed too, reported separately
 
     def __init__(self, ops, torch):
@@ -515,7 +515,7 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
             res[g].update({"x_vectors_per_s": B / (ms20 * 1e-3), "ms_per_step": ms20, "steps": 20,
                            "roofline": _roofline(g, prof.finish(), 20, B, T, float(MFMA_PASSES[g]))})
             if B == 1024:
-                _attach_traffic(res[g]["roofline"], g)
+                _attach_traffic(res[g]["roofline"], g, ops.build_id())
         del m
         torch.cuda.empty_cache()
     # the same step with the shipped YAML's dither (data/tflite_models/0008_sitw_v2_1a.yml:43, `dither: 1.0`: on-device Philox + Box-Muller)
@@ -538,6 +538,27 @@ def _other_configs(torch, ktf, synth, cfg, w, wav, gemm, dev, dev_info, mdl):
     short = torch.clamp(torch.round(1000.0 * torch.randn((B, 24000), generator=torch.Generator(device=dev).manual_seed(77), device=dev)), -32767, 32767)
     ms = _time_ms(torch, lambda: mdl(short), 5)
     res[f"{gemm}_1.5s_windows"] = {"x_vectors_per_s": B / (ms * 1e-3), "ms_per_step": ms, "note": "1024 windows of 1.5 s (148 frames) per step"}
+    if gemm != "f32":
+        # ... with the roofline of the kernels the route runs: for the timed mode the split-bf16 plane kernels on flat row tiles (csrc/tdnn_split.hip,
+        # tdnn_x3s_kernel<flat> and <flat, pooled>), three bf16 MFMA passes per algorithmic flop, against the dense 16-bit peak
+        route = mdl.xvec.SHORT_MODE.get(gemm, gemm) if mdl.xvec.frames_floor(gemm) > 148 else gemm
+        prof = _GemmProfiler(ops, torch)
+        for _ in range(3):
+            mdl(short)
+        prof.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            mdl(short)
+        torch.cuda.synchronize()
+        ms20 = 1e3 * (time.perf_counter() - t0) / 20
+        Ts = mdl.framing.numFrames(short.shape[1])
+        roof = _roofline(route, prof.finish(), 20, B, Ts, float(MFMA_PASSES[route]))
+        if route == "bf16x3":
+            roof["kernel"] = "tdnn_x3s_kernel<flat> (tdnn1-4) + tdnn_x3s_kernel<flat, pooled> (tdnn5 + pooling), csrc/tdnn_split.hip"
+        dv = dev_info.get(gemm, {}).get("speech_1.5s_windows")
+        res[f"{gemm}_1.5s_windows"].update({"x_vectors_per_s": B / (ms20 * 1e-3), "ms_per_step": ms20, "steps": 20, "route": route, "roofline": roof,
+                                            "max_abs_dev_vs_fp64_oracle_on_speech_1.5s_windows": dv})
     del short
     # int16 PCM input: same step, half the input bytes; and the PCIe-inclusive rate of a host-fed step
     wav16 = wav.to(torch.int16)

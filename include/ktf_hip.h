@@ -321,6 +321,19 @@ int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int
 int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
                         const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                         const float* shift, void* y, void* y_lo, int64_t ldy, void* stream);
+/* ktf_tdnn_split_flat fused with the reducing StatsPooling that follows it (ktf_tdnn_split_stats on the flat row tiles: the pooled
+ * layer of 1.5 s windows otherwise computes 256-row tiles of 148 rows). `sums`: with KTF_TDNN_DET_STATS (B, ktf_flat_stats_slots(T), 2,
+ * units) doubles, not zeroed by the caller: an utterance of len rows that starts at flat row s = row_starts[b] gets one partial sum per
+ * 128-row block OF THE FLAT ROW SPACE it touches, in slots 0 .. ((s + len - 1) >> 7) - (s >> 7), and ktf_stats_finalize_flat adds
+ * exactly those in slot order: reproducible run to run; the partition of an utterance's rows into partial sums depends on where the
+ * batch places it, so its pooled values can differ in the last fp64 bits from batch to batch. Without the flag (B, 2, units), zeroed by
+ * the caller, fp64 atomics (finalize with ktf_stats_finalize). */
+int64_t ktf_flat_stats_slots(int64_t T);
+int ktf_tdnn_split_flat_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
+                              const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                              const float* shift, double* sums, void* stream);
+int ktf_stats_finalize_flat(const double* sums, int64_t slots, const int32_t* row_starts, int64_t T, int64_t B, int32_t D,
+                            int32_t include_std, float eps, float* out, int64_t ld_out, void* stream);
 int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* lens,
                          const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                          const float* shift, double* sums, void* stream);

@@ -124,6 +124,8 @@ extern "C" int ktf_tdnn_out_lens(const int32_t* lens, int64_t B, const KtfTdnnDe
     return KTF_OK;
 }
 
+extern "C" int64_t ktf_flat_stats_slots(int64_t T) { return T <= 0 ? 1 : (T + 254) / 128; }
+
 static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,
@@ -181,7 +183,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
     p.act = act_pass ? KTF_ACT_NONE : d->act; p.y_dtype = y_pair ? KTF_F32 : d->y_dtype; p.y_pair = y_pair ? 1 : 0; p.ktot = d->nctx * d->din_pad;
     if (act_pass) p.scale = p.shift = nullptr;          // (the BatchNorm affine follows the activation: applied by the pass)
-    p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_stats_slots(Tout) : 0;
+    p.stat_slots = (stats_sums && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)(row_starts ? ktf_flat_stats_slots(Tout) : ktf_stats_slots(Tout)) : 0;
     p.kinter = (d->flags & KTF_TDNN_K_INTERLEAVED) ? 1 : 0;
     p.wtiled = (d->flags & KTF_TDNN_W_TILED) ? 1 : 0;
     if (p.wtiled) KTF_REQUIRE((split_in && d->units > 128 && ldy % 4 == 0), "ktf_tdnn: KTF_TDNN_W_TILED is implemented by the split-plane kernel only");
@@ -251,6 +253,15 @@ extern "C" int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B
     return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, y, ldy, nullptr, nullptr, stream, x_lo, y_lo, row_starts);
 }
 
+// ... with the reducing StatsPooling fused (ktf_tdnn_split_stats on flat row tiles)
+extern "C" int ktf_tdnn_split_flat_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
+                                         const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                                         const float* shift, double* sums, void* stream) {
+    KTF_REQUIRE(x_hi && x_lo && row_starts && d && w && w_lo && sums, "ktf_tdnn_split_flat_stats: null argument");
+    KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_flat_stats: needs KTF_GEMM_BF16X3 on bf16 hi / lo planes");
+    return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream, x_lo, nullptr, row_starts);
+}
+
 extern "C" int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx,
                                     const int32_t* lens, const KtfTdnnDesc* d, const void* w, const void* w_lo,
                                     const float* bias, const float* scale, const float* shift, double* sums, void* stream) {
@@ -298,19 +309,22 @@ extern "C" int64_t ktf_tdnn_stats_slots(int64_t T, int32_t gemm) {
 
 // mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)
 __global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t slots, int slot_rows, const int32_t* __restrict__ lens, int64_t T,
-                                      int64_t B, int D, int include_std, float eps, float* __restrict__ out, int64_t ldo) {
+                                      int64_t B, int D, int include_std, float eps, float* __restrict__ out, int64_t ldo,
+                                      const int32_t* __restrict__ row_starts = nullptr) {
     const int64_t total = B * D;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = e / D;
         const int c = (int)(e - b * D);
-        const int len = lens ? lens[b] : (int)T;
+        const int rs0 = row_starts ? row_starts[b] : 0;
+        const int len = row_starts ? row_starts[b + 1] - rs0 : (lens ? lens[b] : (int)T);
         const double n = (double)len;
         double s = 0.0, q = 0.0;
         if (slots == 0) {
             s = sums[(b * 2) * D + c];
             q = sums[(b * 2 + 1) * D + c];
         } else {
-            const int used = (len + slot_rows - 1) / slot_rows;   // blocks holding valid rows, added in block order
+            // blocks holding valid rows, added in block order (flat row tiles: the 128-row blocks of the flat row space the utterance touches)
+            const int used = row_starts ? (len > 0 ? ((rs0 + len - 1) >> 7) - (rs0 >> 7) + 1 : 0) : (len + slot_rows - 1) / slot_rows;
             for (int k = 0; k < used; ++k) {
                 s += sums[((b * slots + k) * 2) * D + c];
                 q += sums[((b * slots + k) * 2 + 1) * D + c];
@@ -347,6 +361,21 @@ extern "C" int ktf_stats_finalize_slots(const double* sums, int64_t slots, int32
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, slots, (int)slot_rows, lens, T, B, D, include_std, eps, out, ld_out);
     KTF_CHECK_LAUNCH("ktf_stats_finalize_slots");
+    return KTF_OK;
+}
+
+extern "C" int ktf_stats_finalize_flat(const double* sums, int64_t slots, const int32_t* row_starts, int64_t T, int64_t B, int32_t D,
+                                       int32_t include_std, float eps, float* out, int64_t ld_out, void* stream) {
+    KTF_REQUIRE(sums && out && row_starts, "ktf_stats_finalize_flat: null argument");
+    KTF_REQUIRE(B >= 0 && D > 0 && ld_out >= (include_std ? 2 : 1) * (int64_t)D, "ktf_stats_finalize_flat: bad sizes");
+    KTF_REQUIRE(slots == 0 || slots >= ktf_flat_stats_slots(T), "ktf_stats_finalize_flat: %lld slots, utterances of up to %lld rows touch %lld blocks",
+                (long long)slots, (long long)T, (long long)ktf_flat_stats_slots(T));
+    if (B == 0) return KTF_OK;
+    int blocks = ktf_cdiv(B * D, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, sums, slots, 128, (const int32_t*)nullptr, T, B, D, include_std, eps,
+                       out, ld_out, row_starts);
+    KTF_CHECK_LAUNCH("ktf_stats_finalize_flat");
     return KTF_OK;
 }
 

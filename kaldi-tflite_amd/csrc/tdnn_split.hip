@@ -168,17 +168,96 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // SKIP: row groups (two 16-row blocks) of the wave's 128 rows that hold no valid output row issue no MFMAs -- for launches whose
 // tiles are mostly padding (1.5 s windows: 148 rows of a 256-row tile, -17 % per step; the launcher decides from T). On full tiles the
 // test costs 1.7 % (it splits the scheduler's K-step into regions), so the plain instantiation keeps them.
-// FLAT (with SKIP; SAME padding, no subsampling, row-major planes, no fused pooling): the M-tiles cover the batch's VALID rows laid end
+// FLAT (with SKIP; SAME padding, no subsampling): the M-tiles cover the batch's VALID rows laid end
 // to end (p.row_starts: exclusive prefix sums of lens) instead of 256-row tiles per utterance -- a 1.5 s window is 148 rows, 0.58 of a
 // tile. A tile's rows belong to several utterances: each row's (utterance, frame, length) comes from an LDS table built at entry
 // (two 64-way steps over p.row_starts find the tile's first utterance, a search in the 258 staged prefix sums each row's own), the
 // context offsets clamp against the row's own utterance, and the epilogue scatters rows through the same table. `mtiles` carries B.
 #define XS_FLAT_OFF XS_LDS_BYTES                        // rs[260] | out_row[256] | t[256] | len[256]
 #define XS_FLAT_BYTES (260 * 4 + 3 * 256 * 4)
+
+// Fused pooling on flat row tiles: a wave's 128-row block holds rows of several utterances, each a run of consecutive rows. Per run
+// (wave-uniform loop over the row table) the wave sums its columns over the run's rows -- in fp32 relative to the run's first row, as
+// ring_epilogue16 does per block, so that a constant column sums to exactly (n v, n v^2) -- and stores the fp64 result in the slot
+// (flat 128-row block of the run) - (flat 128-row block of the utterance's first row) of its utterance: every slot has one writer, an
+// utterance of len rows starting at flat row s uses slots 0 .. ((s + len - 1) >> 7) - (s >> 7) (ktf_stats_finalize_flat adds exactly
+// those, in order; ktf_flat_stats_slots(T) of them are allocated per utterance), or, without KTF_TDNN_DET_STATS, is added atomically.
+// `tab`: out_row[256] | t[256] | len[256] of the tile's rows.
+template <int ACT>
+__device__ __forceinline__ void flat_stats_epilogue(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats, const int* tab,
+                                                    int R0, int rows_valid, int n0, int wm, int wn, int lane, const Epi16Prm& prm) {
+    const int* trow = tab;
+    const int* tt = tab + 256;
+    const int* tlen = tab + 512;
+    const int g4 = lane >> 4;
+    const int blk0 = wm * 128;
+    const int blk_end = min(blk0 + 128, rows_valid);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[i][j][r] + prm.bias[j];
+                if (ACT == KTF_ACT_RELU) v = fmaxf(v, 0.0f);
+                else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
+                acc[i][j][r] = v * prm.sc[j] + prm.sh[j];
+            }
+    int m = blk0;
+    while (m < blk_end) {
+        const int t_m = __builtin_amdgcn_readfirstlane(tt[m]);
+        const int len_m = __builtin_amdgcn_readfirstlane(tlen[m]);
+        const int orow = __builtin_amdgcn_readfirstlane(trow[m]);
+        const int b = (orow - t_m) / (int)p.T;
+        const int seg_end = min(blk_end, m + (len_m - t_m));
+        const int lm = m - blk0, le = seg_end - blk0;                 // the run's rows inside the block: [lm, le)
+        const int slot = ((R0 + blk0) >> 7) - ((R0 + m - t_m) >> 7);
+        const int rb = g4 * 4 - lm;                                    // lane's row (i, r) relative to the run's first: rb + 16 i + r
+        const unsigned span = (unsigned)(le - lm);
+        float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool first = rb + 16 * i + r == 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[j] = first ? acc[i][j][r] : pv[j];
+            }
+        const int src = ((lm >> 2) & 3) * 16 + (lane & 15);           // the lane that holds the run's first row of this column
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = __shfl(pv[j], src, 64);
+        float s32[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q32[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool in = (unsigned)(rb + 16 * i + r) < span;
+                cnt += in ? 1 : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float u = in ? acc[i][j][r] - pv[j] : 0.0f;
+                    s32[j] += u;
+                    q32[j] = fmaf(u, u, q32[j]);
+                }
+            }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double pd = (double)pv[j], sd = (double)s32[j], nd = (double)cnt;
+            double s = sd + nd * pd;
+            double q = (double)q32[j] + 2.0 * pd * sd + nd * pd * pd;
+            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
+            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
+            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+            if (lane < 16 && n < p.units) stats_out(stats, p, b, slot, n, s, q);
+        }
+        m = seg_end;
+    }
+}
 template <int ACT, bool STATS, bool SKIP = false, bool FLAT = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
-    static_assert(!FLAT || (SKIP && !STATS), "flat row tiling: rows out");
+    static_assert(!FLAT || SKIP, "flat row tiling: with the row-group test");
     // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered
     constexpr int NST = 2;
     constexpr int STG = XS_STAGE_BYTES;
@@ -463,8 +542,11 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
     }
 #undef XS_STAGE
     if (!STATS) __syncthreads();      // all fragment reads done before the LDS is reused as the store staging area
-    ring_epilogue16<ACT, STATS, FLAT>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm,
-                                           FLAT ? reinterpret_cast<const int*>(rsm + XS_FLAT_OFF) + 260 : nullptr);
+    if constexpr (STATS && FLAT)
+        flat_stats_epilogue<ACT>(acc, p, stats, reinterpret_cast<const int*>(rsm + XS_FLAT_OFF) + 260, mt * R_BM, out_len, n0, wm, wn, lane, eprm);
+    else
+        ring_epilogue16<ACT, STATS, FLAT>(acc, p, stats, rsm, b, t0, n0, out_len, wm, wn, wave, lane, eprm,
+                                          FLAT ? reinterpret_cast<const int*>(rsm + XS_FLAT_OFF) + 260 : nullptr);
 }
 
 
@@ -507,7 +589,7 @@ int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int6
     } while (0)
             // hi / lo planes in: the 16x16x32 plane kernel; fp32 activations in: the kernel that splits them in registers
             if (split_in && p.row_starts) {              // ktf_tdnn_split_flat: M-tiles over the batch's valid rows laid end to end
-                KTF_REQUIRE(!stats_sums && !d->valid && d->subsampling == 1, "ktf_tdnn_split_flat: SAME padding, no subsampling, rows out");
+                KTF_REQUIRE(!d->valid && d->subsampling == 1, "ktf_tdnn_split_flat: SAME padding, no subsampling");
                 KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "ktf_tdnn_split_flat: fuses ReLU or no activation");
                 KTF_REQUIRE(B <= 4095 && B * p.T * p.ldx * 2 < (1ll << 32), "ktf_tdnn_split_flat: B <= 4095 and B * T * ldx * 2 < 2^32");
                 const int64_t ftiles = ktf_cdiv(B * p.T, R_BM);
@@ -515,6 +597,16 @@ int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int6
                 KTF_REQUIRE(fblocks < (1ll << 31), "ktf_tdnn: grid too large");
                 constexpr int lds_ = XS_LDS_BYTES + XS_FLAT_BYTES;
                 KTF_NOTE_KERNEL("tdnn_x3s_kernel<flat>");
+                if (stats_sums) {
+                    KTF_NOTE_KERNEL("tdnn_x3s_kernel<flat, pooled>");
+                    if (d->act == KTF_ACT_RELU) {
+                        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, true, true, true>);
+                        hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, true, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, stats_sums);
+                    } else {
+                        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, true, true, true>);
+                        hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, true, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, stats_sums);
+                    }
+                } else
                 if (d->act == KTF_ACT_RELU) {
                     KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, false, true, true>);
                     hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, false, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);

@@ -177,6 +177,10 @@ class Sequential:
                                      # and takes every batch that fills the chip; 5 ... 24 and ~48 utterances of 10 s leave it
                                      # partly empty and run 8-16 % faster on the smaller flat tiles (tools/mid_batch.py)
         self.flat_rows = True        # bf16x3 plane layers of short utterances: M-tiles over the valid rows laid end to end (ktf_tdnn_split_flat)
+        self.flat_pooling = True     # ... the layer pooled in its epilogue included (ktf_tdnn_split_flat_stats). Its partial sums are cut along the
+                                     # flat row space: reproducible run to run, but an utterance's pooled values can differ in the last bits of the
+                                     # fp32 partial sums (<= 2e-6 on an x-vector) with the batch it arrives in; False: per-utterance tiles for
+                                     # that layer, x-vectors of the split-bf16 route independent of the batch bit for bit, 3.5 % slower on 1.5 s windows
         self.small_tile_pairs = True # batches below `min_tiles` of a reduced-precision model: bf16-pair small tiles instead of fp32 ones
         self.fuse_stats = True       # pool inside the epilogue of the GEMM that feeds a reducing StatsPooling
         self.deterministic = True    # ... with per-block partial sums added in a fixed order (bitwise reproducible runs)
@@ -315,15 +319,23 @@ class Sequential:
         cost_loader = rounds(2 * ((B * T + 191) // 192)) * 192 * 1.05
         return cost_loader < cost_256
 
-    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, defer_to=None):
+    def _flat_tiles(self, l, B, T, ldx):
+        """Split-bf16 plane layers of utterances that fill their 256-row tiles badly (a 1.5 s window: 148 rows) run on M-tiles over the
+        batch's valid rows laid end to end (ktf_tdnn_split_flat*)."""
+        return bool(self.flat_rows and l.padding == "SAME" and l.subsamplingFactor == 1 and l.activation in (None, "linear", "relu")
+                    and B <= 4095 and B * T * ldx * 2 < 2 ** 32 and 5 * (-(-T // 16)) < 4 * (-(-T // 256)) * 16)
+
+    def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, defer_to=None, row_starts=None):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.
-        `split`: the input is a (2,B,T,ld) pair of bf16 planes read by the split-plane kernel. Returns the pooled (1, B, od) view."""
+        `split`: the input is a (2,B,T,ld) pair of bf16 planes read by the split-plane kernel; `row_starts`: ... on flat row tiles
+        (reproducible form only). Returns the pooled (1, B, od) view."""
         sp = nxt[1]
         D = l.units
         od = 2 * D if sp.includeStd else D
         ld = ops.round_up(od, 32)
         B = x_or_planes.shape[1] if x_or_planes.dim() == 4 else x_or_planes.shape[0]
-        slots = ops.stats_slots(T) if self.deterministic else 0
+        flat = row_starts is not None
+        slots = (ops.flat_stats_slots(T) if flat else ops.stats_slots(T)) if self.deterministic else 0
         sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev, padded=False)
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev, padded=od if ld != od else False)
         kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
@@ -333,6 +345,15 @@ class Sequential:
         xdt = x_or_planes.dtype
         d = l.desc(gemm, xdt, xdt if split else L.act_torch_dtype(gemm), act="relu" if relu else None,
                    flags=(L.TDNN_DET_STATS if slots else 0) | (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if wt else 0))
+        if flat:
+            ops.tdnn_split_flat_stats(x_or_planes, row_starts, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
+            if slots:
+                ops.stats_finalize_flat(sums, row_starts, T, D, sp.includeStd, sp.epsilon, sbuf, slots)
+            else:
+                ops.stats_finalize(sums, lens, T, D, sp.includeStd, sp.epsilon, sbuf)
+            if defer_to is not None:     # (the fused tail reads finished pooled rows here: its own finalize knows per-utterance slots only)
+                self._deferred = DeferredTail(defer_to, B, D, sp.includeStd, sp.epsilon, pooled=sbuf, lens=lens, T=T)
+            return sbuf[:, :od].unsqueeze(0)
         (ops.tdnn_split_stats if split else ops.tdnn_stats)(x_or_planes, lens, d, w, w_lo, bias, scale, shift, sums, zero=not slots)
         if defer_to is not None:         # the caller's fused tail finalizes the sums itself
             self._deferred = DeferredTail(defer_to, B, D, sp.includeStd, sp.epsilon, sums=sums, slots=slots, lens=lens, T=T)
@@ -465,8 +486,11 @@ class Sequential:
                     ops.split_bf16(src, D, planes)
                 B, T = planes.shape[1], planes.shape[2]
                 if can_pool:
+                    flat = self.flat_pooling and self._flat_tiles(l, B, T, planes.shape[3])
+                    if flat and row_starts is None:
+                        row_starts = ops.row_starts(lens, B, T, self._ws.get("row_starts", (B + 1,), torch.int32, dev, padded=False))
                     x = self._pooled_by_gemm(l, relu, bn, nxt, planes, lens, gemm, True, dev, T,
-                                             defer_to=steps[tail_at][1] if si + 2 == tail_at else None)
+                                             defer_to=steps[tail_at][1] if si + 2 == tail_at else None, row_starts=row_starts if flat else None)
                     lens, pooled, skip, planes = None, True, True, None
                     continue
                 kint = bool(self.k_interleaved and l.kernelWidth > 1)
@@ -482,9 +506,7 @@ class Sequential:
                         nxt[1].effective_gemm(gemm, nxt[2]) == gemm)
                 # utterances that fill their 256-row tiles badly (a 1.5 s window: 148 rows): M-tiles over the batch's valid rows laid
                 # end to end (ktf_tdnn_split_flat), same bits
-                flat = (self.flat_rows and gemm == L.GEMM_BF16X3 and l.padding == "SAME" and l.subsamplingFactor == 1
-                        and l.activation in (None, "linear", "relu") and B <= 4095 and B * T * planes.shape[3] * 2 < 2 ** 32
-                        and 5 * (-(-T // 16)) < 4 * (-(-T // 256)) * 16)
+                flat = self._flat_tiles(l, B, T, planes.shape[3])
                 if flat and row_starts is None:
                     row_starts = ops.row_starts(lens, B, T, self._ws.get("row_starts", (B + 1,), torch.int32, dev, padded=False))
                 split = (lambda d_, y_, ylo_: ops.tdnn_split_flat(planes, row_starts, d_, w, w_lo, bias, scale, shift, y_, ylo_)) if flat else \

@@ -456,6 +456,35 @@ def tdnn_split_stats(xp, lens, desc, w, w_lo, bias, scale, shift, sums, zero=Tru
     return sums
 
 
+def flat_stats_slots(T):
+    return int(L.load().ktf_flat_stats_slots(int(T)))
+
+
+def tdnn_split_flat_stats(xp, starts, desc, w, w_lo, bias, scale, shift, sums, zero=False):
+    """tdnn_split_stats on flat row tiles (`starts` = row_starts(lens, ...)). sums: (B, flat_stats_slots(T), 2, units) fp64 with
+    KTF_TDNN_DET_STATS in desc.flags (not zeroed: stats_finalize_flat reads the slots that were written), else (B, 2, units), zero=True."""
+    lib = L.load()
+    hi, lo, B, T, ldx = _planes(xp)
+    with L.on_device(xp.device):
+        if zero:
+            sums.zero_()
+        rc = lib.ktf_tdnn_split_flat_stats(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(starts), C.byref(desc), L.ptr(w), L.ptr(w_lo),
+                                           L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_split_flat_stats")
+    return sums
+
+
+def stats_finalize_flat(sums, starts, T, D, include_std, eps, out, slots):
+    """sums (B, slots, 2, D) fp64 of tdnn_split_flat_stats -> out (B, ld) mean | std."""
+    lib = L.load()
+    B = sums.shape[0]
+    with L.on_device(sums.device):
+        rc = lib.ktf_stats_finalize_flat(L.ptr(sums), slots, L.ptr(starts), T, B, D, int(include_std), eps, L.ptr(out), out.stride(0),
+                                         L.stream_ptr())
+    L.check(rc, "ktf_stats_finalize_flat")
+    return out
+
+
 def mx_planes(src, D, lens, planes):
     """fp32 (B,T,ld) rows -> the four KTF_GEMM_F16MX planes (mx.Planes); rows >= lens[b] are left unwritten."""
     lib = L.load()

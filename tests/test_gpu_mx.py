@@ -276,6 +276,11 @@ def test_fused_tail_equals_the_three_launch_tail(gemm):
     mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
     fused = mdl(dev(wav))
     assert torch.equal(mdl(dev(wav)), fused), "not reproducible"
+    if gemm == "bf16x3":           # 3 s utterances run on flat row tiles; the pooled layer's partial sums follow the flat row space (Sequential.flat_pooling)
+        for b in (0, 4):
+            assert (mdl(dev(wav[b:b + 1])).reshape(-1) - fused[b]).abs().max().item() <= 2e-6
+        mdl.xvec.flat_pooling = False
+        fused = mdl(dev(wav))
     for b in (0, 4):
         assert torch.equal(mdl(dev(wav[b:b + 1])).reshape(-1), fused[b]), "batch != single"
     mdl.fuse_tail = False
@@ -284,7 +289,9 @@ def test_fused_tail_equals_the_three_launch_tail(gemm):
     want = O.xvector_forward(wav, cfg, synth.oracle_layers(w), w["mean"], w["lda"], dtype=np.float64)
     assert np.abs(fused.cpu().numpy() - want).max() <= 1e-4
     # graph capture covers the ticket counters (reset by the kernel itself)
-    run = synth.build_extractor(ktf, cfg, w, gemm=gemm).compile(dev(wav))
+    m2 = synth.build_extractor(ktf, cfg, w, gemm=gemm)
+    m2.xvec.flat_pooling = mdl.xvec.flat_pooling
+    run = m2.compile(dev(wav))
     assert torch.equal(run(dev(wav)), fused) and torch.equal(run(dev(wav)), fused)
 
 

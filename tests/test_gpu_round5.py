@@ -12,6 +12,7 @@ import torch
 import synth
 import kaldi_tflite_amd as ktf
 from kaldi_tflite_amd import ops
+from oracle import ktf_oracle as O
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -60,3 +61,75 @@ def test_build_id_and_clock_probe():
     assert 1_900_000 <= ticks <= 2_600_000               # 100 MHz ticks of 20 ms (+ the loop's last sleep)
     mhz = 100.0 * clk / ticks
     assert 400.0 <= mhz <= 2500.0 and 0 < lo <= hi <= 2_600_000, (mhz, lo, hi)
+
+
+# ----------------------------------------------------------------------------- pooled layer on flat row tiles (short utterances)
+def _pooled_model(U, D, ctx, gemm="bf16x3"):
+    cfg = {"type": "sequential", "layers": [
+        {"name": "input", "type": "input", "shape": [None, None, D]},
+        {"name": "t0", "type": ["affine", "relu", "batchnorm"], "cfg": {"units": D, "context": [0]}},
+        {"name": "t", "type": ["affine", "relu", "batchnorm"], "cfg": {"units": U, "context": ctx}},
+        {"name": "stats", "type": "stats_pooling", "cfg": {"left_context": 0, "right_context": 5, "include_std": True, "reduce_time_axis": True}}]}
+    return ktf.models.SequentialFromConfig(cfg, None, "m", gemm=gemm)
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+@pytest.mark.parametrize("case", [(1500, 512, [0], 200, 148), (300, 256, [-1, 0, 1], 37, 100), (257, 160, [-2, 0, 2], 700, 23)])
+def test_pooled_layer_on_flat_row_tiles_matches_the_per_utterance_tiles_and_the_oracle(case, deterministic):
+    """ktf_tdnn_split_flat_stats (csrc/tdnn_split.hip, flat_stats_epilogue): [affine, relu, batchnorm] -> reducing StatsPooling with the
+    M-tiles over the batch's valid rows laid end to end. Ragged lengths (empty utterances, single rows, tens of utterances inside one
+    128-row block, utterances across tile boundaries) against the per-utterance tiles (same MFMA operands; the fp32 partial sums
+    relative to each block's pivot row are cut differently) and against the fp64 oracle; a dead ReLU unit and a constant one give
+    std = sqrt(eps) exactly; run-to-run reproducible in the slot form."""
+    U, D, ctx, B, T = case
+    rng = np.random.default_rng(U + B)
+    m = _pooled_model(U, D, ctx)
+    W0 = (rng.standard_normal((D, D)) / np.sqrt(D)).astype(np.float32)
+    W = (rng.standard_normal((U, len(ctx) * D)) / np.sqrt(len(ctx) * D)).astype(np.float32)
+    b = (rng.standard_normal(U) * 0.1).astype(np.float32)
+    W[5], b[5] = 0.0, -1.0
+    W[6], b[6] = 0.0, 0.7
+    bn0 = (np.float32(1.0), rng.uniform(0.2, 1.0, D).astype(np.float32), rng.uniform(0.5, 2.0, D).astype(np.float32))
+    bn = (np.float32(1.0), rng.uniform(0.2, 1.0, U).astype(np.float32), rng.uniform(0.5, 2.0, U).astype(np.float32))
+    m.get_layer("t0.affine").set_weights([W0, np.zeros(D, np.float32)])
+    m.get_layer("t0.batchnorm").set_weights(list(bn0))
+    m.get_layer("t.affine").set_weights([W, b])
+    m.get_layer("t.batchnorm").set_weights(list(bn))
+    m.min_tiles, m.min_frames = {}, {}
+    m.deterministic = deterministic
+    x = rng.standard_normal((B, T, D)).astype(np.float32)
+    lens = rng.integers(1, T + 1, B).astype(np.int32)
+    lens[[0, B // 2]] = T
+    lens[[1, B - 1]] = 0
+    lens[2] = 1
+    xd, ld = torch.as_tensor(x, device="cuda"), torch.as_tensor(lens, device="cuda")
+    seen, orig = [], ops.tdnn_split_flat_stats
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        seen.append(ops.last_kernel())
+        return r
+
+    ops.tdnn_split_flat_stats = spy
+    try:
+        flat = m.run_ragged(xd, ld).float().cpu().numpy()
+        flat2 = m.run_ragged(xd, ld).float().cpu().numpy()
+    finally:
+        ops.tdnn_split_flat_stats = orig
+    assert seen == ["tdnn_x3s_kernel<flat, pooled>"] * 2, seen
+    m.flat_pooling = False
+    tiles = m.run_ragged(xd, ld).float().cpu().numpy()
+    ok = lens > 0
+    assert np.isnan(flat[~ok][:, 0, :U]).all() and np.isnan(tiles[~ok][:, 0, :U]).all()      # no frame: the mean is 0 / 0, as the reference's pooling gives
+    if deterministic:
+        assert np.array_equal(flat[ok], flat2[ok])
+    scale = np.abs(tiles[ok]).max()
+    assert np.abs(flat[ok] - tiles[ok]).max() <= 1e-5 * max(1.0, scale), np.abs(flat[ok] - tiles[ok]).max()     # (fp32 partial sums, cut differently)
+    assert np.abs(flat[ok][:, 0, U + 5] - 1e-5).max() < 1e-7 and np.abs(flat[ok][:, 0, U + 6] - 1e-5).max() < 1e-7
+    layers = [{"kind": "tdnn", "W": W0, "b": np.zeros(D, np.float32), "context": [0]}, {"kind": "relu"},
+              {"kind": "bn", "rms": bn0[0], "mean": bn0[1], "var": bn0[2]},
+              {"kind": "tdnn", "W": W, "b": b, "context": ctx}, {"kind": "relu"}, {"kind": "bn", "rms": bn[0], "mean": bn[1], "var": bn[2]},
+              {"kind": "stats", "left_context": 0, "right_context": 5, "include_std": True, "reduce_time_axis": True}]
+    for i in list(np.flatnonzero(ok)[:6]) + [int(np.flatnonzero(ok)[-1])]:
+        want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)
+        assert np.abs(flat[i] - want[0]).max() < 2e-4 * max(1.0, np.abs(want).max()), (i, lens[i])
