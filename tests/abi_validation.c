@@ -92,6 +92,17 @@ int main(void) {
     EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));           /* fuses ReLU / none */
     t.act = KTF_ACT_NONE;
     EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 5000, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));        /* B > 4095 */
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, d, NULL));             /* no row map */
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, NULL, NULL));             /* no sums */
+    t.valid = 1;
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, d, NULL));                /* VALID padding */
+    t.valid = 0; t.flags = 16;
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, d, NULL));                /* a flag that left the interface */
+    t.flags = 0; t.gemm = 4;
+    EXPECT_EINVAL(ktf_tdnn_split(f, f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL, NULL));       /* a mode that left the interface */
+    t.gemm = KTF_GEMM_BF16X3;
+    EXPECT_EINVAL(ktf_stats_finalize_flat(d, 1, l, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));                              /* too few slots */
+    EXPECT_EINVAL(ktf_stats_finalize_flat(d, 9, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));                           /* no row map */
     t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32; t.units = 8;
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));
