@@ -318,7 +318,7 @@ int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int
  * utterance as in ktf_tdnn_split, and rows at or beyond an utterance's length are not written. KTF_GEMM_BF16X3 on row-major hi / lo
  * planes, SAME padding, no subsampling, ReLU or no activation, y as for ktf_tdnn_split (planes or fp32); B <= 4095 and
  * B * T * ldx * 2 < 2^32. Results equal ktf_tdnn_split's bit for bit (same operands into the same MFMAs in the same order). */
-int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
+int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts, const int32_t* row_map,
                         const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                         const float* shift, void* y, void* y_lo, int64_t ldy, void* stream);
 /* ktf_tdnn_split_flat fused with the reducing StatsPooling that follows it (ktf_tdnn_split_stats on the flat row tiles: the pooled
@@ -329,8 +329,14 @@ int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T
  * batch places it, so its pooled values can differ in the last fp64 bits from batch to batch. Without the flag (B, 2, units), zeroed by
  * the caller, fp64 atomics (finalize with ktf_stats_finalize). */
 int64_t ktf_flat_stats_slots(int64_t T);
+/* The row table of the flat tiles: 4 int32 per flat row R < ktf_flat_row_map_rows(B, T) = round_up(B * T, 256) -- (output row b * T + t, or
+ * -1 at and beyond row_starts[B]; frame t; length of the row's utterance; b). `row_map` of ktf_tdnn_split_flat / _flat_stats: NULL (every
+ * workgroup then derives its 256 entries from row_starts: four dependent loads in front of its first DMA, ~3 us per tile) or this table,
+ * made once per batch for all its layers -- same rows, same results. */
+int64_t ktf_flat_row_map_rows(int64_t B, int64_t T);
+int ktf_flat_row_map(const int32_t* row_starts, int64_t B, int64_t T, int32_t* map, void* stream);
 int ktf_tdnn_split_flat_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
-                              const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                              const int32_t* row_map, const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                               const float* shift, double* sums, void* stream);
 int ktf_stats_finalize_flat(const double* sums, int64_t slots, const int32_t* row_starts, int64_t T, int64_t B, int32_t D,
                             int32_t include_std, float eps, float* out, int64_t ld_out, void* stream);

@@ -12,7 +12,7 @@ void ktf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int32_t ktf_version(void) { return 116; /* 0.1.1 + KTF_TDNN_MX_SLAB, KTF_ACT_ELU .. KTF_ACT_SOFTMAX, ktf_activation_f32, KTF_BF16P / KTF_GEMM_BF16X4, ktf_tdnn_split_flat, ktf_tdnn_out_lens; 115: KTF_TDNN_MX_PERSIST, ktf_build_id, ktf_clock_probe; 116: KTF_TDNN_MX_SLAB and KTF_TDNN_MX_PERSIST gone (tools/mx/experiments/) */ }
+extern "C" int32_t ktf_version(void) { return 117; /* 0.1.1 + KTF_TDNN_MX_SLAB, KTF_ACT_ELU .. KTF_ACT_SOFTMAX, ktf_activation_f32, KTF_BF16P / KTF_GEMM_BF16X4, ktf_tdnn_split_flat, ktf_tdnn_out_lens; 115: KTF_TDNN_MX_PERSIST, ktf_build_id, ktf_clock_probe; 116: KTF_TDNN_MX_SLAB and KTF_TDNN_MX_PERSIST gone (tools/mx/experiments/); 117: KTF_GEMM_F16 / F16X2 / KTF_F16 gone, ktf_tdnn_split_flat_stats, ktf_stats_finalize_flat, ktf_flat_row_map, row_map argument of ktf_tdnn_split_flat */ }
 
 extern "C" size_t ktf_last_error(char* buf, size_t cap) {
     const size_t n = strlen(g_err);

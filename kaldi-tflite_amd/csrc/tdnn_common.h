@@ -22,6 +22,7 @@ typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef __attribute__((address_space(1))) const void glb_ptr_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bfrag8;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
 typedef __attribute__((ext_vector_type(4))) float fv4;
 typedef __attribute__((ext_vector_type(2))) unsigned uv2;
 
@@ -45,6 +46,7 @@ struct TdnnParams {
     int32_t stat_slots;     // fused pooling: 0 = fp64 atomics into (B, 2, units); > 0 = one slot per 128-row block (KTF_TDNN_DET_STATS)
     int32_t y_pair;         // fp32-sized output slots hold the KTF_BF16P pair of the value (y_dtype is KTF_F32 to the store paths)
     const int32_t* row_starts;  // ktf_tdnn_split_flat: (B + 1) exclusive prefix sums of lens (flat row tiling of tdnn_x3s_kernel), else NULL
+    const int32_t* row_map;     // ... and optionally ktf_flat_row_map's table: (output row or -1, frame, utterance length, utterance) per flat row
 };
 
 // KTF_BF16P: bf16(v) in the low half, bf16(v - bf16(v)) in the high half of a 32-bit slot (tdnn_pair.hip), returned as the float

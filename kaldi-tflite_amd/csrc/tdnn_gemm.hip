@@ -129,7 +129,7 @@ extern "C" int64_t ktf_flat_stats_slots(int64_t T) { return T <= 0 ? 1 : (T + 25
 static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const int32_t* lens, const KtfTdnnDesc* d,
                        const void* w, const void* w_lo, const float* bias, const float* scale, const float* shift,
                        void* y, int64_t ldy, int32_t* out_lens, double* stats_sums, void* stream,
-                       const void* x_lo = nullptr, void* y_lo = nullptr, const int32_t* row_starts = nullptr) {
+                       const void* x_lo = nullptr, void* y_lo = nullptr, const int32_t* row_starts = nullptr, const int32_t* row_map = nullptr) {
     KTF_REQUIRE(d, "ktf_tdnn: null descriptor");
     // Everything that does not depend on the data is validated first -- descriptor, gemm / dtype combination, activation, scale / shift
     // pairing, sizes --, so that a malformed call is rejected whether or not its input happens to be empty; only the null-pointer checks
@@ -178,7 +178,7 @@ static int tdnn_launch(const void* x, int64_t B, int64_t T, int64_t ldx, const i
     TdnnParams p;
     memset(&p, 0, sizeof(p));
     p.x = x; p.lens = lens; p.w = w; p.w_lo = w_lo; p.bias = bias; p.scale = scale; p.shift = shift; p.y = y;
-    p.x_lo = x_lo; p.y_lo = y_lo; p.row_starts = row_starts;
+    p.x_lo = x_lo; p.y_lo = y_lo; p.row_starts = row_starts; p.row_map = row_map;
     p.out_lens = out_lens; p.T = T; p.ldx = ldx; p.ldy = ldy; p.Tout = Tout;
     p.units = d->units; p.din_pad = d->din_pad; p.nctx = d->nctx; p.sub = d->subsampling; p.valid = d->valid;
     p.act = act_pass ? KTF_ACT_NONE : d->act; p.y_dtype = y_pair ? KTF_F32 : d->y_dtype; p.y_pair = y_pair ? 1 : 0; p.ktot = d->nctx * d->din_pad;
@@ -245,21 +245,51 @@ extern "C" int ktf_tdnn_split(const void* x_hi, const void* x_lo, int64_t B, int
 }
 
 // ktf_tdnn_split over the batch's valid rows laid end to end (short utterances: a 1.5 s window fills 0.58 of a 256-row tile)
-extern "C" int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
+// the row table of the flat tiles, made once per batch for all its layers: (output row b * T + t or -1, frame t, utterance length, utterance b)
+// of flat row R, for R < round_up(B * T, 256)
+__global__ __launch_bounds__(256) void flat_row_map_kernel(const int32_t* __restrict__ rs, int B, int T, i32x4* __restrict__ map, int64_t rows) {
+    const int64_t R = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (R >= rows) return;
+    i32x4 e = {-1, 0, 1, 0};
+    if (R < rs[B]) {
+        int lo = 0, hi = B - 1;                              // the last b with rs[b] <= R (empty utterances repeat a start: the last one wins)
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rs[mid] <= R) lo = mid; else hi = mid - 1;
+        }
+        const int s0 = rs[lo], t = (int)R - s0;
+        e = i32x4{lo * T + t, t, rs[lo + 1] - s0, lo};
+    }
+    map[R] = e;
+}
+
+extern "C" int64_t ktf_flat_row_map_rows(int64_t B, int64_t T) { return B <= 0 || T <= 0 ? 0 : (B * T + 255) / 256 * 256; }
+extern "C" int ktf_flat_row_map(const int32_t* row_starts, int64_t B, int64_t T, int32_t* map, void* stream) {
+    KTF_REQUIRE(B >= 0 && T >= 0 && B <= 4095 && B * T < (1ll << 31), "ktf_flat_row_map: bad sizes");
+    const int64_t rows = ktf_flat_row_map_rows(B, T);
+    if (rows == 0) return KTF_OK;
+    KTF_REQUIRE(row_starts && map, "ktf_flat_row_map: null argument");
+    hipLaunchKernelGGL(flat_row_map_kernel, dim3((unsigned)(rows / 256)), dim3(256), 0, (hipStream_t)stream, row_starts, (int)B, (int)T,
+                       reinterpret_cast<i32x4*>(map), rows);
+    KTF_CHECK_LAUNCH("ktf_flat_row_map");
+    return KTF_OK;
+}
+
+extern "C" int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts, const int32_t* row_map,
                                    const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                                    const float* shift, void* y, void* y_lo, int64_t ldy, void* stream) {
     KTF_REQUIRE(x_hi && x_lo && row_starts && d && w && w_lo && y, "ktf_tdnn_split_flat: null argument");
     KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_flat: needs KTF_GEMM_BF16X3 on bf16 hi / lo planes");
-    return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, y, ldy, nullptr, nullptr, stream, x_lo, y_lo, row_starts);
+    return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, y, ldy, nullptr, nullptr, stream, x_lo, y_lo, row_starts, row_map);
 }
 
 // ... with the reducing StatsPooling fused (ktf_tdnn_split_stats on flat row tiles)
 extern "C" int ktf_tdnn_split_flat_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
-                                         const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
+                                         const int32_t* row_map, const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                                          const float* shift, double* sums, void* stream) {
     KTF_REQUIRE(x_hi && x_lo && row_starts && d && w && w_lo && sums, "ktf_tdnn_split_flat_stats: null argument");
     KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_flat_stats: needs KTF_GEMM_BF16X3 on bf16 hi / lo planes");
-    return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream, x_lo, nullptr, row_starts);
+    return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream, x_lo, nullptr, row_starts, row_map);
 }
 
 extern "C" int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx,

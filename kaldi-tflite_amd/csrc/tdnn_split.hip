@@ -318,6 +318,15 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
         int* trow = rs + 260;                                           // output row (b * T + t) of tile row m
         int* tt = trow + 256;                                           // its frame
         int* tlen = tt + 256;                                           // its utterance's length
+        if (p.row_map) {      // the table was made once for all the step's layers (ktf_flat_row_map): one coalesced load instead of four dependent ones
+            if (tid < 256) {
+                const i32x4 e = reinterpret_cast<const i32x4*>(p.row_map)[R0 + tid];
+                trow[tid] = e.x;
+                tt[tid] = e.y;
+                tlen[tid] = e.z;
+            }
+            __syncthreads();
+        } else {
         // first utterance of the tile: the last b with row_starts[b] <= R0, by two 64-way steps (every wave, same result)
         const int S = (B + 64) >> 6;                                    // ceil((B + 1) / 64) entries per lane of the first step
         int cnt = __popcll(__ballot(lane * S <= B && rs_g[min(lane * S, B)] <= R0));
@@ -355,6 +364,7 @@ __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles,
             tlen[tid] = ln;
         }
         __syncthreads();
+        }
         len = (int)p.T;
         t0 = 0;
         out_len = min(R_BM, total - R0);                                // valid rows of the tile

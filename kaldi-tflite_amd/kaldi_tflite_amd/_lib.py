@@ -105,9 +105,11 @@ PROTOTYPES = {
     "ktf_tdnn": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
     "ktf_tdnn_stats": (C.c_int, [_P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
     "ktf_tdnn_split": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _i64, _P, _P]),
-    "ktf_tdnn_split_flat": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
+    "ktf_tdnn_split_flat": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "ktf_tdnn_split_stats": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
-    "ktf_tdnn_split_flat_stats": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ktf_tdnn_split_flat_stats": (C.c_int, [_P, _P, _i64, _i64, _i64, _P, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "ktf_flat_row_map_rows": (_i64, [_i64, _i64]),
+    "ktf_flat_row_map": (C.c_int, [_P, _i64, _i64, _P, _P]),
     "ktf_flat_stats_slots": (_i64, [_i64]),
     "ktf_stats_finalize_flat": (C.c_int, [_P, _i64, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_split_bf16": (C.c_int, [_P, _i64, _i32, _i64, _P, _P, _i64, _P]),

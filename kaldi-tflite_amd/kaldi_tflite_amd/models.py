@@ -488,7 +488,7 @@ class Sequential:
                 if can_pool:
                     flat = self.flat_pooling and self._flat_tiles(l, B, T, planes.shape[3])
                     if flat and row_starts is None:
-                        row_starts = ops.row_starts(lens, B, T, self._ws.get("row_starts", (B + 1,), torch.int32, dev, padded=False))
+                        row_starts = ops.flat_rows(lens, B, T, lambda role, shape, dt: self._ws.get(role, shape, dt, dev, padded=False))
                     x = self._pooled_by_gemm(l, relu, bn, nxt, planes, lens, gemm, True, dev, T,
                                              defer_to=steps[tail_at][1] if si + 2 == tail_at else None, row_starts=row_starts if flat else None)
                     lens, pooled, skip, planes = None, True, True, None
@@ -508,7 +508,7 @@ class Sequential:
                 # end to end (ktf_tdnn_split_flat), same bits
                 flat = self._flat_tiles(l, B, T, planes.shape[3])
                 if flat and row_starts is None:
-                    row_starts = ops.row_starts(lens, B, T, self._ws.get("row_starts", (B + 1,), torch.int32, dev, padded=False))
+                    row_starts = ops.flat_rows(lens, B, T, lambda role, shape, dt: self._ws.get(role, shape, dt, dev, padded=False))
                 split = (lambda d_, y_, ylo_: ops.tdnn_split_flat(planes, row_starts, d_, w, w_lo, bias, scale, shift, y_, ylo_)) if flat else \
                         (lambda d_, y_, ylo_: ops.tdnn_split(planes, lens, d_, w, w_lo, bias, scale, shift, y_, ylo_, out_lens))
                 if keep:

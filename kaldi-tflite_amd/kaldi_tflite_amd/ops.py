@@ -433,12 +433,37 @@ def row_starts(lens, B, T, out):
     return out
 
 
+class FlatRows:
+    """Row bookkeeping of a batch on flat row tiles: `starts` (B + 1,) int32 prefix sums of the lengths, `map` the per-row table
+    ktf_flat_row_map makes from them (or None: every workgroup derives its entries itself)."""
+
+    def __init__(self, starts, map=None):
+        self.starts, self.map = starts, map
+
+
+def flat_rows(lens, B, T, get):
+    """FlatRows of a batch: `get(role, shape, dtype)` hands out the two buffers (a workspace)."""
+    lib = L.load()
+    starts = row_starts(lens, B, T, get("row_starts", (B + 1,), torch.int32))
+    table = get("row_map", (int(lib.ktf_flat_row_map_rows(B, T)), 4), torch.int32)
+    with L.on_device(starts.device):
+        rc = lib.ktf_flat_row_map(L.ptr(starts), B, T, L.ptr(table), L.stream_ptr())
+    L.check(rc, "ktf_flat_row_map")
+    return FlatRows(starts, table)
+
+
+def _flat(starts):
+    return (starts.starts, starts.map) if isinstance(starts, FlatRows) else (starts, None)
+
+
 def tdnn_split_flat(xp, starts, desc, w, w_lo, bias, scale, shift, y, y_lo=None):
-    """tdnn_split with M-tiles over the batch's valid rows laid end to end (`starts` = row_starts(lens, ...)): short utterances."""
+    """tdnn_split with M-tiles over the batch's valid rows laid end to end (`starts` = row_starts(lens, ...) or flat_rows(...)): short
+    utterances."""
     lib = L.load()
     hi, lo, B, T, ldx = _planes(xp)
+    starts, rmap = _flat(starts)
     with L.on_device(xp.device):
-        rc = lib.ktf_tdnn_split_flat(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(starts), C.byref(desc), L.ptr(w), L.ptr(w_lo),
+        rc = lib.ktf_tdnn_split_flat(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(starts), L.ptr(rmap), C.byref(desc), L.ptr(w), L.ptr(w_lo),
                                      L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(y), L.ptr(y_lo), y.stride(1), L.stream_ptr())
     L.check(rc, "ktf_tdnn_split_flat")
     return y
@@ -465,10 +490,11 @@ def tdnn_split_flat_stats(xp, starts, desc, w, w_lo, bias, scale, shift, sums, z
     KTF_TDNN_DET_STATS in desc.flags (not zeroed: stats_finalize_flat reads the slots that were written), else (B, 2, units), zero=True."""
     lib = L.load()
     hi, lo, B, T, ldx = _planes(xp)
+    starts, rmap = _flat(starts)
     with L.on_device(xp.device):
         if zero:
             sums.zero_()
-        rc = lib.ktf_tdnn_split_flat_stats(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(starts), C.byref(desc), L.ptr(w), L.ptr(w_lo),
+        rc = lib.ktf_tdnn_split_flat_stats(L.ptr(hi), L.ptr(lo), B, T, ldx, L.ptr(starts), L.ptr(rmap), C.byref(desc), L.ptr(w), L.ptr(w_lo),
                                            L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
     L.check(rc, "ktf_tdnn_split_flat_stats")
     return sums
@@ -478,6 +504,7 @@ def stats_finalize_flat(sums, starts, T, D, include_std, eps, out, slots):
     """sums (B, slots, 2, D) fp64 of tdnn_split_flat_stats -> out (B, ld) mean | std."""
     lib = L.load()
     B = sums.shape[0]
+    starts, _ = _flat(starts)
     with L.on_device(sums.device):
         rc = lib.ktf_stats_finalize_flat(L.ptr(sums), slots, L.ptr(starts), T, B, D, int(include_std), eps, L.ptr(out), out.stride(0),
                                          L.stream_ptr())

@@ -85,23 +85,25 @@ int main(void) {
     EXPECT_EINVAL(ktf_stats_finalize_slots(d, 1, 128, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));       /* too few slots */
     EXPECT_EINVAL(ktf_route_short(NULL, 1, 400, l, l, NULL, 0, NULL));
     t.gemm = KTF_GEMM_BF16X3; t.x_dtype = KTF_BF16; t.w_dtype = KTF_BF16; t.y_dtype = KTF_F32; t.units = 256;
-    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));        /* no row map */
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, NULL, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));        /* no row map */
     t.valid = 1;
-    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));           /* VALID padding */
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, l, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));           /* VALID padding */
     t.valid = 0; t.act = KTF_ACT_TANH;
-    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));           /* fuses ReLU / none */
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 1, 1, 32, l, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));           /* fuses ReLU / none */
     t.act = KTF_ACT_NONE;
-    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 5000, 1, 32, l, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));        /* B > 4095 */
-    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, d, NULL));             /* no row map */
-    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, NULL, NULL));             /* no sums */
+    EXPECT_EINVAL(ktf_tdnn_split_flat(f, f, 5000, 1, 32, l, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL));        /* B > 4095 */
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, NULL, NULL, &t, f, f, NULL, NULL, NULL, d, NULL));             /* no row map */
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, NULL, &t, f, f, NULL, NULL, NULL, NULL, NULL));             /* no sums */
     t.valid = 1;
-    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, d, NULL));                /* VALID padding */
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, NULL, &t, f, f, NULL, NULL, NULL, d, NULL));                /* VALID padding */
     t.valid = 0; t.flags = 16;
-    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, &t, f, f, NULL, NULL, NULL, d, NULL));                /* a flag that left the interface */
+    EXPECT_EINVAL(ktf_tdnn_split_flat_stats(f, f, 1, 1, 32, l, NULL, &t, f, f, NULL, NULL, NULL, d, NULL));                /* a flag that left the interface */
     t.flags = 0; t.gemm = 4;
     EXPECT_EINVAL(ktf_tdnn_split(f, f, 1, 1, 32, NULL, &t, f, f, NULL, NULL, NULL, f, NULL, 256, NULL, NULL));       /* a mode that left the interface */
     t.gemm = KTF_GEMM_BF16X3;
     EXPECT_EINVAL(ktf_stats_finalize_flat(d, 1, l, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));                              /* too few slots */
+    EXPECT_EINVAL(ktf_flat_row_map(NULL, 4, 100, (int32_t*)l, NULL));                                                 /* no prefix sums */
+    EXPECT_EINVAL(ktf_flat_row_map(l, 5000, 100, (int32_t*)l, NULL));                                                /* B > 4095 */
     EXPECT_EINVAL(ktf_stats_finalize_flat(d, 9, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));                           /* no row map */
     t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32; t.units = 8;
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));

@@ -360,6 +360,17 @@ def test_flat_row_tiles_random_batches():
         ops.tdnn_split(planes, dl, d, w, w_lo, bias, None, None, ref[0], ref[1])
         ops.tdnn_split_flat(planes, starts, d, w, w_lo, bias, None, None, got[0], got[1])
         assert torch.equal(got, ref), (trial, B, T, D, U, ctx)
+        # ... and with the row table made once per batch (ktf_flat_row_map) instead of derived by every workgroup: the same rows
+        fr = ops.flat_rows(dl, B, T, lambda role, shape, dt: torch.zeros(shape, dtype=dt, device="cuda"))
+        rs = np.concatenate([[0], np.cumsum(lens)])
+        want = np.tile(np.array([[-1, 0, 1, 0]], np.int32), (fr.map.shape[0], 1))
+        for bi in range(B):
+            r = np.arange(rs[bi], rs[bi + 1])
+            want[r] = np.stack([bi * T + (r - rs[bi]), r - rs[bi], np.full(len(r), lens[bi]), np.full(len(r), bi)], 1)
+        assert np.array_equal(fr.map.cpu().numpy(), want), (trial, B, T)
+        got2 = torch.full((2, B, T, ldy), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.tdnn_split_flat(planes, fr, d, w, w_lo, bias, None, None, got2[0], got2[1])
+        assert torch.equal(got2, ref), (trial, B, T, D, U, ctx)
 
 
 def test_short_windows_run_flat_rows_and_equal_the_tiled_route():

@@ -28,7 +28,7 @@ def test_library_exports_every_header_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.ktf_version() == 116
+    assert lib.ktf_version() == 117
 
 
 def test_abi_argument_validation_without_gpu():
