@@ -3,7 +3,8 @@
 HBM bytes of the FULL-SIZE TDNN GEMM launches only (grid >= 2^20 threads: the timed 1024-utterance steps; the parity pass and
 the fp32 comparison model launch other grids / kernels), per step = per five launches.
 
-usage: make_traffic_r3.py <fetch_dir> <write_dir> <kernel name prefix> <out.json> <algorithmic_gemm_bytes_per_step>
+usage: make_traffic_r3.py <fetch_dir> <write_dir> <kernel name prefix> <out.json> <algorithmic_gemm_bytes_per_step> [library build id]
+(the build id -- ktf_build_id() of the profiled library -- ties the figure to its build: bench.py attaches it only to that build)
 
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE counts the 128-byte requests of 16 B/lane
 coalesced reads at 64 B, so it is doubled; WRITE_SIZE is exact for 16 B/lane stores. Both counters are in KB."""
@@ -35,6 +36,8 @@ steps = n / 5.0
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, MI355X, B = 1024 x 10 s, full-size TDNN GEMM launches only",
        "units": "KB per counter; gfx950 correction: FETCH_SIZE x 2, WRITE_SIZE exact", "full_size_launches": n, "steps": steps, "kernels": rows,
        "tdnn_gemm_bytes_per_step_corrected": (2 * tot_f + tot_w) * 1024 / steps, "tdnn_gemm_algorithmic_bytes_per_step": alg}
+if len(sys.argv) > 6:
+    doc["library_build_id"] = sys.argv[6]
 json.dump(doc, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in doc.items() if k != "kernels"}, indent=1))
 for k, v in rows.items():
