@@ -1,9 +1,9 @@
 """Round-4 GPU tests (run with `-m gpu` on an MI355X): the N > 1 bench path on ONE GPU, and the fused-tail guard.
 
 * `bench.py --gpus 2` is what the driver runs on an 8-GPU node (one rank per GPU over RCCL). No such node is available to the test
-  run, so two ranks share the one GPU (`KTF_SHARE_GPU=1`) over the gloo backend (`KTF_DIST_BACKEND=gloo`): fresh child processes
-  started by bench.py's own self-launch before they touch the GPU. Checked: two ranks seen by the collective backend, the gather ran,
-  and the gathered x-vectors are rank 0's and rank 1's own, bit for bit (BASELINE.json config 4: batch-sharded utterances, gather of
+  run, so two and four ranks share the one GPU (`KTF_SHARE_GPU=1`) over the gloo backend (`KTF_DIST_BACKEND=gloo`): fresh child processes
+  started by bench.py's own self-launch before they touch the GPU. Checked: every rank seen by the collective backend, the gather ran, the
+  per-rank step times are reported, and the gathered x-vectors are each rank's own, bit for bit (BASELINE.json config 4: batch-sharded utterances, gather of
   the embeddings).
 * an extractor whose LDA keeps more than 256 dimensions takes the three-launch tail (ktf_xvec_tail_f32 serves out_dim <= 256).
 """
@@ -27,26 +27,29 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_two_ranks_on_one_gpu_gathers_both_shards(tmp_path):
+@pytest.mark.parametrize("N", [2, 4])
+def test_bench_ranks_on_one_gpu_gather_every_shard(tmp_path, N):
     B, sec = 48, 3.0
     dump = str(tmp_path / "xv.npy")
     env = dict(os.environ, KTF_SHARE_GPU="1", KTF_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(N), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline",
            "--no-parity", "--batch", str(B), "--seconds", str(sec), "--gemm", "f32", "--dump-xvectors", dump]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak"
-    assert line["config"]["ranks_seen_by_collective_backend"] == 2 and line["config"]["gather"] is True
+    assert line["n_gpus"] == N and line["scaling"] == "weak"
+    assert line["config"]["ranks_seen_by_collective_backend"] == N and line["config"]["gather"] is True
+    pr = line["per_rank_ms_per_step"]
+    assert pr["ranks"] == N and 0 < pr["min"] <= pr["max"] and abs(pr["max"] - line["ms_per_step"]) < 1e-6 * pr["max"]
     assert line["config"]["collective_backend"] == "gloo"
-    assert line["value"] > 0 and abs(line["value"] - 2 * B * 2 / (line["ms_per_step"] * 2e-3)) < 1e-6 * line["value"]
+    assert line["value"] > 0 and abs(line["value"] - N * B / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
     got = np.load(dump)
-    assert got.shape == (2 * B, 128)
+    assert got.shape == (N * B, 128)
     # the same extraction in this process: rank r's waveforms come from generator seed 1234 + r (bench.py)
     cfg = synth.extractor_cfg(dither=0.0)
     mdl = synth.build_extractor(ktf, cfg, synth.make_weights(seed=4321, narrow=False), gemm="f32")
-    for r in range(2):
+    for r in range(N):
         g = torch.Generator(device="cuda").manual_seed(1234 + r)
         wav = torch.clamp(torch.round(1000.0 * torch.randn((B, int(sec * 16000)), generator=g, device="cuda")), -32767, 32767)
         want = mdl(wav).cpu().numpy()
