@@ -57,6 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-mx-flat", action="store_true", help="A/B: f16mx plane layers on per-utterance 256-row tiles instead of flat row tiles")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region (exactly --steps steps between barrier + synchronize) is run this many "
                                                            "times back to back; `value` / `ms_per_step` are the MEDIAN region, `value_runs` lists all")
     ap.add_argument("--batch", type=int, default=1024, help="utterances per GPU per step")
@@ -127,6 +128,7 @@ def main(argv=None):
     w = synth.make_weights(seed=4321, narrow=False)
     mdl = synth.build_extractor(ktf, cfg, w, gemm=args.gemm)
     mdl.xvec.deterministic = not args.atomic_pooling
+    mdl.xvec.mx_flat_rows = not args.no_mx_flat
     mdl.xvec.mx_loader = True if args.mx_loader else None          # (None: the model picks per batch; 1024 x 10 s takes the 256-row kernel)
     mdl.route_short_utterances = not args.no_short_routing
     mdl.xvec.k_interleaved = not args.ctx_major_k
@@ -255,7 +257,7 @@ def main(argv=None):
 class _GemmProfiler:
     """Brackets every ktf_tdnn launch of the frame-level layers with HIP events on the launch stream."""
 
-    NAMES = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_split_flat", "tdnn_split_flat_stats", "tdnn_mx", "tdnn_mx_stats")
+    NAMES = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_split_flat", "tdnn_split_flat_stats", "tdnn_mx", "tdnn_mx_flat", "tdnn_mx_stats")
     AUX = ("mx_planes", "split_bf16")      # conversions a mode needs in front of its first GEMM: timed too, reported separately
 
     def __init__(self, ops, torch):

@@ -384,6 +384,18 @@ int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, int64_t ld_
 int ktf_tdnn_mx(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,
                 const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale, const float* shift,
                 void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, void* stream);
+/* ktf_tdnn_mx with a plane output on FLAT ROW TILES: the 256-row M-tiles cover the batch's valid rows laid end to end (row_starts, row_map:
+ * ktf_flat_row_map; as ktf_tdnn_split_flat) instead of ceil(T / 256) tiles per utterance -- 998-frame utterances fill 3.9 of their 4 tiles, a
+ * batch the VAD left ragged fewer. SAME padding, no subsampling; B <= 4095, B * T * din_pad * 2 < 2^32. The planes equal ktf_tdnn_mx's bit for
+ * bit (same operands into the same MFMAs in the same order); rows at and beyond an utterance's length are not written. */
+int ktf_tdnn_mx_flat(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* row_starts,
+                     const int32_t* row_map, const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
+                     const float* shift, void* yh, void* yl4, void* y4, void* ys, void* stream);
+/* ... and ktf_tdnn_mx_stats on flat row tiles: `sums` as for ktf_tdnn_split_flat_stats ((B, ktf_flat_stats_slots(T), 2, units) with
+ * KTF_TDNN_DET_STATS, reduced by ktf_stats_finalize_flat; else (B, 2, units), zeroed by the caller) */
+int ktf_tdnn_mx_flat_stats(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* row_starts,
+                           const int32_t* row_map, const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
+                           const float* shift, double* sums, void* stream);
 int ktf_tdnn_mx_stats(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,
                       const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
                       const float* shift, double* sums, void* stream);

@@ -110,24 +110,39 @@ extern "C" int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, 
 // ------------------------------------------------------------------------------------ the GEMM
 // PADK: the layer's K-steps do not fill its last super-step (nk % 4 != 0: the first layer, 5 x 32 features): the zero-padded K-steps
 // skip their fragments, MFMAs and stage. An instantiation of its own: as a run-time test inside every K-step it costs the other layers 3-4 %.
-template <int ACT, int OUT, bool PADK>
+// FLAT (plane output or fused pooling, SAME padding, no subsampling): the M-tiles cover the batch's VALID rows laid end to end (p.row_starts / p.row_map:
+// ktf_flat_row_map) instead of 256-row tiles per utterance -- a 998-frame utterance fills 3.9 tiles, a ragged batch fewer. A tile's rows
+// belong to several utterances: a thread keeps (frame, last frame, first record) of the rows it fetches, context offsets clamp against
+// the row's own utterance, and the epilogue scatters rows through the same table. `mtiles` carries B. Same operands into the same MFMAs
+// in the same order: the planes are bit-identical to the per-utterance tiles'.
+template <int ACT, int OUT, bool PADK, bool FLAT = false>
 __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mtiles, int ntiles, int gtiles, double* __restrict__ stats,
                                         unsigned char* rsm) {
+    static_assert(!FLAT || OUT != MX_OUT_F32, "flat row tiles: plane output or fused pooling");
     const int xcd = id & 7, slot = id >> 3;             // an XCD runs all N-tiles of an M-tile back to back (its L2 keeps the A tile)
     const int g = (slot / ntiles) * 8 + xcd;
     const int nt = slot - (slot / ntiles) * ntiles;
     if (g >= gtiles) return;
-    const int b = g / mtiles, mt = g - b * mtiles;
-    const int n0 = nt * 256, t0 = mt * 256;
+    const int b = FLAT ? 0 : g / mtiles, mt = FLAT ? g : g - b * mtiles;
+    const int n0 = nt * 256, t0 = FLAT ? 0 : mt * 256;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int len = p.lens ? p.lens[b] : (int)p.T;
-    const int out_len = len - p.cut - p.start <= 0 ? 0 : (len - p.cut - p.start + p.sub - 1) / p.sub;      // (== len: SAME, no subsampling)
-    if (t0 >= out_len) return;
+    const int R0 = mt * 256;                              // FLAT: first flat row of the tile
+    int len, out_len;
+    if constexpr (FLAT) {
+        const int total = p.row_starts[mtiles];
+        if (R0 >= total) return;
+        len = (int)p.T;
+        out_len = total - R0 < 256 ? total - R0 : 256;    // valid rows of the tile
+    } else {
+        len = p.lens ? p.lens[b] : (int)p.T;
+        out_len = len - p.cut - p.start <= 0 ? 0 : (len - p.cut - p.start + p.sub - 1) / p.sub;      // (== len: SAME, no subsampling)
+        if (t0 >= out_len) return;
+    }
     const int lenm1 = len - 1;
     const unsigned Tu = (unsigned)p.T;
-    const int64_t ub = (int64_t)b * p.nch_in * p.T;       // first (chunk, row) record of this utterance
+    const int64_t ub = FLAT ? 0 : (int64_t)b * p.nch_in * p.T;       // first (chunk, row) record of this utterance
     const char* xh = p.xh + ub * 64;
     const char* xl4 = p.xl4 + ub * 16;
     const char* x4 = p.x4 + ub * 16;
@@ -146,6 +161,23 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         const int row = q >> 2;
         a_cb[i] = (unsigned)(((q & 3) ^ ((4 - ((row >> 2) & 3)) & 3)) * 16);
         a_row[i] = p.start + (t0 + row) * p.sub;          // input row of output row t0 + row at context offset 0
+    }
+    // FLAT: (frame, last frame of its utterance, first record of its utterance) of the two stage rows and of the side row of this thread
+    [[maybe_unused]] int a_lm1[2] = {lenm1, lenm1}, s_row = 0, s_lm1 = lenm1;
+    [[maybe_unused]] unsigned a_ub[2] = {0u, 0u}, s_ub = 0u;
+    if constexpr (FLAT) {
+        const i32x4* map = reinterpret_cast<const i32x4*>(p.row_map) + R0;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const i32x4 e = map[(i * 512 + tid) >> 2];    // (output row b * T + t or -1, t, utterance length, b); rows beyond the last: (-1, 0, 1, 0)
+            a_row[i] = e.y;
+            a_lm1[i] = e.z - 1;
+            a_ub[i] = e.x < 0 ? 0u : (unsigned)(e.x - e.y) * (unsigned)p.nch_in;
+        }
+        const i32x4 e = map[lane + 64 * (wave & 3)];
+        s_row = e.y;
+        s_lm1 = e.z - 1;
+        s_ub = e.x < 0 ? 0u : (unsigned)(e.x - e.y) * (unsigned)p.nch_in;
     }
     // Which (32-feature chunk, context offset) a K-step reads is tracked in scalar registers, advanced once per stage: no division
     // and no table load sits between the MFMAs (a scalar load there is a ~200-cycle stall of the wave's whole instruction
@@ -176,8 +208,9 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         unsigned char* st_ = rsm + ((ks_) & 1) * MX_STAGE + wave * 1024;                                               \
         if ((n_) < 2) {                                                                                                \
             int r_ = a_row[(n_) & 1] + f_off;                                                                          \
-            r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                               \
-            const unsigned vo_ = (f_base + (unsigned)r_) * 64u + a_cb[(n_) & 1];                                       \
+            const int hi_ = FLAT ? a_lm1[(n_) & 1] : lenm1;                                                            \
+            r_ = r_ < 0 ? 0 : (r_ > hi_ ? hi_ : r_);                                                                   \
+            const unsigned vo_ = ((FLAT ? a_ub[(n_) & 1] : 0u) + f_base + (unsigned)r_) * 64u + a_cb[(n_) & 1];        \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + ((n_) & 1) * 8192), 16, 0, 0); \
         } else {                                                                                                       \
             const unsigned vo_ = (unsigned)(ks_) * (unsigned)MX_TILE + (unsigned)(((n_) & 1) * 512 + tid) * 16u;       \
@@ -205,14 +238,16 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         const int plane_ = idx_ >> 4, kb_ = (n_) < 4 ? (idx_ >> 2) & 3 : idx_ >> 2, rg_ = idx_ & 3;                    \
         const unsigned base_ = kb_ == 0 ? sa_base[0] : kb_ == 1 ? sa_base[1] : kb_ == 2 ? sa_base[2] : sa_base[3];     \
         const int off__ = kb_ == 0 ? sa_off[0] : kb_ == 1 ? sa_off[1] : kb_ == 2 ? sa_off[2] : sa_off[3];              \
-        int r_ = sa_row0 + rg_ * sa_rg + off__;                                                                        \
-        r_ = r_ < 0 ? 0 : (r_ > lenm1 ? lenm1 : r_);                                                                   \
+        int r_ = (FLAT ? s_row : sa_row0 + rg_ * sa_rg) + off__;                                                       \
+        const int hi_ = FLAT ? s_lm1 : lenm1;                                                                          \
+        r_ = r_ < 0 ? 0 : (r_ > hi_ ? hi_ : r_);                                                                       \
+        const unsigned rec_ = (FLAT ? s_ub : 0u) + base_ + (unsigned)r_;                                               \
         if ((n_) < 4) {                                                                                                \
-            const unsigned vo_ = (base_ + (unsigned)r_) * 16u;                                                         \
+            const unsigned vo_ = rec_ * 16u;                                                                           \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)((plane_ ? x4 : xl4) + vo_),                                  \
                                              (lds_ptr_t*)(rsm + MX_SA_OFF + plane_ * 16384 + (kb_ * 256 + rg_ * 64) * 16), 16, 0, 0); \
         } else {                                                                                                       \
-            const unsigned vo_ = (base_ + (unsigned)r_) * 4u;                                                          \
+            const unsigned vo_ = rec_ * 4u;                                                                            \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xs + vo_),                                                   \
                                              (lds_ptr_t*)(rsm + MX_SA_OFF + 32768 + (kb_ * 256 + rg_ * 64) * 4), 4, 0, 0); \
         }                                                                                                              \
@@ -372,16 +407,17 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
 // (The tile body is a function of its own: a persistent form -- one workgroup per CU looping over tiles, tried for the pooled
 // layer so that a tile's statistics stores drain under the next tile's prologue -- keeps the 160-byte parameter block live across
 // the loop, spills 67 scalar registers and runs 5 % slower than one workgroup per tile.)
-template <int ACT, int OUT, bool PADK>
+template <int ACT, int OUT, bool PADK, bool FLAT = false>
 __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, int ntiles, int gtiles, double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
-    mx_tile<ACT, OUT, PADK>(p, blockIdx.x, mtiles, ntiles, gtiles, stats, rsm);
+    mx_tile<ACT, OUT, PADK, FLAT>(p, blockIdx.x, mtiles, ntiles, gtiles, stats, rsm);
 }
 
 // x planes (see the head of this file) -> one TDNN layer. Exactly one of {y planes, yf, stats} is written.
 static int mx_launch(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* lens,
                      const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale, const float* shift,
-                     void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, double* stats, void* stream, const char* who) {
+                     void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, double* stats, void* stream, const char* who,
+                     const int32_t* row_starts = nullptr, const int32_t* row_map = nullptr) {
     KTF_REQUIRE(xh && xl4 && x4 && xs && d && wh && wq, "%s: null argument", who);
     KTF_REQUIRE(d->gemm == KTF_GEMM_F16MX, "%s: needs KTF_GEMM_F16MX", who);
     KTF_REQUIRE(B >= 0 && T >= 0 && B < 65536, "%s: bad size", who);
@@ -427,6 +463,35 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
         KTF_CHECK_LAUNCH(who);
         return KTF_OK;
     }
+    if (row_starts) {                           // flat row tiles: M-tiles over the batch's valid rows laid end to end
+        KTF_REQUIRE(row_map && plain && o != MX_OUT_F32 && !loader, "%s: flat row tiles take the row table, SAME padding, no subsampling, a plane or pooled output", who);
+        p.stat_slots = (stats && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_flat_stats_slots(T) : 0;
+        KTF_REQUIRE(B <= 4095 && B * T * (int64_t)p.nch_in * 64 < (1ll << 32) && B * T < (1ll << 31) / (p.nch_out > 0 ? p.nch_out : 1),
+                    "%s: flat row tiles need B <= 4095 and B * T * din_pad * 2 < 2^32", who);
+        p.row_starts = row_starts; p.row_map = row_map;
+        const int ntiles = ktf_cdiv(d->units, 256);
+        const int64_t ftiles = ktf_cdiv(B * T, 256);
+        const int64_t fblocks = ((ftiles + 7) / 8) * 8 * ntiles;
+        KTF_NOTE_KERNEL("tdnn_mx_kernel<flat>");
+#define MX_LAUNCH_FLAT(A, O)                                                                                           \
+    {                                                                                                                  \
+        if (p.nk & 3) {                                                                                                \
+            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, true, true>);                                              \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, true, true>), dim3((unsigned)fblocks), dim3(512), MX_LDS_BYTES, st, p, (int)B, ntiles, (int)ftiles, stats); \
+        } else {                                                                                                       \
+            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, false, true>);                                             \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, false, true>), dim3((unsigned)fblocks), dim3(512), MX_LDS_BYTES, st, p, (int)B, ntiles, (int)ftiles, stats); \
+        }                                                                                                              \
+    }
+        if (o == MX_OUT_STATS) {
+            if (d->act == KTF_ACT_RELU) MX_LAUNCH_FLAT(KTF_ACT_RELU, MX_OUT_STATS) else MX_LAUNCH_FLAT(KTF_ACT_NONE, MX_OUT_STATS)
+        } else {
+            if (d->act == KTF_ACT_RELU) MX_LAUNCH_FLAT(KTF_ACT_RELU, MX_OUT_PLANES) else MX_LAUNCH_FLAT(KTF_ACT_NONE, MX_OUT_PLANES)
+        }
+#undef MX_LAUNCH_FLAT
+        KTF_CHECK_LAUNCH(who);
+        return KTF_OK;
+    }
     const int mtiles = ktf_cdiv(p.Tout, 256), ntiles = ktf_cdiv(d->units, 256);
     const int64_t gtiles = B * mtiles;
     const int64_t nblocks = ((gtiles + 7) / 8) * 8 * ntiles;
@@ -455,6 +520,25 @@ extern "C" int ktf_tdnn_mx(const void* xh, const void* xl4, const void* x4, cons
                            const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
                            const float* shift, void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, void* stream) {
     return mx_launch(xh, xl4, x4, xs, B, T, lens, d, wh, wq, bias, scale, shift, yh, yl4, y4, ys, yf, ldy, nullptr, stream, "ktf_tdnn_mx");
+}
+
+// ktf_tdnn_mx (plane output) with the M-tiles over the batch's valid rows laid end to end: bit-identical planes
+extern "C" int ktf_tdnn_mx_flat(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* row_starts,
+                                const int32_t* row_map, const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
+                                const float* shift, void* yh, void* yl4, void* y4, void* ys, void* stream) {
+    KTF_REQUIRE(row_starts && row_map && yh, "ktf_tdnn_mx_flat: null argument");
+    return mx_launch(xh, xl4, x4, xs, B, T, nullptr, d, wh, wq, bias, scale, shift, yh, yl4, y4, ys, nullptr, 0, nullptr, stream, "ktf_tdnn_mx_flat",
+                     row_starts, row_map);
+}
+
+// ... and ktf_tdnn_mx_stats on them: one partial sum per run of an utterance's rows in a wave's 128-row block (flat_stats.h), slots and finalize
+// as ktf_tdnn_split_flat_stats
+extern "C" int ktf_tdnn_mx_flat_stats(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* row_starts,
+                                      const int32_t* row_map, const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias,
+                                      const float* scale, const float* shift, double* sums, void* stream) {
+    KTF_REQUIRE(row_starts && row_map && sums, "ktf_tdnn_mx_flat_stats: null argument");
+    return mx_launch(xh, xl4, x4, xs, B, T, nullptr, d, wh, wq, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, 0, sums, stream,
+                     "ktf_tdnn_mx_flat_stats", row_starts, row_map);
 }
 
 extern "C" int ktf_tdnn_mx_stats(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T,

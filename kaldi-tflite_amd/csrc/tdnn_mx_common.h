@@ -2,6 +2,7 @@
 // tile on eight matrix waves + four loader waves): operand types, the parameter block, the E8M0 scale rule.
 #pragma once
 #include "tdnn_common.h"
+#include "flat_stats.h"
 #include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
@@ -42,6 +43,8 @@ struct MxParams {
     int32_t sub, start, cut; // output row t reads the input rows start + t * sub + ctx[k] (clamped to the utterance); an utterance of len
                              // rows has ceil((len - cut - start) / sub) output rows (tdnn.py:224-249: VALID padding, subsampling_factor)
     unsigned long long ctx_pk[2];      // the (sorted) context offsets as signed bytes, offset k in byte k
+    const int32_t* row_starts;         // ktf_tdnn_mx_flat: (B + 1) prefix sums of the lengths and ktf_flat_row_map's table (flat row tiles), else NULL
+    const int32_t* row_map;
 };
 
 // E8M0 scale byte of an e2m1 block whose largest magnitude is m: the maximum lands in the top binade [4, 8) x scale, one

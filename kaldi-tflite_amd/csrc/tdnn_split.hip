@@ -1,6 +1,7 @@
 // The plane kernels of KTF_GEMM_BF16X3 (split-bf16: x = hi + lo, w = hi + lo, three bf16 MFMA passes, fp32-grade accuracy) on the
 // 256 x 256 ring tile.
 #include "tdnn_ring.h"
+#include "flat_stats.h"
 
 // ------------------------------------------------------------------------------------ BF16X3, 256x256 tile
 // Split-bf16 on the 256x256 structure: fp32 activations are staged RAW (256 rows x 32 k x 4 B = 128-byte rows, chunk
@@ -176,22 +177,11 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 #define XS_FLAT_OFF XS_LDS_BYTES                        // rs[260] | out_row[256] | t[256] | len[256]
 #define XS_FLAT_BYTES (260 * 4 + 3 * 256 * 4)
 
-// Fused pooling on flat row tiles: a wave's 128-row block holds rows of several utterances, each a run of consecutive rows. Per run
-// (wave-uniform loop over the row table) the wave sums its columns over the run's rows -- in fp32 relative to the run's first row, as
-// ring_epilogue16 does per block, so that a constant column sums to exactly (n v, n v^2) -- and stores the fp64 result in the slot
-// (flat 128-row block of the run) - (flat 128-row block of the utterance's first row) of its utterance: every slot has one writer, an
-// utterance of len rows starting at flat row s uses slots 0 .. ((s + len - 1) >> 7) - (s >> 7) (ktf_stats_finalize_flat adds exactly
-// those, in order; ktf_flat_stats_slots(T) of them are allocated per utterance), or, without KTF_TDNN_DET_STATS, is added atomically.
-// `tab`: out_row[256] | t[256] | len[256] of the tile's rows.
+// Fused pooling on flat row tiles (flat_stats.h): the finished values replace the accumulators, then one partial sum per run of an
+// utterance's rows in the wave's 128-row block. `tab`: out_row[256] | t[256] | len[256] of the tile's rows.
 template <int ACT>
 __device__ __forceinline__ void flat_stats_epilogue(f32x4v (&acc)[8][4], const TdnnParams& p, double* __restrict__ stats, const int* tab,
                                                     int R0, int rows_valid, int n0, int wm, int wn, int lane, const Epi16Prm& prm) {
-    const int* trow = tab;
-    const int* tt = tab + 256;
-    const int* tlen = tab + 512;
-    const int g4 = lane >> 4;
-    const int blk0 = wm * 128;
-    const int blk_end = min(blk0 + 128, rows_valid);
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -203,56 +193,17 @@ __device__ __forceinline__ void flat_stats_epilogue(f32x4v (&acc)[8][4], const T
                 else if (ACT != KTF_ACT_NONE) v = apply_act(v, ACT);
                 acc[i][j][r] = v * prm.sc[j] + prm.sh[j];
             }
-    int m = blk0;
-    while (m < blk_end) {
-        const int t_m = __builtin_amdgcn_readfirstlane(tt[m]);
-        const int len_m = __builtin_amdgcn_readfirstlane(tlen[m]);
-        const int orow = __builtin_amdgcn_readfirstlane(trow[m]);
-        const int b = (orow - t_m) / (int)p.T;
-        const int seg_end = min(blk_end, m + (len_m - t_m));
-        const int lm = m - blk0, le = seg_end - blk0;                 // the run's rows inside the block: [lm, le)
-        const int slot = ((R0 + blk0) >> 7) - ((R0 + m - t_m) >> 7);
-        const int rb = g4 * 4 - lm;                                    // lane's row (i, r) relative to the run's first: rb + 16 i + r
-        const unsigned span = (unsigned)(le - lm);
-        float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool first = rb + 16 * i + r == 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pv[j] = first ? acc[i][j][r] : pv[j];
-            }
-        const int src = ((lm >> 2) & 3) * 16 + (lane & 15);           // the lane that holds the run's first row of this column
-#pragma unroll
-        for (int j = 0; j < 4; ++j) pv[j] = __shfl(pv[j], src, 64);
-        float s32[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q32[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool in = (unsigned)(rb + 16 * i + r) < span;
-                cnt += in ? 1 : 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float u = in ? acc[i][j][r] - pv[j] : 0.0f;
-                    s32[j] += u;
-                    q32[j] = fmaf(u, u, q32[j]);
-                }
-            }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double pd = (double)pv[j], sd = (double)s32[j], nd = (double)cnt;
-            double s = sd + nd * pd;
-            double q = (double)q32[j] + 2.0 * pd * sd + nd * pd * pd;
-            s += __shfl_xor(s, 16, 64); q += __shfl_xor(q, 16, 64);
-            s += __shfl_xor(s, 32, 64); q += __shfl_xor(q, 32, 64);
-            const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-            if (lane < 16 && n < p.units) stats_out(stats, p, b, slot, n, s, q);
-        }
-        m = seg_end;
-    }
+    const int T = (int)p.T;
+    flat_stats_runs(acc, R0, rows_valid, wm, lane,
+                    [&](int m, int& t_m, int& len_m, int& b) {
+                        t_m = __builtin_amdgcn_readfirstlane(tab[256 + m]);
+                        len_m = __builtin_amdgcn_readfirstlane(tab[512 + m]);
+                        b = (__builtin_amdgcn_readfirstlane(tab[m]) - t_m) / T;
+                    },
+                    [&](int b, int slot, int j, double s, double q) {
+                        const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+                        if (n < p.units) stats_out(stats, p, b, slot, n, s, q);
+                    });
 }
 template <int ACT, bool STATS, bool SKIP = false, bool FLAT = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,

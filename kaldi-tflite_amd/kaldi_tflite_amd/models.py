@@ -176,8 +176,10 @@ class Sequential:
                                      # per tile (_mx_use_loader): the 256-row kernel is 4-6 % faster per unit of work
                                      # and takes every batch that fills the chip; 5 ... 24 and ~48 utterances of 10 s leave it
                                      # partly empty and run 8-16 % faster on the smaller flat tiles (tools/mid_batch.py)
+        self.mx_flat_rows = True     # f16mx, 256-row kernel, plane outputs: M-tiles over the batch's valid rows laid end to end where that saves
+                                     # tiles (ktf_tdnn_mx_flat: 998-frame utterances fill 3.9 of their 4 tiles; bit-identical planes)
         self.flat_rows = True        # bf16x3 plane layers of short utterances: M-tiles over the valid rows laid end to end (ktf_tdnn_split_flat)
-        self.flat_pooling = True     # ... the layer pooled in its epilogue included (ktf_tdnn_split_flat_stats). Its partial sums are cut along the
+        self.flat_pooling = True     # ... the layer pooled in its epilogue included (ktf_tdnn_split_flat_stats, ktf_tdnn_mx_flat_stats). Its partial sums are cut along the
                                      # flat row space: reproducible run to run, but an utterance's pooled values can differ in the last bits of the
                                      # fp32 partial sums (<= 2e-6 on an x-vector) with the batch it arrives in; False: per-utterance tiles for
                                      # that layer, x-vectors of the split-bf16 route independent of the batch bit for bit, 3.5 % slower on 1.5 s windows
@@ -436,6 +438,30 @@ class Sequential:
                 wh, wq, bias = l.device_weights_mx(dev, fold=fold, kernel=kern)
                 mxf = L.TDNN_MX_LOADER if use_loader else 0
                 d = l.desc(gemm, torch.float32, torch.float32, act="relu" if relu else None, flags=mxf)      # (the MX entry points read no dtype field)
+                nch_in = ops.round_up(l.inputDim, 32) // 32
+                mx_flat = (self.mx_flat_rows and plain and not use_loader and B <= 4095 and B * T * nch_in * 64 < 2 ** 32
+                           and B * T * (ops.round_up(l.units, 32) // 32) < 2 ** 31
+                           and -(-(B * T) // 256) * 200 <= B * (-(-T // 256)) * 197)          # at least 1.5 % fewer tiles even if no frame was dropped
+                if mx_flat and row_starts is None:
+                    row_starts = ops.flat_rows(lens, B, T, lambda role, shape, dt: self._ws.get(role, shape, dt, dev, padded=False))
+                if can_pool and mx_flat and self.flat_pooling:      # ... on flat row tiles (partial sums per run of an utterance's rows: flat_pooling)
+                    sp = nxt[1]
+                    od = 2 * l.units if sp.includeStd else l.units
+                    slots = ops.flat_stats_slots(T) if self.deterministic else 0
+                    sums = self._ws.get("sums", (B, max(slots, 1), 2, l.units), torch.float64, dev, padded=False)
+                    sbuf = self._ws.get("pooled", (B, ops.round_up(od, 32)), torch.float32, dev)
+                    scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
+                    d.flags = L.TDNN_DET_STATS if slots else 0
+                    ops.tdnn_mx_flat_stats(mxp, row_starts, d, wh, wq, bias, scale, shift, sums, zero=not slots)
+                    if slots:
+                        ops.stats_finalize_flat(sums, row_starts, T, l.units, sp.includeStd, sp.epsilon, sbuf, slots)
+                    else:
+                        ops.stats_finalize(sums, lens, T, l.units, sp.includeStd, sp.epsilon, sbuf)
+                    if si + 2 == tail_at:            # (the fused tail reads finished pooled rows: its own finalize knows per-utterance slots only)
+                        self._deferred = DeferredTail(steps[tail_at][1], B, l.units, sp.includeStd, sp.epsilon, pooled=sbuf, lens=lens, T=T)
+                    x = sbuf[:, :od].unsqueeze(0)
+                    lens, pooled, skip, mxp = None, True, True, None
+                    continue
                 if can_pool:                             # ... -> reducing StatsPooling inside the epilogue (BatchNorm applied there)
                     sp = nxt[1]
                     od = 2 * l.units if sp.includeStd else l.units
@@ -460,7 +486,10 @@ class Sequential:
                 scale, shift = (None, None) if (bn is None or defer_bn) else bn.affine_device(dev)
                 if in_route:
                     out = Planes.buffers(self._ws.get, out_role + "mx", B, Tout, l.units, dev)
-                    ops.tdnn_mx(mxp, lens, d, wh, wq, bias, scale, shift, out)
+                    if mx_flat:
+                        ops.tdnn_mx_flat(mxp, row_starts, d, wh, wq, bias, scale, shift, out)
+                    else:
+                        ops.tdnn_mx(mxp, lens, d, wh, wq, bias, scale, shift, out)
                     mxp = out
                     x = out.xh                            # (shape carrier only)
                 else:

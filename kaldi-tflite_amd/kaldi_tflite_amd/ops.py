@@ -537,6 +537,31 @@ def tdnn_mx(xp, lens, desc, wh, wq, bias, scale, shift, y):
     return y
 
 
+def tdnn_mx_flat(xp, rows, desc, wh, wq, bias, scale, shift, y):
+    """tdnn_mx with a plane output on flat row tiles (`rows` = flat_rows(lens, ...)): the same planes, bit for bit."""
+    lib = L.load()
+    B, T, _ = xp.shape
+    with L.on_device(xp.device):
+        rc = lib.ktf_tdnn_mx_flat(L.ptr(xp.xh), L.ptr(xp.xl4), L.ptr(xp.x4), L.ptr(xp.xs), B, T, L.ptr(rows.starts), L.ptr(rows.map), C.byref(desc),
+                                  L.ptr(wh), L.ptr(wq), L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(y.xh), L.ptr(y.xl4), L.ptr(y.x4),
+                                  L.ptr(y.xs), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_mx_flat")
+    return y
+
+
+def tdnn_mx_flat_stats(xp, rows, desc, wh, wq, bias, scale, shift, sums, zero=False):
+    """tdnn_mx_stats on flat row tiles; sums as for tdnn_split_flat_stats (finalize: stats_finalize_flat)."""
+    lib = L.load()
+    B, T, _ = xp.shape
+    with L.on_device(xp.device):
+        if zero:
+            sums.zero_()
+        rc = lib.ktf_tdnn_mx_flat_stats(L.ptr(xp.xh), L.ptr(xp.xl4), L.ptr(xp.x4), L.ptr(xp.xs), B, T, L.ptr(rows.starts), L.ptr(rows.map),
+                                        C.byref(desc), L.ptr(wh), L.ptr(wq), L.ptr(bias), L.ptr(scale), L.ptr(shift), L.ptr(sums), L.stream_ptr())
+    L.check(rc, "ktf_tdnn_mx_flat_stats")
+    return sums
+
+
 def tdnn_mx_stats(xp, lens, desc, wh, wq, bias, scale, shift, sums, zero=True):
     lib = L.load()
     B, T, _ = xp.shape

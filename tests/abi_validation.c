@@ -105,6 +105,14 @@ int main(void) {
     EXPECT_EINVAL(ktf_flat_row_map(NULL, 4, 100, (int32_t*)l, NULL));                                                 /* no prefix sums */
     EXPECT_EINVAL(ktf_flat_row_map(l, 5000, 100, (int32_t*)l, NULL));                                                /* B > 4095 */
     EXPECT_EINVAL(ktf_stats_finalize_flat(d, 9, NULL, 1000, 1, 4, 1, 1e-10f, f, 8, NULL));                           /* no row map */
+    t.gemm = KTF_GEMM_F16MX; t.units = 256; t.din = 32; t.din_pad = 32;
+    EXPECT_EINVAL(ktf_tdnn_mx_flat(f, f, f, f, 1, 1, NULL, (int32_t*)l, &t, f, f, NULL, NULL, NULL, f, f, f, f, NULL));           /* no prefix sums */
+    EXPECT_EINVAL(ktf_tdnn_mx_flat(f, f, f, f, 1, 1, l, NULL, &t, f, f, NULL, NULL, NULL, f, f, f, f, NULL));                     /* no row table */
+    EXPECT_EINVAL(ktf_tdnn_mx_flat(f, f, f, f, 5000, 1, l, (int32_t*)l, &t, f, f, NULL, NULL, NULL, f, f, f, f, NULL));           /* B > 4095 */
+    t.subsampling = 2;
+    EXPECT_EINVAL(ktf_tdnn_mx_flat(f, f, f, f, 1, 8, l, (int32_t*)l, &t, f, f, NULL, NULL, NULL, f, f, f, f, NULL));              /* subsampling */
+    t.subsampling = 1;
+    EXPECT_EINVAL(ktf_tdnn_mx_flat_stats(f, f, f, f, 1, 1, l, (int32_t*)l, &t, f, f, NULL, NULL, NULL, NULL, NULL));              /* no sums */
     t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32; t.units = 8;
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));

@@ -29,7 +29,8 @@ def _reduced_modes_reach_their_kernels():
 def trace(mdl, wav):
     """[(layer shape, kernel family)] of every TDNN launch of one extraction."""
     seen = []
-    names = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_mx", "tdnn_mx_stats")
+    names = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_split_flat", "tdnn_split_flat_stats", "tdnn_mx", "tdnn_mx_flat", "tdnn_mx_stats",
+             "tdnn_mx_flat_stats")
     orig = {n: getattr(ops, n) for n in names}
 
     def wrap(fn):
@@ -52,7 +53,7 @@ EXPECT = {   # mode -> kernel family of tdnn1 .. tdnn5 for a batch of full-lengt
     "f32": ["tdnn_f32t_kernel"] * 5,
     "bf16": ["tdnn_bf16h_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16h_kernel", "tdnn_bf16h_kernel"],
     "bf16x3": ["tdnn_x3s_kernel"] * 5,
-    "f16mx": ["tdnn_mx_kernel"] * 5,
+    "f16mx": ["tdnn_mx_kernel<flat>"] * 5,        # 998-frame utterances fill 3.9 of their four 256-row tiles: flat row tiles (Sequential.mx_flat_rows)
 }
 
 
@@ -81,7 +82,7 @@ def test_f16mx_kernel_by_batch_size():
     try:
         mdl = synth.build_extractor(ktf, synth.extractor_cfg(), synth.make_weights(seed=4321), gemm="f16mx")
         wav = synth.make_wav(32, 160000, seed=3)
-        for B, family in ((6, "tdnn_mxl_kernel"), (32, "tdnn_mx_kernel")):
+        for B, family in ((6, "tdnn_mxl_kernel"), (32, "tdnn_mx_kernel<flat>")):
             got = [k for _, k in trace(mdl, wav[:B])]
             assert got[:5] == [family] * 5, (B, got)
     finally:

@@ -255,6 +255,7 @@ def test_loader_wave_kernel_against_the_256_row_kernel():
     for loader in (True, False):
         mdl = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
         mdl.xvec.mx_loader = loader
+        mdl.xvec.flat_pooling = False                          # (batch == single bit for bit below: the pooled layer on per-utterance tiles)
         y = mdl(dev(wav))
         assert ops.last_kernel() == ("tdnn_mxl_kernel" if loader else "tdnn_mx_kernel")
         got[loader] = y.cpu().numpy()
@@ -276,7 +277,7 @@ def test_fused_tail_equals_the_three_launch_tail(gemm):
     mdl = synth.build_extractor(ktf, cfg, w, gemm=gemm)
     fused = mdl(dev(wav))
     assert torch.equal(mdl(dev(wav)), fused), "not reproducible"
-    if gemm == "bf16x3":           # 3 s utterances run on flat row tiles; the pooled layer's partial sums follow the flat row space (Sequential.flat_pooling)
+    if gemm in ("bf16x3", "f16mx"):   # flat row tiles; the pooled layer's partial sums follow the flat row space (Sequential.flat_pooling)
         for b in (0, 4):
             assert (mdl(dev(wav[b:b + 1])).reshape(-1) - fused[b]).abs().max().item() <= 2e-6
         mdl.xvec.flat_pooling = False
@@ -498,3 +499,98 @@ def test_f16mx_model_with_valid_and_subsampled_layers_stays_on_the_mx_kernels():
         err = np.abs(got[i, :n] - want).max() / np.abs(want).max()
         print(f"utterance {i}: {n} output rows, max-abs deviation / max |y| = {err:.2e}")
         assert err < 2e-3                                    # frame-level outputs (no pooling to average the rounding noise)
+
+
+# ----------------------------------------------------------------------------- f16mx on flat row tiles (round 5)
+@pytest.mark.parametrize("relu", [True, False])
+@pytest.mark.parametrize("case", CASES + [(512, [-2, 0, 2], 512, 37, 333, None), (30, [-2, -1, 0, 1, 2], 512, 300, 40, None)])
+def test_tdnn_mx_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case, relu):
+    """ktf_tdnn_mx_flat: the M-tiles of the 256-row kernel over the batch's valid rows laid end to end (row table from ktf_flat_row_map).
+    Same operands into the same MFMAs in the same order: all four output planes equal ktf_tdnn_mx's bit for bit on the valid rows, and
+    nothing is written beyond an utterance's length. Ragged batches with empty and one-row utterances, tens of utterances per tile."""
+    rng = np.random.default_rng(31)
+    D, ctx, units, B, T, lens = case
+    if lens is None:
+        lens = rng.integers(0, T + 1, B)
+        lens[[0, B // 2]] = T
+        lens[[1, B - 1]] = 0
+        lens[2] = 1
+    layer, W, bias, x, lens = _layer_case(rng, D, ctx, units, B, T, lens)
+    p = mx.Planes.empty(B, T, D, "cuda")
+    dl = dev(lens, torch.int32)
+    ops.mx_planes(dev(x), D, dl, p)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel="tile")
+    d = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu" if relu else None)
+    scale = torch.rand(units, device="cuda") + 0.5 if not relu else None
+    shift = torch.randn(units, device="cuda") if not relu else None
+    outs = []
+    for flat in (False, True):
+        o = mx.Planes.empty(B, T, units, "cuda")
+        for t in (o.xh, o.xl4, o.x4, o.xs):
+            t.view(torch.uint8).fill_(0x5a)
+        if flat:
+            rows = ops.flat_rows(dl, B, T, lambda role, shape, dt: torch.zeros(shape, dtype=dt, device="cuda"))
+            ops.tdnn_mx_flat(p, rows, d, wh, wq, bd, scale, shift, o)
+            assert ops.last_kernel() == "tdnn_mx_kernel<flat>"
+        else:
+            ops.tdnn_mx(p, dl, d, wh, wq, bd, scale, shift, o)
+        outs.append([t.view(torch.uint8).cpu().numpy() for t in (o.xh, o.xl4, o.x4, o.xs)])
+    for a, b_ in zip(*outs):                                 # planes are (B, nch, T, bytes): every byte, written or not, must agree
+        assert a.shape == b_.shape and np.array_equal(a, b_)
+    for bi in range(B):                                      # ... and rows beyond the length keep the fill
+        for a in outs[1]:
+            assert (a.reshape(B, a.shape[1], T, -1)[bi, :, lens[bi]:] == 0x5a).all()
+
+
+@pytest.mark.parametrize("deterministic", [True, False])
+@pytest.mark.parametrize("case", [(512, [0], 1500, 60, 333), (96, [-2, 0, 2], 300, 300, 40), (160, [-1, 0, 1], 257, 9, 700)])
+def test_tdnn_mx_fused_pooling_on_flat_row_tiles(case, deterministic):
+    """ktf_tdnn_mx_flat_stats against ktf_tdnn_mx_stats (same MFMA operands; the fp32 partial sums relative to each block's pivot row are
+    cut along the flat row space instead of per utterance): pooled mean | std agree to 1e-5, a dead ReLU unit and a constant one give
+    std = sqrt(eps) exactly, empty utterances give a NaN mean, the slot form is reproducible run to run."""
+    D, ctx, units, B, T = case
+    rng = np.random.default_rng(units + B)
+    lens = rng.integers(1, T + 1, B)
+    lens[[0, B // 2]] = T
+    lens[[1, B - 1]] = 0
+    lens[2] = 1
+    layer, W, bias, x, lens = _layer_case(rng, D, ctx, units, B, T, lens)
+    Wk = W.reshape(units, len(ctx) * D).copy()
+    bias = bias.copy()
+    Wk[5], bias[5] = 0.0, -1.0
+    Wk[6], bias[6] = 0.0, 0.7
+    layer.set_weights([Wk, bias])
+    p = mx.Planes.empty(B, T, D, "cuda")
+    dl = dev(lens, torch.int32)
+    ops.mx_planes(dev(x), D, dl, p)
+    wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel="tile")
+    scale = torch.as_tensor(rng.uniform(0.5, 1.5, units).astype(np.float32), device="cuda")
+    shift = torch.as_tensor(rng.standard_normal(units).astype(np.float32), device="cuda")
+    d = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu", flags=L.TDNN_DET_STATS if deterministic else 0)
+    rows = ops.flat_rows(dl, B, T, lambda role, shape, dt: torch.zeros(shape, dtype=dt, device="cuda"))
+    out = {}
+    for flat in (True, False):
+        slots = (ops.flat_stats_slots(T) if flat else ops.stats_slots(T)) if deterministic else 0
+        res = []
+        for _ in range(2):
+            sums = torch.full((B, max(slots, 1), 2, units), 123.0, dtype=torch.float64, device="cuda")
+            pooled = torch.zeros((B, 2 * units), device="cuda")
+            if flat:
+                ops.tdnn_mx_flat_stats(p, rows, d, wh, wq, bd, scale, shift, sums, zero=not slots)
+                assert ops.last_kernel() == "tdnn_mx_kernel<flat>"
+                if slots:
+                    ops.stats_finalize_flat(sums, rows, T, units, True, 1e-10, pooled, slots)
+                else:
+                    ops.stats_finalize(sums, dl, T, units, True, 1e-10, pooled)
+            else:
+                ops.tdnn_mx_stats(p, dl, d, wh, wq, bd, scale, shift, sums, zero=not slots)
+                ops.stats_finalize(sums, dl, T, units, True, 1e-10, pooled, slots=slots)
+            res.append(pooled.cpu().numpy())
+        if deterministic:
+            assert np.array_equal(res[0], res[1], equal_nan=True)
+        out[flat] = res[0]
+    ok = lens > 0
+    assert np.isnan(out[True][~ok][:, :units]).all() and np.isnan(out[False][~ok][:, :units]).all()
+    sc = max(1.0, float(np.abs(out[False][ok]).max()))
+    assert np.abs(out[True][ok] - out[False][ok]).max() <= 1e-5 * sc, np.abs(out[True][ok] - out[False][ok]).max()
+    assert np.abs(out[True][ok][:, units + 5] - 1e-5).max() < 1e-7 and np.abs(out[True][ok][:, units + 6] - 1e-5).max() < 1e-7

@@ -165,7 +165,7 @@ def test_fused_pooling_is_reproducible_and_matches_the_atomic_form(gemm):
     a = det(wav)
     for _ in range(3):
         assert torch.equal(det(wav), a)
-    if gemm == "bf16x3":          # 4 s utterances run on flat row tiles: the pooled layer's partial sums follow the flat row space (Sequential.flat_pooling)
+    if gemm in ("bf16x3", "f16mx"):   # utterances that fill their tiles badly run on flat row tiles: the pooled layer's partial sums follow the flat row space (Sequential.flat_pooling)
         for i in (0, 7, 23):
             assert float((det(wav[i:i + 1]) - a[i]).abs().max()) <= 2e-6
         det.xvec.flat_pooling = False

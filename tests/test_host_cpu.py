@@ -523,7 +523,7 @@ def test_library_kernel_families():
     assert fam["tdnn_x3r_kernel"] == 8                  # 4 activations x {store, pooled}: fp32 activations only
     assert fam["tdnn_x3s_kernel"] == 8 + 8 + 4          # split-bf16 (4 activations x {rows, pooled}, plain and row-group-skipping; flat rows: {ReLU, none} x {rows, pooled})
     assert fam["tdnn_x4s_kernel"] == 8                  # bf16-pair small tiles: 64 x 32 / 64 / 96 and the K-step-32 form, x {rows, pooled}
-    assert fam["tdnn_mx_kernel"] == 12                  # {ReLU, none} x {planes, fp32, pooled} x {K-steps fill the super-steps, padded}
+    assert fam["tdnn_mx_kernel"] == 12 + 8              # {ReLU, none} x {planes, fp32, pooled} x {K-steps fill the super-steps, padded} + flat row tiles: {ReLU, none} x {planes, pooled} x {...}
     assert fam["tdnn_mxl_kernel"] == 6                  # the same on the loader-wave kernel (KTF_TDNN_MX_LOADER)
     assert not any("probe" in k for k in kernels)
     assert "getenv" not in out
