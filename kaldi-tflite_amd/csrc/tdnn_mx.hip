@@ -418,9 +418,12 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
                      const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale, const float* shift,
                      void* yh, void* yl4, void* y4, void* ys, float* yf, int64_t ldy, double* stats, void* stream, const char* who,
                      const int32_t* row_starts = nullptr, const int32_t* row_map = nullptr) {
-    KTF_REQUIRE(xh && xl4 && x4 && xs && d && wh && wq, "%s: null argument", who);
+    // (the descriptor and the weights are validated whether or not the input is empty; the planes of an EMPTY input -- B == 0, or T == 0
+    // behind a VALID-padded layer that kept no row -- may be null pointers, as for ktf_tdnn)
+    KTF_REQUIRE(d && wh && wq, "%s: null argument", who);
     KTF_REQUIRE(d->gemm == KTF_GEMM_F16MX, "%s: needs KTF_GEMM_F16MX", who);
     KTF_REQUIRE(B >= 0 && T >= 0 && B < 65536, "%s: bad size", who);
+    KTF_REQUIRE(B == 0 || T == 0 || (xh && xl4 && x4 && xs), "%s: null argument", who);
     KTF_REQUIRE(d->units > 0 && d->din > 0 && d->din_pad % 32 == 0 && d->din_pad >= d->din, "%s: bad units / din / din_pad", who);
     KTF_REQUIRE(d->nctx >= 1 && d->nctx <= 16, "%s: nctx %d outside [1,16]", who, d->nctx);
     for (int i = 1; i < d->nctx; ++i) KTF_REQUIRE(d->ctx[i] > d->ctx[i - 1], "%s: context must be strictly ascending", who);

@@ -133,3 +133,24 @@ def test_pooled_layer_on_flat_row_tiles_matches_the_per_utterance_tiles_and_the_
     for i in list(np.flatnonzero(ok)[:6]) + [int(np.flatnonzero(ok)[-1])]:
         want = O.sequential_forward(layers, x[i:i + 1, : lens[i]], dtype=np.float64)
         assert np.abs(flat[i] - want[0]).max() < 2e-4 * max(1.0, np.abs(want).max()), (i, lens[i])
+
+
+def test_f16mx_layer_behind_a_valid_padded_layer_that_kept_no_row():
+    """Found by tools/fuzz_models.py (round 5, seed 606): a VALID-padded layer whose context is longer than what the layers in front of it
+    left (12 frames -> 4 after a subsampling layer -> none) hands EMPTY planes to the next f16mx layer; ktf_tdnn_mx took their null
+    pointers for a missing argument. Like ktf_tdnn it now returns without a launch: the runner's result has no row, as the oracle's."""
+    D = 40
+    spec = [(16, [2], "SAME", 1, "affine", None), (256, [4], "SAME", 3, ["affine", "relu"], None), (300, [-3, -1, 1], "VALID", 2, "affine", "relu"),
+            (130, [-4], "SAME", 2, "affine", "relu")]
+    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
+    for i, (U, ctx, pad, sub, kinds, act) in enumerate(spec):
+        c = {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}
+        if act:
+            c["activation"] = act
+        lcfg.append({"name": f"t{i}", "type": kinds, "cfg": c})
+    mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm="f16mx")
+    mdl.min_tiles, mdl.min_frames = {}, {}
+    x = torch.randn((7, 12, D), device="cuda")
+    lens = torch.tensor([7, 4, 10, 5, 12, 5, 12], dtype=torch.int32, device="cuda")
+    y = mdl.run_ragged(x, lens)
+    assert tuple(y.shape) == (7, 0, 130)

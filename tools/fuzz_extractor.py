@@ -93,7 +93,7 @@ for r in range(rounds):
     seen["nan_expected"] += int(np.isnan(want).any(axis=1).sum())
     knobs = {}
     if KNOBS:
-        knobs = {"mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)),
+        knobs = {"mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)), "mx_flat_rows": bool(rng.integers(0, 2)), "flat_pooling": bool(rng.integers(0, 2)),
                  "split_planes": bool(rng.integers(0, 2)), "fuse_stats": bool(rng.integers(0, 2)), "deterministic": bool(rng.integers(0, 2)),
                  "small_tile_pairs": bool(rng.integers(0, 2)), "min_tiles": [None, {}][int(rng.integers(0, 2))]}
         xk = {"fuse_tail": bool(rng.integers(0, 2)), "route_short_utterances": True}

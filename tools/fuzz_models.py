@@ -58,9 +58,13 @@ for case in range(n_cases):
         continue
     knobs = {}
     if "--knobs" in sys.argv:                            # random settings of the runner's A/B knobs: schedules and kernels change, the contract does not
-        knobs = {"mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)),
+        knobs = {"mx_loader": [None, True, False][int(rng.integers(0, 3))], "flat_rows": bool(rng.integers(0, 2)), "mx_flat_rows": bool(rng.integers(0, 2)), "flat_pooling": bool(rng.integers(0, 2)),
                  "split_planes": bool(rng.integers(0, 2)), "fuse_stats": bool(rng.integers(0, 2)), "deterministic": bool(rng.integers(0, 2)),
                  "small_tile_pairs": bool(rng.integers(0, 2))}
+        if os.environ.get("FUZZ_FORCE"):                # "knob=value,...": pin knobs after the draw (same random sequence): bisecting a mismatch
+            for kv in os.environ["FUZZ_FORCE"].split(","):
+                k, v = kv.split("=")
+                knobs[k] = {"True": True, "False": False, "None": None}[v]
         for k, v in knobs.items():
             setattr(mdl, k, v)
         if rng.random() < 0.5:
