@@ -178,6 +178,7 @@ class Sequential:
                                      # partly empty and run 8-16 % faster on the smaller flat tiles (tools/mid_batch.py)
         self.mx_flat_rows = True     # f16mx, 256-row kernel, plane outputs: M-tiles over the batch's valid rows laid end to end where that saves
                                      # tiles (ktf_tdnn_mx_flat: 998-frame utterances fill 3.9 of their 4 tiles; bit-identical planes)
+        self.flat_rows_long = True   # ... and of any batch whose utterances do not fill their last tile (like mx_flat_rows)
         self.flat_rows = True        # bf16x3 plane layers of short utterances: M-tiles over the valid rows laid end to end (ktf_tdnn_split_flat)
         self.flat_pooling = True     # ... the layer pooled in its epilogue included (ktf_tdnn_split_flat_stats, ktf_tdnn_mx_flat_stats). Its partial sums are cut along the
                                      # flat row space: reproducible run to run, but an utterance's pooled values can differ in the last bits of the
@@ -324,8 +325,12 @@ class Sequential:
     def _flat_tiles(self, l, B, T, ldx):
         """Split-bf16 plane layers of utterances that fill their 256-row tiles badly (a 1.5 s window: 148 rows) run on M-tiles over the
         batch's valid rows laid end to end (ktf_tdnn_split_flat*)."""
-        return bool(self.flat_rows and l.padding == "SAME" and l.subsamplingFactor == 1 and l.activation in (None, "linear", "relu")
-                    and B <= 4095 and B * T * ldx * 2 < 2 ** 32 and 5 * (-(-T // 16)) < 4 * (-(-T // 256)) * 16)
+        if not (self.flat_rows and l.padding == "SAME" and l.subsamplingFactor == 1 and l.activation in (None, "linear", "relu")
+                and B <= 4095 and B * T * ldx * 2 < 2 ** 32):
+            return False
+        # tiles that are mostly padding (fewer than 80 % of the 16-row blocks computed hold a row of a full-length utterance), or at least
+        # 1.5 % fewer tiles even if the VAD dropped no frame (a ragged batch saves half a tile per utterance on top)
+        return bool(5 * (-(-T // 16)) < 4 * (-(-T // 256)) * 16 or (self.flat_rows_long and -(-(B * T) // 256) * 200 <= B * (-(-T // 256)) * 197))
 
     def _pooled_by_gemm(self, l, relu, bn, nxt, x_or_planes, lens, gemm, split, dev, T, defer_to=None, row_starts=None):
         """[affine, relu, batchnorm] -> reducing StatsPooling inside the GEMM epilogue: the layer output is never written.

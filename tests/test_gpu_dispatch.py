@@ -52,7 +52,7 @@ def trace(mdl, wav):
 EXPECT = {   # mode -> kernel family of tdnn1 .. tdnn5 for a batch of full-length utterances
     "f32": ["tdnn_f32t_kernel"] * 5,
     "bf16": ["tdnn_bf16h_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16r16_kernel", "tdnn_bf16h_kernel", "tdnn_bf16h_kernel"],
-    "bf16x3": ["tdnn_x3s_kernel"] * 5,
+    "bf16x3": ["tdnn_x3s_kernel<flat>"] * 4 + ["tdnn_x3s_kernel<flat, pooled>"],       # flat row tiles (Sequential.flat_rows_long), as for f16mx
     "f16mx": ["tdnn_mx_kernel<flat>"] * 5,        # 998-frame utterances fill 3.9 of their four 256-row tiles: flat row tiles (Sequential.mx_flat_rows)
 }
 

@@ -380,7 +380,8 @@ def test_short_windows_run_flat_rows_and_equal_the_tiled_route():
     """A split-bf16 model on 1.5 s windows (what an f16mx model routes its short utterances to): the plane layers run on flat row
     tiles (Sequential.flat_rows), the pooled layer included (round 5: its partial sums are cut along the flat row space, so the
     x-vectors agree with the per-utterance tiles' to the last bits of the fp32 partial sums, not bit for bit; the frame-level layers do:
-    test_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit above); 10 s utterances keep the tiles."""
+    test_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit above); 10 s utterances keep the tiles with
+    `flat_rows_long` off (and take the flat ones, like the f16mx layers, with it on: tests/test_gpu_dispatch.py)."""
     cfg = synth.extractor_cfg()
     w = synth.make_weights(seed=4321)
     wav = synth.make_wav(48, 24000, seed=21, ragged=True)
@@ -407,6 +408,7 @@ def test_short_windows_run_flat_rows_and_equal_the_tiled_route():
     assert float((got[True] - got[False]).abs().max()) <= 2e-6
     mdl = synth.build_extractor(ktf, cfg, w, gemm="bf16x3")
     mdl.xvec.min_tiles = {}
+    mdl.xvec.flat_rows_long = False                     # (round 5: long batches take the flat tiles too unless this is off)
     calls = []
     real = ops.tdnn_split_flat
     ops.tdnn_split_flat = lambda *a, **k: calls.append(1) or real(*a, **k)

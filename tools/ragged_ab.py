@@ -19,8 +19,9 @@ for frac in [float(v) for v in os.environ.get("FRACS", "0.0,0.1,0.3,0.5").split(
     row = {}
     for rep in range(2):
         for flat in ((False, True) if os.environ.get("ORDER") == "rev" else (True, False)):
-            m = synth.build_extractor(ktf, cfg, w, gemm="f16mx")
+            m = synth.build_extractor(ktf, cfg, w, gemm=os.environ.get("GEMM", "f16mx"))
             m.xvec.mx_flat_rows = flat
+            m.xvec.flat_rows_long = flat if os.environ.get("LONG_AB", "1") == "1" else True
             ms = bench._time_ms(torch, lambda: m(x), 10)
             row.setdefault(flat, []).append(ms)
             lens = m.last_lens.float()
