@@ -257,7 +257,8 @@ def main(argv=None):
 class _GemmProfiler:
     """Brackets every ktf_tdnn launch of the frame-level layers with HIP events on the launch stream."""
 
-    NAMES = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_split_flat", "tdnn_split_flat_stats", "tdnn_mx", "tdnn_mx_flat", "tdnn_mx_stats")
+    NAMES = ("tdnn", "tdnn_stats", "tdnn_split", "tdnn_split_stats", "tdnn_split_flat", "tdnn_split_flat_stats", "tdnn_mx", "tdnn_mx_flat", "tdnn_mx_stats",
+             "tdnn_mx_flat_stats")
     AUX = ("mx_planes", "split_bf16")      # conversions a mode needs in front of its first GEMM: timed too, reported separately
 
     def __init__(self, ops, torch):
@@ -320,6 +321,9 @@ class _GemmProfiler:
             ms = s.elapsed_time(e)
             total += ms
             per[name] = per.get(name, 0.0) + ms
+        if len(self.events) % 5:
+            raise RuntimeError(f"bench: {len(self.events)} frame-level GEMM launches recorded, not a multiple of the five layers -- an ops entry point "
+                               "is missing from _GemmProfiler.NAMES (the roofline would leave a layer out)")
         steps = max(len(self.events) // 5, 1)
         return {"total_ms": total, "launches": len(self.events), "per_layer_ms": {k: v / steps for k, v in per.items()},
                 "aux_ms_per_step": {k: v / steps for k, v in aux.items()}}
