@@ -69,8 +69,13 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     v += dpp_mov<DPP_QUAD_XOR2>(v);
     v += dpp_mov<DPP_ROW_ROR4>(v);
     v += dpp_mov<DPP_ROW_ROR8>(v);           // every lane: sum of its row of 16
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST15, 0xA, 0xF, false));
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_ROW_BCAST31, 0xC, 0xF, false));
+    // rows 1, 3 += lane 15 of rows 0, 2; rows 2, 3 += lane 31: one v_add_f32_dpp each, written under the row mask (the rows outside it keep
+    // their value: from the builtin the compiler builds v_mov 0 / v_mov_dpp / v_add, three instructions per step, adding a zero to the
+    // masked rows -- the same bits). The s_nop covers the DPP read-after-write hazard the compiler cannot see inside an asm statement.
+    asm("s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
