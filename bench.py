@@ -57,6 +57,8 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-clock-probe", action="store_true", help="do not run the one-wave shader-clock probe beside the timed regions (profiling runs: "
+                                                                  "it would top the kernel statistics with its own duration); shader_clock_mhz is then null")
     ap.add_argument("--no-mx-flat", action="store_true", help="A/B: f16mx plane layers on per-utterance 256-row tiles instead of flat row tiles")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region (exactly --steps steps between barrier + synchronize) is run this many "
                                                            "times back to back; `value` / `ms_per_step` are the MEDIAN region, `value_runs` lists all")
@@ -167,7 +169,8 @@ def main(argv=None):
         ops_prof.reset()
         parallel.barrier(world)
         torch.cuda.synchronize()
-        ops.clock_probe(probe_out[rep_i], max(1000, min(int(0.9 * est_us), 9_000_000)), probe_stream)
+        if not args.no_clock_probe:
+            ops.clock_probe(probe_out[rep_i], max(1000, min(int(0.9 * est_us), 9_000_000)), probe_stream)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = step()
