@@ -130,11 +130,13 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     const int wm = wave >> 2, wn = wave & 3;
     const int R0 = mt * 256;                              // FLAT: first flat row of the tile
     int len, out_len;
+    [[maybe_unused]] bool dense = false;                  // FLAT: every utterance has all T rows: row -> (utterance, frame) by division, no table load
     if constexpr (FLAT) {
         const int total = p.row_starts[mtiles];
         if (R0 >= total) return;
         len = (int)p.T;
         out_len = total - R0 < 256 ? total - R0 : 256;    // valid rows of the tile
+        dense = total == mtiles * len;
     } else {
         len = p.lens ? p.lens[b] : (int)p.T;
         out_len = len - p.cut - p.start <= 0 ? 0 : (len - p.cut - p.start + p.sub - 1) / p.sub;      // (== len: SAME, no subsampling)
@@ -165,16 +167,25 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     // FLAT: (frame, last frame of its utterance, first record of its utterance) of the two stage rows and of the side row of this thread
     [[maybe_unused]] int a_lm1[2] = {lenm1, lenm1}, s_row = 0, s_lm1 = lenm1;
     [[maybe_unused]] unsigned a_ub[2] = {0u, 0u}, s_ub = 0u;
+    // (output row b * T + t or -1, t, utterance length, b) of tile row m; rows beyond the batch's last: (-1, 0, 1, 0)
+    [[maybe_unused]] auto flat_row = [&](int m) -> i32x4 {
+        if (dense) {
+            const int R = R0 + m;
+            if (m >= out_len) return i32x4{-1, 0, 1, 0};
+            const int bb = p.t_div_m ? (int)(__umulhi((unsigned)R, p.t_div_m) >> p.t_div_s) : R;
+            return i32x4{R, R - bb * len, len, bb};
+        }
+        return reinterpret_cast<const i32x4*>(p.row_map)[R0 + m];
+    };
     if constexpr (FLAT) {
-        const i32x4* map = reinterpret_cast<const i32x4*>(p.row_map) + R0;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const i32x4 e = map[(i * 512 + tid) >> 2];    // (output row b * T + t or -1, t, utterance length, b); rows beyond the last: (-1, 0, 1, 0)
+            const i32x4 e = flat_row((i * 512 + tid) >> 2);
             a_row[i] = e.y;
             a_lm1[i] = e.z - 1;
             a_ub[i] = e.x < 0 ? 0u : (unsigned)(e.x - e.y) * (unsigned)p.nch_in;
         }
-        const i32x4 e = map[lane + 64 * (wave & 3)];
+        const i32x4 e = flat_row(lane + 64 * (wave & 3));
         s_row = e.y;
         s_lm1 = e.z - 1;
         s_ub = e.x < 0 ? 0u : (unsigned)(e.x - e.y) * (unsigned)p.nch_in;
@@ -472,6 +483,12 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
         KTF_REQUIRE(B <= 4095 && B * T * (int64_t)p.nch_in * 64 < (1ll << 32) && B * T < (1ll << 31) / (p.nch_out > 0 ? p.nch_out : 1),
                     "%s: flat row tiles need B <= 4095 and B * T * din_pad * 2 < 2^32", who);
         p.row_starts = row_starts; p.row_map = row_map;
+        if (T > 1) {                            // x / T for x < 2^31: m = 2^(31 + l) / T + 1, s = l - 1, l = ceil(log2 T)
+            uint32_t l = 0;
+            while ((1ull << l) < (uint64_t)T) ++l;
+            p.t_div_m = (uint32_t)((1ull << (31 + l)) / (uint64_t)T + 1);
+            p.t_div_s = l - 1;
+        }
         const int ntiles = ktf_cdiv(d->units, 256);
         const int64_t ftiles = ktf_cdiv(B * T, 256);
         const int64_t fblocks = ((ftiles + 7) / 8) * 8 * ntiles;

@@ -45,6 +45,8 @@ struct MxParams {
     unsigned long long ctx_pk[2];      // the (sorted) context offsets as signed bytes, offset k in byte k
     const int32_t* row_starts;         // ktf_tdnn_mx_flat: (B + 1) prefix sums of the lengths and ktf_flat_row_map's table (flat row tiles), else NULL
     const int32_t* row_map;
+    uint32_t t_div_m, t_div_s;         // ... x / T as __umulhi(x, t_div_m) >> t_div_s for x < 2^31 (t_div_m == 0: T == 1): the row lookups of a batch
+                                       // whose every utterance has all T rows (row_starts[B] == B * T) are arithmetic, no table load
 };
 
 // E8M0 scale byte of an e2m1 block whose largest magnitude is m: the maximum lands in the top binade [4, 8) x scale, one

@@ -503,11 +503,13 @@ def test_f16mx_model_with_valid_and_subsampled_layers_stays_on_the_mx_kernels():
 
 # ----------------------------------------------------------------------------- f16mx on flat row tiles (round 5)
 @pytest.mark.parametrize("relu", [True, False])
-@pytest.mark.parametrize("case", CASES + [(512, [-2, 0, 2], 512, 37, 333, None), (30, [-2, -1, 0, 1, 2], 512, 300, 40, None)])
+@pytest.mark.parametrize("case", CASES + [(512, [-2, 0, 2], 512, 37, 333, None), (30, [-2, -1, 0, 1, 2], 512, 300, 40, None),
+                                          (64, [-2, 0, 2], 512, 5, 300, [300] * 5), (96, [-3, 0, 3], 300, 9, 998, [998] * 9), (64, [0], 256, 700, 1, [1] * 700)])
 def test_tdnn_mx_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case, relu):
     """ktf_tdnn_mx_flat: the M-tiles of the 256-row kernel over the batch's valid rows laid end to end (row table from ktf_flat_row_map).
     Same operands into the same MFMAs in the same order: all four output planes equal ktf_tdnn_mx's bit for bit on the valid rows, and
-    nothing is written beyond an utterance's length. Ragged batches with empty and one-row utterances, tens of utterances per tile."""
+    nothing is written beyond an utterance's length. Ragged batches with empty and one-row utterances, tens of utterances per tile; and
+    batches whose every utterance has all T rows (the kernel then derives a row's utterance and frame by division instead of from the table)."""
     rng = np.random.default_rng(31)
     D, ctx, units, B, T, lens = case
     if lens is None:
@@ -543,17 +545,19 @@ def test_tdnn_mx_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case, 
 
 
 @pytest.mark.parametrize("deterministic", [True, False])
-@pytest.mark.parametrize("case", [(512, [0], 1500, 60, 333), (96, [-2, 0, 2], 300, 300, 40), (160, [-1, 0, 1], 257, 9, 700)])
+@pytest.mark.parametrize("case", [(512, [0], 1500, 60, 333), (96, [-2, 0, 2], 300, 300, 40), (160, [-1, 0, 1], 257, 9, 700), (512, [0], 1500, 7, 998, "dense")])
 def test_tdnn_mx_fused_pooling_on_flat_row_tiles(case, deterministic):
     """ktf_tdnn_mx_flat_stats against ktf_tdnn_mx_stats (same MFMA operands; the fp32 partial sums relative to each block's pivot row are
     cut along the flat row space instead of per utterance): pooled mean | std agree to 1e-5, a dead ReLU unit and a constant one give
     std = sqrt(eps) exactly, empty utterances give a NaN mean, the slot form is reproducible run to run."""
-    D, ctx, units, B, T = case
+    D, ctx, units, B, T = case[:5]
     rng = np.random.default_rng(units + B)
     lens = rng.integers(1, T + 1, B)
     lens[[0, B // 2]] = T
     lens[[1, B - 1]] = 0
     lens[2] = 1
+    if len(case) > 5:                                        # every utterance complete: the kernel's division path
+        lens[:] = T
     layer, W, bias, x, lens = _layer_case(rng, D, ctx, units, B, T, lens)
     Wk = W.reshape(units, len(ctx) * D).copy()
     bias = bias.copy()
@@ -590,7 +594,8 @@ def test_tdnn_mx_fused_pooling_on_flat_row_tiles(case, deterministic):
             assert np.array_equal(res[0], res[1], equal_nan=True)
         out[flat] = res[0]
     ok = lens > 0
-    assert np.isnan(out[True][~ok][:, :units]).all() and np.isnan(out[False][~ok][:, :units]).all()
+    if (~ok).any():
+        assert np.isnan(out[True][~ok][:, :units]).all() and np.isnan(out[False][~ok][:, :units]).all()
     sc = max(1.0, float(np.abs(out[False][ok]).max()))
     assert np.abs(out[True][ok] - out[False][ok]).max() <= 1e-5 * sc, np.abs(out[True][ok] - out[False][ok]).max()
     assert np.abs(out[True][ok][:, units + 5] - 1e-5).max() < 1e-7 and np.abs(out[True][ok][:, units + 6] - 1e-5).max() < 1e-7
