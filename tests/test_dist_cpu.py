@@ -53,8 +53,7 @@ def _worker(rank, world, port, total, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def _run(total, tmp_path):
-    world = 2
+def _run(total, tmp_path, world=2):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
     g = torch.Generator().manual_seed(1234)
@@ -70,6 +69,12 @@ def test_two_rank_equal_shards(tmp_path):
 
 def test_two_rank_ragged_shards(tmp_path):
     _run(7, tmp_path)
+
+
+def test_four_rank_shards(tmp_path):
+    """The same host path at world size 4 (equal and ragged shards): what `bench.py --gpus 4` runs per rank."""
+    _run(8, tmp_path, world=4)
+    _run(10, tmp_path, world=4)
 
 
 def test_shard_range_partitions():
