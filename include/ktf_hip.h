@@ -345,6 +345,10 @@ int ktf_tdnn_split_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t 
                          const float* shift, double* sums, void* stream);
 int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, void* hi, void* lo, int64_t ld_dst,
                    void* stream);
+/* ... of a ragged batch: src (B, T, ld_src) -> planes (B, T, ld_dst); only the rows t < lens[b] are converted (lens NULL: all T): the
+ * consumers clamp their row reads to the utterance, so the rest is never read. Same values as ktf_split_bf16 on the rows it writes. */
+int ktf_split_bf16_rows(const float* src, int64_t B, int64_t T, int32_t D, int64_t ld_src, const int32_t* lens, void* hi, void* lo,
+                        int64_t ld_dst, void* stream);
 /* KTF_GEMM_F16MX (tdnn.py:251-280 + ReLU + BatchNorm, as ktf_tdnn). Activations are FOUR chunk-major planes; with nch = ceil(D / 32)
  * and record r = (b * nch + d / 32) * T + t of element (b, t, d):
  *   xh  : r * 64 B  32 halves, x_h = half(x) (saturating at +-65504), element d % 32

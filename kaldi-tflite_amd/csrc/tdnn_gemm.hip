@@ -328,6 +328,36 @@ extern "C" int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t
     return KTF_OK;
 }
 
+// ... of the VALID rows of a ragged batch only (rows at and beyond lens[b] are never read: every consumer clamps its row reads to the
+// utterance): the second pass of an f16mx model over its few short utterances used to split all B x T rows (64 us per 1024 x 998)
+#define SPLIT_RB 32
+__global__ __launch_bounds__(256) void split_bf16_rows_kernel(const float* __restrict__ src, int64_t T, int D, int64_t lds_, const int32_t* __restrict__ lens,
+                                                              unsigned short* __restrict__ hi, unsigned short* __restrict__ lo, int64_t ldd) {
+    const int64_t b = blockIdx.y, t0 = (int64_t)blockIdx.x * SPLIT_RB;
+    const int64_t len = lens ? (int64_t)lens[b] : T;
+    if (t0 >= len) return;
+    const int64_t rows = len - t0 < SPLIT_RB ? len - t0 : SPLIT_RB, r0 = b * T + t0;
+    for (int64_t e = threadIdx.x; e < rows * ldd; e += 256) {
+        const int64_t r = r0 + e / ldd;
+        const int d = (int)(e % ldd);
+        const float v = d < D ? src[r * lds_ + d] : 0.0f;
+        const unsigned short h = f2bf(v);
+        hi[r * ldd + d] = h;
+        lo[r * ldd + d] = f2bf(v - bf2f(h));
+    }
+}
+
+extern "C" int ktf_split_bf16_rows(const float* src, int64_t B, int64_t T, int32_t D, int64_t ld_src, const int32_t* lens, void* hi, void* lo,
+                                   int64_t ld_dst, void* stream) {
+    KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ld_src >= D && ld_dst >= D && B < 65536, "ktf_split_bf16_rows: bad sizes");
+    if (B == 0 || T == 0) return KTF_OK;
+    KTF_REQUIRE(src && hi && lo, "ktf_split_bf16_rows: null argument");
+    hipLaunchKernelGGL(split_bf16_rows_kernel, dim3((unsigned)ktf_cdiv(T, SPLIT_RB), (unsigned)B), dim3(256), 0, (hipStream_t)stream, src, T, D, ld_src,
+                       lens, (unsigned short*)hi, (unsigned short*)lo, ld_dst);
+    KTF_CHECK_LAUNCH("ktf_split_bf16_rows");
+    return KTF_OK;
+}
+
 // 128-row blocks, rounded up to whole 256-row tiles (a 256-row tile always writes both of its blocks)
 extern "C" int64_t ktf_stats_slots(int64_t T) { return T <= 0 ? 2 : 2 * ((T + 255) / 256); }
 // ... of ktf_tdnn_stats by GEMM mode: KTF_GEMM_BF16X4 pools per 64-row tile (csrc/tdnn_pair.hip), the others per 128-row block

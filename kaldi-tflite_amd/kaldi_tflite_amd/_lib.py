@@ -113,6 +113,7 @@ PROTOTYPES = {
     "ktf_flat_stats_slots": (_i64, [_i64]),
     "ktf_stats_finalize_flat": (C.c_int, [_P, _i64, _P, _i64, _i64, _i32, _i32, _f32, _P, _i64, _P]),
     "ktf_split_bf16": (C.c_int, [_P, _i64, _i32, _i64, _P, _P, _i64, _P]),
+    "ktf_split_bf16_rows": (C.c_int, [_P, _i64, _i64, _i32, _i64, _P, _P, _P, _i64, _P]),
     "ktf_mx_planes": (C.c_int, [_P, _i64, _i64, _i32, _i64, _P, _P, _P, _P, _P, _P]),
     "ktf_tdnn_mx": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _i64, _P]),
     "ktf_tdnn_mx_flat": (C.c_int, [_P, _P, _P, _P, _i64, _i64, _P, _P, C.POINTER(TdnnDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -517,7 +517,7 @@ class Sequential:
                     B, T, D = x.shape
                     planes = self._ws.get("split_in", (2, B, T, ops.round_up(D, 32)), torch.bfloat16, dev)
                     src = x if (x.dtype == torch.float32 and x.stride(2) == 1 and x.stride(0) == T * x.stride(1)) else x.to(torch.float32).contiguous()
-                    ops.split_bf16(src, D, planes)
+                    ops.split_bf16(src, D, planes, lens)
                 B, T = planes.shape[1], planes.shape[2]
                 if can_pool:
                     flat = self.flat_pooling and self._flat_tiles(l, B, T, planes.shape[3])

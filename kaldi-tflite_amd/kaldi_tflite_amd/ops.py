@@ -393,13 +393,17 @@ def plda_score(test_tr, enroll_tr, psi):
     return scores
 
 
-def split_bf16(src, D, planes):
-    """fp32 (B,T,ld_src) rows -> planes (2,B,T,ld) bf16: hi = bf16(v), lo = bf16(v - hi); pad columns zero."""
+def split_bf16(src, D, planes, lens=None):
+    """fp32 (B,T,ld_src) rows -> planes (2,B,T,ld) bf16: hi = bf16(v), lo = bf16(v - hi); pad columns zero. `lens`: only the rows
+    t < lens[b] are converted (the consumers never read the rest)."""
     lib = L.load()
-    rows = src.shape[0] * src.shape[1]
     with L.on_device(src.device):
-        rc = lib.ktf_split_bf16(L.ptr(src), rows, D, src.stride(1), L.ptr(planes[0]), L.ptr(planes[1]), planes.shape[-1],
-                                L.stream_ptr())
+        if lens is None:
+            rc = lib.ktf_split_bf16(L.ptr(src), src.shape[0] * src.shape[1], D, src.stride(1), L.ptr(planes[0]), L.ptr(planes[1]), planes.shape[-1],
+                                    L.stream_ptr())
+        else:
+            rc = lib.ktf_split_bf16_rows(L.ptr(src), src.shape[0], src.shape[1], D, src.stride(1), L.ptr(lens), L.ptr(planes[0]), L.ptr(planes[1]),
+                                         planes.shape[-1], L.stream_ptr())
     L.check(rc, "ktf_split_bf16")
     return planes
 

@@ -116,6 +116,8 @@ int main(void) {
     t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32; t.units = 8;
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));
+    EXPECT_EINVAL(ktf_split_bf16_rows(NULL, 1, 1, 4, 4, NULL, f, f, 32, NULL));
+    EXPECT_EINVAL(ktf_split_bf16_rows(f, 1, 1, 4, 2, NULL, f, f, 32, NULL));                             /* ld_src < D */
     EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, 99, NULL, NULL, f, NULL));
     EXPECT_EINVAL(ktf_affine_act_f32(f, 1, 4, KTF_ACT_SOFTMAX, NULL, NULL, f, NULL));                     /* a row operation: ktf_activation_f32 */
     EXPECT_EINVAL(ktf_activation_f32(NULL, 1, 1, 4, 4, NULL, KTF_ACT_ELU, NULL, NULL, NULL));

@@ -154,3 +154,20 @@ def test_f16mx_layer_behind_a_valid_padded_layer_that_kept_no_row():
     lens = torch.tensor([7, 4, 10, 5, 12, 5, 12], dtype=torch.int32, device="cuda")
     y = mdl.run_ragged(x, lens)
     assert tuple(y.shape) == (7, 0, 130)
+
+
+def test_split_bf16_of_a_ragged_batch_converts_the_valid_rows_only():
+    """ktf_split_bf16_rows: the same hi / lo planes as ktf_split_bf16 on the rows t < lens[b], nothing written beyond them (the f16mx
+    model's second pass over a few short utterances used to convert all B x T rows)."""
+    rng = np.random.default_rng(5)
+    B, T, D = 9, 77, 30
+    x = torch.as_tensor(rng.standard_normal((B, T, D)).astype(np.float32) * 100, device="cuda")
+    lens = torch.as_tensor(np.array([77, 0, 1, 32, 33, 64, 5, 77, 0], np.int32), device="cuda")
+    full = torch.zeros((2, B, T, 32), dtype=torch.bfloat16, device="cuda")
+    ops.split_bf16(x, D, full)
+    got = torch.full((2, B, T, 32), 7.0, dtype=torch.bfloat16, device="cuda")
+    ops.split_bf16(x, D, got, lens)
+    for b in range(B):
+        n = int(lens[b])
+        assert torch.equal(got[:, b, :n], full[:, b, :n]) and bool((got[:, b, n:] == 7.0).all())
+    assert float(((full[0].float() + full[1].float())[:, :, :D] - x).abs().max()) <= 2e-4 * 100
