@@ -10,7 +10,7 @@ import bench
 import kaldi_tflite_amd as ktf
 from kaldi_tflite_amd import ops, _lib
 g = torch.Generator(device="cuda").manual_seed(1234)
-wav = torch.clamp(torch.round(1000.0 * torch.randn((1024, 160000), generator=g, device="cuda")), -32767, 32767)
+wav = torch.clamp(torch.round(1000.0 * torch.randn((1024, int(os.environ.get("N_SAMPLES", 160000))), generator=g, device="cuda")), -32767, 32767)
 for dither in (0.0, 1.0):
     m = synth.build_extractor(ktf, synth.extractor_cfg(dither=dither), synth.make_weights(seed=4321), gemm="f16mx")
     m(wav[:8])
