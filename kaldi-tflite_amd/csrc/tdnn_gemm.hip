@@ -278,7 +278,7 @@ extern "C" int ktf_flat_row_map(const int32_t* row_starts, int64_t B, int64_t T,
 extern "C" int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts, const int32_t* row_map,
                                    const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                                    const float* shift, void* y, void* y_lo, int64_t ldy, void* stream) {
-    KTF_REQUIRE(x_hi && x_lo && row_starts && d && w && w_lo && y, "ktf_tdnn_split_flat: null argument");
+    KTF_REQUIRE(d && w && w_lo && (B == 0 || T == 0 || (x_hi && x_lo && row_starts && y)), "ktf_tdnn_split_flat: null argument");      // (empty tensors: null pointers)
     KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_flat: needs KTF_GEMM_BF16X3 on bf16 hi / lo planes");
     return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, y, ldy, nullptr, nullptr, stream, x_lo, y_lo, row_starts, row_map);
 }
@@ -287,7 +287,7 @@ extern "C" int ktf_tdnn_split_flat(const void* x_hi, const void* x_lo, int64_t B
 extern "C" int ktf_tdnn_split_flat_stats(const void* x_hi, const void* x_lo, int64_t B, int64_t T, int64_t ldx, const int32_t* row_starts,
                                          const int32_t* row_map, const KtfTdnnDesc* d, const void* w, const void* w_lo, const float* bias, const float* scale,
                                          const float* shift, double* sums, void* stream) {
-    KTF_REQUIRE(x_hi && x_lo && row_starts && d && w && w_lo && sums, "ktf_tdnn_split_flat_stats: null argument");
+    KTF_REQUIRE(d && w && w_lo && sums && (B == 0 || T == 0 || (x_hi && x_lo && row_starts)), "ktf_tdnn_split_flat_stats: null argument");
     KTF_REQUIRE(d->gemm == KTF_GEMM_BF16X3 && d->x_dtype == KTF_BF16, "ktf_tdnn_split_flat_stats: needs KTF_GEMM_BF16X3 on bf16 hi / lo planes");
     return tdnn_launch(x_hi, B, T, ldx, nullptr, d, w, w_lo, bias, scale, shift, nullptr, 0, nullptr, sums, stream, x_lo, nullptr, row_starts, row_map);
 }
@@ -316,9 +316,9 @@ __global__ void split_bf16_kernel(const float* __restrict__ src, int64_t rows, i
 
 extern "C" int ktf_split_bf16(const float* src, int64_t rows, int32_t D, int64_t ld_src, void* hi, void* lo, int64_t ld_dst,
                               void* stream) {
-    KTF_REQUIRE(src && hi && lo, "ktf_split_bf16: null argument");
     KTF_REQUIRE(rows >= 0 && D > 0 && ld_src >= D && ld_dst >= D, "ktf_split_bf16: bad sizes");
-    if (rows == 0) return KTF_OK;
+    if (rows == 0) return KTF_OK;                        // (an empty tensor: null pointers)
+    KTF_REQUIRE(src && hi && lo, "ktf_split_bf16: null argument");
     const int64_t total = rows * ld_dst;
     int blocks = ktf_cdiv(total, 256);
     if (blocks > 8192) blocks = 8192;
@@ -456,10 +456,10 @@ extern "C" int ktf_affine_act_f32(const float* x, int64_t rows, int32_t D, int32
 
 extern "C" int ktf_convert_pad(const void* src, int32_t src_dtype, int64_t rows, int32_t D, int64_t ld_src, void* dst,
                                int32_t dst_dtype, int64_t ld_dst, void* stream) {
-    KTF_REQUIRE(src && dst, "ktf_convert_pad: null argument");
     KTF_REQUIRE(rows >= 0 && D > 0 && ld_src >= D && ld_dst >= D, "ktf_convert_pad: bad sizes");
     const int64_t total = rows * ld_dst;
-    if (total == 0) return KTF_OK;
+    if (total == 0) return KTF_OK;                       // (an empty tensor: null pointers)
+    KTF_REQUIRE(src && dst, "ktf_convert_pad: null argument");
     int blocks = ktf_cdiv(total, 256);
     if (blocks > 4096) blocks = 4096;
     hipStream_t st = (hipStream_t)stream;

@@ -96,9 +96,9 @@ __global__ __launch_bounds__(MXP_ROWS) void mx_planes_kernel(const float* __rest
 
 extern "C" int ktf_mx_planes(const float* src, int64_t B, int64_t T, int32_t D, int64_t ld_src, const int32_t* lens, void* xh,
                              void* xl4, void* x4, void* xs, void* stream) {
-    KTF_REQUIRE(src && xh && xl4 && x4 && xs, "ktf_mx_planes: null argument");
     KTF_REQUIRE(B >= 0 && T >= 0 && D > 0 && ld_src >= D, "ktf_mx_planes: bad size");
-    if (B == 0 || T == 0) return KTF_OK;
+    if (B == 0 || T == 0) return KTF_OK;                 // (an empty tensor: null pointers)
+    KTF_REQUIRE(src && xh && xl4 && x4 && xs, "ktf_mx_planes: null argument");
     const int nch = (D + 31) / 32;
     KTF_REQUIRE(B < 65536 && nch < 65536, "ktf_mx_planes: B and D / 32 must be below 65536");
     hipLaunchKernelGGL(mx_planes_kernel, dim3((unsigned)((T + MXP_ROWS - 1) / MXP_ROWS), (unsigned)nch, (unsigned)B), dim3(MXP_ROWS), 0,
@@ -546,7 +546,7 @@ extern "C" int ktf_tdnn_mx(const void* xh, const void* xl4, const void* x4, cons
 extern "C" int ktf_tdnn_mx_flat(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* row_starts,
                                 const int32_t* row_map, const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias, const float* scale,
                                 const float* shift, void* yh, void* yl4, void* y4, void* ys, void* stream) {
-    KTF_REQUIRE(row_starts && row_map && yh, "ktf_tdnn_mx_flat: null argument");
+    KTF_REQUIRE(B == 0 || T == 0 || (row_starts && row_map && yh), "ktf_tdnn_mx_flat: null argument");      // (empty tensors: null pointers)
     return mx_launch(xh, xl4, x4, xs, B, T, nullptr, d, wh, wq, bias, scale, shift, yh, yl4, y4, ys, nullptr, 0, nullptr, stream, "ktf_tdnn_mx_flat",
                      row_starts, row_map);
 }
@@ -556,7 +556,7 @@ extern "C" int ktf_tdnn_mx_flat(const void* xh, const void* xl4, const void* x4,
 extern "C" int ktf_tdnn_mx_flat_stats(const void* xh, const void* xl4, const void* x4, const void* xs, int64_t B, int64_t T, const int32_t* row_starts,
                                       const int32_t* row_map, const KtfTdnnDesc* d, const void* wh, const void* wq, const float* bias,
                                       const float* scale, const float* shift, double* sums, void* stream) {
-    KTF_REQUIRE(row_starts && row_map && sums, "ktf_tdnn_mx_flat_stats: null argument");
+    KTF_REQUIRE(sums && (B == 0 || T == 0 || (row_starts && row_map)), "ktf_tdnn_mx_flat_stats: null argument");
     return mx_launch(xh, xl4, x4, xs, B, T, nullptr, d, wh, wq, bias, scale, shift, nullptr, nullptr, nullptr, nullptr, nullptr, 0, sums, stream,
                      "ktf_tdnn_mx_flat_stats", row_starts, row_map);
 }

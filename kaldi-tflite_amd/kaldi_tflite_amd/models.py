@@ -325,7 +325,7 @@ class Sequential:
     def _flat_tiles(self, l, B, T, ldx):
         """Split-bf16 plane layers of utterances that fill their 256-row tiles badly (a 1.5 s window: 148 rows) run on M-tiles over the
         batch's valid rows laid end to end (ktf_tdnn_split_flat*)."""
-        if not (self.flat_rows and l.padding == "SAME" and l.subsamplingFactor == 1 and l.activation in (None, "linear", "relu")
+        if not (self.flat_rows and B * T > 0 and l.padding == "SAME" and l.subsamplingFactor == 1 and l.activation in (None, "linear", "relu")
                 and B <= 4095 and B * T * ldx * 2 < 2 ** 32):
             return False
         # tiles that are mostly padding (fewer than 80 % of the 16-row blocks computed hold a row of a full-length utterance), or at least
@@ -444,7 +444,7 @@ class Sequential:
                 mxf = L.TDNN_MX_LOADER if use_loader else 0
                 d = l.desc(gemm, torch.float32, torch.float32, act="relu" if relu else None, flags=mxf)      # (the MX entry points read no dtype field)
                 nch_in = ops.round_up(l.inputDim, 32) // 32
-                mx_flat = (self.mx_flat_rows and plain and not use_loader and B <= 4095 and B * T * nch_in * 64 < 2 ** 32
+                mx_flat = (self.mx_flat_rows and plain and not use_loader and B * T > 0 and B <= 4095 and B * T * nch_in * 64 < 2 ** 32
                            and B * T * (ops.round_up(l.units, 32) // 32) < 2 ** 31
                            and -(-(B * T) // 256) * 200 <= B * (-(-T // 256)) * 197)          # at least 1.5 % fewer tiles even if no frame was dropped
                 if mx_flat and row_starts is None:

@@ -171,3 +171,29 @@ def test_split_bf16_of_a_ragged_batch_converts_the_valid_rows_only():
         n = int(lens[b])
         assert torch.equal(got[:, b, :n], full[:, b, :n]) and bool((got[:, b, n:] == 7.0).all())
     assert float(((full[0].float() + full[1].float())[:, :, :D] - x).abs().max()) <= 2e-4 * 100
+
+
+@pytest.mark.parametrize("gemm", ["bf16x3", "f16mx", "bf16", "f32"])
+def test_dense_call_through_a_valid_padded_layer_that_keeps_no_row(gemm):
+    """Found by tools/fuzz_models.py (round 5, seed 99): Sequential.__call__ on a dense batch whose second layer (VALID padding, context
+    longer than the four rows the subsampling layer in front left) keeps no row; the layers behind it receive EMPTY tensors, and
+    ktf_convert_pad / ktf_split_bf16 / ktf_mx_planes took their null pointers for missing arguments. They return without a launch now, as
+    ktf_tdnn does; the result has no row, like the reference's."""
+    D = 40
+    spec = [(130, [3], "SAME", 3, ["affine", "relu"], None), (16, [0, 4], "VALID", 3, "affine", "tanh"), (300, [-2, 0, 4], "SAME", 1, ["affine", "relu"], None),
+            (96, [0, 3], "SAME", 1, ["affine", "relu", "batchnorm"], None)]
+    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
+    for i, (U, ctx, pad, sub, kinds, act) in enumerate(spec):
+        c = {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}
+        if act:
+            c["activation"] = act
+        lcfg.append({"name": f"t{i}", "type": kinds, "cfg": c})
+    mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm=gemm)
+    mdl.min_tiles, mdl.min_frames = {}, {}
+    x = torch.randn((7, 12, D), device="cuda")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = mdl(x)
+        z = mdl.run_ragged(x, torch.full((7,), 12, dtype=torch.int32, device="cuda"))
+    assert tuple(y.shape) == (7, 0, 96) and tuple(z.shape) == (7, 0, 96)
