@@ -391,6 +391,16 @@ class Sequential:
         self._ws.enter(dev)
         gemm, pairs = self._batch_route(x.shape[0], x.shape[1], mode=mode)
         x_pair = False                                   # x holds KTF_BF16P pairs (in a float32 tensor)
+        rows_T = [None]                                  # the frame count the flat-row bookkeeping below was made for
+
+        def flat_rows_for(rs, B_, T_):
+            """The flat-row bookkeeping of the current (lens, B, T): made when the first flat layer runs, made again when a VALID-padded or
+            subsampling layer has changed the lengths (the callers reset it) OR the frame count -- a dense batch (lens None) has no lengths to
+            replace, only T changes (tools/fuzz_models.py seeds 202 / 203: stale rows behind a VALID-padded layer of a dense batch)."""
+            if rs is None or rows_T[0] != (B_, T_):
+                rs = ops.flat_rows(lens, B_, T_, lambda role, shape, dt: self._ws.get(role, shape, dt, dev, padded=False))
+                rows_T[0] = (B_, T_)
+            return rs
         row_starts = None                                # prefix sums of lens for the layers on flat row tiles: made when the first one runs,
                                                          # again when a VALID-padded or subsampling layer has changed the lengths
         act_dtype = L.act_torch_dtype(gemm)
@@ -447,8 +457,8 @@ class Sequential:
                 mx_flat = (self.mx_flat_rows and plain and not use_loader and B * T > 0 and B <= 4095 and B * T * nch_in * 64 < 2 ** 32
                            and B * T * (ops.round_up(l.units, 32) // 32) < 2 ** 31
                            and -(-(B * T) // 256) * 200 <= B * (-(-T // 256)) * 197)          # at least 1.5 % fewer tiles even if no frame was dropped
-                if mx_flat and row_starts is None:
-                    row_starts = ops.flat_rows(lens, B, T, lambda role, shape, dt: self._ws.get(role, shape, dt, dev, padded=False))
+                if mx_flat:
+                    row_starts = flat_rows_for(row_starts, B, T)
                 if can_pool and mx_flat and self.flat_pooling:      # ... on flat row tiles (partial sums per run of an utterance's rows: flat_pooling)
                     sp = nxt[1]
                     od = 2 * l.units if sp.includeStd else l.units
@@ -521,8 +531,8 @@ class Sequential:
                 B, T = planes.shape[1], planes.shape[2]
                 if can_pool:
                     flat = self.flat_pooling and self._flat_tiles(l, B, T, planes.shape[3])
-                    if flat and row_starts is None:
-                        row_starts = ops.flat_rows(lens, B, T, lambda role, shape, dt: self._ws.get(role, shape, dt, dev, padded=False))
+                    if flat:
+                        row_starts = flat_rows_for(row_starts, B, T)
                     x = self._pooled_by_gemm(l, relu, bn, nxt, planes, lens, gemm, True, dev, T,
                                              defer_to=steps[tail_at][1] if si + 2 == tail_at else None, row_starts=row_starts if flat else None)
                     lens, pooled, skip, planes = None, True, True, None
@@ -541,8 +551,8 @@ class Sequential:
                 # utterances that fill their 256-row tiles badly (a 1.5 s window: 148 rows): M-tiles over the batch's valid rows laid
                 # end to end (ktf_tdnn_split_flat), same bits
                 flat = self._flat_tiles(l, B, T, planes.shape[3])
-                if flat and row_starts is None:
-                    row_starts = ops.flat_rows(lens, B, T, lambda role, shape, dt: self._ws.get(role, shape, dt, dev, padded=False))
+                if flat:
+                    row_starts = flat_rows_for(row_starts, B, T)
                 split = (lambda d_, y_, ylo_: ops.tdnn_split_flat(planes, row_starts, d_, w, w_lo, bias, scale, shift, y_, ylo_)) if flat else \
                         (lambda d_, y_, ylo_: ops.tdnn_split(planes, lens, d_, w, w_lo, bias, scale, shift, y_, ylo_, out_lens))
                 if keep:

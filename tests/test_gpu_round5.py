@@ -197,3 +197,38 @@ def test_dense_call_through_a_valid_padded_layer_that_keeps_no_row(gemm):
         y = mdl(x)
         z = mdl.run_ragged(x, torch.full((7,), 12, dtype=torch.int32, device="cuda"))
     assert tuple(y.shape) == (7, 0, 96) and tuple(z.shape) == (7, 0, 96)
+
+
+@pytest.mark.parametrize("gemm,B,T,spec,pooled", [
+    ("bf16x3", 40, 150, [(300, [-3, 2], "SAME", 1, ["affine", "relu", "batchnorm"], None), (512, [3], "VALID", 1, ["affine", "relu"], None),
+                         (130, [-2, 1], "SAME", 1, "affine", "relu"), (300, [2, 4], "SAME", 3, "affine", "tanh")], False),
+    ("f16mx", 40, 700, [(16, [0, 4], "VALID", 1, "affine", "relu"), (512, [4], "SAME", 1, ["affine", "relu"], None), (300, [-2], "VALID", 1, "affine", None),
+                        (256, [1], "SAME", 1, ["affine", "relu"], None)], True)])
+def test_flat_row_tiles_behind_a_valid_padded_layer_of_a_dense_batch(gemm, B, T, spec, pooled):
+    """Found by tools/fuzz_models.py (round 5, seeds 202 / 203): a DENSE batch (no lengths) whose frame count a VALID-padded layer changed kept
+    the flat-row bookkeeping of the old frame count: the flat layers behind it read and wrote the wrong rows (deviation 2e-2 ... 2). The
+    bookkeeping is remade when the frame count changes; flat tiles on and off agree bit for bit on frame-level outputs."""
+    D = 40
+    lcfg = [{"name": "input", "type": "input", "shape": [None, None, D]}]
+    for i, (U, ctx, pad, sub, kinds, act) in enumerate(spec):
+        c = {"units": U, "context": ctx, "padding": pad, "subsampling_factor": sub}
+        if act:
+            c["activation"] = act
+        lcfg.append({"name": f"t{i}", "type": kinds, "cfg": c})
+    if pooled:
+        lcfg.append({"name": "stats", "type": "stats", "cfg": {"left_context": 0, "right_context": 10000, "reduce_time_axis": True, "include_std": True}})
+    x = torch.randn((B, T, D), generator=torch.Generator().manual_seed(3)).cuda()
+    out = {}
+    import warnings
+    for flat in (True, False):
+        mdl = ktf.models.SequentialFromConfig({"type": "sequential", "layers": lcfg}, None, "m", gemm=gemm)
+        mdl.min_tiles, mdl.min_frames = {}, {}
+        mdl.flat_rows = mdl.flat_rows_long = mdl.mx_flat_rows = flat
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out[flat] = mdl.run_ragged(x, None).float().cpu().numpy()
+    assert out[True].shape == out[False].shape and np.isfinite(out[False]).all()
+    if pooled:
+        assert np.abs(out[True] - out[False]).max() <= 1e-5 * max(1.0, np.abs(out[False]).max())
+    else:
+        assert np.array_equal(out[True], out[False])
