@@ -618,6 +618,11 @@ def test_differential_fuzzing_of_the_sequential_runner_finds_nothing():
     """tools/fuzz_models.py: random TDNN stacks on ragged batches in every arithmetic mode against the oracle; a fixed seed here."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "60", "21"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "60 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    # ... and with random settings of the runner's A/B knobs (kernel choices, flat row tiles, fused pooling): the seeds that found round 5's
+    # three discrepancies (empty planes / tensors behind a VALID-padded layer that keeps no row; stale flat rows of a dense batch)
+    for seed in ("606", "99", "202"):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "120", seed, "--knobs"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "120 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_differential_fuzzing_of_the_extractor_finds_nothing():
