@@ -599,3 +599,58 @@ def test_tdnn_mx_fused_pooling_on_flat_row_tiles(case, deterministic):
     sc = max(1.0, float(np.abs(out[False][ok]).max()))
     assert np.abs(out[True][ok] - out[False][ok]).max() <= 1e-5 * sc, np.abs(out[True][ok] - out[False][ok]).max()
     assert np.abs(out[True][ok][:, units + 5] - 1e-5).max() < 1e-7 and np.abs(out[True][ok][:, units + 6] - 1e-5).max() < 1e-7
+
+
+def test_tdnn_mx_flat_row_tiles_random_batches():
+    """Twenty random ragged batches (1 ... 300 utterances of up to 20 ... 400 frames, empty and one-frame ones among them, 1-5 context
+    offsets within +-9, input widths 40 ... 512, 129 ... 700 units; every fourth batch dense): flat row tiles == per-utterance tiles --
+    every byte of the four output planes -- and the pooled form agrees to the cut of the fp32 partial sums."""
+    rng = np.random.default_rng(2025)
+    for trial in range(20):
+        B = int(rng.integers(1, 301))
+        T = int(rng.integers(20, 401))
+        D = int(rng.choice([40, 64, 96, 200, 512]))
+        U = int(rng.integers(129, 701))
+        K = int(rng.integers(1, 6))
+        ctx = sorted(rng.choice(np.arange(-9, 10), size=K, replace=False).tolist())
+        relu = bool(rng.random() < 0.5)
+        lens = rng.integers(0, T + 1, size=B)
+        lens[rng.integers(0, B)] = T
+        lens[rng.integers(0, B)] = min(T, 1)
+        if trial % 4 == 3:
+            lens[:] = T
+        layer, W, bias, x, lens = _layer_case(rng, D, ctx, U, B, T, lens)
+        p = mx.Planes.empty(B, T, D, "cuda")
+        dl = dev(lens, torch.int32)
+        ops.mx_planes(dev(x), D, dl, p)
+        wh, wq, bd = layer.device_weights_mx(torch.device("cuda"), kernel="tile")
+        d = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu" if relu else None)
+        rows = ops.flat_rows(dl, B, T, lambda role, shape, dt: torch.zeros(shape, dtype=dt, device="cuda"))
+        outs = []
+        for flat in (False, True):
+            o = mx.Planes.empty(B, T, U, "cuda")
+            for t in (o.xh, o.xl4, o.x4, o.xs):
+                t.view(torch.uint8).fill_(0x5a)
+            if flat:
+                ops.tdnn_mx_flat(p, rows, d, wh, wq, bd, None, None, o)
+            else:
+                ops.tdnn_mx(p, dl, d, wh, wq, bd, None, None, o)
+            outs.append([t.view(torch.uint8) for t in (o.xh, o.xl4, o.x4, o.xs)])
+        for a, b_ in zip(*outs):
+            assert torch.equal(a, b_), (trial, B, T, D, U, ctx)
+        ds = layer.desc(L.GEMM_F16MX, torch.float32, torch.float32, act="relu", flags=L.TDNN_DET_STATS)
+        pooled = []
+        for flat in (False, True):
+            slots = ops.flat_stats_slots(T) if flat else ops.stats_slots(T)
+            sums = torch.full((B, slots, 2, U), 7.0, dtype=torch.float64, device="cuda")
+            out = torch.zeros((B, 2 * U), device="cuda")
+            if flat:
+                ops.tdnn_mx_flat_stats(p, rows, ds, wh, wq, bd, None, None, sums)
+                ops.stats_finalize_flat(sums, rows, T, U, True, 1e-10, out, slots)
+            else:
+                ops.tdnn_mx_stats(p, dl, ds, wh, wq, bd, None, None, sums, zero=False)
+                ops.stats_finalize(sums, dl, T, U, True, 1e-10, out, slots=slots)
+            pooled.append(out.cpu().numpy())
+        ok = lens > 0
+        sc = max(1.0, float(np.abs(pooled[0][ok]).max()))
+        assert np.abs(pooled[1][ok] - pooled[0][ok]).max() <= 1e-5 * sc, (trial, B, T, D, U, ctx)
