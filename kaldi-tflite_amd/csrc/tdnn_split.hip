@@ -169,7 +169,8 @@ __global__ __launch_bounds__(512) void tdnn_x3r_kernel(TdnnParams p, int mtiles,
 // SKIP: row groups (two 16-row blocks) of the wave's 128 rows that hold no valid output row issue no MFMAs -- for launches whose
 // tiles are mostly padding (1.5 s windows: 148 rows of a 256-row tile, -17 % per step; the launcher decides from T). On full tiles the
 // test costs 1.7 % (it splits the scheduler's K-step into regions), so the plain instantiation keeps them.
-// FLAT (with SKIP; SAME padding, no subsampling): the M-tiles cover the batch's VALID rows laid end
+// FLAT (without SKIP: flat tiles are full but for the batch's last one, whose rows beyond the end are computed and not stored; SAME padding,
+// no subsampling): the M-tiles cover the batch's VALID rows laid end
 // to end (p.row_starts: exclusive prefix sums of lens) instead of 256-row tiles per utterance -- a 1.5 s window is 148 rows, 0.58 of a
 // tile. A tile's rows belong to several utterances: each row's (utterance, frame, length) comes from an LDS table built at entry
 // (two 64-way steps over p.row_starts find the tile's first utterance, a search in the 258 staged prefix sums each row's own), the
@@ -208,7 +209,7 @@ __device__ __forceinline__ void flat_stats_epilogue(f32x4v (&acc)[8][4], const T
 template <int ACT, bool STATS, bool SKIP = false, bool FLAT = false>
 __global__ __launch_bounds__(512) void tdnn_x3s_kernel(TdnnParams p, int mtiles, int ntiles, int gtiles,
                                                        double* __restrict__ stats) {
-    static_assert(!FLAT || SKIP, "flat row tiling: with the row-group test");
+    static_assert(!FLAT || !SKIP, "flat row tiling: full tiles, no row-group test");
     // LDS ring: 64 KiB stages (A hi | A lo | W hi | W lo), double buffered
     constexpr int NST = 2;
     constexpr int STG = XS_STAGE_BYTES;
@@ -561,19 +562,19 @@ int tdnn_launch_split(const TdnnParams& p, const KtfTdnnDesc* d, int64_t B, int6
                 if (stats_sums) {
                     KTF_NOTE_KERNEL("tdnn_x3s_kernel<flat, pooled>");
                     if (d->act == KTF_ACT_RELU) {
-                        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, true, true, true>);
-                        hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, true, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, stats_sums);
+                        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, true, false, true>);
+                        hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, true, false, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, stats_sums);
                     } else {
-                        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, true, true, true>);
-                        hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, true, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, stats_sums);
+                        KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, true, false, true>);
+                        hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, true, false, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, stats_sums);
                     }
                 } else
                 if (d->act == KTF_ACT_RELU) {
-                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, false, true, true>);
-                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, false, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
+                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_RELU, false, false, true>);
+                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_RELU, false, false, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
                 } else {
-                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, false, true, true>);
-                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, false, true, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
+                    KTF_LDS_ONCE(lds_, tdnn_x3s_kernel<KTF_ACT_NONE, false, false, true>);
+                    hipLaunchKernelGGL((tdnn_x3s_kernel<KTF_ACT_NONE, false, false, true>), dim3((unsigned)fblocks), dim3(512), lds_, st, p, (int)B, ntiles_r, (int)ftiles, nullptr);
                 }
             } else
             if (split_in) {
