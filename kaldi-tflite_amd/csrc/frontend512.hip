@@ -21,7 +21,12 @@
 //   + twiddles in LDS, 4 waves per workgroup                        82 VGPR, 5 waves/SIMD   0.90  ms   (LDS-limited: 5 workgroups)
 //   + 8 waves per workgroup (tables shared by twice the waves)      80 VGPR, 6 waves/SIMD   0.854 ms   <- this build
 // 0.854 ms = 2040 cycles per frame and SIMD for ~490 vector instructions: 4.2 cycles per instruction, i.e. the VALU issue
-// rate of this DPP / permlane / transcendental mix; more resident waves no longer help.
+// rate of this DPP / permlane / transcendental mix; more resident waves no longer help. Every later step removed instructions:
+//   rounds 2-4 (register pairs, packed complex products, DPP sums and swaps, compile-time configuration)               0.659 ms
+//   round 5: one-instruction row-broadcast adds                                                                          0.597 ms
+//            DCT on two half-waves (16 + 2 instead of 32), mel segment sums as DPP multiply-adds (3 instead of 10),
+//            no arithmetic on the register past the frame's last sample (-7), logf without its denormal branch (-6),
+//            the spectrum's quarter in the mel weights (-4): ~330 issue slots per frame                                  0.549 ms
 #ifndef F5_WAVES
 #define F5_WAVES 8
 #endif
@@ -77,6 +82,20 @@ __device__ __forceinline__ float wave_sum_f(float v) {
         "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// logf for an argument that is a normal number or +inf (here: a non-negative sum + eps with eps >= FLT_MIN, which the kernel tests:
+// KtfFrontendCfg.eps is FLT_EPSILON in every shipped configuration; any other eps takes logf itself): the bits of libm's logf -- v_log_f32 (log2, 1 ulp) times
+// ln 2 as a compensated product -- without the rescaling of denormal arguments that logf carries (6 of its 18 instructions; a wave
+// spends them once per frame on the log-energy).
+__device__ __forceinline__ float log_normal(float x) {
+    const float l = __builtin_amdgcn_logf(x);
+    const float c = __uint_as_float(0x3f317217u), c_lo = __uint_as_float(0x3377d1cfu);
+    const float p = c * l;
+    float r = fmaf(l, c, -p);
+    r = fmaf(c_lo, l, r);
+    r = fmaf(c, l, r);
+    return (fabsf(l) < __builtin_inff()) ? r : l;
 }
 
 // Complex product on the packed fp32 pipe: two instructions, the operand swizzles and the sign in the op_sel / neg modifiers (from C
@@ -239,6 +258,10 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                                                                  int out_stage, float* __restrict__ out,
                                                                  uint64_t seed, int64_t T) {
     constexpr int NF = 512, N2 = 256, NV = 8;
+    // registers that hold samples of the frame: with the frame size known (400: v[7] = samples 448.. holds none) the last register is
+    // zero by construction and its share of the sums, the pre-emphasis and the window multiply is never issued (its pre-emphasis
+    // neighbour, lane 63 of v[6], is beyond the frame too: zero before and after)
+    constexpr int NVA = MFIX ? (MFIX + KTF_WAVE - 1) / KTF_WAVE : NV;
     constexpr bool PLAIN = KIND != 0;
     extern __shared__ __attribute__((aligned(16))) float lds5[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,9 +321,13 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     const int mel_start = tab.fast_mel_meta[lane * 4 + 0];
     const int mel_filter = tab.fast_mel_meta[lane * 4 + 2];
     const int mel_flags = tab.fast_mel_meta[lane * 4 + 3];      // bit0: lane+1 same filter, bit1: lane+2 same, bit2: first
+    const float mel_f1 = (mel_flags & 1) ? 1.0f : 0.0f, mel_f2 = (mel_flags & 2) ? 1.0f : 0.0f;
+    // |X|^2 = |2 E + rw 2 O|^2 / 4 (below): the quarter lives in the LDS copy of the mel weights, not in a multiply per bin (a power of
+    // two: every product and every partial sum is the same number either way; the magnitude spectrum carries the half of it)
+    const float mel_scale = c_pow ? 0.25f : 0.5f;
     for (int i = tid; i < F5_MAXW * KTF_WAVE; i += F5_THREADS) {          // weights are zero beyond an item's length
         const int e = i & 3, l = (i >> 2) & 63, j4 = i >> 8;
-        melw4[i] = tab.fast_mel_w[l * F5_MAXW + 4 * j4 + e];
+        melw4[i] = mel_scale * tab.fast_mel_w[l * F5_MAXW + 4 * j4 + e];
     }
     float lift = 1.0f;
     if (out_stage == KTF_OUT_MFCC) {
@@ -310,6 +337,10 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         }
         if (cfg.use_lifter && tab.lifter && lane < nc) lift = tab.lifter[lane];
     }
+    const bool eps_normal = cfg.eps >= 1.17549435e-38f;        // wave-uniform: the log-energy's argument is then a normal number
+    const bool dct_halves = nc <= 32;                           // wave-uniform
+    const int dct_row0 = 16 * (lane >> 5);
+    const float* dct_col = dct4 + ((4 * (lane >> 5)) * KTF_WAVE + (lane & 31)) * 4;
     // output index of this lane's FFT results: X[mo + 64*r4]
     const int mo = (2 * (lane & 1) + ((lane >> 5) & 1)) + 4 * ((lane >> 3) & 3) + 16 * ((lane >> 1) & 3);
     const float invM = 1.0f / (float)M;
@@ -402,22 +433,24 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                     if (lane + KTF_WAVE * j < M) v[j] += g[j] * cfg.dither;
             }
             if (c_dc) {
-                float s = 0.0f;
+                float s = v[0];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) s += v[j];
+                for (int j = 1; j < NVA; ++j) s += v[j];
                 const float mean = wave_sum_f(s) * invM;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) {
+                for (int j = 0; j < NVA; ++j) {
                     const int i = lane + KTF_WAVE * j;
                     if (i < M) v[j] -= mean;
                 }
             }
             if (c_raw_e) {
-                float s = 0.0f;
+                float s = v[0] * v[0];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) s = fmaf(v[j], v[j], s);
-                const float e = logf(fmaxf(wave_sum_f(s), 0.0f) + cfg.eps);
-                logE = fmaxf(e, cfg.energy_floor);
+                for (int j = 1; j < NVA; ++j) s = fmaf(v[j], v[j], s);
+                {
+                    const float en = fmaxf(wave_sum_f(s), 0.0f) + cfg.eps;
+                    logE = fmaxf(eps_normal ? log_normal(en) : logf(en), cfg.energy_floor);
+                }
             }
             if (c_pre) {
                 // y[i] = x[i] - c x[i-1] (x[-1] := x[0]). Sample i - 1 lives in lane l - 1 of the same register, for lane 0 in lane 63
@@ -425,7 +458,9 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                 // (which has no source for lane 0) leaves it -- two DPP moves per register, no readlane / select
                 float y[NV];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) {
+                for (int j = NVA; j < NV; ++j) y[j] = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NVA; ++j) {
                     const int wrap = (j > 0) ? __builtin_amdgcn_update_dpp(0, __float_as_int(v[j > 0 ? j - 1 : 0]), DPP_WAVE_ROR1, 0xF, 0xF, true)
                                              : __float_as_int(v[0]);
                     const float prev = __int_as_float(__builtin_amdgcn_update_dpp(wrap, __float_as_int(v[j]), DPP_WAVE_SHR1, 0xF, 0xF, false));
@@ -435,13 +470,15 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
                 for (int j = 0; j < NV; ++j) v[j] = y[j];
             }
 #pragma unroll
-            for (int j = 0; j < NV; ++j) v[j] *= win[lane + KTF_WAVE * j];       // window is zero beyond M
+            for (int j = 0; j < NVA; ++j) v[j] *= win[lane + KTF_WAVE * j];       // window is zero beyond M
             if (c_post_e) {
-                float s = 0.0f;
+                float s = v[0] * v[0];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) s = fmaf(v[j], v[j], s);
-                const float e = logf(fmaxf(wave_sum_f(s), 0.0f) + cfg.eps);
-                logE = fmaxf(e, cfg.energy_floor);
+                for (int j = 1; j < NVA; ++j) s = fmaf(v[j], v[j], s);
+                {
+                    const float en = fmaxf(wave_sum_f(s), 0.0f) + cfg.eps;
+                    logE = fmaxf(eps_normal ? log_normal(en) : logf(en), cfg.energy_floor);
+                }
             }
         }
 
@@ -495,7 +532,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(u) : "v"(o2), "v"(rv), "v"(e2));               // e2 + o2 * rw.x
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[0,0,0]" : "=v"(x2) : "v"(o2), "v"(rv), "v"(u));   // (-o2.y rw.y, o2.x rw.y) + u
             // |X|^2 directly (what Kaldi's ComputePowerSpectrum does; the reference's abs-then-square differs by an ulp)
-            pw[j] = 0.25f * fmaf(x2.x, x2.x, x2.y * x2.y);
+            pw[j] = fmaf(x2.x, x2.x, x2.y * x2.y);           // 4 |X|^2: the mel weights carry the quarter
         }
         if (!c_pow) {                        // wave-uniform branch: the magnitude spectrum pays for its sqrt only when asked
 #pragma unroll
@@ -519,12 +556,15 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
             }
         }
         {   // segmented reduction over <= 4 adjacent lanes: lane i takes lane i + 1, then lane i + 2, by whole-wave DPP shifts (no
-            // ds_bpermute and none of its address arithmetic)
-            const float t1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), DPP_WAVE_SHL1, 0xF, 0xF, false));
-            acc += (mel_flags & 1) ? t1 : 0.0f;
-            float t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), DPP_WAVE_SHL1, 0xF, 0xF, false));
-            t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t2), DPP_WAVE_SHL1, 0xF, 0xF, false));
-            acc += (mel_flags & 2) ? t2 : 0.0f;
+            // ds_bpermute and none of its address arithmetic). The per-lane "same filter" flags are 0.0 / 1.0 factors of a v_fmac_f32
+            // whose first operand comes through the DPP crossbar: acc += flag * acc[lane + 1] is ONE instruction (select forms: zero,
+            // move, select, add), the same bits for finite sums (x * 1 + acc rounds once, x * 0 + acc = acc). Lane 63 has no source
+            // lane: its write is dropped, and the shifted copy gets a zero there (bound_ctrl) so that lane 62 multiplies a number.
+            asm("s_nop 1\n\t"
+                "v_fmac_f32_dpp %0, %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(mel_f1));
+            const float t2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(acc), DPP_WAVE_SHL1, 0xF, 0xF, true));
+            asm("s_nop 1\n\t"
+                "v_fmac_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(t2), "v"(mel_f2));
         }
         // (v_log_f32 is log2 to 1 ulp; its argument here is >= eps, a normal number: none of logf's denormal handling is needed)
         if (c_log) acc = 0.6931471805599453f * __builtin_amdgcn_logf(fmaxf(acc, 0.0f) + cfg.eps);
@@ -539,14 +579,31 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         F5_WAVE_SYNC();
         // ---- DCT (this lane's column, coefficients in registers; log-mel vector broadcast from LDS) + lifter + C0
         float c = 0.0f;
+        if (dct_halves) {
+            // <= 32 coefficients: lanes 0-31 sum mel rows 0-15 of their column, lanes 32-63 rows 16-31 of the same columns, one
+            // v_permlane32_swap brings the upper half's sums down: 16 + 2 vector instructions and 8 LDS reads instead of 32 and 16
+            // (fp32 sum order: rows 0-15 and 16-31 separately, then added)
 #pragma unroll
-        for (int m4 = 0; m4 < F5_MAXMEL / 4; ++m4) {
-            const f32x4 f = *reinterpret_cast<const f32x4*>(feat + 4 * m4);   // rows >= num_mels are zero
-            const f32x4 d = *reinterpret_cast<const f32x4*>(dct4 + (m4 * KTF_WAVE + lane) * 4);
-            c = fmaf(f.x, d.x, c);
-            c = fmaf(f.y, d.y, c);
-            c = fmaf(f.z, d.z, c);
-            c = fmaf(f.w, d.w, c);
+            for (int m4 = 0; m4 < F5_MAXMEL / 8; ++m4) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(feat + dct_row0 + 4 * m4);   // rows >= num_mels are zero
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dct_col + m4 * KTF_WAVE * 4);
+                c = fmaf(f.x, d.x, c);
+                c = fmaf(f.y, d.y, c);
+                c = fmaf(f.z, d.z, c);
+                c = fmaf(f.w, d.w, c);
+            }
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+            c += __uint_as_float(sw[1]);         // lanes 0-31: + lanes 32-63's sum (the upper lanes double theirs: never stored)
+        } else {
+#pragma unroll
+            for (int m4 = 0; m4 < F5_MAXMEL / 4; ++m4) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(feat + 4 * m4);   // rows >= num_mels are zero
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dct4 + (m4 * KTF_WAVE + lane) * 4);
+                c = fmaf(f.x, d.x, c);
+                c = fmaf(f.y, d.y, c);
+                c = fmaf(f.z, d.z, c);
+                c = fmaf(f.w, d.w, c);
+            }
         }
         c *= lift;
         if (lane == 0 && c_energy) c = logE;

@@ -207,7 +207,7 @@ def test_dct_layer_and_unfused_chain_equal_fused():
                        low_freq_cutoff=m["low_freq_cutoff"], epsilon=m["epsilon"])(w)
     c = host(Ls.DCT(m["num_mfccs"])(fb)) * O.lifter_coeffs(m["num_mfccs"], m["cepstral_lifter"]).astype(np.float32)
     c[..., 0] = host(e)[..., 0]
-    assert np.abs(c - fused).max() < 2e-5
+    assert np.abs(c - fused).max() < 5e-5       # |x| up to 1e2: a few ulp (the fused kernel sums mel rows 0-15 and 16-31 separately, the layer in one chain)
     ref = O.dct(host(fb), m["num_mfccs"], dtype=np.float64)
     assert np.abs(host(Ls.DCT(m["num_mfccs"])(fb)) - ref).max() < 5e-5     # 30-term fp32 dot products of |x| ~ 20
 
