@@ -134,20 +134,29 @@ __global__ void stats_pool_windowed_kernel(const float* __restrict__ x, int64_t 
 }
 
 // ------------------------------------------------------------------------------------ x-vector post-processing
-// one workgroup per embedding: LDS holds (x - mean); thread j owns output column j.
+// EB embeddings per workgroup: LDS holds their (x - mean); thread = (output column j, slice `part` of the input dimension): the 512-long
+// dot products are split into P partial sums (fixed order -> deterministic) so a single embedding is not a serial chain. A workgroup
+// streams the whole LDA matrix through its threads (512 x 150 floats = 300 KiB from L2): with one embedding per workgroup a batch of
+// 1024 read it 1024 times -- 0.31 GB of L2 reads, the 29 us the launch took -- so batches beyond one round of workgroups put FOUR
+// embeddings behind every A element (one 16-byte LDS read of the four inputs, four multiply-adds). The chains, their split and the
+// order of every sum are the same for any EB: the same bits.
 #define XP_THREADS 1024
-__global__ __launch_bounds__(XP_THREADS) void xvec_post_kernel(const float* __restrict__ x, int in_dim, int out_dim,
+template <int EB>
+__global__ __launch_bounds__(XP_THREADS) void xvec_post_kernel(const float* __restrict__ x, int64_t B, int in_dim, int out_dim,
                                                                const float* __restrict__ mean, const float* __restrict__ A,
                                                                const float* __restrict__ off, float* __restrict__ y) {
-    // one workgroup per embedding; thread = (output column j, slice `part` of the input dimension): the 512-long dot
-    // products are split into P partial sums (fixed order -> deterministic) so a single embedding is not a serial chain
-    extern __shared__ float sm[];  // in_dim | out_dim | XP_THREADS partials | 16
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // EB x in_dim (input-major: [i][EB]) | EB x out_dim | EB x XP_THREADS partials | EB x 16
     float* xc = sm;
-    float* yo = sm + in_dim;
-    float* part_s = yo + out_dim;
-    float* red = part_s + XP_THREADS;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < in_dim; i += XP_THREADS) xc[i] = x[(int64_t)b * in_dim + i] - (mean ? mean[i] : 0.f);
+    float* yo = sm + EB * in_dim;
+    float* part_s = yo + EB * out_dim;
+    float* red = part_s + EB * XP_THREADS;
+    const int64_t b0 = (int64_t)blockIdx.x * EB;
+    const int nb = (int)(B - b0 < EB ? B - b0 : EB);
+    const int tid = threadIdx.x;
+    for (int q = tid; q < EB * in_dim; q += XP_THREADS) {
+        const int e = q / in_dim, i = q - e * in_dim;        // (consecutive threads read consecutive inputs of one embedding)
+        xc[i * EB + e] = e < nb ? x[(b0 + e) * in_dim + i] - (mean ? mean[i] : 0.f) : 0.f;
+    }
     __syncthreads();
     int J = (out_dim + 63) & ~63;
     if (J > XP_THREADS) J = XP_THREADS;
@@ -155,33 +164,50 @@ __global__ __launch_bounds__(XP_THREADS) void xvec_post_kernel(const float* __re
     const int jl = tid % J, part = tid / J;
     const int chunk = (in_dim + P - 1) / P;
     const int i_lo = part * chunk, i_hi = (i_lo + chunk < in_dim) ? i_lo + chunk : in_dim;
-    float ss = 0.f;
+    float ss[EB];
+#pragma unroll
+    for (int e = 0; e < EB; ++e) ss[e] = 0.f;
     for (int j0 = 0; j0 < out_dim; j0 += J) {
         const int j = j0 + jl;
-        float acc = 0.f;
+        float acc[EB];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) acc[e] = 0.f;
         if (part < P && j < out_dim) {
             const float* ap = A + (int64_t)i_lo * out_dim + j;
-#pragma unroll 16                                           // loads of 16 rows in flight; the sum stays one ordered chain
-            for (int i = i_lo; i < i_hi; ++i, ap += out_dim) acc += xc[i] * *ap;
+#pragma unroll 16                                           // loads of 16 rows in flight; every sum stays one ordered chain
+            for (int i = i_lo; i < i_hi; ++i, ap += out_dim) {
+                const float a = *ap;
+#pragma unroll
+                for (int e = 0; e < EB; ++e) acc[e] = fmaf(xc[i * EB + e], a, acc[e]);       // (explicit: as `+= x * a` the vectoriser splits one pair into v_pk_mul / v_pk_add)
+            }
         }
-        part_s[tid] = acc;
+#pragma unroll
+        for (int e = 0; e < EB; ++e) part_s[e * XP_THREADS + tid] = acc[e];
         __syncthreads();
         if (part == 0 && j < out_dim) {
-            float t = 0.f;
-            for (int q = 0; q < P; ++q) t += part_s[q * J + jl];
-            t += off ? off[j] : 0.f;
-            yo[j] = t;
-            ss += t * t;
+#pragma unroll
+            for (int e = 0; e < EB; ++e) {
+                float t = 0.f;
+                for (int q = 0; q < P; ++q) t += part_s[e * XP_THREADS + q * J + jl];
+                t += off ? off[j] : 0.f;
+                yo[e * out_dim + j] = t;
+                ss[e] = fmaf(t, t, ss[e]);
+            }
         }
         __syncthreads();
     }
-    ss = wave_sum(ss);
-    if ((tid & 63) == 0) red[tid >> 6] = ss;
+#pragma unroll
+    for (int e = 0; e < EB; ++e) {
+        const float w = wave_sum(ss[e]);
+        if ((tid & 63) == 0) red[e * 16 + (tid >> 6)] = w;
+    }
     __syncthreads();
-    float tot = 0.f;
-    for (int w = 0; w < XP_THREADS / 64; ++w) tot += red[w];
-    const float ratio = sqrtf(tot) / sqrtf((float)out_dim);   // xvector_extractor.py:178-181
-    for (int j = tid; j < out_dim; j += XP_THREADS) y[(int64_t)b * out_dim + j] = yo[j] / ratio;
+    for (int e = 0; e < nb; ++e) {
+        float tot = 0.f;
+        for (int w = 0; w < XP_THREADS / 64; ++w) tot += red[e * 16 + w];
+        const float ratio = sqrtf(tot) / sqrtf((float)out_dim);   // xvector_extractor.py:178-181
+        for (int jj = tid; jj < out_dim; jj += XP_THREADS) y[(b0 + e) * out_dim + jj] = yo[e * out_dim + jj] / ratio;
+    }
 }
 
 // ------------------------------------------------------------------------------------ fused tail (a11 finalize + tdnn6 + a12)
@@ -673,9 +699,14 @@ extern "C" int ktf_xvec_post_f32(const float* x, int64_t B, int32_t in_dim, int3
     KTF_REQUIRE(x && A && y, "ktf_xvec_post_f32: null argument");
     KTF_REQUIRE(B >= 0 && in_dim > 0 && out_dim > 0, "ktf_xvec_post_f32: bad sizes");
     if (B == 0) return KTF_OK;
-    const size_t lds = sizeof(float) * ((size_t)in_dim + out_dim + XP_THREADS + 16);
-    KTF_REQUIRE(lds <= 64 * 1024, "ktf_xvec_post_f32: dims too large");
-    hipLaunchKernelGGL(xvec_post_kernel, dim3((unsigned)B), dim3(XP_THREADS), lds, (hipStream_t)stream, x, in_dim, out_dim, mean, A, off, y);
+    KTF_REQUIRE(sizeof(float) * ((size_t)in_dim + out_dim + XP_THREADS + 16) <= 64 * 1024, "ktf_xvec_post_f32: dims too large");
+    // one embedding per workgroup while the batch fits one round of the chip; four from there on, if their rows fit the LDS
+    const int eb = (B > 256 && sizeof(float) * 4 * ((size_t)in_dim + out_dim + XP_THREADS + 16) <= 64 * 1024) ? 4 : 1;
+    const size_t lds = sizeof(float) * eb * ((size_t)in_dim + out_dim + XP_THREADS + 16);
+    if (eb == 4)
+        hipLaunchKernelGGL(xvec_post_kernel<4>, dim3((unsigned)((B + 3) / 4)), dim3(XP_THREADS), lds, (hipStream_t)stream, x, B, in_dim, out_dim, mean, A, off, y);
+    else
+        hipLaunchKernelGGL(xvec_post_kernel<1>, dim3((unsigned)B), dim3(XP_THREADS), lds, (hipStream_t)stream, x, B, in_dim, out_dim, mean, A, off, y);
     KTF_CHECK_LAUNCH("ktf_xvec_post_f32");
     return KTF_OK;
 }

@@ -232,3 +232,25 @@ def test_flat_row_tiles_behind_a_valid_padded_layer_of_a_dense_batch(gemm, B, T,
         assert np.abs(out[True] - out[False]).max() <= 1e-5 * max(1.0, np.abs(out[False]).max())
     else:
         assert np.array_equal(out[True], out[False])
+
+
+# ----------------------------------------------------------------------------- ktf_xvec_post_f32: four embeddings per workgroup beyond 256
+def test_xvec_post_same_bits_for_any_batch_split_and_close_to_fp64():
+    """Batches beyond one round of workgroups put four embeddings behind every element of the LDA matrix; an embedding's x-vector has the
+    same bits whatever batch it arrives in (1, 256 and 1027 at a time), and sits at fp32 rounding distance from an fp64 restatement of
+    xvector_extractor.py:174-184 (mean subtraction, LDA + offset, length normalisation)."""
+    g = torch.Generator(device="cuda").manual_seed(21)
+    for B, din, dout in ((1027, 512, 150), (700, 200, 200), (515, 512, 300)):
+        x = torch.randn((B, din), generator=g, device="cuda")
+        mean = torch.randn((din,), generator=g, device="cuda") * 0.1
+        A = torch.randn((din, dout), generator=g, device="cuda") / din ** 0.5
+        off = torch.randn((dout,), generator=g, device="cuda") * 0.01
+        whole = ops.xvec_post(x, mean, A, off)
+        parts = torch.cat([ops.xvec_post(x[i:i + 256].contiguous(), mean, A, off) for i in range(0, B, 256)])
+        assert torch.equal(whole, parts), (B, din, dout)
+        ones = torch.cat([ops.xvec_post(x[i:i + 1].contiguous(), mean, A, off) for i in (0, 1, 2, 3, 4, 5, B - 1)])
+        assert torch.equal(whole[[0, 1, 2, 3, 4, 5, B - 1]], ones), (B, din, dout)
+        x64, A64 = x.double().cpu().numpy(), A.double().cpu().numpy()
+        y = (x64 - mean.double().cpu().numpy()) @ A64 + off.double().cpu().numpy()
+        y = y / (np.sqrt((y * y).sum(1, keepdims=True)) / np.sqrt(dout))
+        assert np.abs(whole.cpu().numpy() - y).max() <= 5e-6, (B, din, dout)
