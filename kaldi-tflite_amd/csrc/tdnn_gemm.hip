@@ -367,7 +367,7 @@ extern "C" int64_t ktf_tdnn_stats_slots(int64_t T, int32_t gemm) {
     return T <= 0 ? 1 : (T + 63) / 64;
 }
 
-// mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(max(E[x^2]-mean^2,0)+eps)
+// mean / std from the fp64 column sums of ktf_tdnn_stats: out[b, c] = mean, out[b, D + c] = sqrt(relu(E[x^2]-mean^2)+eps), NaN kept
 __global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t slots, int slot_rows, const int32_t* __restrict__ lens, int64_t T,
                                       int64_t B, int D, int include_std, float eps, float* __restrict__ out, int64_t ldo,
                                       const int32_t* __restrict__ row_starts = nullptr) {
@@ -393,8 +393,10 @@ __global__ void stats_finalize_kernel(const double* __restrict__ sums, int64_t s
         const double mean = s / n;
         out[b * ldo + c] = (float)mean;
         if (include_std) {
+            // relu as tf.nn.relu (stats_pooling.py:238): a NaN variance -- an utterance without a frame (0 / 0), NaN activations -- stays NaN;
+            // fmax(NaN, 0) = 0 made sqrt(eps) of it (tools/fuzz_models.py seed 9102: an utterance a VALID-padded layer leaves no frame of)
             const double var = q / n - mean * mean;
-            out[b * ldo + D + c] = (float)sqrt(fmax(var, 0.0) + (double)eps);
+            out[b * ldo + D + c] = (float)sqrt((var < 0.0 ? 0.0 : var) + (double)eps);
         }
     }
 }

@@ -623,6 +623,9 @@ def test_differential_fuzzing_of_the_sequential_runner_finds_nothing():
     for seed in ("606", "99", "202"):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "120", seed, "--knobs"], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "120 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    # ... and the seed that found the finalize of the fused pooling turning the NaN deviation of an utterance without a frame into sqrt(eps)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_models.py"), "150", "9102"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "150 rounds, 0 mismatches" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_differential_fuzzing_of_the_extractor_finds_nothing():

@@ -254,3 +254,30 @@ def test_xvec_post_same_bits_for_any_batch_split_and_close_to_fp64():
         y = (x64 - mean.double().cpu().numpy()) @ A64 + off.double().cpu().numpy()
         y = y / (np.sqrt((y * y).sum(1, keepdims=True)) / np.sqrt(dout))
         assert np.abs(whole.cpu().numpy() - y).max() <= 5e-6, (B, din, dout)
+
+
+def test_fused_pooling_finalize_keeps_nan_deviation():
+    """ktf_stats_finalize / _slots / _flat: mean AND standard deviation of an utterance without a frame are NaN (0 / 0 through tf.nn.relu,
+    stats_pooling.py:231-240), and a NaN sum of squares stays NaN; a negative variance from rounding is clamped to zero."""
+    D, eps = 8, 1e-5
+    sums = torch.zeros((4, 2, D), dtype=torch.float64, device="cuda")
+    sums[0, 0], sums[0, 1] = 6.0, 12.5             # three rows: mean 2, E[x^2] - mean^2 = 1/6
+    sums[2, 0], sums[2, 1] = 4.0, float("nan")    # NaN activations
+    sums[3, 0], sums[3, 1] = 4.0, 7.999999        # two rows of 2.0, variance slightly negative
+    lens = torch.tensor([3, 0, 2, 2], dtype=torch.int32, device="cuda")
+    out = torch.full((4, 2 * D), 7.0, dtype=torch.float32, device="cuda")
+    ops.stats_finalize(sums, lens, 5, D, True, eps, out)
+    o = out.cpu().numpy()
+    assert np.allclose(o[0, :D], 2.0) and np.allclose(o[0, D:], np.sqrt(12.5 / 3 - 4.0 + eps), rtol=1e-6)
+    assert np.isnan(o[1]).all()
+    assert np.allclose(o[2, :D], 2.0) and np.isnan(o[2, D:]).all()
+    assert np.allclose(o[3, :D], 2.0) and np.allclose(o[3, D:], np.sqrt(eps), rtol=1e-6)
+    # the flat form: utterance 1 owns no row of the flat row space
+    starts = torch.tensor([0, 3, 3, 5, 7], dtype=torch.int32, device="cuda")
+    slots = ops.flat_stats_slots(5)
+    fs = torch.zeros((4, slots, 2, D), dtype=torch.float64, device="cuda")
+    fs[:, 0] = sums
+    out2 = torch.full((4, 2 * D), 7.0, dtype=torch.float32, device="cuda")
+    ops.stats_finalize_flat(fs, starts, 5, D, True, eps, out2, slots)
+    o2 = out2.cpu().numpy()
+    assert np.array_equal(np.isnan(o2), np.isnan(o)) and np.allclose(o2[~np.isnan(o2)], o[~np.isnan(o)])

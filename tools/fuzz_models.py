@@ -149,7 +149,8 @@ for case in range(n_cases):
         okw = np.isfinite(want)
         if not np.array_equal(okw, np.isfinite(g)):
             bad += 1
-            print(f"MISMATCH {desc} utterance {b}: non-finite pattern differs", flush=True)
+            print(f"MISMATCH {desc} utterance {b}: non-finite pattern differs (oracle finite {int(okw.sum())} of {okw.size}, runner finite {int(np.isfinite(g).sum())}; "
+                  f"runner values {g.ravel()[:4]}, oracle {want.ravel()[:4]})", flush=True)
             break
         err = np.abs(g[okw] - want[okw]).max() / max(1e-6, np.abs(want[okw]).max()) if okw.any() else 0.0
         if not err <= TOL[gemm]:
