@@ -201,7 +201,10 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     unsigned s_base = 0;
     unsigned sa_base[4];
     int sa_off[4];
-    const int sa_row0 = p.start + (t0 + lane) * p.sub, sa_rg = 64 * p.sub;      // side A: input row of the lane's row in row group 0; per group
+    const bool wave_hi = wave >= 4;                                              // side A: the wave's K blocks are (0, 2) or (1, 3)
+    [[maybe_unused]] const int sa_row_w = p.start + (t0 + lane + 64 * (wave & 3)) * p.sub;       // ... input row of the lane's row in the wave's row group
+    unsigned char* const sa_dst = rsm + MX_SA_OFF + (wave & 3) * 1024;           // ... its pieces of the e2m1 images (+ plane, K block)
+    unsigned char* const sa_dst_s = rsm + MX_SA_OFF + 32768 + (wave & 3) * 256;  // ... and of the scale words
     // position of K-step ks_ (the next stage to issue) from the position of ks_ - 1; padded K-steps re-read step 0 (zero weights)
 #define MX_F_ADV(ks_)                                                                                                  \
     {                                                                                                                  \
@@ -242,27 +245,28 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
             }                                                                                                          \
         }                                                                                                              \
     }
-    // side A of super-step ss_: n_ = 0..3 the e2m1 pieces (32 KiB: plane, K block, 64-row group by wave), 4, 5 the scale words
-#define MX_DMA_SA(ss_, n_)                                                                                             \
+    // side A of super-step ss_: n_ = 0..3 the e2m1 pieces (32 KiB: plane, K block, 64-row group by wave), 4, 5 the scale words. Piece
+    // n_ * 8 + wave is (plane n_ >> 1, K block 2 (n_ & 1) + (wave >> 2), row group wave & 3): a wave fetches two of the four K blocks, the
+    // same two for every piece. WH_ = wave >> 2 as a compile-time constant (the call site branches on it once per DMA slot): with the K
+    // block a run-time value every DMA chose its chunk base and context offset by three scalar selects each, and the ~100 scalar
+    // instructions of a super-step's six side-A DMAs sat between two MFMA groups of BOTH waves of a SIMD at the same time.
+#define MX_DMA_SA(ss_, n_, WH_)                                                                                        \
     {                                                                                                                  \
-        const int idx_ = ((n_) < 4 ? (n_) : (n_) - 4) * 8 + wave;                                                      \
-        const int plane_ = idx_ >> 4, kb_ = (n_) < 4 ? (idx_ >> 2) & 3 : idx_ >> 2, rg_ = idx_ & 3;                    \
-        const unsigned base_ = kb_ == 0 ? sa_base[0] : kb_ == 1 ? sa_base[1] : kb_ == 2 ? sa_base[2] : sa_base[3];     \
-        const int off__ = kb_ == 0 ? sa_off[0] : kb_ == 1 ? sa_off[1] : kb_ == 2 ? sa_off[2] : sa_off[3];              \
-        int r_ = (FLAT ? s_row : sa_row0 + rg_ * sa_rg) + off__;                                                       \
+        constexpr int plane_ = ((n_) < 4 ? (n_) : 0) >> 1, kb_ = (n_) < 4 ? 2 * ((n_) & 1) + (WH_) : 2 * ((n_) - 4) + (WH_);                    \
+        int r_ = (FLAT ? s_row : sa_row_w) + sa_off[kb_];                                                              \
         const int hi_ = FLAT ? s_lm1 : lenm1;                                                                          \
         r_ = r_ < 0 ? 0 : (r_ > hi_ ? hi_ : r_);                                                                       \
-        const unsigned rec_ = (FLAT ? s_ub : 0u) + base_ + (unsigned)r_;                                               \
+        const unsigned rec_ = (FLAT ? s_ub : 0u) + sa_base[kb_] + (unsigned)r_;                                        \
         if ((n_) < 4) {                                                                                                \
             const unsigned vo_ = rec_ * 16u;                                                                           \
             __builtin_amdgcn_global_load_lds((glb_ptr_t*)((plane_ ? x4 : xl4) + vo_),                                  \
-                                             (lds_ptr_t*)(rsm + MX_SA_OFF + plane_ * 16384 + (kb_ * 256 + rg_ * 64) * 16), 16, 0, 0); \
+                                             (lds_ptr_t*)(sa_dst + plane_ * 16384 + kb_ * 4096), 16, 0, 0);            \
         } else {                                                                                                       \
             const unsigned vo_ = rec_ * 4u;                                                                            \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xs + vo_),                                                   \
-                                             (lds_ptr_t*)(rsm + MX_SA_OFF + 32768 + (kb_ * 256 + rg_ * 64) * 4), 4, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xs + vo_), (lds_ptr_t*)(sa_dst_s + kb_ * 1024), 4, 0, 0);    \
         }                                                                                                              \
     }
+#define MX_DMA_SA_W(ss_, n_) { if (wave_hi) MX_DMA_SA(ss_, n_, 1) else MX_DMA_SA(ss_, n_, 0) }
     // side W of super-step ss_: piece n_ = 0..5 of one contiguous 48 KiB block
 #define MX_DMA_SW(ss_, n_)                                                                                             \
     {                                                                                                                  \
@@ -324,10 +328,15 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (live) {
+                    // the next row block's fragment is read BEHIND this group's first MFMA: the compiler waits for a_cur with lgkmcnt(0) right
+                    // in front of the group, and with the read of a_nxt issued before that wait (as it was in every other group) the wave sat
+                    // out the whole LDS latency of a fragment it needs 64 matrix cycles later -- both waves of a SIMD at the same place
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[0], acc[i][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                     hfrag8 a_nxt = a_cur;
                     if (i < 7) a_nxt = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 1) * 1024);
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
+                    for (int jj = 1; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
                     a_cur = a_nxt;
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -339,10 +348,10 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
                 }
                 if (j == 0) {
                     if (i == 3) MX_SA_SETUP(ss)
-                    if (i == 4) { MX_DMA_SA(ss, 0) MX_DMA_SA(ss, 1) }
-                    if (i == 5) { MX_DMA_SA(ss, 2) MX_DMA_SA(ss, 3) }
-                    if (i == 6) MX_DMA_SA(ss, 4)
-                    if (i == 7) MX_DMA_SA(ss, 5)
+                    if (i == 4) { MX_DMA_SA_W(ss, 0) MX_DMA_SA_W(ss, 1) }
+                    if (i == 5) { MX_DMA_SA_W(ss, 2) MX_DMA_SA_W(ss, 3) }
+                    if (i == 6) MX_DMA_SA_W(ss, 4)
+                    if (i == 7) MX_DMA_SA_W(ss, 5)
                 }
                 if (j == 1) {
                     if (i == 4) { MX_DMA_SW(ss, 0) MX_DMA_SW(ss, 1) }
@@ -407,6 +416,7 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     }
 #undef MX_DMA_F16
 #undef MX_DMA_SA
+#undef MX_DMA_SA_W
 #undef MX_DMA_SW
 #undef MX_SA_SETUP
 #undef MX_F_ADV
