@@ -322,6 +322,12 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
                 for (int jj = 0; jj < 4; ++jj) bh[jj] = *reinterpret_cast<const hfrag8*>(sw + b_row_off + jj * 1024);
                 a_cur = *reinterpret_cast<const hfrag8*>(sa + a_row_off);
             }
+            // the first two DMAs of the next half stage (the A rows: their address arithmetic is the longer one) go out HERE, between the
+            // fragment reads above and their first use: both waves of a SIMD come out of the barrier together and sit out the LDS latency
+            // in front of the first MFMA group anyway
+            __builtin_amdgcn_sched_barrier(0);
+            if (next) { MX_DMA_F16(ks + 1, 0) MX_DMA_F16(ks + 1, 1) MX_F_ADV(ks + 2) }
+            __builtin_amdgcn_sched_barrier(0);
             // the step's DMAs go out one or two at a time between the row blocks' MFMAs (issued in one burst behind the barrier,
             // all eight waves sit in DMA issue while the matrix pipes idle): the next half stage first, then -- F0: side A,
             // F1: side W of this super-step (the side area was released by the barrier of F0: M of ss - 1 is done)
@@ -341,10 +347,8 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (next) {
-                    if (i == 0) MX_DMA_F16(ks + 1, 0)
-                    if (i == 1) { MX_DMA_F16(ks + 1, 1) MX_F_ADV(ks + 2) }
-                    if (i == 2) MX_DMA_F16(ks + 1, 2)
-                    if (i == 3) MX_DMA_F16(ks + 1, 3)
+                    if (i == 0) MX_DMA_F16(ks + 1, 2)
+                    if (i == 1) MX_DMA_F16(ks + 1, 3)
                 }
                 if (j == 0) {
                     if (i == 3) MX_SA_SETUP(ss)
