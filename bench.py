@@ -57,7 +57,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--no-clock-probe", action="store_true", help="do not run the one-wave shader-clock probe beside the timed regions (profiling runs: "
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip the extra region that runs beside the one-wave shader-clock probe (profiling runs: "
                                                                   "it would top the kernel statistics with its own duration); shader_clock_mhz is then null")
     ap.add_argument("--no-mx-flat", action="store_true", help="A/B: f16mx plane layers on per-utterance 256-row tiles instead of flat row tiles")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region (exactly --steps steps between barrier + synchronize) is run this many "
@@ -75,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument("--atomic-pooling", action="store_true", help="fp64-atomic fused pooling instead of the reproducible form")
     ap.add_argument("--ctx-major-k", action="store_true", help="A/B: weights in (context, feature) K order instead of the chunk-interleaved one")
     ap.add_argument("--row-major-w", action="store_true", help="A/B: row-major weights instead of the LDS-image tiles")
+    ap.add_argument("--n1-json", default=None, help="a file holding the JSON line of the N = 1 run of this bench: the N > 1 line then carries "
+                                                    "`scaling_summary` (value / (N x value at N = 1)); the driver computes efficiency itself, this is a convenience")
     return ap.parse_args(argv)
 
 
@@ -162,15 +164,22 @@ def main(argv=None):
     # ---- timed region: exactly K steps between barrier + synchronize; run `repeats` times back to back, the MEDIAN region is reported
     # (one 0.2 s window could not tell a 3 % kernel change from a slow box). Beside every region a one-wave probe on a
     # stream of its own reads the shader clock the chip holds under this load (ktf_clock_probe).
+    # Round 6: the probe runs beside ONE MORE region of the same steps behind the timed ones, not beside them: a second active hardware
+    # queue stretches every kernel-to-kernel transition of the step (same box, same build, alternating runs: 8.58 ms of GEMM brackets per
+    # step with the probe resident, 8.40 without -- 2 % of the step, the pooled layer's bracket most), so the timed regions are measured
+    # alone and the clock is sampled under the same load right after them (`shader_clock_region_ms_per_step` says what that region took).
     probe_stream = torch.cuda.Stream(device=dev)
-    probe_out = torch.zeros((max(args.repeats, 1), 4), dtype=torch.int64, device=dev)
+    probe_out = torch.zeros((1, 4), dtype=torch.int64, device=dev)
     regions = []
-    for rep_i in range(max(args.repeats, 1)):
+    probe_region_ms = None
+    n_regions = max(args.repeats, 1)
+    for rep_i in range(n_regions + (0 if args.no_clock_probe else 1)):
+        probing = rep_i == n_regions
         ops_prof.reset()
         parallel.barrier(world)
         torch.cuda.synchronize()
-        if not args.no_clock_probe:
-            ops.clock_probe(probe_out[rep_i], max(1000, min(int(0.9 * est_us), 9_000_000)), probe_stream)
+        if probing:
+            ops.clock_probe(probe_out[0], max(1000, min(int(0.9 * est_us), 9_000_000)), probe_stream)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             y = step()
@@ -179,14 +188,17 @@ def main(argv=None):
         dt_local = time.perf_counter() - t0
         torch.cuda.synchronize()                     # (the probe wave: it ends inside the region by construction, 0.9 x its estimate)
         dt_i = parallel.max_over_ranks(dt_local, world, dev)
-        regions.append({"dt": dt_i, "dt_local": dt_local, "gemm": ops_prof.finish(restore=False)})
+        if probing:
+            probe_region_ms = 1e3 * dt_i / args.steps
+        else:
+            regions.append({"dt": dt_i, "dt_local": dt_local, "gemm": ops_prof.finish(restore=False)})
     ops_prof.restore()
     order = sorted(range(len(regions)), key=lambda i: regions[i]["dt"])
     med = order[len(order) // 2]
     dt, gemm_stats = regions[med]["dt"], regions[med]["gemm"]
     per_rank = parallel.gather_floats(regions[med]["dt_local"], world, dev)         # every rank's own time of the median region
     pc = probe_out.cpu().numpy()
-    clocks_mhz = [float(100.0 * r[0] / r[1]) if r[1] else None for r in pc]
+    clock_mhz = float(100.0 * pc[0][0] / pc[0][1]) if pc[0][1] else None
 
     lens = mdl.last_lens.cpu().numpy()
     assert int(lens.min()) == T and int(lens.max()) == T, "synthetic stationary noise must keep every frame voiced"
@@ -211,8 +223,8 @@ def main(argv=None):
         "repeats": len(regions), "value_runs": [world * B * args.steps / r["dt"] for r in regions],
         "ms_per_step_runs": [1e3 * r["dt"] / args.steps for r in regions],
         # shader clock held during each region (rank 0's device): in-kernel s_memtime against the 100 MHz s_memrealtime
-        "shader_clock_mhz": clocks_mhz[med], "shader_clock_mhz_runs": clocks_mhz,
-        "shader_clock_mhz_1ms_window_min_max": [float(pc[med][2]) / 1e3, float(pc[med][3]) / 1e3],
+        "shader_clock_mhz": clock_mhz, "shader_clock_region_ms_per_step": probe_region_ms if clock_mhz else None,
+        "shader_clock_mhz_1ms_window_min_max": [float(pc[0][2]) / 1e3, float(pc[0][3]) / 1e3],
         "per_rank_ms_per_step": {"min": 1e3 * min(per_rank) / args.steps, "max": 1e3 * max(per_rank) / args.steps, "ranks": len(per_rank)},
         "config": {"workload": f"0008_sitw_v2_1a wav->x-vector, {args.seconds:g} s @16 kHz utterances, {B} per GPU "
                                f"(BASELINE config: 8192 utterances batch-sharded over 8 GPUs = 1024 per GPU), dither 0, all {T} frames voiced",
@@ -225,11 +237,19 @@ def main(argv=None):
     # ---- roofline of the dominant kernel: TDNN GEMM launches (5 per step), algorithmic FLOPs / measured duration
     passes = float(MFMA_PASSES[args.gemm])
     out["roofline"] = _roofline(args.gemm, gemm_stats, args.steps, B, T, passes)
-    if clocks_mhz[med]:
+    if clock_mhz:
         # the dense-MFMA peak is quoted at the 2.4 GHz maximum clock; the governor holds less under this load, by amounts that differ from
-        # device to device: the same achieved rate against the peak AT THE CLOCK THE CHIP HELD separates kernel quality from the box
-        out["roofline"]["peak_at_measured_clock"] = out["roofline"]["peak"] * clocks_mhz[med] / 2400.0
-        out["roofline"]["frac_at_measured_clock"] = out["roofline"]["achieved"] / out["roofline"]["peak_at_measured_clock"]
+        # device to device. The probe wave reads the clock of ITS OWN CU, which does nothing else: the CUs inside the GEMM K-loops hold
+        # 2.0-2.1 GHz by their own stamps (docs/lab_notes_r5.md section 4), so this figure under-corrects -- it separates boxes, it is not
+        # the clock of the matrix pipes (named for what it is)
+        out["roofline"]["probe_cu_clock_mhz"] = clock_mhz
+        out["roofline"]["peak_at_probe_cu_clock"] = out["roofline"]["peak"] * clock_mhz / 2400.0
+        out["roofline"]["frac_at_probe_cu_clock"] = out["roofline"]["achieved"] / out["roofline"]["peak_at_probe_cu_clock"]
+    # (flat scalars beside the nested blocks: a record that keeps only the scalar members of `roofline` / `config` still carries them)
+    out["config"]["shader_clock_mhz_probe_cu"] = clock_mhz
+    out["config"]["library_build_id"] = ops.build_id()
+    for k_, v_ in out["roofline"]["per_layer_ms"].items():
+        out["roofline"]["ms_" + k_.replace("->", "_to_").replace("+", "_")] = v_
     if args.gemm == "f16mx" and args.mx_loader:
         out["roofline"]["kernel"] = "tdnn_mxl_kernel (csrc/tdnn_mxl.hip: 192 x 256 tile, 8 matrix + 4 loader waves; --mx-loader A/B)"
     # HBM traffic of those launches comes from separate rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950, WRITE_SIZE),
@@ -237,6 +257,13 @@ def main(argv=None):
     if B == 1024:
         _attach_traffic(out["roofline"], args.gemm, ops.build_id())
     out["mfcc"] = _bench_mfcc(torch, mdl, wav, ops)
+    # the second half of BASELINE.json's metric ("MFCC frames/sec per GPU") as scalars of the roofline block too: the fused front-end launch alone,
+    # against its two ceilings (760 algorithmic bytes per frame of HBM; ~25 kFLOP per frame of fp32 vector work)
+    for k_ in ("frames_per_s", "ms", "frac_of_hbm_peak", "frac_of_valu_peak", "achieved_GBps"):
+        out["roofline"]["frontend_" + k_] = out["mfcc"][k_]
+    out["roofline"]["frontend_kernel"] = "frontend512_kernel (csrc/frontend512.hip): Framing + Windowing + FFT-512 + mel + DCT + lifter, one wave per frame"
+    if args.n1_json:
+        out["scaling_summary"] = _scaling_summary(args.n1_json, value, world)
     # side measurements and the CPU baseline belong to the single-GPU run only (rank 0 at N = 1)
     if world == 1 and not args.no_parity:
         # the deviation of the TIMED mode from the fp64 CPU oracle at the full utterance length: part of the headline
@@ -461,6 +488,20 @@ def _attach_traffic(roof, gemm, build_id):
                                     f"{tj['tdnn_gemm_bytes_per_step_corrected']:.4g}) / {nl} GEMM launches"
                                     + (f"; algorithmic {alg / nl:.4g} per launch" if alg else ""))
             return
+
+
+def _scaling_summary(path, value, world):
+    """Weak-scaling efficiency of this run against a stored N = 1 line of the same bench (per-GPU batch fixed)."""
+    try:
+        with open(path) as f:
+            lines = [ln for ln in f.read().splitlines() if ln.startswith("{")]
+        n1 = json.loads(lines[-1])
+        if int(n1.get("n_gpus", 0)) != 1 or not n1.get("value"):
+            return {"error": f"{path}: not an N = 1 line"}
+        return {"n1_value": n1["value"], "n_gpus": world, "value": value, "efficiency_vs_n1": value / (world * n1["value"]),
+                "n1_build_id": n1.get("library_build_id")}
+    except (OSError, ValueError, IndexError) as e:
+        return {"error": f"{path}: {e}"}
 
 
 def _layer_flops(key, B, T):

@@ -372,7 +372,8 @@ int ktf_split_bf16_rows(const float* src, int64_t B, int64_t T, int32_t D, int64
  * TDNN.device_weights_mx). VALID padding and subsampling (tdnn.py:224-249) on the 256-row kernel: the output (planes or fp32 rows)
  * then has ktf_tdnn_out_len(T, d) rows per utterance and the valid rows of utterance b are ktf_tdnn_out_len(lens[b], d)
  * (ktf_tdnn_out_lens makes them for the next layer); ktf_tdnn_mx_stats and KTF_TDNN_MX_LOADER take SAME padding without
- * subsampling only.
+ * subsampling only. The 256-row kernel keeps a table of its K-steps in LDS: at most 1144 of them (ceil(D / 32) * nctx, padded to a multiple
+ * of 4; K <= 36,608); the planes are read through 32-bit buffer offsets: T * din_pad * 2 < 2^31 - 2^20.
  * With KtfTdnnDesc.flags & KTF_TDNN_MX_LOADER the call runs the loader-wave kernel (csrc/tdnn_mxl.hip: 192 x 256 tiles over the flat row
  * space b * T + t, eight matrix + four loader waves) on the SAME activation planes and on weight images of its own
  * (mx.weight_images_loader): every operand fragment is 64 lanes x 16 (8, 4) consecutive bytes, and inside each 32-unit chunk the image

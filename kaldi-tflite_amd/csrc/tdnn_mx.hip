@@ -119,6 +119,14 @@ template <int ACT, int OUT, bool PADK, bool FLAT = false>
 __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mtiles, int ntiles, int gtiles, double* __restrict__ stats,
                                         unsigned char* rsm) {
     static_assert(!FLAT || OUT != MX_OUT_F32, "flat row tiles: plane output or fused pooling");
+    // Every kernel argument the tile needs before its first DMA is consumed in ONE place: the compiler otherwise loads the 240-byte parameter
+    // block in five or six dependent pieces (s_load, wait, s_load, wait ...), each a trip to the scalar cache in front of the first DMA
+    // issue -- a microsecond of the ~2.5 a tile spends before its first MFMA. One batch of scalar loads, one wait; placed BEHIND the tile's
+    // one scalar load from global memory (the row count / the utterance's length), which it then overlaps: in front of it the asm counts as
+    // a possible store and that load became a vector load.
+#define MX_ARG_BATCH()                                                                                                                     \
+    asm volatile("" ::"s"(p.xh), "s"(p.wh), "s"(p.T), "s"(p.nss), "s"(p.nk), "s"(p.nctx), "s"(p.nch_in), "s"(p.ctx_pk[0]), "s"(p.ctx_pk[1]), \
+                 "s"(p.t_div_m), "s"(p.t_div_s), "s"(p.start), "s"(p.sub), "s"(p.cut))
     const int xcd = id & 7, slot = id >> 3;             // an XCD runs all N-tiles of an M-tile back to back (its L2 keeps the A tile)
     const int g = (slot / ntiles) * 8 + xcd;
     const int nt = slot - (slot / ntiles) * ntiles;
@@ -133,25 +141,27 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     [[maybe_unused]] bool dense = false;                  // FLAT: every utterance has all T rows: row -> (utterance, frame) by division, no table load
     if constexpr (FLAT) {
         const int total = p.row_starts[mtiles];
+        MX_ARG_BATCH();
         if (R0 >= total) return;
         len = (int)p.T;
         out_len = total - R0 < 256 ? total - R0 : 256;    // valid rows of the tile
         dense = total == mtiles * len;
     } else {
         len = p.lens ? p.lens[b] : (int)p.T;
+        MX_ARG_BATCH();
         out_len = len - p.cut - p.start <= 0 ? 0 : (len - p.cut - p.start + p.sub - 1) / p.sub;      // (== len: SAME, no subsampling)
         if (t0 >= out_len) return;
     }
     const int lenm1 = len - 1;
-    const unsigned Tu = (unsigned)p.T;
     const int64_t ub = FLAT ? 0 : (int64_t)b * p.nch_in * p.T;       // first (chunk, row) record of this utterance
-    const char* xh = p.xh + ub * 64;
-    const char* xl4 = p.xl4 + ub * 16;
-    const char* x4 = p.x4 + ub * 16;
-    const char* xs = p.xs + ub * 4;
     const int nkp = p.nss * 4;
-    const char* wh = p.wh + (int64_t)nt * nkp * MX_TILE;
-    const char* wq = p.wq + (int64_t)nt * p.nss * MX_WQ_BLOCK;
+    // The six operand streams as buffer resources: an LDS-DMA is then `buffer_load_dwordx4 voffset, rsrc, soffset offen lds` -- the lane's
+    // part of the address in ONE loop-invariant register, the K-step's part in ONE scalar register, no 64-bit address arithmetic per
+    // instruction. The activation planes start MX_KQ_BIAS records early: the scalar part (chunk * T + context offset + MX_KQ_BIAS) is
+    // never negative.
+    const __amdgpu_buffer_rsrc_t r_xh = mx_rsrc(p.xh + (ub - MX_KQ_BIAS) * 64);
+    const __amdgpu_buffer_rsrc_t r_wh = mx_rsrc(p.wh + (int64_t)nt * nkp * MX_TILE);
+    const __amdgpu_buffer_rsrc_t r_wq = mx_rsrc(p.wq + (int64_t)nt * p.nss * MX_WQ_BLOCK);
 
     // half stage: thread q = i * 512 + tid moves the 16-byte piece at LDS offset q * 16 (row q >> 2, position q & 3 holds chunk
     // (q & 3) ^ ((4 - ((row >> 2) & 3)) & 3): conflict-free 16-byte fragment reads)
@@ -165,7 +175,8 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         a_row[i] = p.start + (t0 + row) * p.sub;          // input row of output row t0 + row at context offset 0
     }
     // FLAT: (frame, last frame of its utterance, first record of its utterance) of the two stage rows and of the side row of this thread
-    [[maybe_unused]] int a_lm1[2] = {lenm1, lenm1}, s_row = 0, s_lm1 = lenm1;
+    [[maybe_unused]] int a_lm1[2] = {lenm1, lenm1}, s_lm1 = lenm1;
+    int s_row = p.start + (t0 + lane + 64 * (wave & 3)) * p.sub;     // side A: input row of the lane's row in the wave's row group
     [[maybe_unused]] unsigned a_ub[2] = {0u, 0u}, s_ub = 0u;
     // (output row b * T + t or -1, t, utterance length, b) of tile row m; rows beyond the batch's last: (-1, 0, 1, 0)
     [[maybe_unused]] auto flat_row = [&](int m) -> i32x4 {
@@ -177,261 +188,338 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         }
         return reinterpret_cast<const i32x4*>(p.row_map)[R0 + m];
     };
+    const unsigned long long cpk0 = p.ctx_pk[0], cpk1 = p.ctx_pk[1];     // the context offsets: packed signed bytes in two 64-bit kernel arguments
+#define MX_CTX(ci_) ((int)(signed char)(((ci_) < 8 ? cpk0 : cpk1) >> (((ci_) & 7) * 8)))
+    // INTERIOR tile (flat row tiles): all 256 rows belong to ONE utterance and no context offset leaves it -- no row of the tile is clamped in
+    // any K-step (layers/tdnn/tdnn.py:246-247 of the reference replicates the edge frames: that is the clamp), so a lane's source address is
+    // (its own row's record, loop-invariant) + (the K-step's chunk and context offset, a scalar): the K-loop's DMAs issue without a vector
+    // instruction. 998-frame utterances on flat 256-row tiles: three tiles in four.
+    [[maybe_unused]] bool interior = false;
     if constexpr (FLAT) {
+        // (one branch around the three lookups: as three calls of flat_row() the table form was three dependent round trips to memory,
+        // each behind its own vmcnt(0))
+        i32x4 er[3];
+        const int mr[3] = {tid >> 2, (512 + tid) >> 2, lane + 64 * (wave & 3)};
+        if (dense) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) er[i] = flat_row(mr[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) er[i] = reinterpret_cast<const i32x4*>(p.row_map)[R0 + mr[i]];
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const i32x4 e = flat_row((i * 512 + tid) >> 2);
-            a_row[i] = e.y;
-            a_lm1[i] = e.z - 1;
-            a_ub[i] = e.x < 0 ? 0u : (unsigned)(e.x - e.y) * (unsigned)p.nch_in;
+            a_row[i] = er[i].y;
+            a_lm1[i] = er[i].z - 1;
+            a_ub[i] = er[i].x < 0 ? 0u : (unsigned)(er[i].x - er[i].y) * (unsigned)p.nch_in;
         }
-        const i32x4 e = flat_row(lane + 64 * (wave & 3));
-        s_row = e.y;
-        s_lm1 = e.z - 1;
-        s_ub = e.x < 0 ? 0u : (unsigned)(e.x - e.y) * (unsigned)p.nch_in;
+        s_row = er[2].y;
+        s_lm1 = er[2].z - 1;
+        s_ub = er[2].x < 0 ? 0u : (unsigned)(er[2].x - er[2].y) * (unsigned)p.nch_in;
     }
-    // Which (32-feature chunk, context offset) a K-step reads is tracked in scalar registers, advanced once per stage: no division
-    // and no table load sits between the MFMAs (a scalar load there is a ~200-cycle stall of the wave's whole instruction
-    // stream). The context offsets travel as packed signed bytes in two 64-bit kernel arguments.
-    const unsigned long long cpk0 = p.ctx_pk[0], cpk1 = p.ctx_pk[1];
-#define MX_CTX(ci_) ((int)(signed char)(((ci_) < 8 ? cpk0 : cpk1) >> (((ci_) & 7) * 8)))
-    int f_ci = 0, f_off = MX_CTX(0);                      // K-step whose half stage is issued next: context index, offset,
-    unsigned f_base = 0;                                  // ... first record of its chunk (chunk * T)
-    int s_ci = 0;                                         // first K-step of the super-step whose side A is issued next
-    unsigned s_base = 0;
-    unsigned sa_base[4];
-    int sa_off[4];
-    const bool wave_hi = wave >= 4;                                              // side A: the wave's K blocks are (0, 2) or (1, 3)
-    [[maybe_unused]] const int sa_row_w = p.start + (t0 + lane + 64 * (wave & 3)) * p.sub;       // ... input row of the lane's row in the wave's row group
-    unsigned char* const sa_dst = rsm + MX_SA_OFF + (wave & 3) * 1024;           // ... its pieces of the e2m1 images (+ plane, K block)
-    unsigned char* const sa_dst_s = rsm + MX_SA_OFF + 32768 + (wave & 3) * 256;  // ... and of the scale words
-    // position of K-step ks_ (the next stage to issue) from the position of ks_ - 1; padded K-steps re-read step 0 (zero weights)
-#define MX_F_ADV(ks_)                                                                                                  \
+    // The first stage goes out HERE, in front of everything only the K-loop needs (side-plane resources, the interior test, the K-step table):
+    // a tile's time to its first MFMA is the latency of these four DMAs plus whatever is issued in front of them. Rows in the clamped form.
+    const unsigned vw = (unsigned)tid * 16u;              // loop-invariant lane part of the W image / side W addresses
+    // LDS destinations: (the wave's offset, passed through an empty asm at each use) + a constant = ONE `s_add_i32 m0` per DMA. Left to the
+    // compiler, every destination of the loop became a loop-invariant scalar register of its own (~25 of them: with the six buffer
+    // resources the kernel ran out of scalar registers and spilled the epilogue's pointers around the loop).
+    const int wave_k = wave * 1024;                        // the wave's piece of a stage image / of an 8 KiB side-W slice
+#define MX_LDS_AT(off_, c_) ({ int o_ = (off_); asm volatile("" : "+s"(o_)); (lds_ptr_t*)(rsm + o_ + (c_)); })
+    int kb[5], ko[5];                                     // table entries of K-steps 4 ss .. 4 ss + 4 (scalar registers)
+    kb[0] = MX_KQ_BIAS;
+    ko[0] = MX_CTX(0);
+    // one 16-byte-per-lane DMA of the half stage of K-step ks_ (table entry e_ of the super-step): n_ = 0, 1 the A image (rows 0-127 / 128-255);
+    // _E: rows clamped to their utterance, _I: interior tiles (below)
+#define MX_DMA_A_E(ks_, e_, n_)                                                                                        \
     {                                                                                                                  \
-        if ((ks_) < p.nk) {                                                                                            \
-            if (++f_ci == p.nctx) { f_ci = 0; f_base += Tu; }                                                          \
-            f_off = MX_CTX(f_ci);                                                                                      \
-        } else {                                                                                                       \
-            f_base = 0;                                                                                                \
-            f_off = MX_CTX(0);                                                                                         \
-        }                                                                                                              \
-    }
-    // one 16-byte-per-lane DMA of the half stage of K-step ks_: n_ = 0, 1 the A image (rows 0-127 / 128-255), 2, 3 the W image
-#define MX_DMA_F16(ks_, n_)                                                                                            \
-    {                                                                                                                  \
-        unsigned char* st_ = rsm + ((ks_) & 1) * MX_STAGE + wave * 1024;                                               \
-        if ((n_) < 2) {                                                                                                \
-            int r_ = a_row[(n_) & 1] + f_off;                                                                          \
-            const int hi_ = FLAT ? a_lm1[(n_) & 1] : lenm1;                                                            \
-            r_ = r_ < 0 ? 0 : (r_ > hi_ ? hi_ : r_);                                                                   \
-            const unsigned vo_ = ((FLAT ? a_ub[(n_) & 1] : 0u) + f_base + (unsigned)r_) * 64u + a_cb[(n_) & 1];        \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xh + vo_), (lds_ptr_t*)(st_ + ((n_) & 1) * 8192), 16, 0, 0); \
-        } else {                                                                                                       \
-            const unsigned vo_ = (unsigned)(ks_) * (unsigned)MX_TILE + (unsigned)(((n_) & 1) * 512 + tid) * 16u;       \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wh + vo_), (lds_ptr_t*)(st_ + MX_TILE + ((n_) & 1) * 8192), 16, 0, 0); \
-        }                                                                                                              \
-    }
-    // the four K-steps of super-step ss_ (K blocks of its scaled MFMAs): chunk bases and offsets for the side A DMAs
-#define MX_SA_SETUP(ss_)                                                                                               \
-    {                                                                                                                  \
-        _Pragma("unroll") for (int kb_ = 0; kb_ < 4; ++kb_) {                                                          \
-            if (4 * (ss_) + kb_ < p.nk) {                                                                              \
-                sa_base[kb_] = s_base;                                                                                 \
-                sa_off[kb_] = MX_CTX(s_ci);                                                                            \
-                if (++s_ci == p.nctx) { s_ci = 0; s_base += Tu; }                                                      \
-            } else {                                                                                                   \
-                sa_base[kb_] = 0;                                                                                      \
-                sa_off[kb_] = MX_CTX(0);                                                                               \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-    // side A of super-step ss_: n_ = 0..3 the e2m1 pieces (32 KiB: plane, K block, 64-row group by wave), 4, 5 the scale words. Piece
-    // n_ * 8 + wave is (plane n_ >> 1, K block 2 (n_ & 1) + (wave >> 2), row group wave & 3): a wave fetches two of the four K blocks, the
-    // same two for every piece. WH_ = wave >> 2 as a compile-time constant (the call site branches on it once per DMA slot): with the K
-    // block a run-time value every DMA chose its chunk base and context offset by three scalar selects each, and the ~100 scalar
-    // instructions of a super-step's six side-A DMAs sat between two MFMA groups of BOTH waves of a SIMD at the same time.
-#define MX_DMA_SA(ss_, n_, WH_)                                                                                        \
-    {                                                                                                                  \
-        constexpr int plane_ = ((n_) < 4 ? (n_) : 0) >> 1, kb_ = (n_) < 4 ? 2 * ((n_) & 1) + (WH_) : 2 * ((n_) - 4) + (WH_);                    \
-        int r_ = (FLAT ? s_row : sa_row_w) + sa_off[kb_];                                                              \
-        const int hi_ = FLAT ? s_lm1 : lenm1;                                                                          \
+        int r_ = a_row[n_] + ko[e_];                                                                                   \
+        const int hi_ = FLAT ? a_lm1[n_] : lenm1;                                                                      \
         r_ = r_ < 0 ? 0 : (r_ > hi_ ? hi_ : r_);                                                                       \
-        const unsigned rec_ = (FLAT ? s_ub : 0u) + sa_base[kb_] + (unsigned)r_;                                        \
-        if ((n_) < 4) {                                                                                                \
-            const unsigned vo_ = rec_ * 16u;                                                                           \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)((plane_ ? x4 : xl4) + vo_),                                  \
-                                             (lds_ptr_t*)(sa_dst + plane_ * 16384 + kb_ * 4096), 16, 0, 0);            \
+        const unsigned vo_ = ((FLAT ? a_ub[n_] : 0u) + (unsigned)r_) * 64u + a_cb[n_];                                 \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r_xh, MX_LDS_AT(wave_k, ((ks_) & 1) * MX_STAGE + (n_) * 8192), 16, vo_, kb[e_] << 6, 0, 0); \
+    }
+#define MX_DMA_A_I(ks_, e_, n_)                                                                                        \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_xh, MX_LDS_AT(wave_k, ((ks_) & 1) * MX_STAGE + (n_) * 8192), 16, (n_) ? va1 : va0, \
+                                             (kb[e_] + ko[e_]) << 6, 0, 0);
+#define MX_DMA_A(ks_, e_, n_) { if constexpr (INTERIOR) MX_DMA_A_I(ks_, e_, n_) else MX_DMA_A_E(ks_, e_, n_) }
+    // ... n_ = 0, 1 the halves of the W image
+#define MX_DMA_W(ks_, n_)                                                                                              \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wh, MX_LDS_AT(wave_k, ((ks_) & 1) * MX_STAGE + MX_TILE + (n_) * 8192), 16, vw, \
+                                             (ks_) * MX_TILE + (n_) * 8192, 0, 0);
+    MX_DMA_W(0, 0) MX_DMA_W(0, 1) MX_DMA_A_E(0, 0, 0) MX_DMA_A_E(0, 0, 1)
+    const __amdgpu_buffer_rsrc_t r_xl4 = mx_rsrc(p.xl4 + (ub - MX_KQ_BIAS) * 16);
+    const __amdgpu_buffer_rsrc_t r_x4 = mx_rsrc(p.x4 + (ub - MX_KQ_BIAS) * 16);
+    const __amdgpu_buffer_rsrc_t r_xs = mx_rsrc(p.xs + (ub - MX_KQ_BIAS) * 4);
+    if constexpr (FLAT) {
+        if (p.nctx == 1 && MX_CTX(0) == 0) {
+            interior = true;      // one context at offset 0: no row is ever clamped (rows beyond the batch's last read row 0 of the plane and are not stored)
+        } else if (out_len == 256) {
+            const i32x4 e0 = flat_row(0), e1 = flat_row(255);
+            interior = __builtin_amdgcn_readfirstlane(e0.w) == __builtin_amdgcn_readfirstlane(e1.w) &&
+                       __builtin_amdgcn_readfirstlane(e0.y) + MX_CTX(0) >= 0 &&
+                       __builtin_amdgcn_readfirstlane(e1.y) + MX_CTX(p.nctx - 1) <= __builtin_amdgcn_readfirstlane(e1.z) - 1;
+        }
+    }
+    // ... and -- interior tiles -- of the lane's own rows
+    [[maybe_unused]] const unsigned va0 = (a_ub[0] + (unsigned)a_row[0]) * 64u + a_cb[0], va1 = (a_ub[1] + (unsigned)a_row[1]) * 64u + a_cb[1];
+    [[maybe_unused]] const unsigned vs16 = (s_ub + (unsigned)s_row) * 16u, vs4 = (s_ub + (unsigned)s_row) * 4u;
+
+    const int sa_k = (wave & 3) * 1024 + (wave >> 2) * 4096;     // side A: the wave's pieces of the e2m1 images (+ plane, K block pair)
+    const int sa_ks = (wave & 3) * 256 + (wave >> 2) * 1024;     // ... and of the scale words
+    const bool wave_hi = wave >= 4;                                              // side A: the wave's K blocks are (0, 2) or (1, 3)
+
+    // Which (32-feature chunk, context offset) a K-step reads comes from a table in LDS, made once per tile: entry k - 1 of `tkb` is
+    // (chunk * T + MX_KQ_BIAS) of K-step k, of `tko` its context offset; padded K-steps (k >= nk) re-read K-step 0 (their weights are
+    // zero). A super-step fetches its four entries with two 16-byte LDS reads one K-step ahead and keeps them in scalar registers: no
+    // division, no scalar load (a ~200-cycle stall of the wave's whole instruction stream) and no bookkeeping between the MFMAs -- the
+    // running (context index, chunk base) pairs of rounds 2-5 cost ~12 scalar instructions per half stage and ~60 per super-step's side A.
+    int* const tkb = reinterpret_cast<int*>(rsm + MX_KQ_OFF);
+    int* const tko = tkb + (nkp + 4);
+
+    // side A of the super-step: n_ = 0..3 the e2m1 pieces (32 KiB: plane, K block, 64-row group by wave), 4, 5 the scale words. Piece
+    // n_ * 8 + wave is (plane n_ >> 1, K block 2 (n_ & 1) + (wave >> 2), row group wave & 3): a wave fetches two of the four K blocks, the
+    // same two for every piece; their table entries are chosen once per super-step by four scalar selects (sk_b / sk_o: K block
+    // (wave >> 2) and 2 + (wave >> 2)), the destinations carry the wave half as a constant offset.
+#define MX_DMA_SA(n_)                                                                                                  \
+    {                                                                                                                  \
+        constexpr int plane_ = ((n_) < 4 ? (n_) : 0) >> 1, h_ = (n_) < 4 ? ((n_) & 1) : (n_) - 4;                      \
+        unsigned rec_ = 0u;                                                                                            \
+        int so_;                                                                                                       \
+        if constexpr (INTERIOR) {                                                                                      \
+            so_ = sk_b[h_] + sk_o[h_];                                                                                 \
         } else {                                                                                                       \
-            const unsigned vo_ = rec_ * 4u;                                                                            \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t*)(xs + vo_), (lds_ptr_t*)(sa_dst_s + kb_ * 1024), 4, 0, 0);    \
+            int r_ = s_row + sk_o[h_];                                                                                 \
+            const int hi_ = FLAT ? s_lm1 : lenm1;                                                                      \
+            r_ = r_ < 0 ? 0 : (r_ > hi_ ? hi_ : r_);                                                                   \
+            rec_ = (FLAT ? s_ub : 0u) + (unsigned)r_;                                                                  \
+            so_ = sk_b[h_];                                                                                            \
+        }                                                                                                              \
+        if ((n_) < 4) {                                                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(plane_ ? r_x4 : r_xl4, MX_LDS_AT(sa_k, MX_SA_OFF + plane_ * 16384 + h_ * 8192), 16, \
+                                                     INTERIOR ? vs16 : rec_ * 16u, so_ << 4, 0, 0);                    \
+        } else {                                                                                                       \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r_xs, MX_LDS_AT(sa_ks, MX_SA_OFF + 32768 + h_ * 2048), 4, INTERIOR ? vs4 : rec_ * 4u, so_ << 2, 0, 0); \
         }                                                                                                              \
     }
-#define MX_DMA_SA_W(ss_, n_) { if (wave_hi) MX_DMA_SA(ss_, n_, 1) else MX_DMA_SA(ss_, n_, 0) }
-    // side W of super-step ss_: piece n_ = 0..5 of one contiguous 48 KiB block
+    // side W of super-step ss_: slice n_ = 0..5 of one contiguous 48 KiB block (a wave moves its 1 KiB of every 8 KiB slice)
 #define MX_DMA_SW(ss_, n_)                                                                                             \
-    {                                                                                                                  \
-        const int idx_ = (n_) * 8 + wave;                                                                              \
-        const unsigned vo_ = (unsigned)(ss_) * (unsigned)MX_WQ_BLOCK + (unsigned)idx_ * 1024u + (unsigned)lane * 16u;  \
-        __builtin_amdgcn_global_load_lds((glb_ptr_t*)(wq + vo_), (lds_ptr_t*)(rsm + MX_SW_OFF + idx_ * 1024), 16, 0, 0); \
-    }
-    MX_DMA_F16(0, 2) MX_DMA_F16(0, 3) MX_DMA_F16(0, 0) MX_DMA_F16(0, 1)
-    MX_F_ADV(1)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wq, MX_LDS_AT(wave_k, MX_SW_OFF + (n_) * 8192), 16, vw, (ss_) * MX_WQ_BLOCK + (n_) * 8192, 0, 0);
 
     f32x4 acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-
-    // epilogue constants of the tile's columns: parked in LDS now (their global-load latency hides under the K-loop, and they
-    // hold no registers during it)
-    if (tid < 256) {
-        float* prm = reinterpret_cast<float*>(rsm + MX_PRM_OFF);
-        const int n = n0 + tid;
-        const bool nv = n < p.units;
-        prm[tid] = (nv && p.bias) ? p.bias[n] : 0.0f;
-        prm[256 + tid] = (nv && p.scale) ? p.scale[n] : 1.0f;
-        prm[512 + tid] = (nv && p.shift) ? p.shift[n] : 0.0f;
-    }
-
     const int r16 = lane & 15, q4 = lane >> 4;
     const int fr = (4 - ((r16 >> 2) & 3)) & 3;
     const int coff = ((q4 ^ fr) << 4);
     const int a_row_off = (wm * 128 + r16) * 64 + coff;
     const int b_row_off = (wn * 64 + r16) * 64 + coff;
-    const int sa_row = q4 * 256 + wm * 128 + r16;          // side A record of row block 0 (+ 16 per block)
-    const int sw_col = q4 * 256 + wn * 64 + r16;           // side W record of column block 0
+    const int klim = PADK ? p.nk : nkp;
 
-    for (int ss = 0; ss < p.nss; ++ss) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ks = 4 * ss + j;
-            // stage ks has landed; behind it only this super-step's side DMAs may still be in flight (six per wave)
-            if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            const bool live = PADK ? ks < p.nk : true;
-            const bool next = ks + 1 < (PADK ? p.nk : nkp);
-            const unsigned char* sa = rsm + (ks & 1) * MX_STAGE;
-            const unsigned char* sw = sa + MX_TILE;
-            hfrag8 bh[4];
-            hfrag8 a_cur;
-            if (live) {
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) bh[jj] = *reinterpret_cast<const hfrag8*>(sw + b_row_off + jj * 1024);
-                a_cur = *reinterpret_cast<const hfrag8*>(sa + a_row_off);
-            }
-            // the first two DMAs of the next half stage (the A rows: their address arithmetic is the longer one) go out HERE, between the
-            // fragment reads above and their first use: both waves of a SIMD come out of the barrier together and sit out the LDS latency
-            // in front of the first MFMA group anyway
-            __builtin_amdgcn_sched_barrier(0);
-            if (next) { MX_DMA_F16(ks + 1, 0) MX_DMA_F16(ks + 1, 1) MX_F_ADV(ks + 2) }
-            __builtin_amdgcn_sched_barrier(0);
-            // the step's DMAs go out one or two at a time between the row blocks' MFMAs (issued in one burst behind the barrier,
-            // all eight waves sit in DMA issue while the matrix pipes idle): the next half stage first, then -- F0: side A,
-            // F1: side W of this super-step (the side area was released by the barrier of F0: M of ss - 1 is done)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (live) {
-                    // the next row block's fragment is read BEHIND this group's first MFMA: the compiler waits for a_cur with lgkmcnt(0) right
-                    // in front of the group, and with the read of a_nxt issued before that wait (as it was in every other group) the wave sat
-                    // out the whole LDS latency of a fragment it needs 64 matrix cycles later -- both waves of a SIMD at the same place
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[0], acc[i][0], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    hfrag8 a_nxt = a_cur;
-                    if (i < 7) a_nxt = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 1) * 1024);
-#pragma unroll
-                    for (int jj = 1; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
-                    a_cur = a_nxt;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (next) {
-                    if (i == 0) MX_DMA_F16(ks + 1, 2)
-                    if (i == 1) MX_DMA_F16(ks + 1, 3)
-                }
-                if (j == 0) {
-                    if (i == 3) MX_SA_SETUP(ss)
-                    if (i == 4) { MX_DMA_SA_W(ss, 0) MX_DMA_SA_W(ss, 1) }
-                    if (i == 5) { MX_DMA_SA_W(ss, 2) MX_DMA_SA_W(ss, 3) }
-                    if (i == 6) MX_DMA_SA_W(ss, 4)
-                    if (i == 7) MX_DMA_SA_W(ss, 5)
-                }
-                if (j == 1) {
-                    if (i == 4) { MX_DMA_SW(ss, 0) MX_DMA_SW(ss, 1) }
-                    if (i == 5) { MX_DMA_SW(ss, 2) MX_DMA_SW(ss, 3) }
-                    if (i == 6) MX_DMA_SW(ss, 4)
-                    if (i == 7) MX_DMA_SW(ss, 5)
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        // M: the two block-scaled terms of this super-step (side data complete since the barrier of F3).
-        __builtin_amdgcn_sched_barrier(0);
+    auto kloop = [&](auto itag) {
+        constexpr bool INTERIOR = decltype(itag)::value;
+        // epilogue constants of the tile's columns (bias | scale | shift -> MX_PRM_OFF): by LDS-DMA too, 64 columns per wave and vector, behind the
+        // first stage (no register, no wait of their own: the K-loop's first vmcnt(0) covers them; the epilogue reads them many barriers later).
+        // The resources end at the layer's last unit: columns beyond it read as 0. An absent vector is written as its neutral element.
         {
-            // (the two record indices pass through an empty asm: the fragment addresses are then recomputed here, a few VALU
-            // operations per super-step, instead of living in ~20 loop-invariant registers -- which is what spilled)
-            int sw_rec = sw_col, sa_rec = sa_row;
-            asm volatile("" : "+v"(sw_rec), "+v"(sa_rec));
-            const unsigned char* sA = rsm + MX_SA_OFF;
-            const unsigned char* sW = rsm + MX_SW_OFF;
-            // the B fragments of all four column blocks stay resident (44 registers) while the eight row blocks stream past them
-            // once: read per column half, the A side crossed the LDS twice and the M-step ran at the LDS's read rate
-            // (3,008 clk of reads against 2,048 clk of MFMA per CU; now 1,856)
-            u32x4 w4[4], wl6a[4];
-            u32x2 wl6b[4];
-            unsigned wsc[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int rec = sw_rec + jj * 16;
-                w4[jj] = *reinterpret_cast<const u32x4*>(sW + rec * 16);
-                wl6a[jj] = *reinterpret_cast<const u32x4*>(sW + 16384 + rec * 16);
-                wl6b[jj] = *reinterpret_cast<const u32x2*>(sW + 32768 + rec * 8);
-                wsc[jj] = *reinterpret_cast<const unsigned*>(sW + 40960 + rec * 4);
-            }
-            u32x4 l_n = *reinterpret_cast<const u32x4*>(sA + sa_rec * 16);
-            u32x4 h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + sa_rec * 16);
-            unsigned s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + sa_rec * 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const u32x4 l = l_n, h = h_n;
-                const unsigned asc = s_n;
-                if (i < 7) {                             // the next row block's fragments are read under this one's MFMAs
-                    const int rec = sa_rec + (i + 1) * 16;
-                    l_n = *reinterpret_cast<const u32x4*>(sA + rec * 16);
-                    h_n = *reinterpret_cast<const u32x4*>(sA + 16384 + rec * 16);
-                    s_n = *reinterpret_cast<const unsigned*>(sA + 32768 + rec * 4);
-                }
-                const i32x8 al = i32x8{(int)l.x, (int)l.y, (int)l.z, (int)l.w, 0, 0, 0, 0};
-                const i32x8 ah = i32x8{(int)h.x, (int)h.y, (int)h.z, (int)h.w, 0, 0, 0, 0};
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {     // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
-                    const i32x8 bw = i32x8{(int)w4[jj].x, (int)w4[jj].y, (int)w4[jj].z, (int)w4[jj].w, 0, 0, 0, 0};
-                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, bw, acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);
-                }
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {     // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
-                    const i32x8 bw = i32x8{(int)wl6a[jj].x, (int)wl6a[jj].y, (int)wl6a[jj].z, (int)wl6a[jj].w, (int)wl6b[jj].x, (int)wl6b[jj].y, 0, 0};
-                    acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, bw, acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            unsigned char* const prm_w = rsm + MX_PRM_OFF + (wave & 3) * 256;
+            const unsigned vcol = (unsigned)(n0 + (wave & 3) * 64 + lane) * 4u;
+            const float* const vec0 = wave_hi ? p.scale : p.bias;            // waves 0-3: bias, then shift; waves 4-7: scale
+            if (vec0) __builtin_amdgcn_raw_ptr_buffer_load_lds(mx_rsrc(vec0, p.units * 4), (lds_ptr_t*)(prm_w + (wave_hi ? 1024 : 0)), 4, vcol, 0, 0, 0);
+            else reinterpret_cast<float*>(prm_w + (wave_hi ? 1024 : 0))[lane] = wave_hi ? 1.0f : 0.0f;
+            if (!wave_hi) {
+                if (p.shift) __builtin_amdgcn_raw_ptr_buffer_load_lds(mx_rsrc(p.shift, p.units * 4), (lds_ptr_t*)(prm_w + 2048), 4, vcol, 0, 0, 0);
+                else reinterpret_cast<float*>(prm_w + 2048)[lane] = 0.0f;
             }
         }
+        for (int k = tid; k < nkp + 4; k += 512) {        // the K-step table (the first stage is on its way); first read in F2 of super-step 0
+            const int kk = k + 1 < p.nk ? k + 1 : 0;
+            const int ch = kk / p.nctx, ci = kk - ch * p.nctx;
+            tkb[k] = ch * (int)p.T + MX_KQ_BIAS;
+            tko[k] = MX_CTX(ci);
+        }
+        {                                                 // K-steps 1 .. 4 directly (scalar, once per tile): no barrier in front of the loop
+            int ch = 0, ci = 0;
+#pragma unroll
+            for (int e = 1; e <= 4; ++e) {
+                if (++ci == p.nctx) { ci = 0; ++ch; }
+                const bool real = e < p.nk;
+                kb[e] = (real ? ch * (int)p.T : 0) + MX_KQ_BIAS;
+                ko[e] = real ? MX_CTX(ci) : MX_CTX(0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int ss = 0; ss < p.nss; ++ss) {
+            i32x4 tb_n, to_n;                             // the next super-step's entries: read in F2, moved to scalar registers in F3
+            int sk_b[2], sk_o[2];                         // side A: the table entries of this wave's two K blocks
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ks = 4 * ss + j;
+                // stage ks has landed; behind it only this super-step's side DMAs may still be in flight (six per wave)
+                // (lgkmcnt at the head of a super-step: the K-step table and the epilogue constants written before the loop are in LDS before
+                // the barrier lets anyone read them; inside the loop nothing is outstanding there)
+                if (j == 1 || j == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (j == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const bool live = PADK ? ks < p.nk : true;
+                // (the test is made afresh at each of its three uses: carried across the scheduling barriers as ONE boolean it went through a
+                // vector register -- v_cndmask + v_cmp per K-step)
+#define MX_NEXT() ({ int k1_ = ks + 1; asm volatile("" : "+s"(k1_)); k1_ < klim; })
+                const unsigned char* sa = rsm + (ks & 1) * MX_STAGE;
+                const unsigned char* sw = sa + MX_TILE;
+                hfrag8 bh[4];
+                hfrag8 a_cur;
+                if (live) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) bh[jj] = *reinterpret_cast<const hfrag8*>(sw + b_row_off + jj * 1024);
+                    a_cur = *reinterpret_cast<const hfrag8*>(sa + a_row_off);
+                }
+                // the first two DMAs of the next half stage (the A rows) go out HERE, between the fragment reads above and their first use: both
+                // waves of a SIMD come out of the barrier together and sit out the LDS latency in front of the first MFMA group anyway
+                __builtin_amdgcn_sched_barrier(0);
+                if (MX_NEXT()) { MX_DMA_A(ks + 1, j + 1, 0) MX_DMA_A(ks + 1, j + 1, 1) }
+                __builtin_amdgcn_sched_barrier(0);
+                // the step's DMAs go out one or two at a time between the row blocks' MFMAs (issued in one burst behind the barrier,
+                // all eight waves sit in DMA issue while the matrix pipes idle): the next half stage first, then -- F0: side A,
+                // F1: side W of this super-step (the side area was released by the barrier of F0: M of ss - 1 is done)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (live) {
+                        // the next row block's fragment is read BEHIND this group's first MFMA: the compiler waits for a_cur with lgkmcnt(0) right
+                        // in front of the group, and with the read of a_nxt issued before that wait (as it was in every other group) the wave sat
+                        // out the whole LDS latency of a fragment it needs 64 matrix cycles later -- both waves of a SIMD at the same place
+                        acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[0], acc[i][0], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        hfrag8 a_nxt = a_cur;
+                        if (i < 7) a_nxt = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 1) * 1024);
+#pragma unroll
+                        for (int jj = 1; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
+                        a_cur = a_nxt;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (i == 0) { if (MX_NEXT()) MX_DMA_W(ks + 1, 0) }
+                    if (i == 1) { if (MX_NEXT()) MX_DMA_W(ks + 1, 1) }
+                    if (j == 0) {
+                        if (i == 3) {
+                            sk_b[0] = wave_hi ? kb[1] : kb[0]; sk_o[0] = wave_hi ? ko[1] : ko[0];
+                            sk_b[1] = wave_hi ? kb[3] : kb[2]; sk_o[1] = wave_hi ? ko[3] : ko[2];
+                        }
+                        if (i == 4) { MX_DMA_SA(0) MX_DMA_SA(1) }
+                        if (i == 5) { MX_DMA_SA(2) MX_DMA_SA(3) }
+                        if (i == 6) MX_DMA_SA(4)
+                        if (i == 7) MX_DMA_SA(5)
+                    }
+                    if (j == 1) {
+                        if (i == 4) { MX_DMA_SW(ss, 0) MX_DMA_SW(ss, 1) }
+                        if (i == 5) { MX_DMA_SW(ss, 2) MX_DMA_SW(ss, 3) }
+                        if (i == 6) MX_DMA_SW(ss, 4)
+                        if (i == 7) MX_DMA_SW(ss, 5)
+                    }
+                    if (j == 2 && i == 3) {               // the table entries of K-steps 4 ss + 5 .. 4 ss + 8
+                        tb_n = *reinterpret_cast<const i32x4*>(tkb + 4 * ss + 4);
+                        to_n = *reinterpret_cast<const i32x4*>(tko + 4 * ss + 4);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#undef MX_NEXT
+            }
+            // M: the two block-scaled terms of this super-step (side data complete since the barrier of F3).
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // Fragment addresses: five byte offsets made here from the two record indices (which pass through an empty asm: the offsets
+                // are then recomputed per super-step instead of living in loop-invariant registers -- that spilled), each laundered once more so
+                // that every read below is `ds_read base offset:constant`: written as record arithmetic the compiler re-derived each of the
+                // ~40 addresses with two or three vector instructions (55 per wave and super-step, in front of and between the scaled MFMAs).
+                // are then recomputed per super-step instead of living in loop-invariant registers
+                int tl;                                  // the lane index, made afresh (v_mbcnt: no register lives across the loop for it)
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tl));
+                const int sw_rec = ((tl & 63) >> 4) * 256 + wn * 64 + (tl & 15);      // side W record of column block 0 (+ 16 per block)
+                const int sa_rec = ((tl & 63) >> 4) * 256 + wm * 128 + (tl & 15);                      // side A record of row block 0 (+ 16 per block)
+                unsigned o_a16 = MX_SA_OFF + sa_rec * 16, o_a4 = MX_SA_OFF + 32768 + sa_rec * 4;
+                asm volatile("" : "+v"(o_a16), "+v"(o_a4));
+                const unsigned char* const pa16 = rsm + o_a16;
+                const unsigned char* const pa4 = rsm + o_a4;
+                // the B fragments of all four column blocks stay resident (44 registers) while the eight row blocks stream past them
+                // once: read per column half, the A side crossed the LDS twice and the M-step ran at the LDS's read rate
+                // (3,008 clk of reads against 2,048 clk of MFMA per CU; now 1,856)
+                unsigned o_w16 = MX_SW_OFF + sw_rec * 16, o_w8 = MX_SW_OFF + 32768 + sw_rec * 8, o_w4 = MX_SW_OFF + 40960 + sw_rec * 4;
+                asm volatile("" : "+v"(o_w16), "+v"(o_w8), "+v"(o_w4));
+                const unsigned char* const pw16 = rsm + o_w16;
+                const unsigned char* const pw8 = rsm + o_w8;
+                const unsigned char* const pw4 = rsm + o_w4;
+                u32x4 w4[4], wl6a[4];
+                u32x2 wl6b[4];
+                unsigned wsc[4];
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    w4[jj] = *reinterpret_cast<const u32x4*>(pw16 + jj * 256);
+                    wl6a[jj] = *reinterpret_cast<const u32x4*>(pw16 + 16384 + jj * 256);
+                    wl6b[jj] = *reinterpret_cast<const u32x2*>(pw8 + jj * 128);
+                    wsc[jj] = *reinterpret_cast<const unsigned*>(pw4 + jj * 64);
+                }
+                u32x4 l_n = *reinterpret_cast<const u32x4*>(pa16);
+                u32x4 h_n = *reinterpret_cast<const u32x4*>(pa16 + 16384);
+                unsigned s_n = *reinterpret_cast<const unsigned*>(pa4);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const u32x4 l = l_n, h = h_n;
+                    const unsigned asc = s_n;
+                    if (i < 7) {                             // the next row block's fragments are read under this one's MFMAs
+                        l_n = *reinterpret_cast<const u32x4*>(pa16 + (i + 1) * 256);
+                        h_n = *reinterpret_cast<const u32x4*>(pa16 + 16384 + (i + 1) * 256);
+                        s_n = *reinterpret_cast<const unsigned*>(pa4 + (i + 1) * 64);
+                    }
+                    const i32x8 al = i32x8{(int)l.x, (int)l.y, (int)l.z, (int)l.w, 0, 0, 0, 0};
+                    const i32x8 ah = i32x8{(int)h.x, (int)h.y, (int)h.z, (int)h.w, 0, 0, 0, 0};
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {     // residual of x (fp4, scale byte 0) times the fp4 image of w (scale byte 0)
+                        const i32x8 bw = i32x8{(int)w4[jj].x, (int)w4[jj].y, (int)w4[jj].z, (int)w4[jj].w, 0, 0, 0, 0};
+                        acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(al, bw, acc[i][jj], 4, 4, 0, asc, 0, wsc[jj]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {     // fp4 image of x (scale byte 1) times the fp6 (e2m3) residual of w (scale byte 1)
+                        const i32x8 bw = i32x8{(int)wl6a[jj].x, (int)wl6a[jj].y, (int)wl6a[jj].z, (int)wl6a[jj].w, (int)wl6b[jj].x, (int)wl6b[jj].y, 0, 0};
+                        acc[i][jj] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(ah, bw, acc[i][jj], 4, 2, 1, asc, 1, wsc[jj]);
+                    }
+                    if (i == 3) {                        // the next super-step's table entries become scalars (read in F2: long landed)
+                        kb[0] = kb[4];
+                        ko[0] = ko[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            kb[e + 1] = __builtin_amdgcn_readfirstlane(tb_n[e]);
+                            ko[e + 1] = __builtin_amdgcn_readfirstlane(to_n[e]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    };
+    if constexpr (FLAT) {
+        if (interior) kloop(std::true_type{});
+        else kloop(std::false_type{});
+    } else {
+        kloop(std::false_type{});
     }
-#undef MX_DMA_F16
+#undef MX_DMA_A
+#undef MX_DMA_A_E
+#undef MX_DMA_A_I
+#undef MX_DMA_W
 #undef MX_DMA_SA
-#undef MX_DMA_SA_W
 #undef MX_DMA_SW
-#undef MX_SA_SETUP
-#undef MX_F_ADV
+#undef MX_ARG_BATCH
+#undef MX_LDS_AT
 #undef MX_CTX
 
 #include "tdnn_mx_epilogue.inc"
 }
 
-// (The tile body is a function of its own: a persistent form -- one workgroup per CU looping over tiles, tried for the pooled
-// layer so that a tile's statistics stores drain under the next tile's prologue -- keeps the 160-byte parameter block live across
-// the loop, spills 67 scalar registers and runs 5 % slower than one workgroup per tile.)
+// (The tile body is a function of its own. A persistent form -- one workgroup per CU looping over tiles -- was measured three times and is not
+// kept: round 3 for the pooled layer (67 spilled scalar registers, + 5 %), round 5 with cross-tile prefetch and a register epilogue (+ 6 %),
+// round 6 as a plain loop around this body with the next tile's id from a per-XCD counter fetched at the tile's start (+ 1.8 % of GEMM time,
+// same box, alternating runs: the ~1.4 us between two workgroups of a CU is not what it recovers -- docs/lab_notes_r6.md).)
 template <int ACT, int OUT, bool PADK, bool FLAT = false>
 __global__ __launch_bounds__(512) void tdnn_mx_kernel(MxParams p, int mtiles, int ntiles, int gtiles, double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
@@ -457,7 +545,8 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     KTF_REQUIRE(plain || !stats, "%s: the fused pooling takes SAME padding without subsampling", who);
     KTF_REQUIRE(d->act == KTF_ACT_NONE || d->act == KTF_ACT_RELU, "%s: fuses ReLU or no activation", who);
     KTF_REQUIRE((scale == nullptr) == (shift == nullptr), "%s: scale and shift go together", who);
-    KTF_REQUIRE(T * (int64_t)d->din_pad * 2 < (1ll << 31), "%s: T * din_pad too large", who);
+    KTF_REQUIRE(T * (int64_t)d->din_pad * 2 < (1ll << 31) - (1ll << 20), "%s: T * din_pad too large", who);
+    KTF_REQUIRE((((int64_t)d->din_pad / 32 * d->nctx + 3) / 4) * 4 <= MX_KQ_MAX_STEPS || (d->flags & KTF_TDNN_MX_LOADER), "%s: more than %d K-steps (din_pad / 32 * contexts)", who, MX_KQ_MAX_STEPS);
     if (B == 0 || T == 0 || ktf_tdnn_out_len(T, d) <= 0) return KTF_OK;       // (no output row: VALID padding of an input shorter than the context)
     const int outs = (yh ? 1 : 0) + (yf ? 1 : 0) + (stats ? 1 : 0);
     KTF_REQUIRE(outs == 1, "%s: exactly one of the plane / fp32 / pooled outputs", who);
@@ -494,7 +583,7 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     if (row_starts) {                           // flat row tiles: M-tiles over the batch's valid rows laid end to end
         KTF_REQUIRE(row_map && plain && o != MX_OUT_F32 && !loader, "%s: flat row tiles take the row table, SAME padding, no subsampling, a plane or pooled output", who);
         p.stat_slots = (stats && (d->flags & KTF_TDNN_DET_STATS)) ? (int32_t)ktf_flat_stats_slots(T) : 0;
-        KTF_REQUIRE(B <= 4095 && B * T * (int64_t)p.nch_in * 64 < (1ll << 32) && B * T < (1ll << 31) / (p.nch_out > 0 ? p.nch_out : 1),
+        KTF_REQUIRE(B <= 4095 && B * T * (int64_t)p.nch_in * 64 < (1ll << 32) - (1ll << 20) && B * T < (1ll << 31) / (p.nch_out > 0 ? p.nch_out : 1),
                     "%s: flat row tiles need B <= 4095 and B * T * din_pad * 2 < 2^32", who);
         p.row_starts = row_starts; p.row_map = row_map;
         if (T > 1) {                            // x / T for x < 2^31: m = 2^(31 + l) / T + 1, s = l - 1, l = ceil(log2 T)
@@ -510,11 +599,11 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
 #define MX_LAUNCH_FLAT(A, O)                                                                                           \
     {                                                                                                                  \
         if (p.nk & 3) {                                                                                                \
-            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, true, true>);                                              \
-            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, true, true>), dim3((unsigned)fblocks), dim3(512), MX_LDS_BYTES, st, p, (int)B, ntiles, (int)ftiles, stats); \
+            KTF_LDS_ONCE(MX_LDS_TOTAL(MX_KQ_MAX_STEPS), tdnn_mx_kernel<A, O, true, true>);                                              \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, true, true>), dim3((unsigned)fblocks), dim3(512), MX_LDS_TOTAL(p.nss * 4), st, p, (int)B, ntiles, (int)ftiles, stats); \
         } else {                                                                                                       \
-            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, false, true>);                                             \
-            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, false, true>), dim3((unsigned)fblocks), dim3(512), MX_LDS_BYTES, st, p, (int)B, ntiles, (int)ftiles, stats); \
+            KTF_LDS_ONCE(MX_LDS_TOTAL(MX_KQ_MAX_STEPS), tdnn_mx_kernel<A, O, false, true>);                                             \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, false, true>), dim3((unsigned)fblocks), dim3(512), MX_LDS_TOTAL(p.nss * 4), st, p, (int)B, ntiles, (int)ftiles, stats); \
         }                                                                                                              \
     }
         if (o == MX_OUT_STATS) {
@@ -533,11 +622,11 @@ static int mx_launch(const void* xh, const void* xl4, const void* x4, const void
     {                                                                                                                  \
         KTF_NOTE_KERNEL("tdnn_mx_kernel");                                                                             \
         if (p.nk & 3) {                                                                                                \
-            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, true>);                                                    \
-            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, true>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
+            KTF_LDS_ONCE(MX_LDS_TOTAL(MX_KQ_MAX_STEPS), tdnn_mx_kernel<A, O, true>);                                                    \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, true>), dim3((unsigned)nblocks), dim3(512), MX_LDS_TOTAL(p.nss * 4), st, p, mtiles, ntiles, (int)gtiles, stats); \
         } else {                                                                                                       \
-            KTF_LDS_ONCE(MX_LDS_BYTES, tdnn_mx_kernel<A, O, false>);                                                   \
-            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, false>), dim3((unsigned)nblocks), dim3(512), MX_LDS_BYTES, st, p, mtiles, ntiles, (int)gtiles, stats); \
+            KTF_LDS_ONCE(MX_LDS_TOTAL(MX_KQ_MAX_STEPS), tdnn_mx_kernel<A, O, false>);                                                   \
+            hipLaunchKernelGGL((tdnn_mx_kernel<A, O, false>), dim3((unsigned)nblocks), dim3(512), MX_LDS_TOTAL(p.nss * 4), st, p, mtiles, ntiles, (int)gtiles, stats); \
         }                                                                                                              \
     }
     if (d->act == KTF_ACT_RELU) {

@@ -17,6 +17,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define MX_WQ_BLOCK 49152                   // bytes of one (N-tile, super-step) block of the MX weight planes (last 4 KiB unused)
 #define MX_PRM_OFF (MX_SW_OFF + MX_WQ_BLOCK)        // bias | scale | shift of the tile's 256 columns (read by the epilogue)
 #define MX_LDS_BYTES (MX_PRM_OFF + 3 * 256 * 4)     // 154,624 B
+// tdnn_mx.hip: behind it the K-step table of the tile, two int32 arrays of (padded K-steps + 4) entries: (chunk * T + MX_KQ_BIAS) and the
+// context offset of K-step k + 1 in entry k
+#define MX_KQ_OFF MX_LDS_BYTES
+#define MX_KQ_BIAS 128                              // records: the activation planes' buffer resources start this far in front of the plane
+#define MX_KQ_MAX_STEPS 1144                        // padded K-steps a layer may have: 8 * (steps + 4) B of table must fit the CU's 160 KiB (K <= 36,608)
+#define MX_LDS_TOTAL(nkp) (MX_LDS_BYTES + 8 * ((nkp) + 4))
 static_assert(8 * 64 * 68 * 4 <= MX_PRM_OFF, "epilogue staging regions");
 #define MX_EPW_PITCH 68                             // wave-private epilogue staging: 64 rows x 64 columns per wave and pass, 8 x 17,408 B
 
@@ -48,6 +54,11 @@ struct MxParams {
     uint32_t t_div_m, t_div_s;         // ... x / T as __umulhi(x, t_div_m) >> t_div_s for x < 2^31 (t_div_m == 0: T == 1): the row lookups of a batch
                                        // whose every utterance has all T rows (row_starts[B] == B * T) are arithmetic, no table load
 };
+
+// raw buffer resource over [ptr, ptr + 4 GiB): stride 0, no range limit below 2^32 - 1, gfx950's dword-3 (32-bit data format)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mx_rsrc(const void* ptr, int bytes = -1) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);      // (bytes: offsets at or beyond it read as 0)
+}
 
 // E8M0 scale byte of an e2m1 block whose largest magnitude is m: the maximum lands in the top binade [4, 8) x scale, one
 // binade lower when it would round past 6 (mantissa >= 1.75)

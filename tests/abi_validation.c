@@ -113,6 +113,9 @@ int main(void) {
     EXPECT_EINVAL(ktf_tdnn_mx_flat(f, f, f, f, 1, 8, l, (int32_t*)l, &t, f, f, NULL, NULL, NULL, f, f, f, f, NULL));              /* subsampling */
     t.subsampling = 1;
     EXPECT_EINVAL(ktf_tdnn_mx_flat_stats(f, f, f, f, 1, 1, l, (int32_t*)l, &t, f, f, NULL, NULL, NULL, NULL, NULL));              /* no sums */
+    t.din = t.din_pad = 32 * 1200;                                                                                                  /* 1200 K-steps: the tile's K-step table ... */
+    EXPECT_EINVAL(ktf_tdnn_mx(f, f, f, f, 1, 1, NULL, &t, f, f, NULL, NULL, NULL, f, f, f, f, NULL, 0, NULL));                   /* ... would not fit the LDS (1144) */
+    t.din = t.din_pad = 32;
     t.gemm = KTF_GEMM_F32; t.x_dtype = t.w_dtype = t.y_dtype = KTF_F32; t.units = 8;
     EXPECT_EINVAL(ktf_convert_pad(NULL, KTF_F32, 1, 4, 4, f, KTF_F32, 4, NULL));
     EXPECT_EINVAL(ktf_split_bf16(NULL, 1, 4, 4, f, f, 32, NULL));

@@ -232,6 +232,16 @@ SCHEMES = {
     "mx_NNNFF": [("exact", "mx:none:e2m1/e2m3")] * 3 + [("exact", "mx:e2m1:e2m1/e2m3")] * 2,
     "mx_FFFNN": [("exact", "mx:e2m1:e2m1/e2m3")] * 3 + [("exact", "mx:none:e2m1/e2m3")] * 2,
     "mx_FNFFF": [("exact", "mx:e2m1:e2m1/e2m3")] + [("exact", "mx:none:e2m1/e2m3")] + [("exact", "mx:e2m1:e2m1/e2m3")] * 3,
+    # ... round 6: which residual term does each layer need? (F = full; N = no activation-residual term x_l4 w_4; W = no weight-residual term x_4 w_l6)
+    "mx_FFFFN": [("exact", "mx:e2m1:e2m1/e2m3")] * 4 + [("exact", "mx:none:e2m1/e2m3")],
+    "mx_FFFNF": [("exact", "mx:e2m1:e2m1/e2m3")] * 3 + [("exact", "mx:none:e2m1/e2m3")] + [("exact", "mx:e2m1:e2m1/e2m3")],
+    "mx_FFNFF": [("exact", "mx:e2m1:e2m1/e2m3")] * 2 + [("exact", "mx:none:e2m1/e2m3")] + [("exact", "mx:e2m1:e2m1/e2m3")] * 2,
+    "mx_NFFFF": [("exact", "mx:none:e2m1/e2m3")] + [("exact", "mx:e2m1:e2m1/e2m3")] * 4,
+    "mx_FFFFW": [("exact", "mx:e2m1:e2m1/e2m3")] * 4 + [("exact", "mx:e2m1:none")],
+    "mx_FFFWF": [("exact", "mx:e2m1:e2m1/e2m3")] * 3 + [("exact", "mx:e2m1:none")] + [("exact", "mx:e2m1:e2m1/e2m3")],
+    "mx_FFWFF": [("exact", "mx:e2m1:e2m1/e2m3")] * 2 + [("exact", "mx:e2m1:none")] + [("exact", "mx:e2m1:e2m1/e2m3")] * 2,
+    "mx_FWFFF": [("exact", "mx:e2m1:e2m1/e2m3")] + [("exact", "mx:e2m1:none")] + [("exact", "mx:e2m1:e2m1/e2m3")] * 3,
+    "mx_WFFFF": [("exact", "mx:e2m1:none")] + [("exact", "mx:e2m1:e2m1/e2m3")] * 4,
 }
 
 if __name__ == "__main__":
@@ -239,6 +249,8 @@ if __name__ == "__main__":
     seeds = [int(s) for s in os.environ.get("SEEDS", "4321,1,2,3").split(",")]
     ins = inputs()
     feats = {k: features(v) for k, v in ins.items()}
+    if os.environ.get("FRAMES"):                      # FRAMES=400,640: every input cut to its first n voiced frames (round 6: what each layer's residual terms are worth on short utterances)
+        feats = {f"{k}[:{n}]": f[: int(n)] for k, f in feats.items() for n in os.environ["FRAMES"].split(",") if f.shape[0] >= int(n)}
     print("voiced frames:", {k: v.shape[0] for k, v in feats.items()}, flush=True)
     exact_s = [("exact", "exact")] * 5
     for seed in seeds:
