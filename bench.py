@@ -471,8 +471,8 @@ def _attach_traffic(roof, gemm, build_id):
     under profiles/: it cannot be collected from inside this process. A stored figure belongs to the build it was measured on
     (`library_build_id` in the file = ktf_build_id() of that library): for any other build `traffic` stays null and the note says
     whose number is on file (the figure used to be pasted whatever the loaded library was)."""
-    for tpath in (os.path.join(ROOT, "profiles", "r5", f"traffic_{gemm}.json"), os.path.join(ROOT, "profiles", "r4", f"traffic_{gemm}.json"),
-                  os.path.join(ROOT, "profiles", "r3", f"traffic_{gemm}.json")):
+    for tpath in (os.path.join(ROOT, "profiles", "r6", f"traffic_{gemm}.json"), os.path.join(ROOT, "profiles", "r5", f"traffic_{gemm}.json"),
+                  os.path.join(ROOT, "profiles", "r4", f"traffic_{gemm}.json"), os.path.join(ROOT, "profiles", "r3", f"traffic_{gemm}.json")):
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)

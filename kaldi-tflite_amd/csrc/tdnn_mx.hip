@@ -381,9 +381,9 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
                 __builtin_amdgcn_sched_barrier(0);
                 if (MX_NEXT()) { MX_DMA_A(ks + 1, j + 1, 0) MX_DMA_A(ks + 1, j + 1, 1) }
                 __builtin_amdgcn_sched_barrier(0);
-                // the step's DMAs go out one or two at a time between the row blocks' MFMAs (issued in one burst behind the barrier,
-                // all eight waves sit in DMA issue while the matrix pipes idle): the next half stage first, then -- F0: side A,
-                // F1: side W of this super-step (the side area was released by the barrier of F0: M of ss - 1 is done)
+                // the step's other DMAs go out ONE at a time between the row blocks' MFMAs (issued in one burst behind the barrier, all eight waves
+                // sit in DMA issue while the matrix pipes idle: every DMA of a K-step in that gap is 2 % slower): the W half of the next stage
+                // first, then -- F0: side A, F1: side W of this super-step (the side area was released by the barrier of F0: M of ss - 1 is done)
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     if (live) {
@@ -401,19 +401,25 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
                     __builtin_amdgcn_sched_barrier(0);
                     if (i == 0) { if (MX_NEXT()) MX_DMA_W(ks + 1, 0) }
                     if (i == 1) { if (MX_NEXT()) MX_DMA_W(ks + 1, 1) }
+                    // side A (F0) / side W (F1): ONE DMA behind each of the MFMA groups 2 .. 7 (round 5 issued 2 + 2 + 1 + 1 behind groups 4 .. 7: the
+                    // same instructions spread over six gaps instead of bursts in four are 1.7 % of the GEMM time, docs/lab_notes_r6.md 2a)
                     if (j == 0) {
-                        if (i == 3) {
+                        if (i == 1) {
                             sk_b[0] = wave_hi ? kb[1] : kb[0]; sk_o[0] = wave_hi ? ko[1] : ko[0];
                             sk_b[1] = wave_hi ? kb[3] : kb[2]; sk_o[1] = wave_hi ? ko[3] : ko[2];
                         }
-                        if (i == 4) { MX_DMA_SA(0) MX_DMA_SA(1) }
-                        if (i == 5) { MX_DMA_SA(2) MX_DMA_SA(3) }
+                        if (i == 2) MX_DMA_SA(0)
+                        if (i == 3) MX_DMA_SA(1)
+                        if (i == 4) MX_DMA_SA(2)
+                        if (i == 5) MX_DMA_SA(3)
                         if (i == 6) MX_DMA_SA(4)
                         if (i == 7) MX_DMA_SA(5)
                     }
                     if (j == 1) {
-                        if (i == 4) { MX_DMA_SW(ss, 0) MX_DMA_SW(ss, 1) }
-                        if (i == 5) { MX_DMA_SW(ss, 2) MX_DMA_SW(ss, 3) }
+                        if (i == 2) MX_DMA_SW(ss, 0)
+                        if (i == 3) MX_DMA_SW(ss, 1)
+                        if (i == 4) MX_DMA_SW(ss, 2)
+                        if (i == 5) MX_DMA_SW(ss, 3)
                         if (i == 6) MX_DMA_SW(ss, 4)
                         if (i == 7) MX_DMA_SW(ss, 5)
                     }
