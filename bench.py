@@ -73,8 +73,6 @@ def parse_args(argv=None):
     ap.add_argument("--mx-loader", action="store_true", help="A/B: f16mx on the loader-wave kernel (csrc/tdnn_mxl.hip) instead of the 256 x 256 eight-wave kernel")
     ap.add_argument("--no-short-routing", action="store_true", help="A/B: without the device-side second pass over utterances below MIN_FRAMES voiced frames")
     ap.add_argument("--atomic-pooling", action="store_true", help="fp64-atomic fused pooling instead of the reproducible form")
-    ap.add_argument("--ctx-major-k", action="store_true", help="A/B: weights in (context, feature) K order instead of the chunk-interleaved one")
-    ap.add_argument("--row-major-w", action="store_true", help="A/B: row-major weights instead of the LDS-image tiles")
     ap.add_argument("--n1-json", default=None, help="a file holding the JSON line of the N = 1 run of this bench: the N > 1 line then carries "
                                                     "`scaling_summary` (value / (N x value at N = 1)); the driver computes efficiency itself, this is a convenience")
     return ap.parse_args(argv)
@@ -100,7 +98,8 @@ def self_launch(args, argv):
     Runs BEFORE this process touches the GPU (a process that has initialised HIP must not exec or share its context)."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "8")
+    # (host threads per rank: the ranks share the node's CPUs -- eight ranks x eight threads oversubscribed a 16-CPU lease)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // max(args.gpus, 1)))))
     cmd = launch_command(args.gpus, argv)
     return subprocess.call(cmd, env=env)
 
@@ -135,8 +134,6 @@ def main(argv=None):
     mdl.xvec.mx_flat_rows = not args.no_mx_flat
     mdl.xvec.mx_loader = True if args.mx_loader else None          # (None: the model picks per batch; 1024 x 10 s takes the 256-row kernel)
     mdl.route_short_utterances = not args.no_short_routing
-    mdl.xvec.k_interleaved = not args.ctx_major_k
-    mdl.xvec.w_tiled = not args.row_major_w
 
     B, N = args.batch, int(args.seconds * 16000)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)

@@ -132,8 +132,8 @@ class Sequential:
     inside the 1e-4 x-vector tolerance at half the split-bf16 matrix work, the timed mode), "bf16" (one pass, outside that tolerance)."""
 
     split_planes = True         # bf16x3: hi/lo bf16 activation planes between the wide layers (no in-loop conversion)
-    k_interleaved = True        # ... with the contexts of a multi-context layer walked inside each 32-feature chunk (L2 reuse)
-    w_tiled = True              # ... and the weights stored as the kernel's LDS stage images (contiguous 1 KiB per DMA instruction)
+    # (the split-plane layers always walk the contexts of a multi-context layer inside each 32-feature chunk -- KTF_TDNN_K_INTERLEAVED: L2 reuse --
+    #  and read their weights as the kernel's LDS stage images -- KTF_TDNN_W_TILED: 1 KiB per DMA instruction; both were A/B switches until round 6)
     # Routing defaults, copied into every instance (`self.min_tiles`, `self.min_frames`: per-model knobs, no shared mutable state).
     # MIN_TILES: batches with fewer 256-row tiles than this run on the exact fp32 kernels (crossover of the measured per-layer times).
     # MIN_FRAMES: batches whose utterances are shorter than this many frames run the next tighter mode: the block-scaled residuals
@@ -345,8 +345,8 @@ class Sequential:
         slots = (ops.flat_stats_slots(T) if flat else ops.stats_slots(T)) if self.deterministic else 0
         sums = self._ws.get("sums", (B, max(slots, 1), 2, D), torch.float64, dev, padded=False)
         sbuf = self._ws.get("pooled", (B, ld), torch.float32, dev, padded=od if ld != od else False)
-        kint = bool(split and self.k_interleaved and l.kernelWidth > 1)
-        wt = bool(split and self.w_tiled)
+        kint = bool(split and l.kernelWidth > 1)
+        wt = bool(split)
         w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, w_tiled=wt)
         scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
         xdt = x_or_planes.dtype
@@ -537,9 +537,9 @@ class Sequential:
                                              defer_to=steps[tail_at][1] if si + 2 == tail_at else None, row_starts=row_starts if flat else None)
                     lens, pooled, skip, planes = None, True, True, None
                     continue
-                kint = bool(self.k_interleaved and l.kernelWidth > 1)
-                kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | (L.TDNN_W_TILED if self.w_tiled else 0)
-                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, w_tiled=self.w_tiled)
+                kint = bool(l.kernelWidth > 1)
+                kflag = (L.TDNN_K_INTERLEAVED if kint else 0) | L.TDNN_W_TILED
+                w, w_lo, bias = l.device_weights(dev, gemm, k_interleaved=kint, w_tiled=True)
                 scale, shift = bn.affine_device(dev) if bn is not None else (None, None)
                 Tout = l.outputTimesteps(T)
                 ldy = ops.round_up(l.units, 32)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Timing-only ablation builds of csrc/tdnn_mx.hip (measurement tool; results of these builds are WRONG by design). The product
+"""ROUNDS 3-5: its text patches match csrc/tdnn_mx.hip as of commit 1d9b8c1 (`git show 1d9b8c1:kaldi-tflite_amd/csrc/tdnn_mx.hip`); round 6
+rewrote the K-loop and ablates it with tools/mx/ablate6.py (same idea, new anchors).
+Timing-only ablation builds of csrc/tdnn_mx.hip (measurement tool; results of these builds are WRONG by design). The product
 source carries no ablation switches: this script patches a scratch copy, builds libktf_abl_<name>.so beside the product
 library and prints the `KTF_LIBRARY=... KTF_ALLOW_LIBRARY_OVERRIDE=1 python bench.py --gemm f16mx --no-extra --no-cpu-baseline`
 lines to run on the GPU box (tools/mx/run_ablations.sh does)."""

@@ -35,6 +35,9 @@ V["no_f16_mfma"] = lambda s: rep(rep(s, "                        acc[i][0] = __b
 # every tile reads (not writes) the rows of the first 8 tiles: no A operand comes from HBM -- the upper bound of any deeper A prefetch
 V["hot_a"] = lambda s: rep(s, "    const int R0 = mt * 256;                              // FLAT: first flat row of the tile",
                            "    const int R0 = (mt & 7) * 256;                        // ABLATION: hot rows")
+# ... the rows READ only (dense batches): the plane stores go where they belong -- separates the first touch of the A rows from the faster stores
+V["hot_reads"] = lambda s: rep(s, "            for (int i = 0; i < 3; ++i) er[i] = flat_row(mr[i]);",
+                               "            for (int i = 0; i < 3; ++i) { const int R = (mt & 7) * 256 + mr[i]; const int bb = (int)(__umulhi((unsigned)R, p.t_div_m) >> p.t_div_s); er[i] = i32x4{R, R - bb * len, len, bb}; }")
 V["no_table"] = lambda s: rep(s, "                    if (j == 2 && i == 3) {               // the table entries of K-steps 4 ss + 5 .. 4 ss + 8\n                        tb_n = *reinterpret_cast<const i32x4*>(tkb + 4 * ss + 4);\n                        to_n = *reinterpret_cast<const i32x4*>(tko + 4 * ss + 4);",
                               "                    if (j == 2 && i == 3) {\n                        tb_n = i32x4{kb[1], kb[2], kb[3], kb[4]};\n                        to_n = i32x4{ko[1], ko[2], ko[3], ko[4]};")
 
