@@ -14,6 +14,7 @@
 // Used by ktf_frontend_f32 when the caller provides the KtfFrontendTables.fast_* tables; any other configuration runs
 // the generic kernel of frontend.hip.
 #include "common.h"
+#include <type_traits>
 
 // Measured on MI355X (1024 x 998 frames, tools/ab_f5.sh; VGPRs / waves per SIMD of the hot <no dither, fp32 input, 400> instance):
 //   constants in registers, 4 waves per workgroup                 136 VGPR, 3 waves/SIMD   0.945 ms   (round 1)
@@ -27,12 +28,18 @@
 //            DCT on two half-waves (16 + 2 instead of 32), mel segment sums as DPP multiply-adds (3 instead of 10),
 //            no arithmetic on the register past the frame's last sample (-7), logf without its denormal branch (-6),
 //            the spectrum's quarter in the mel weights (-4): ~330 issue slots per frame                                  0.549 ms
+//   round 6: the LDS side (PMC: the LDS array was busy 81 % of the launch, 38 % of those cycles bank conflicts, SQ_WAIT_INST_LDS 22 % of the
+//            wave cycles): the spectrum under an XOR swizzle of its index (the 8-byte writes were 4-way conflicts; per-lane constants only), the
+//            mel items' bins as aligned 16-byte pieces with shifted weights (five reads issued together instead of <= 16 four-byte reads at
+//            per-lane starts, each behind a wait of its own), 3 / 4 / 5 pieces by table for the shipped configuration: conflicts - 65 %,
+//            LDS-active cycles - 25 %, SQ_WAIT_INST_LDS - 73 %, every MFCC bit the same                                   0.545 -> 0.525 ms (same box)
 #ifndef F5_WAVES
 #define F5_WAVES 8
 #endif
 #define F5_WAVE_FLOATS (2 * 256 + 64)   // per-wave LDS: Z[256] float2 (reused for P[256] float once the spectrum is split) | feat[64]
 #define F5_THREADS (F5_WAVES * KTF_WAVE)
 #define F5_MAXW 16          // bins per mel work item (upper bound; the table says how many are used)
+#define F5_MELQ 5           // 16-byte pieces of the power spectrum a work item reads: its <= 16 bins start at any bin, the pieces at a multiple of 4
 #define F5_MAXMEL 32        // DCT rows per lane
 #ifndef F5_MINWAVES
 #define F5_MINWAVES 6       // waves per SIMD the register allocation of the hot instance is held to (__launch_bounds__); the
@@ -252,7 +259,7 @@ __device__ __forceinline__ void gauss_noise8(uint64_t seed, uint64_t row, uint32
 // STD: the configuration of the shipped models (MFCC's defaults, data/kaldi_models/configs/*.yml) known at compile time -- waveform in,
 // MFCC out, DC removal, raw log-energy into C0, pre-emphasis, power spectrum, log mel: the run-time tests of those switches, and the
 // register copies the compiler keeps for values a skipped branch would have left unchanged, fold away (~25 instructions per frame).
-template <bool DITHER, int KIND, int MFIX, bool STD = false>
+template <bool DITHER, int KIND, int MFIX, bool STD = false, int NQ = F5_MELQ>
 __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 4) void frontend512_kernel(const void* __restrict__ in_v, int64_t B, int64_t n,
                                                                  int in_kind, KtfFrontendCfg cfg, KtfFrontendTables tab,
                                                                  int out_stage, float* __restrict__ out,
@@ -267,7 +274,6 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = MFIX ? MFIX : cfg.frame_size;
     const int nm = cfg.num_mels, nc = cfg.num_ceps;
-    const int maxw = tab.reserved;          // bins per mel work item actually used (<= F5_MAXW)
     if (STD) { in_kind = (KIND == 2) ? KTF_IN_WAV_I16 : KTF_IN_WAV; out_stage = KTF_OUT_MFCC; }
     const bool c_dc = STD ? true : cfg.remove_dc != 0;
     const bool c_energy = STD ? true : cfg.use_energy != 0;
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     float* win = lds5;
     float* dct4 = lds5 + NF;                                   // record (m4, lane) = dct[4 m4 .. 4 m4 + 3][lane]
     float* melw4 = dct4 + F5_MAXMEL * KTF_WAVE;                // record (j4, lane) = this lane's mel weights 4 j4 .. 4 j4 + 3
-    float* twl = melw4 + F5_MAXW * KTF_WAVE;                    // F5_TW_LDS: record (q, lane), q < 7
+    float* twl = melw4 + F5_MELQ * 4 * KTF_WAVE;                // F5_TW_LDS: record (q, lane), q < 7
     float* wbase = twl + (F5_TW_LDS ? F5_TWREC * KTF_WAVE : 0) + wave * F5_WAVE_FLOATS;
     float2* Zb = reinterpret_cast<float2*>(wbase);
     float* Pb = wbase;               // the power spectrum overwrites Z: a wave's LDS operations execute in program order, and
@@ -325,9 +331,14 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     // |X|^2 = |2 E + rw 2 O|^2 / 4 (below): the quarter lives in the LDS copy of the mel weights, not in a multiply per bin (a power of
     // two: every product and every partial sum is the same number either way; the magnitude spectrum carries the half of it)
     const float mel_scale = c_pow ? 0.25f : 0.5f;
-    for (int i = tid; i < F5_MAXW * KTF_WAVE; i += F5_THREADS) {          // weights are zero beyond an item's length
-        const int e = i & 3, l = (i >> 2) & 63, j4 = i >> 8;
-        melw4[i] = mel_scale * tab.fast_mel_w[l * F5_MAXW + 4 * j4 + e];
+    // A work item's bins are read as ALIGNED 16-byte pieces of the power spectrum (five cover any 16 bins) and its weights are stored shifted
+    // by (first bin & 3), zeros in front and behind: the products that matter are the same, in the same order (a zero weight leaves the sum's
+    // bits alone), and the 16 four-byte reads at per-lane starts -- each behind a wait of its own, 2-way bank conflicts on average: the other
+    // half of the kernel's LDS conflict cycles -- become five reads issued together.
+    for (int i = tid; i < F5_MELQ * 4 * KTF_WAVE; i += F5_THREADS) {      // weights are zero beyond an item's length
+        const int e = i & 3, l = (i >> 2) & 63, q = i >> 8;
+        const int idx = 4 * q + e - (tab.fast_mel_meta[l * 4 + 0] & 3);
+        melw4[i] = (idx >= 0 && idx < F5_MAXW) ? mel_scale * tab.fast_mel_w[l * F5_MAXW + idx] : 0.0f;
     }
     float lift = 1.0f;
     if (out_stage == KTF_OUT_MFCC) {
@@ -343,6 +354,14 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
     const float* dct_col = dct4 + ((4 * (lane >> 5)) * KTF_WAVE + (lane & 31)) * 4;
     // output index of this lane's FFT results: X[mo + 64*r4]
     const int mo = (2 * (lane & 1) + ((lane >> 5) & 1)) + 4 * ((lane >> 3) & 3) + 16 * ((lane >> 1) & 3);
+    // Z lives in LDS under an XOR swizzle of its index, bits 4 and 5 folded into bits 0 and 3 (F5_ZSW): the 16 lanes that one LDS cycle of the
+    // 8-byte writes serves differ in mo's bits 1, 2, 4, 5 -- dword bits 2, 3, 5, 6, of which the bank (dword index mod 32) sees two: a 4-way
+    // conflict on every write of the spectrum (PMC, round 5: 38 % of the kernel's LDS cycles were conflict cycles, the LDS array busy 81 % of
+    // the launch -- as busy as the vector pipe). The swizzle term depends on index bits below 6 only: for the writer (mo + 64 r) and for both
+    // readers (k = lane + 64 j and its mirror 256 - k, whose low six bits are the lane's alone) it is a per-lane constant -- no instruction in
+    // the frame loop changes, the same numbers travel, and each of the three access patterns touches 16 (32) distinct bank pairs.
+#define F5_ZSW(k_) ((k_) ^ (((k_) >> 4) & 1) ^ ((((k_) >> 5) & 1) << 3))
+    const int mo_s = F5_ZSW(mo), zk_s = F5_ZSW(lane);
     const float invM = 1.0f / (float)M;
     __syncthreads();
 
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         bfly4(z);
         // natural order through LDS (wave-private): Z[mo + 64 r4]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Zb[mo + 64 * r] = make_float2(z[r].x, z[r].y);
+        for (int r = 0; r < 4; ++r) Zb[mo_s + 64 * r] = make_float2(z[r].x, z[r].y);
         F5_WAVE_SYNC();
         // ---- split the packed spectrum, |X[k]|(^2)  (filterbank.py:232-235; bin 256 carries no mel weight)
         float pw[4];
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int k = lane + 64 * j;
-            const float2 zk = Zb[k], zm = Zb[(N2 - k) & (N2 - 1)];
+            const float2 zk = Zb[zk_s + 64 * j], zm = Zb[F5_ZSW((N2 - k) & (N2 - 1))];
             // X[k] = E + rw O with E = (zk + conj zm) / 2, O = -i (zk - conj zm) / 2 = ((zk.y + zm.y), (zm.x - zk.x)) / 2. The halves are
             // factored out (powers of two: exact): |X|^2 = |2 E + rw 2 O|^2 / 4, each step one packed instruction
             const f5v2 kv = {zk.x, zk.y}, mv = {zm.x, zm.y}, rv = {rw[j].x, rw[j].y};
@@ -545,14 +564,24 @@ __global__ __launch_bounds__(F5_THREADS, (KIND != 0 && !DITHER) ? F5_MINWAVES : 
         // ---- sparse mel bank: this lane's slice of one filter (weights are zero beyond the slice; the reads stay inside
         //      the wave's own P/feat area), then a segmented reduction over <= 4 adjacent lanes
         float acc = 0.0f;
+        {
+            const float* pq = Pb + (mel_start & ~3);           // (beyond bin 255 the pieces read this frame's own Z values: finite, times zero)
+            // (no test per piece at run time: a wave-uniform test per piece compiled to a select, a compare and two branches each, and ONE
+            // branch per frame around straight-line bodies of three / four / five pieces measured 2.7 % slower than five unconditional pieces,
+            // 0.555 against 0.540 ms, with 18 more vector instructions per frame in the counters)
+            // NQ: the shipped configuration's instances know how many pieces their table needs (the launcher picks 3, 4 or 5 from its longest item)
+            f32x4 pv[NQ], wv[NQ];
 #pragma unroll
-        for (int j4 = 0; j4 < F5_MAXW / 4; ++j4) {
-            if (4 * j4 < maxw) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(melw4 + (j4 * KTF_WAVE + lane) * 4);
-                acc = fmaf(Pb[mel_start + 4 * j4 + 0], w.x, acc);
-                if (4 * j4 + 1 < maxw) acc = fmaf(Pb[mel_start + 4 * j4 + 1], w.y, acc);
-                if (4 * j4 + 2 < maxw) acc = fmaf(Pb[mel_start + 4 * j4 + 2], w.z, acc);
-                if (4 * j4 + 3 < maxw) acc = fmaf(Pb[mel_start + 4 * j4 + 3], w.w, acc);
+            for (int q = 0; q < NQ; ++q) {
+                pv[q] = *reinterpret_cast<const f32x4*>(pq + 4 * q);
+                wv[q] = *reinterpret_cast<const f32x4*>(melw4 + (q * KTF_WAVE + lane) * 4);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                acc = fmaf(pv[q].x, wv[q].x, acc);
+                acc = fmaf(pv[q].y, wv[q].y, acc);
+                acc = fmaf(pv[q].z, wv[q].z, acc);
+                acc = fmaf(pv[q].w, wv[q].w, acc);
             }
         }
         {   // segmented reduction over <= 4 adjacent lanes: lane i takes lane i + 1, then lane i + 2, by whole-wave DPP shifts (no
@@ -623,7 +652,7 @@ int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind
     if (gx < 1) gx = 1;
     if (gx > gmax) gx = gmax;
     const dim3 grid((unsigned)gx, (unsigned)B);
-    const size_t lds = sizeof(float) * (512 + (F5_MAXMEL + F5_MAXW + (F5_TW_LDS ? F5_TWREC : 0)) * KTF_WAVE + F5_WAVES * F5_WAVE_FLOATS);
+    const size_t lds = sizeof(float) * (512 + (F5_MAXMEL + F5_MELQ * 4 + (F5_TW_LDS ? F5_TWREC : 0)) * KTF_WAVE + F5_WAVES * F5_WAVE_FLOATS);
     const bool dither = cfg->dither != 0.0f && in_kind != KTF_IN_WINDOWED;
     const bool padded = (in_kind == KTF_IN_WAV || in_kind == KTF_IN_WAV_I16) && cfg->pad_mode;
     const int kind = padded ? 0 : (in_kind == KTF_IN_WAV_I16 ? 2 : 1);
@@ -634,8 +663,13 @@ int ktf_frontend512_launch(const void* in, int64_t B, int64_t n, int32_t in_kind
                          out_stage == KTF_OUT_MFCC && cfg->remove_dc && cfg->use_energy && cfg->raw_energy && cfg->preemph > 0.0f &&
                          cfg->use_power && cfg->use_log;
     if (std_cfg) {
-        if (kind == 2) hipLaunchKernelGGL((frontend512_kernel<false, 2, 400, true>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab, out_stage, out, seed, T);
-        else hipLaunchKernelGGL((frontend512_kernel<false, 1, 400, true>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab, out_stage, out, seed, T);
+        // (tab->reserved = the longest mel work item; at any shift it spans (reserved + 3 + 3) / 4 aligned pieces: four for the 10-bin items
+        // of the 30- and 40-mel banks at 16 kHz, five for the 13-bin items of 23 mels)
+        const int nq = (tab->reserved + 6) / 4;
+#define F5_STD(KI, NQ_) hipLaunchKernelGGL((frontend512_kernel<false, KI, 400, true, NQ_>), grid, dim3(F5_THREADS), lds, st, in, B, n, in_kind, *cfg, *tab, out_stage, out, seed, T)
+        if (kind == 2) { if (nq <= 3) F5_STD(2, 3); else if (nq == 4) F5_STD(2, 4); else F5_STD(2, F5_MELQ); }
+        else { if (nq <= 3) F5_STD(1, 3); else if (nq == 4) F5_STD(1, 4); else F5_STD(1, F5_MELQ); }
+#undef F5_STD
         KTF_CHECK_LAUNCH("ktf_frontend_f32(fast512)");
         return KTF_OK;
     }
