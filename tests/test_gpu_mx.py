@@ -504,7 +504,10 @@ def test_f16mx_model_with_valid_and_subsampled_layers_stays_on_the_mx_kernels():
 # ----------------------------------------------------------------------------- f16mx on flat row tiles (round 5)
 @pytest.mark.parametrize("relu", [True, False])
 @pytest.mark.parametrize("case", CASES + [(512, [-2, 0, 2], 512, 37, 333, None), (30, [-2, -1, 0, 1, 2], 512, 300, 40, None),
-                                          (64, [-2, 0, 2], 512, 5, 300, [300] * 5), (96, [-3, 0, 3], 300, 9, 998, [998] * 9), (64, [0], 256, 700, 1, [1] * 700)])
+                                          (64, [-2, 0, 2], 512, 5, 300, [300] * 5), (96, [-3, 0, 3], 300, 9, 998, [998] * 9), (64, [0], 256, 700, 1, [1] * 700),
+                                          # round 6: the interior K-loop (no row of a tile clamped). One context at offset 0: every tile takes it, partial ones and
+                                          # ragged batches included; five contexts on complete utterances (the first layer's shape: zero-padded K-steps)
+                                          (64, [0], 256, 37, 333, None), (512, [0], 300, 5, 998, [998] * 5), (30, [-2, -1, 0, 1, 2], 512, 6, 998, [998] * 6)])
 def test_tdnn_mx_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case, relu):
     """ktf_tdnn_mx_flat: the M-tiles of the 256-row kernel over the batch's valid rows laid end to end (row table from ktf_flat_row_map).
     Same operands into the same MFMAs in the same order: all four output planes equal ktf_tdnn_mx's bit for bit on the valid rows, and
