@@ -25,6 +25,11 @@
 //           single-buffered side area that is refilled during F0 / F1 of the NEXT super-step.
 // The im2col matrix is implicit as in tdnn_gemm.hip: a K-step is one context offset of one 32-feature chunk, rows clamped
 // per utterance (SAME padding = edge replication, layers/tdnn/tdnn.py:246-247 of the reference).
+// Operand stream (round 6): every LDS-DMA is `buffer_load ... offen lds` through one buffer resource per tensor -- the lane's part of an
+// address in a loop-invariant register, the K-step's part in a scalar register from a table of the layer's K-steps that each tile writes to
+// LDS once; tiles none of whose rows is clamped (INTERIOR: three in four on 998-frame utterances, all tiles of a single-context layer) run a
+// K-loop without a vector instruction for addresses; the A-row DMAs go out in the LDS-latency gap behind each K-step's barrier, every other
+// DMA alone behind an MFMA group (docs/lab_notes_r6.md: what each of these is worth, and what was tried and is not here).
 //
 // Replaces: layers/tdnn/tdnn.py:251-280 (+ keras ReLU, batchnorm.py:78-88, stats_pooling.py:211-240 when fused).
 #include "tdnn_mx_common.h"
