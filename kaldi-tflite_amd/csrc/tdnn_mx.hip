@@ -164,9 +164,9 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     // part of the address in ONE loop-invariant register, the K-step's part in ONE scalar register, no 64-bit address arithmetic per
     // instruction. The activation planes start MX_KQ_BIAS records early: the scalar part (chunk * T + context offset + MX_KQ_BIAS) is
     // never negative.
-    const __amdgpu_buffer_rsrc_t r_xh = mx_rsrc(p.xh + (ub - MX_KQ_BIAS) * 64);
-    const __amdgpu_buffer_rsrc_t r_wh = mx_rsrc(p.wh + (int64_t)nt * nkp * MX_TILE);
-    const __amdgpu_buffer_rsrc_t r_wq = mx_rsrc(p.wq + (int64_t)nt * p.nss * MX_WQ_BLOCK);
+    const __amdgpu_buffer_rsrc_t r_xh = mx_rsrc_pinned(p.xh + (ub - MX_KQ_BIAS) * 64);
+    const __amdgpu_buffer_rsrc_t r_wh = mx_rsrc_pinned(p.wh + (int64_t)nt * nkp * MX_TILE);
+    const __amdgpu_buffer_rsrc_t r_wq = mx_rsrc_pinned(p.wq + (int64_t)nt * p.nss * MX_WQ_BLOCK);
 
     // half stage: thread q = i * 512 + tid moves the 16-byte piece at LDS offset q * 16 (row q >> 2, position q & 3 holds chunk
     // (q & 3) ^ ((4 - ((row >> 2) & 3)) & 3): conflict-free 16-byte fragment reads)
@@ -225,11 +225,13 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     // The first stage goes out HERE, in front of everything only the K-loop needs (side-plane resources, the interior test, the K-step table):
     // a tile's time to its first MFMA is the latency of these four DMAs plus whatever is issued in front of them. Rows in the clamped form.
     const unsigned vw = (unsigned)tid * 16u;              // loop-invariant lane part of the W image / side W addresses
-    // LDS destinations: (the wave's offset, passed through an empty asm at each use) + a constant = ONE `s_add_i32 m0` per DMA. Left to the
-    // compiler, every destination of the loop became a loop-invariant scalar register of its own (~25 of them: with the six buffer
-    // resources the kernel ran out of scalar registers and spilled the epilogue's pointers around the loop).
-    const int wave_k = wave * 1024;                        // the wave's piece of a stage image / of an 8 KiB side-W slice
-#define MX_LDS_AT(off_, c_) ({ int o_ = (off_); asm volatile("" : "+s"(o_)); (lds_ptr_t*)(rsm + o_ + (c_)); })
+    // LDS destinations: (the wave's LDS address: wave_k, sa_k, sa_ks; inside the K-loop copies of them that pass through an empty asm once per
+    // super-step) + a constant = ONE scalar add per DMA. Left to the compiler, every destination of the loop became a loop-invariant scalar
+    // register of its own (~25 of them: with the six buffer resources the kernel ran out of scalar registers and spilled the epilogue's
+    // pointers around the loop).
+    const int wave_k0 = (int)(unsigned)(size_t)(lds_ptr_t*)(rsm + wave * 1024);       // the wave's piece of a stage image / of an 8 KiB side-W slice (LDS address)
+    [[maybe_unused]] const int wave_k = wave_k0;
+#define MX_LDS_AT(off_, c_) ((lds_ptr_t*)(size_t)(unsigned)((off_) + (c_)))
     int kb[5], ko[5];                                     // table entries of K-steps 4 ss .. 4 ss + 4 (scalar registers)
     kb[0] = MX_KQ_BIAS;
     ko[0] = MX_CTX(0);
@@ -252,9 +254,9 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r_wh, MX_LDS_AT(wave_k, ((ks_) & 1) * MX_STAGE + MX_TILE + (n_) * 8192), 16, vw, \
                                              (ks_) * MX_TILE + (n_) * 8192, 0, 0);
     MX_DMA_W(0, 0) MX_DMA_W(0, 1) MX_DMA_A_E(0, 0, 0) MX_DMA_A_E(0, 0, 1)
-    const __amdgpu_buffer_rsrc_t r_xl4 = mx_rsrc(p.xl4 + (ub - MX_KQ_BIAS) * 16);
-    const __amdgpu_buffer_rsrc_t r_x4 = mx_rsrc(p.x4 + (ub - MX_KQ_BIAS) * 16);
-    const __amdgpu_buffer_rsrc_t r_xs = mx_rsrc(p.xs + (ub - MX_KQ_BIAS) * 4);
+    const __amdgpu_buffer_rsrc_t r_xl4 = mx_rsrc_pinned(p.xl4 + (ub - MX_KQ_BIAS) * 16);
+    const __amdgpu_buffer_rsrc_t r_x4 = mx_rsrc_pinned(p.x4 + (ub - MX_KQ_BIAS) * 16);
+    const __amdgpu_buffer_rsrc_t r_xs = mx_rsrc_pinned(p.xs + (ub - MX_KQ_BIAS) * 4);
     if constexpr (FLAT) {
         if (p.nctx == 1 && MX_CTX(0) == 0) {
             interior = true;      // one context at offset 0: no row is ever clamped (rows beyond the batch's last read row 0 of the plane and are not stored)
@@ -269,8 +271,8 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
     [[maybe_unused]] const unsigned va0 = (a_ub[0] + (unsigned)a_row[0]) * 64u + a_cb[0], va1 = (a_ub[1] + (unsigned)a_row[1]) * 64u + a_cb[1];
     [[maybe_unused]] const unsigned vs16 = (s_ub + (unsigned)s_row) * 16u, vs4 = (s_ub + (unsigned)s_row) * 4u;
 
-    const int sa_k = (wave & 3) * 1024 + (wave >> 2) * 4096;     // side A: the wave's pieces of the e2m1 images (+ plane, K block pair)
-    const int sa_ks = (wave & 3) * 256 + (wave >> 2) * 1024;     // ... and of the scale words
+    const int sa_k0 = (int)(unsigned)(size_t)(lds_ptr_t*)(rsm + (wave & 3) * 1024 + (wave >> 2) * 4096);     // side A: the wave's pieces of the e2m1 images (+ plane, K block pair)
+    const int sa_ks0 = (int)(unsigned)(size_t)(lds_ptr_t*)(rsm + (wave & 3) * 256 + (wave >> 2) * 1024);     // ... and of the scale words
     const bool wave_hi = wave >= 4;                                              // side A: the wave's K blocks are (0, 2) or (1, 3)
 
     // Which (32-feature chunk, context offset) a K-step reads comes from a table in LDS, made once per tile: entry k - 1 of `tkb` is
@@ -357,6 +359,11 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
         for (int ss = 0; ss < p.nss; ++ss) {
             i32x4 tb_n, to_n;                             // the next super-step's entries: read in F2, moved to scalar registers in F3
             int sk_b[2], sk_o[2];                         // side A: the table entries of this wave's two K blocks
+            // the three LDS bases of the wave's DMA destinations, passed through an empty asm ONCE per super-step: a destination is then
+            // `s_add_i32 m0, base, constant` (made afresh per DMA from a loop-invariant base, every one of the ~25 destinations became a
+            // loop-invariant scalar register; laundered per DMA it cost a copy and an add more each)
+            int wave_k = wave_k0, sa_k = sa_k0, sa_ks = sa_ks0;
+            asm volatile("" : "+s"(wave_k), "+s"(sa_k), "+s"(sa_ks));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ks = 4 * ss + j;

@@ -59,6 +59,18 @@ struct MxParams {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mx_rsrc(const void* ptr, int bytes = -1) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ptr), 0, bytes, 0x00020000);      // (bytes: offsets at or beyond it read as 0)
 }
+// ... the same four words assembled by hand and passed through an empty asm: FOUR scalar registers the compiler has to keep as they are. A
+// resource made by the builtin is a recipe to it: around every use it re-assembled the constant upper half (two s_mov per DMA) and lent the
+// registers out in between.
+typedef int mx_rs4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mx_rsrc_pinned(const void* ptr, int bytes = -1) {
+    const unsigned long long a = (unsigned long long)ptr;
+    mx_rs4 w{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xffffu), bytes, 0x00020000};
+    asm volatile("" : "+s"(w));
+    __amdgpu_buffer_rsrc_t r;
+    __builtin_memcpy(&r, &w, 16);
+    return r;
+}
 
 // E8M0 scale byte of an e2m1 block whose largest magnitude is m: the maximum lands in the top binade [4, 8) x scale, one
 // binade lower when it would round past 6 (mantissa >= 1.75)
