@@ -24,33 +24,53 @@ __device__ __forceinline__ void flat_stats_runs(f32x4 (&acc)[8][4], int R0, int 
         const int slot = ((R0 + blk0) >> 7) - ((R0 + m - t_m) >> 7);
         const int rb = g4 * 4 - lm;                                    // lane's row (i, r) relative to the run's first: rb + 16 i + r
         const unsigned span = (unsigned)(le - lm);
+        // (lm, le are the same on every lane: as scalars they steer wave-uniform branches)
+        const int lmu = __builtin_amdgcn_readfirstlane(lm), leu = __builtin_amdgcn_readfirstlane(le);
+        // the run's first row lmu = 16 i0 + 4 g + r0 of the block is held by the lanes of quarter g in acc[i0][.][r0]
         float pv[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int i = 0; i < 8; ++i)
+            if (i == (lmu >> 4)) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool first = rb + 16 * i + r == 0;
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) pv[j] = first ? acc[i][j][r] : pv[j];
+                    for (int j = 0; j < 4; ++j) pv[j] = r == (lmu & 3) ? acc[i][j][r] : pv[j];
             }
-        const int src = ((lm >> 2) & 3) * 16 + (lane & 15);           // the lane that holds the run's first row of this column
+        const int src = ((lmu >> 2) & 3) * 16 + (lane & 15);          // the lane that holds the run's first row of this column
 #pragma unroll
         for (int j = 0; j < 4; ++j) pv[j] = __shfl(pv[j], src, 64);
         float s32[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q32[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         int cnt = 0;
+        // per 16-row group of the block (wave-uniform tests): outside the run -- nothing (its terms were + 0.0f: the sums are the same bits);
+        // inside -- the plain sums, 12 vector instructions per row of four columns; across an end of the run -- per-row tests, 22 per row.
+        // A 998-frame utterance: seven blocks in eight are one run over all eight groups.
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i) {
+            if (16 * i + 16 <= lmu || 16 * i >= leu) continue;
+            if (16 * i >= lmu && 16 * i + 16 <= leu) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool in = (unsigned)(rb + 16 * i + r) < span;
-                cnt += in ? 1 : 0;
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float u = in ? acc[i][j][r] - pv[j] : 0.0f;
-                    s32[j] += u;
-                    q32[j] = fmaf(u, u, q32[j]);
+                    for (int j = 0; j < 4; ++j) {
+                        const float u = acc[i][j][r] - pv[j];
+                        s32[j] += u;
+                        q32[j] = fmaf(u, u, q32[j]);
+                    }
+                cnt += 4;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool in = (unsigned)(rb + 16 * i + r) < span;
+                    cnt += in ? 1 : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u = in ? acc[i][j][r] - pv[j] : 0.0f;
+                        s32[j] += u;
+                        q32[j] = fmaf(u, u, q32[j]);
+                    }
                 }
             }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double pd = (double)pv[j], sd = (double)s32[j], nd = (double)cnt;
