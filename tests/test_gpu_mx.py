@@ -548,7 +548,8 @@ def test_tdnn_mx_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case, 
 
 
 @pytest.mark.parametrize("deterministic", [True, False])
-@pytest.mark.parametrize("case", [(512, [0], 1500, 60, 333), (96, [-2, 0, 2], 300, 300, 40), (160, [-1, 0, 1], 257, 9, 700), (512, [0], 1500, 7, 998, "dense")])
+@pytest.mark.parametrize("case", [(512, [0], 1500, 60, 333), (96, [-2, 0, 2], 300, 300, 40), (160, [-1, 0, 1], 257, 9, 700), (512, [0], 1500, 7, 998, "dense"),
+                                  (64, [0], 256, 400, 20), (64, [-1, 0, 1], 200, 37, 129)])      # (six and more runs per 128-row block; runs one row longer than a block)
 def test_tdnn_mx_fused_pooling_on_flat_row_tiles(case, deterministic):
     """ktf_tdnn_mx_flat_stats against ktf_tdnn_mx_stats (same MFMA operands; the fp32 partial sums relative to each block's pivot row are
     cut along the flat row space instead of per utterance): pooled mean | std agree to 1e-5, a dead ReLU unit and a constant one give
