@@ -507,7 +507,11 @@ def test_f16mx_model_with_valid_and_subsampled_layers_stays_on_the_mx_kernels():
                                           (64, [-2, 0, 2], 512, 5, 300, [300] * 5), (96, [-3, 0, 3], 300, 9, 998, [998] * 9), (64, [0], 256, 700, 1, [1] * 700),
                                           # round 6: the interior K-loop (no row of a tile clamped). One context at offset 0: every tile takes it, partial ones and
                                           # ragged batches included; five contexts on complete utterances (the first layer's shape: zero-padded K-steps)
-                                          (64, [0], 256, 37, 333, None), (512, [0], 300, 5, 998, [998] * 5), (30, [-2, -1, 0, 1, 2], 512, 6, 998, [998] * 6)])
+                                          (64, [0], 256, 37, 333, None), (512, [0], 300, 5, 998, [998] * 5), (30, [-2, -1, 0, 1, 2], 512, 6, 998, [998] * 6),
+                                          # ... and its one-A-image-per-chunk form (three or more contexts within 16 rows, no padded K-step): complete and ragged
+                                          # utterances, the widest span, five contexts, a span that does not fit (the plain interior loop), one chunk only
+                                          (128, [-2, 0, 2], 256, 6, 998, [998] * 6), (128, [-3, 0, 3], 300, 7, 700, None), (128, [-8, 0, 8], 256, 4, 998, [998] * 4),
+                                          (128, [-7, -2, 0, 3, 8], 256, 3, 640, [640] * 3), (128, [-9, 0, 8], 256, 3, 640, [640] * 3), (32, [-4, -1, 0, 3], 256, 3, 640, [640] * 3)])
 def test_tdnn_mx_flat_row_tiles_equal_the_per_utterance_tiles_bit_for_bit(case, relu):
     """ktf_tdnn_mx_flat: the M-tiles of the 256-row kernel over the batch's valid rows laid end to end (row table from ktf_flat_row_map).
     Same operands into the same MFMAs in the same order: all four output planes equal ktf_tdnn_mx's bit for bit on the valid rows, and

@@ -26,6 +26,9 @@ V["no_side_dma"] = lambda s: all_waits_zero(rep(rep(s, "                    if (
                                                     "                    if (j == 1) {\n                        if (i == 4) { MX_DMA_SW", "                    if (false) {\n                        if (i == 4) { MX_DMA_SW"))
 V["no_m_mfma"] = lambda s: rep(s, "                for (int i = 0; i < 8; ++i) {\n                    const u32x4 l = l_n, h = h_n;", "                for (int i = 0; i < 0; ++i) {\n                    const u32x4 l = l_n, h = h_n;")
 V["no_a_dma"] = lambda s: rep(s, "if (MX_NEXT()) { MX_DMA_A(ks + 1, j + 1, 0) MX_DMA_A(ks + 1, j + 1, 1) }", "if (false) { MX_DMA_A(ks + 1, j + 1, 0) MX_DMA_A(ks + 1, j + 1, 1) }")
+# one A-row DMA per wave and K-step instead of two (rows 128-255 of the stage are never refreshed): what a shared A image per chunk -- the
+# three context offsets of a chunk read nearly the same rows -- could give at most on the multi-context layers (tdnn4 / tdnn5 lose a DMA they need)
+V["half_a_dma"] = lambda s: rep(s, "if (MX_NEXT()) { MX_DMA_A(ks + 1, j + 1, 0) MX_DMA_A(ks + 1, j + 1, 1) }", "if (MX_NEXT()) { MX_DMA_A(ks + 1, j + 1, 0) }")
 V["no_w_dma"] = lambda s: rep(rep(s, "if (i == 0) { if (MX_NEXT()) MX_DMA_W(ks + 1, 0) }", "if (i == 0) { if (false) MX_DMA_W(ks + 1, 0) }"),
                               "if (i == 1) { if (MX_NEXT()) MX_DMA_W(ks + 1, 1) }", "if (i == 1) { if (false) MX_DMA_W(ks + 1, 1) }")
 V["no_stage_dma"] = lambda s: V["no_w_dma"](V["no_a_dma"](s))
