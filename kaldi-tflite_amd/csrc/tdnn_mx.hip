@@ -382,11 +382,12 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
                 const unsigned char* sa = rsm + (ks & 1) * MX_STAGE;
                 const unsigned char* sw = sa + MX_TILE;
                 hfrag8 bh[4];
-                hfrag8 a_cur;
+                hfrag8 a_cur, a_nx1;                      // the fragments of row blocks i and i + 1; i + 2's is read behind block i's first MFMA
                 if (live) {
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) bh[jj] = *reinterpret_cast<const hfrag8*>(sw + b_row_off + jj * 1024);
                     a_cur = *reinterpret_cast<const hfrag8*>(sa + a_row_off);
+                    a_nx1 = *reinterpret_cast<const hfrag8*>(sa + a_row_off + 1024);
                 }
                 // the first two DMAs of the next half stage (the A rows) go out HERE, between the fragment reads above and their first use: both
                 // waves of a SIMD come out of the barrier together and sit out the LDS latency in front of the first MFMA group anyway
@@ -404,11 +405,15 @@ __device__ __forceinline__ void mx_tile(const MxParams& p, const int id, int mti
                         // out the whole LDS latency of a fragment it needs 64 matrix cycles later -- both waves of a SIMD at the same place
                         acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[0], acc[i][0], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
-                        hfrag8 a_nxt = a_cur;
-                        if (i < 7) a_nxt = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 1) * 1024);
+                        // (TWO blocks ahead since round 6: one block of MFMAs -- 48 matrix cycles -- does not cover an LDS read's latency, and the
+                        // counted lgkmcnt in front of the next block's first MFMA waited for it; with two reads in flight it waits for the older
+                        // one only. Same registers in the plane kernel; the pooled layer's launch - 2.3 ... - 3 %, docs/lab_notes_r6.md 7f)
+                        hfrag8 a_nx2 = a_nx1;
+                        if (i < 6) a_nx2 = *reinterpret_cast<const hfrag8*>(sa + a_row_off + (i + 2) * 1024);
 #pragma unroll
                         for (int jj = 1; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_cur, bh[jj], acc[i][jj], 0, 0, 0);
-                        a_cur = a_nxt;
+                        a_cur = a_nx1;
+                        a_nx1 = a_nx2;
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (i == 0) { if (MX_NEXT()) MX_DMA_W(ks + 1, 0) }
