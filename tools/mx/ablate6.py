@@ -22,8 +22,8 @@ def all_waits_zero(s):     # a variant that issues fewer DMAs must not leave the
 
 V = {}
 V["force_edge"] = lambda s: rep(s, "        if (interior) kloop(std::true_type{});", "        if (false) kloop(std::true_type{});")
-V["no_side_dma"] = lambda s: all_waits_zero(rep(rep(s, "                    if (j == 0) {\n                        if (i == 3) {", "                    if (false) {\n                        if (i == 3) {"),
-                                                    "                    if (j == 1) {\n                        if (i == 4) { MX_DMA_SW", "                    if (false) {\n                        if (i == 4) { MX_DMA_SW"))
+V["no_side_dma"] = lambda s: all_waits_zero(rep(rep(s, "#define MX_DMA_SA(n_)  ", "#define MX_DMA_SA(n_) {}\n#define MX_DMA_SA_UNUSED(n_)  "),
+                                                    "#define MX_DMA_SW(ss_, n_)  ", "#define MX_DMA_SW(ss_, n_) {}\n#define MX_DMA_SW_UNUSED(ss_, n_)  "))
 V["no_m_mfma"] = lambda s: rep(s, "                for (int i = 0; i < 8; ++i) {\n                    const u32x4 l = l_n, h = h_n;", "                for (int i = 0; i < 0; ++i) {\n                    const u32x4 l = l_n, h = h_n;")
 V["no_a_dma"] = lambda s: rep(s, "if (MX_NEXT()) { MX_DMA_A(ks + 1, j + 1, 0) MX_DMA_A(ks + 1, j + 1, 1) }", "if (false) { MX_DMA_A(ks + 1, j + 1, 0) MX_DMA_A(ks + 1, j + 1, 1) }")
 # one A-row DMA per wave and K-step instead of two (rows 128-255 of the stage are never refreshed): what a shared A image per chunk -- the
